@@ -1,0 +1,88 @@
+"""ctypes binding of librlg_hip.so (the C ABI declared in include/rlg_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing,
+fails to load, or a launch fails, the caller gets a RuntimeError.  `torch` is imported
+first on purpose - the library must bind to the HIP runtime PyTorch already loaded, so
+that raw `data_ptr()` addresses and `torch.cuda.current_stream()` handles are valid.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librlg_hip.so')
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_double = ctypes.c_double
+_c_ll = ctypes.c_longlong
+_P = _c_void_p  # every device pointer crosses the boundary as an address
+
+# name -> argtypes.  Order/meaning: include/rlg_hip.h.  All functions return int.
+_PROTOTYPES = {
+    'rlg_gae_strided': [_P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int,
+                        ctypes.POINTER(_c_ll), _c_int, _c_float, _c_float, _P],
+    'rlg_gae_envmajor_supported': [_c_int],
+    'rlg_gae_envmajor_num_partials': [_c_int],
+    'rlg_gae_envmajor_fused': [_P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float,
+                               _c_float, _P],
+    'rlg_gae_envmajor_raw': [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float, _c_float, _P],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def exported_prototypes():
+    return dict(_PROTOTYPES)
+
+
+def load():
+    """dlopen librlg_hip.so once and attach argtypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} is not built. Run `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C rl_games_amd/csrc`. rl_games_amd has no CPU fallback.')
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise HipLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, argtypes in _PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f'{LIB_PATH} does not export {name}; rebuild it') from e
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        raise HipLibraryError(f'{what} failed with hipError_t {err}')
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle(device=None):
+    """hipStream_t of torch's current stream, as an integer address."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise HipLibraryError(
+            f'{what}: tensor lives on {t.device}; the rl_games_amd hot path only runs on an '
+            f'MI355X (HIP) device and has no CPU fallback')

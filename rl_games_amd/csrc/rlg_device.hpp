@@ -1,0 +1,73 @@
+// Shared device-side helpers for the rl_games_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Wavefronts are 64 lanes wide on CDNA4; every reduction below hard-codes that.
+// The whole library is compiled with -ffp-contract=off so that every fp32
+// multiply/add written in the kernels is rounded individually, exactly like the
+// chain of eager PyTorch ops the reference executes; fused multiply-adds are only
+// used where they are spelled out (fmaf / fma).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rlg {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, kWave);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, kWave);
+  return x;
+}
+
+// Sum `K` doubles per thread across a block of `BLOCK` threads (BLOCK % 64 == 0).
+// Result valid in thread 0 only.  `scratch` must hold K * BLOCK/64 doubles.
+// The combination order is fixed (wave tree, then waves in index order), so the
+// result is bit-reproducible run to run.
+template <int K, int BLOCK>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* scratch) {
+  constexpr int kWaves = BLOCK / kWave;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (kWaves == 1) return;
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) scratch[wave_id() * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double s = scratch[k];
+      for (int w = 1; w < kWaves; ++w) s += scratch[w * K + k];
+      v[k] = s;
+    }
+  }
+}
+
+// 16-byte vector helpers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+}  // namespace rlg
+
+// Host-side launch check used by every extern "C" entry point: launchers never
+// synchronise and never allocate; they return the hipError_t of the launch.
+#define RLG_RETURN_LAUNCH_STATUS()          \
+  do {                                      \
+    hipError_t e__ = hipGetLastError();     \
+    return static_cast<int>(e__);           \
+  } while (0)
