@@ -70,6 +70,150 @@ int rlg_gae_envmajor_raw(const float* rewards, const float* values, const uint8_
                          const float* last_values, const uint8_t* last_dones, float* gae_out,
                          int num_envs, int horizon, float gamma, float gamma_tau, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Rollout buffer (ExperienceBuffer) writes and per-step glue
+ *   replaces rl_games/common/experience.py: ExperienceBuffer.update_data :433-456 and the
+ *   per-step part of rl_games/common/a2c_common.py: A2CBase.play_steps :994-1051.
+ *   Storage is env-major: field[env][t][row], flat index env*H + t (swap_and_flatten01
+ *   order, a2c_common.py:33-40), so get_transformed_list (experience.py:508-522) is a view.
+ * ---------------------------------------------------------------------------------- */
+
+/* One launch for all `update_data(name, step, val)` calls of a step (a2c_common.py:1000-1011):
+ * srcs[k] is [num_envs][row_bytes[k]] contiguous, dsts[k] the env-major field storage.
+ * count <= 12.  srcs/dsts/row_bytes are HOST arrays of device pointers / sizes. */
+int rlg_rollout_store_step(int count, const void* const* srcs, void* const* dsts,
+                           const int* row_bytes, int num_envs, int horizon, int step,
+                           void* stream);
+
+int rlg_rollout_post_step_num_blocks(int num_envs);
+
+/* After vec_env.step: DefaultRewardsShaper (rl_games/common/tr_helpers.py:33-42, log_val
+ * unsupported), time-out bootstrap (a2c_common.py:1021-1023), update_data('rewards') (:1025),
+ * current_rewards/current_shaped_rewards/current_lengths accumulate + zero-on-done
+ * (:1027-1051).  Finished-episode sums go to ep_partials[step][block][2V+2] (fp64) and are
+ * folded into the meters by rlg_episode_meters_update.  time_outs_kind: 0 none, 1 u8/bool,
+ * 2 fp32.  live_rows (next_step autoreset mask, :1002-1006) may be NULL. value_size <= 8. */
+int rlg_rollout_post_step(const float* rewards, const uint8_t* dones, const void* time_outs,
+                          int time_outs_kind, const float* values, const float* live_rows,
+                          float* rewards_buf, float* cur_rewards, float* cur_shaped,
+                          float* cur_lengths, double* ep_partials, float shift, float scale,
+                          float rmin, float rmax, int clamp_rewards, int bootstrap, float gamma,
+                          int num_envs, int horizon, int value_size, int step, void* stream);
+
+/* Replays AverageMeter.update (rl_games/algos_torch/torch_ext.py:333-342) for the three
+ * episode meters (game_rewards, game_shaped_rewards, game_lengths; a2c_common.py:1042-1044)
+ * over steps 0..horizon-1.  current_sizes is int[3], finished_total an int64 counter. */
+int rlg_episode_meters_update(const double* ep_partials, int horizon, int num_blocks,
+                              int value_size, int max_size, float* mean_rewards,
+                              float* mean_shaped, float* mean_lengths, int* current_sizes,
+                              long long* finished_total, void* stream);
+
+/* play_steps_rnn zero-on-done: s[:, done_envs, :] = 0 (a2c_common.py:1150-1153).
+ * states [layers][num_envs][units] contiguous. */
+int rlg_rnn_zero_done_states(float* states, const uint8_t* dones, int layers, int num_envs,
+                             int units, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RunningMeanStd / advantage normalisation
+ *   replaces rl_games/algos_torch/running_mean_std.py: RunningMeanStd.forward :69-114,
+ *   _update_mean_var_count_from_moments :55-67; rl_games/algos_torch/torch_ext.py:
+ *   get_mean_var_with_masks :182-191; ContinuousA2CBase.prepare_dataset value/advantage part
+ *   (rl_games/common/a2c_common.py:1598-1634); GeneralizedMovingStats 'mean_std'
+ *   (rl_games/algos_torch/moving_mean_std.py:52-61,:102-134,:136-150).
+ * ---------------------------------------------------------------------------------- */
+
+int rlg_column_moments_num_blocks(long long rows, int cols);
+
+/* Per-block fp64 partial sums of a row-major fp32 [rows, cols] matrix:
+ * partials[block][2*cols+1] = {sum x*m [cols], sum x*x*m [cols], sum m}; m = row mask or 1. */
+int rlg_column_moments(const float* x, const float* row_mask_or_null, long long rows, int cols,
+                       double* partials, int num_blocks, void* stream);
+
+/* Chan merge of the batch moments into the fp64/int64 running state (running_mean_std.py:
+ * 55-67).  mode 0: population variance, count += rows (:74-75,:83); mode 1: masked moments
+ * of get_mean_var_with_masks, count += rows (:72,:83); mode 2: moments of the selected rows
+ * only, count += #selected (values[valid], a2c_common.py:1609-1611). */
+int rlg_rms_update(const double* partials, int num_blocks, int cols, long long total_rows,
+                   int mode, double* running_mean, double* running_var, long long* count,
+                   void* stream);
+
+/* y = clamp((x-mean)/sqrt(var+eps),-5,5) (mode 0, :112-113); denorm (mode 1, :106-107);
+ * norm_only (mode 2, :110).  mean/var are the fp64 buffers, cast to fp32 like `.float()`. */
+int rlg_rms_apply(const float* x, float* y, long long rows, int cols, const double* running_mean,
+                  const double* running_var, float eps, int mode, void* stream);
+
+int rlg_prepare_stats_bytes(void);
+
+/* value_size==1 prepare_dataset statistics from the GAE kernel's partial moments: updates the
+ * value RunningMeanStd with `values` then `returns` (a2c_common.py:1616-1619), computes the
+ * advantage mean / unbiased std + 1e-8 (:1634) or the EMA statistics (moving_mean_std.py).
+ * flags: 1 normalize_value, 2 normalize_advantage, 4 freeze_critic, 8 normalize_rms_advantage. */
+int rlg_prepare_finalize(const double* gae_partials, int num_tiles, long long batch, int flags,
+                         double* value_running_mean, double* value_running_var,
+                         long long* value_count, float eps, float* ema_mean, float* ema_sqrs,
+                         int* ema_step, float ema_decay, float ema_factor, float ema_max,
+                         float ema_eps, void* stats_out, void* stream);
+
+/* In place: values/returns normalised with their respective statistics, advantages
+ * normalised (a2c_common.py:1618-1619,:1634). */
+int rlg_prepare_apply(float* values, float* returns, float* advantages, long long batch, int flags,
+                      const void* stats, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused clipped-PPO loss forward + backward + KL
+ *   replaces rl_games/algos_torch/models.py: ModelA2CContinuousLogStd epilogue :333-347,
+ *   neglogp :361-364; rl_games/algos_torch/a2c_continuous.py: calc_losses :97-134,
+ *   bound_loss/reg_loss :241-257, the KL block of calc_gradients :215-221;
+ *   rl_games/common/common_losses.py: actor_loss :64-82, smoothed_actor_loss :39-61,
+ *   default_critic_loss :16-29; rl_games/algos_torch/torch_ext.py: apply_masks :157-170,
+ *   policy_kl :27-36; rl_games/common/datasets.py: PPODataset.update_mu_sigma :33-43.
+ * ---------------------------------------------------------------------------------- */
+
+int rlg_ppo_loss_num_blocks(int minibatch);
+int rlg_ppo_loss_partials_per_block(int actions);
+
+/* mu [mb,A], logstd [A] (fixed sigma, 'exp'), values [mb]; dataset slices actions [mb,A],
+ * old_neglogp/advantages/old_values/returns [mb], old_mu/old_sigma [mb,A] (overwritten with
+ * the new mu/sigma when write_back).  Emits d_mu [mb,A], d_values [mb] (already scaled by
+ * 1/mb or mask/sum(mask)) and fp64 partials [blocks][6+A].  bound_kind 0 none / 1 'bound' /
+ * 2 'regularisation'. */
+int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values,
+                       const float* actions, const float* old_neglogp, const float* advantages,
+                       const float* old_values, const float* returns, float* old_mu,
+                       float* old_sigma, const float* mask_or_null, const float* mask_sum_or_null,
+                       float* d_mu, float* d_values, double* partials, int minibatch, int actions_num,
+                       float e_clip, float critic_coef, float bounds_coef, int clip_value,
+                       int use_smooth_clamp, int bound_kind, int write_back, void* stream);
+
+/* scalars8 = {a_loss, c_loss, entropy, b_loss, kl, loss, sum(mask), 0}; d_logstd [A];
+ * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena). */
+int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_num, int minibatch,
+                          int masked, float critic_coef, float entropy_coef, float bounds_coef,
+                          float* scalars8, float* d_logstd, float* kl_slot_or_null, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gradient truncation + Adam + adaptive learning rate on a flat arena
+ *   replaces rl_games/common/a2c_common.py: trancate_gradients_and_step :493-514, update_lr
+ *   :564-576, the per-minibatch schedule :1557-1563; rl_games/common/schedulers.py:
+ *   AdaptiveScheduler.update :27-33; optimiser built at a2c_continuous.py:44-48.
+ * ---------------------------------------------------------------------------------- */
+
+int rlg_grad_norm_num_blocks(long long n);
+int rlg_grad_sumsq(const float* grads, long long n, float grad_scale, double* partials,
+                   int num_blocks, void* stream);
+
+/* One optimiser step over n contiguous parameters.  grads are first scaled by grad_scale
+ * (1/world_size) and by the clip coefficient min(1, max_norm/(norm+1e-6)) when
+ * norm_partials is given.  lr_slots[cur_slot] is the lr of this step; lr_slots[cur_slot^1]
+ * receives the next lr (schedule_kind 1: KL-adaptive on *kl * kl_scale).  stats_out[4] =
+ * {total_norm, clip_coef, lr_used, lr_next}. */
+int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  const double* norm_partials_or_null, int norm_blocks, float grad_scale,
+                  float max_norm, double* lr_slots, int cur_slot, long long step, double beta1,
+                  double beta2, double eps, double weight_decay, int schedule_kind,
+                  const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
+                  double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

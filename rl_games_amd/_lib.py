@@ -29,6 +29,37 @@ _PROTOTYPES = {
     'rlg_gae_envmajor_fused': [_P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float,
                                _c_float, _P],
     'rlg_gae_envmajor_raw': [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float, _c_float, _P],
+    # experience.hip
+    'rlg_rollout_store_step': [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_P),
+                               ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _P],
+    'rlg_rollout_post_step_num_blocks': [_c_int],
+    'rlg_rollout_post_step': [_P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_float, _c_float,
+                              _c_float, _c_float, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int,
+                              _c_int, _P],
+    'rlg_episode_meters_update': [_P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P],
+    'rlg_rnn_zero_done_states': [_P, _P, _c_int, _c_int, _c_int, _P],
+    # running_stats.hip
+    'rlg_column_moments_num_blocks': [_c_ll, _c_int],
+    'rlg_column_moments': [_P, _P, _c_ll, _c_int, _P, _c_int, _P],
+    'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P],
+    'rlg_rms_apply': [_P, _P, _c_ll, _c_int, _P, _P, _c_float, _c_int, _P],
+    'rlg_prepare_stats_bytes': [],
+    'rlg_prepare_finalize': [_P, _c_int, _c_ll, _c_int, _P, _P, _P, _c_float, _P, _P, _P,
+                             _c_float, _c_float, _c_float, _c_float, _P, _P],
+    'rlg_prepare_apply': [_P, _P, _P, _c_ll, _c_int, _P, _P],
+    # ppo_loss.hip
+    'rlg_ppo_loss_num_blocks': [_c_int],
+    'rlg_ppo_loss_partials_per_block': [_c_int],
+    'rlg_ppo_loss_fused': [_P] * 15 + [_c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int,
+                                       _c_int, _c_int, _P],
+    'rlg_ppo_loss_finalize': [_P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _P,
+                              _P, _P, _P],
+    # optim.hip
+    'rlg_grad_norm_num_blocks': [_c_ll],
+    'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P],
+    'rlg_adam_step': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _c_int, _c_ll,
+                      _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
+                      _c_double, _c_double, _c_double, _P, _P],
 }
 
 _lib = None

@@ -1,0 +1,329 @@
+// Rollout-buffer writes and per-step bookkeeping for gfx950 (MI355X).
+//
+// Replaces, per environment step n of A2CBase.play_steps (rl_games/common/a2c_common.py:
+// 985-1069):
+//   * ExperienceBuffer.update_data x7-8 (rl_games/common/experience.py:433-456; call sites
+//     a2c_common.py:1000-1011)                      -> rollout_store_kernel   (one launch)
+//   * reward shaping (rl_games/common/tr_helpers.py:33-42), time-out bootstrap
+//     (a2c_common.py:1021-1023), update_data('rewards') (:1025), episode accumulators and
+//     done handling (:1027-1051)                    -> rollout_post_step_kernel (one launch)
+//   * AverageMeter.update x3 per step (rl_games/algos_torch/torch_ext.py:333-342), replayed
+//     once per rollout from per-step partial sums   -> episode_meters_kernel
+//
+// Storage is ENV-MAJOR: a field with per-env row of `row` elements lives as [N][H][row], so
+// the flat index of (env, t) is env*H + t - exactly the order swap_and_flatten01
+// (a2c_common.py:33-40) produces.  The reference's [H, N, ...] tensors are exposed to Python
+// as strided views of this storage and the epoch-end transpose copy disappears.
+//
+// All kernels are pure data movement / element-wise fp32 (one rounding per op, same op order
+// as the reference), HBM-bound: the store kernel moves (O + 3A + 3)*4 + 1 bytes per env-step
+// in and the same out.
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+constexpr int kMaxSegments = 12;
+
+// One "field" of the step: src is [N][row_bytes] contiguous, dst is env-major storage.
+struct StoreSegments {
+  const void* src[kMaxSegments];
+  void* dst[kMaxSegments];
+  int row_bytes[kMaxSegments];   // bytes per env row
+  int unit[kMaxSegments];        // copy granularity: 16, 4 or 1 bytes
+  int block_begin[kMaxSegments + 1];
+  int count;
+};
+
+template <typename T>
+__device__ __forceinline__ void copy_units(const void* __restrict__ src, void* __restrict__ dst,
+                                           long long units_total, int units_per_row,
+                                           long long dst_row_stride_units, long long dst_off_units,
+                                           long long first, int stride) {
+  const T* s = static_cast<const T*>(src);
+  T* d = static_cast<T*>(dst);
+  for (long long i = first; i < units_total; i += stride) {
+    const long long env = i / units_per_row;
+    const long long c = i - env * units_per_row;
+    d[env * dst_row_stride_units + dst_off_units + c] = s[i];
+  }
+}
+
+constexpr int kStoreBlock = 256;
+constexpr int kStoreUnitsPerThread = 4;
+
+__global__ __launch_bounds__(kStoreBlock) void rollout_store_kernel(StoreSegments seg, int N, int H,
+                                                                    int step) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxSegments; ++k) {
+    if (k < seg.count && static_cast<int>(blockIdx.x) >= seg.block_begin[k]) s = k;
+  }
+  const int local_block = blockIdx.x - seg.block_begin[s];
+  const int nblocks = seg.block_begin[s + 1] - seg.block_begin[s];
+  const int unit = seg.unit[s];
+  const int upr = seg.row_bytes[s] / unit;                 // units per env row
+  const long long total = static_cast<long long>(N) * upr;
+  const long long first = static_cast<long long>(local_block) * kStoreBlock + threadIdx.x;
+  const int stride = nblocks * kStoreBlock;
+  const long long row_stride = static_cast<long long>(H) * upr;
+  const long long off = static_cast<long long>(step) * upr;
+  if (unit == 16) {
+    copy_units<u32x4>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+  } else if (unit == 4) {
+    copy_units<uint32_t>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+  } else {
+    copy_units<uint8_t>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Post-step: rewards, accumulators, finished-episode partial sums
+// ---------------------------------------------------------------------------------
+
+struct PostStepArgs {
+  const float* rewards;        // [N, V] raw env rewards of this step
+  const uint8_t* dones;        // [N] done flags produced by this step
+  const void* time_outs;       // [N] or nullptr   (infos['time_outs'])
+  int time_outs_kind;          // 0 none, 1 uint8/bool, 2 float32
+  const float* values;         // [N, V] critic values of this step (res_dict['values'])
+  const float* live_rows;      // [N] or nullptr: 1 - prev_dones (next_step autoreset mask)
+  float* rewards_buf;          // env-major [N][H][V]
+  float* cur_rewards;          // [N, V]
+  float* cur_shaped;           // [N, V]
+  float* cur_lengths;          // [N]
+  double* ep_partials;         // [H][nblocks][2V+2]: sum rew[V], sum shaped[V], sum len, count
+  float shift, scale, rmin, rmax;
+  int clamp_rewards;           // 0: min/max are -inf/+inf (skip clamp, bit-identical anyway)
+  int bootstrap;               // value_bootstrap and 'time_outs' in infos
+  float gamma;
+  int N, H, V, step;
+};
+
+constexpr int kPostBlock = 256;
+constexpr int kMaxV = 8;
+
+__global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepArgs a) {
+  __shared__ double scratch[(2 * kMaxV + 2) * (kPostBlock / kWave)];
+  const int env = blockIdx.x * kPostBlock + threadIdx.x;
+  const int V = a.V;
+  double acc[2 * kMaxV + 2];
+#pragma unroll
+  for (int k = 0; k < 2 * kMaxV + 2; ++k) acc[k] = 0.0;
+
+  if (env < a.N) {
+    const float done = static_cast<float>(a.dones[env]);
+    const bool is_done = a.dones[env] != 0;
+    float to = 0.0f;
+    if (a.bootstrap) {
+      to = (a.time_outs_kind == 2) ? static_cast<const float*>(a.time_outs)[env]
+                                   : static_cast<float>(static_cast<const uint8_t*>(a.time_outs)[env]);
+    }
+    const float live = a.live_rows ? a.live_rows[env] : 1.0f;
+    const float alive = 1.0f - done;
+#pragma unroll
+    for (int k = 0; k < kMaxV; ++k) {
+      if (k < V) {
+        const float rew = a.rewards[env * V + k];
+        // DefaultRewardsShaper.__call__: (r + shift) * scale, clamp           tr_helpers.py:35-39
+        float shaped = (rew + a.shift) * a.scale;
+        if (a.clamp_rewards) shaped = fminf(fmaxf(shaped, a.rmin), a.rmax);
+        // shaped += gamma * values * time_outs                               a2c_common.py:1022-1023
+        if (a.bootstrap) shaped = shaped + (a.gamma * a.values[env * V + k]) * to;
+        a.rewards_buf[(static_cast<long long>(env) * a.H + a.step) * V + k] = shaped;   // :1025
+        // episode accumulators                                               :1027-1037
+        float cr, cs;
+        if (a.live_rows) {
+          cr = a.cur_rewards[env * V + k] + rew * live;
+          cs = a.cur_shaped[env * V + k] + shaped * live;
+        } else {
+          cr = a.cur_rewards[env * V + k] + rew;
+          cs = a.cur_shaped[env * V + k] + shaped;
+        }
+        if (is_done) {
+          acc[k] = cr;
+          acc[kMaxV + k] = cs;
+        }
+        a.cur_rewards[env * V + k] = cr * alive;                                        // :1049
+        a.cur_shaped[env * V + k] = cs * alive;                                         // :1050
+      }
+    }
+    const float cl = a.cur_lengths[env] + (a.live_rows ? live : 1.0f);
+    if (is_done) {
+      acc[2 * kMaxV] = cl;
+      acc[2 * kMaxV + 1] = 1.0;
+    }
+    a.cur_lengths[env] = cl * alive;                                                    // :1051
+  }
+  block_sum<2 * kMaxV + 2, kPostBlock>(acc, scratch);
+  if (threadIdx.x == 0) {
+    double* out = a.ep_partials + (static_cast<long long>(a.step) * gridDim.x + blockIdx.x) * (2 * V + 2);
+#pragma unroll
+    for (int k = 0; k < kMaxV; ++k) {
+      if (k < V) {
+        out[k] = acc[k];
+        out[V + k] = acc[kMaxV + k];
+      }
+    }
+    out[2 * V] = acc[2 * kMaxV];
+    out[2 * V + 1] = acc[2 * kMaxV + 1];
+  }
+}
+
+// Replays AverageMeter.update for steps 0..H-1 (game_rewards, game_shaped_rewards,
+// game_lengths) from the per-step partial sums.  One thread: the state is a handful of floats.
+//   size = clip(count, 0, max); old = min(max - size, cur); mean = (mean*old + new*size)/(old+size)
+__global__ void episode_meters_kernel(const double* __restrict__ ep_partials, int H, int nblocks,
+                                      int V, int max_size, float* __restrict__ mean_rewards,
+                                      float* __restrict__ mean_shaped,
+                                      float* __restrict__ mean_lengths,
+                                      int* __restrict__ current_sizes /* [3] */,
+                                      long long* __restrict__ finished_total) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int W = 2 * V + 2;
+  for (int t = 0; t < H; ++t) {
+    double s[2 * kMaxV + 2];
+    for (int k = 0; k < W; ++k) s[k] = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+      const double* p = ep_partials + (static_cast<long long>(t) * nblocks + b) * W;
+      for (int k = 0; k < W; ++k) s[k] += p[k];
+    }
+    const long long count = static_cast<long long>(s[2 * V + 1]);
+    if (count == 0) continue;                                     // torch_ext.py:334-336
+    *finished_total += count;
+    const int size = static_cast<int>(count < max_size ? count : max_size);
+    for (int m = 0; m < 3; ++m) {
+      const int old_size = min(max_size - size, current_sizes[m]);
+      const int size_sum = old_size + size;
+      current_sizes[m] = size_sum;
+      if (m < 2) {
+        float* mean = (m == 0) ? mean_rewards : mean_shaped;
+        for (int k = 0; k < V; ++k) {
+          const float new_mean = static_cast<float>(s[m * V + k] / static_cast<double>(count));
+          mean[k] = (mean[k] * static_cast<float>(old_size) + new_mean * static_cast<float>(size)) /
+                    static_cast<float>(size_sum);
+        }
+      } else {
+        const float new_mean = static_cast<float>(s[2 * V] / static_cast<double>(count));
+        mean_lengths[0] = (mean_lengths[0] * static_cast<float>(old_size) +
+                           new_mean * static_cast<float>(size)) /
+                          static_cast<float>(size_sum);
+      }
+    }
+  }
+}
+
+// RNN rollout helpers (a2c_common.py:1081-1083 snapshot, :1150-1153 zero-on-done).
+// states: [L, N, U] contiguous.  snapshot dst: [num_seqs, L, N, U] slice `seq`.
+__global__ __launch_bounds__(256) void rnn_zero_done_kernel(float* __restrict__ states,
+                                                            const uint8_t* __restrict__ dones,
+                                                            int L, int N, int U) {
+  const long long total = static_cast<long long>(L) * N * U;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long e = (i / U) % N;
+    if (dones[e]) states[i] = 0.0f;
+  }
+}
+
+}  // namespace rlg
+
+extern "C" {
+
+int rlg_rollout_store_step(int count, const void* const* srcs, void* const* dsts,
+                           const int* row_bytes, int num_envs, int horizon, int step,
+                           void* stream) {
+  using namespace rlg;
+  if (count <= 0 || num_envs <= 0) return 0;
+  if (count > kMaxSegments || step < 0 || step >= horizon) return static_cast<int>(hipErrorInvalidValue);
+  StoreSegments seg;
+  seg.count = count;
+  int blocks = 0;
+  for (int k = 0; k < count; ++k) {
+    seg.src[k] = srcs[k];
+    seg.dst[k] = dsts[k];
+    seg.row_bytes[k] = row_bytes[k];
+    const uintptr_t a = reinterpret_cast<uintptr_t>(srcs[k]) | reinterpret_cast<uintptr_t>(dsts[k]) |
+                        static_cast<uintptr_t>(row_bytes[k]);
+    seg.unit[k] = (a % 16 == 0) ? 16 : ((a % 4 == 0) ? 4 : 1);
+    const long long units = static_cast<long long>(num_envs) * (row_bytes[k] / seg.unit[k]);
+    long long nb = (units + static_cast<long long>(kStoreBlock) * kStoreUnitsPerThread - 1) /
+                   (static_cast<long long>(kStoreBlock) * kStoreUnitsPerThread);
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    seg.block_begin[k] = blocks;
+    blocks += static_cast<int>(nb);
+  }
+  for (int k = count; k <= kMaxSegments; ++k) seg.block_begin[k] = blocks;
+  hipLaunchKernelGGL(rollout_store_kernel, dim3(blocks), dim3(kStoreBlock), 0,
+                     static_cast<hipStream_t>(stream), seg, num_envs, horizon, step);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_rollout_post_step_num_blocks(int num_envs) {
+  return (num_envs + rlg::kPostBlock - 1) / rlg::kPostBlock;
+}
+
+int rlg_rollout_post_step(const float* rewards, const uint8_t* dones, const void* time_outs,
+                          int time_outs_kind, const float* values, const float* live_rows,
+                          float* rewards_buf, float* cur_rewards, float* cur_shaped,
+                          float* cur_lengths, double* ep_partials, float shift, float scale,
+                          float rmin, float rmax, int clamp_rewards, int bootstrap, float gamma,
+                          int num_envs, int horizon, int value_size, int step, void* stream) {
+  using namespace rlg;
+  if (num_envs <= 0) return 0;
+  if (value_size < 1 || value_size > kMaxV || step < 0 || step >= horizon)
+    return static_cast<int>(hipErrorInvalidValue);
+  PostStepArgs a;
+  a.rewards = rewards;
+  a.dones = dones;
+  a.time_outs = time_outs;
+  a.time_outs_kind = time_outs ? time_outs_kind : 0;
+  a.values = values;
+  a.live_rows = live_rows;
+  a.rewards_buf = rewards_buf;
+  a.cur_rewards = cur_rewards;
+  a.cur_shaped = cur_shaped;
+  a.cur_lengths = cur_lengths;
+  a.ep_partials = ep_partials;
+  a.shift = shift;
+  a.scale = scale;
+  a.rmin = rmin;
+  a.rmax = rmax;
+  a.clamp_rewards = clamp_rewards;
+  a.bootstrap = (bootstrap && time_outs && a.time_outs_kind != 0) ? 1 : 0;
+  a.gamma = gamma;
+  a.N = num_envs;
+  a.H = horizon;
+  a.V = value_size;
+  a.step = step;
+  const int grid = rlg_rollout_post_step_num_blocks(num_envs);
+  hipLaunchKernelGGL(rollout_post_step_kernel, dim3(grid), dim3(kPostBlock), 0,
+                     static_cast<hipStream_t>(stream), a);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_episode_meters_update(const double* ep_partials, int horizon, int num_blocks,
+                              int value_size, int max_size, float* mean_rewards,
+                              float* mean_shaped, float* mean_lengths, int* current_sizes,
+                              long long* finished_total, void* stream) {
+  if (value_size < 1 || value_size > rlg::kMaxV) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::episode_meters_kernel, dim3(1), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), ep_partials, horizon, num_blocks, value_size,
+                     max_size, mean_rewards, mean_shaped, mean_lengths, current_sizes,
+                     finished_total);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_rnn_zero_done_states(float* states, const uint8_t* dones, int layers, int num_envs,
+                             int units, void* stream) {
+  const long long total = static_cast<long long>(layers) * num_envs * units;
+  if (total <= 0) return 0;
+  int grid = static_cast<int>((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rlg::rnn_zero_done_kernel, dim3(grid), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), states, dones, layers, num_envs, units);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

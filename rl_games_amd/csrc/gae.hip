@@ -211,10 +211,23 @@ __device__ __forceinline__ void row_to_lds(float* tile, const float (&x)[H]) {
   }
 }
 
+// Waves per workgroup.  Every wave owns a private LDS tile and only ever synchronises with
+// itself (wave barriers), so the block size is purely a dispatch-granularity choice; 4 waves
+// (one per SIMD) measured ~3 % faster than single-wave workgroups on MI355X.
+constexpr int kGaeWavesPerBlock = 4;
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // LDS accesses across the hand-off between lanes of the same wave.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // kRaw = false: write returns + (returns - values) + fp64 partial moments.
 // kRaw = true : write the raw GAE values A_t only (compute_gae seam on env-major views).
 template <int H, bool kRaw>
-__global__ __launch_bounds__(64) void gae_envmajor_kernel(
+__global__ __launch_bounds__(64 * kGaeWavesPerBlock) void gae_envmajor_kernel(
     const float* __restrict__ rewards,      // [N, H]
     const float* __restrict__ values,       // [N, H]
     const uint8_t* __restrict__ dones,      // [N, H]
@@ -222,14 +235,16 @@ __global__ __launch_bounds__(64) void gae_envmajor_kernel(
     const uint8_t* __restrict__ last_dones, // [N]
     float* __restrict__ out0,               // kRaw ? gae [N,H] : returns [N,H]
     float* __restrict__ out1,               // kRaw ? unused    : advantages [N,H]
-    double* __restrict__ partials,          // !kRaw: [gridDim.x, 6] or nullptr
+    double* __restrict__ partials,          // !kRaw: [num_tiles, 6] or nullptr
     int N, float gamma, float gamma_tau) {
   static_assert(H % 4 == 0 && H >= 4 && H <= 64, "unsupported horizon for the tile kernel");
-  __shared__ __attribute__((aligned(16))) float lds[2 * TileGeom<H>::kTileFloats];
-  float* tile_r = lds;
-  float* tile_v = lds + TileGeom<H>::kTileFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kGaeWavesPerBlock * 2 * TileGeom<H>::kTileFloats];
+  const int tile = blockIdx.x * kGaeWavesPerBlock + wave_id();
+  const int env0 = tile * kWave;
+  if (env0 >= N) return;  // whole wave exits together; no block-wide barrier is used below
+  float* tile_r = lds + wave_id() * 2 * TileGeom<H>::kTileFloats;
+  float* tile_v = tile_r + TileGeom<H>::kTileFloats;
 
-  const int env0 = blockIdx.x * kWave;
   const int rows = min(kWave, N - env0);
   const int lane = lane_id();
   const int env = env0 + lane;
@@ -264,13 +279,13 @@ __global__ __launch_bounds__(64) void gae_envmajor_kernel(
   // ---- transpose through LDS: coalesced chunks -> one env row per lane ----
   tile_regs_to_lds<H>(rbuf, tile_r);
   tile_regs_to_lds<H>(vbuf, tile_v);
-  __syncthreads();
+  wave_lds_fence();
   float r[H], v[H];
+  float a[kRaw ? 1 : H];
   row_from_lds<H>(tile_r, r);
   row_from_lds<H>(tile_v, v);
 
   // ---- the recurrence, entirely in registers ----
-  double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   float A = 0.0f;
 #pragma unroll
   for (int i = 0; i < H; ++i) {
@@ -282,16 +297,8 @@ __global__ __launch_bounds__(64) void gae_envmajor_kernel(
       r[t] = A;
     } else {
       const float ret = A + vt;
-      const float adv = ret - vt;
       r[t] = ret;
-      v[t] = adv;
-      const double da = adv, dv = vt, dr = ret;
-      m[0] += da;
-      m[1] = fma(da, da, m[1]);
-      m[2] += dv;
-      m[3] = fma(dv, dv, m[3]);
-      m[4] += dr;
-      m[5] = fma(dr, dr, m[5]);
+      a[t] = ret - vt;
     }
     nv = vt;
     const uint32_t dbyte = (dw[t >> 2] >> (8 * (t & 3))) & 0xffu;
@@ -299,20 +306,34 @@ __global__ __launch_bounds__(64) void gae_envmajor_kernel(
   }
 
   // ---- transpose back and store coalesced ----
-  __syncthreads();
+  wave_lds_fence();
   row_to_lds<H>(tile_r, r);
-  if constexpr (!kRaw) row_to_lds<H>(tile_v, v);
-  __syncthreads();
+  if constexpr (!kRaw) row_to_lds<H>(tile_v, a);
+  wave_lds_fence();
   tile_lds_to_global<H>(tile_r, out0 + base, rows);
   if constexpr (!kRaw) {
     tile_lds_to_global<H>(tile_v, out1 + base, rows);
     if (partials) {
+      // Moments are taken from registers after the stores have been issued, so the VALU
+      // work overlaps the store drain.  fp64 accumulation: exact enough that the downstream
+      // mean/var are limited by the fp32 inputs, not by the reduction.
+      double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < H; ++t) {
+        const double da = a[t], dv = v[t], dr = r[t];
+        m[0] += da;
+        m[1] = fma(da, da, m[1]);
+        m[2] += dv;
+        m[3] = fma(dv, dv, m[3]);
+        m[4] += dr;
+        m[5] = fma(dr, dr, m[5]);
+      }
       // lanes past the last env scanned a re-read of env0's row: drop their moments
 #pragma unroll
       for (int k = 0; k < 6; ++k) m[k] = wave_sum(live ? m[k] : 0.0);
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) partials[static_cast<long long>(blockIdx.x) * 6 + k] = m[k];
+        for (int k = 0; k < 6; ++k) partials[static_cast<long long>(tile) * 6 + k] = m[k];
       }
     }
   }
@@ -323,8 +344,10 @@ static int launch_envmajor(const float* rewards, const float* values, const uint
                            const float* last_values, const uint8_t* last_dones, float* out0,
                            float* out1, double* partials, int N, float gamma, float gamma_tau,
                            hipStream_t stream) {
-  const int grid = (N + kWave - 1) / kWave;
-  hipLaunchKernelGGL((gae_envmajor_kernel<H, kRaw>), dim3(grid), dim3(kWave), 0, stream, rewards,
+  const int tiles = (N + kWave - 1) / kWave;
+  const int grid = (tiles + kGaeWavesPerBlock - 1) / kGaeWavesPerBlock;
+  hipLaunchKernelGGL((gae_envmajor_kernel<H, kRaw>), dim3(grid), dim3(kWave * kGaeWavesPerBlock), 0,
+                     stream, rewards,
                      values, dones, last_values, last_dones, out0, out1, partials, N, gamma,
                      gamma_tau);
   RLG_RETURN_LAUNCH_STATUS();

@@ -1,0 +1,187 @@
+// Gradient truncation + Adam + KL-adaptive learning rate on a flat parameter arena, gfx950.
+//
+// Replaces A2CBase.trancate_gradients_and_step (rl_games/common/a2c_common.py:493-514):
+//   * multi-GPU averaging of the all-reduced gradients ( / world_size, :505-507);
+//   * torch.nn.utils.clip_grad_norm_(params, grad_norm) (:510-511);
+//   * optim.Adam(..., eps=1e-8).step() (a2c_continuous.py:44-48, a2c_common.py:513);
+// and the per-minibatch learning-rate control: AdaptiveScheduler.update
+// (rl_games/common/schedulers.py:27-33) + update_lr (a2c_common.py:564-576, :1557-1563)
+// without the `.item()` host sync: the learning rate lives in device memory (two fp64 slots,
+// ping-pong by step parity) and is read lazily by the host.
+//
+// All parameters (and their gradients / Adam moments) are views of contiguous fp32 arenas, so
+// one launch covers the whole model (~0.2 M parameters) instead of ~10 foreach kernels.
+// Every block recomputes the (tiny) global-norm reduction from the per-block partial sums, so
+// no grid barrier or atomic is needed and results are bit-reproducible.
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+constexpr int kOptBlock = 256;
+constexpr int kOptVec = 4;
+
+// partial sum of squares of (grad * grad_scale), fp64, one value per block
+__global__ __launch_bounds__(kOptBlock) void grad_sumsq_kernel(const float* __restrict__ grads,
+                                                               long long n, float grad_scale,
+                                                               double* __restrict__ partials) {
+  __shared__ double scratch[kOptBlock / kWave];
+  double s[1] = {0.0};
+  for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * kOptBlock) {
+    const float g = grads[i] * grad_scale;
+    s[0] = fma(static_cast<double>(g), static_cast<double>(g), s[0]);
+  }
+  block_sum<1, kOptBlock>(s, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s[0];
+}
+
+struct AdamArgs {
+  float* params;
+  float* grads;            // overwritten with the scaled/clipped gradient (like clip_grad_norm_)
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long n;
+  const double* norm_partials;  // [norm_blocks] from grad_sumsq_kernel, or nullptr (no truncation)
+  int norm_blocks;
+  float grad_scale;        // 1/world_size (multi-GPU average), 1 otherwise
+  float max_norm;          // grad_norm
+  double* lr_slots;        // [2] fp64; slot `cur` is read, slot cur^1 receives the next lr
+  int cur;
+  long long step;          // Adam step count AFTER this update (1-based)
+  double beta1, beta2, eps, weight_decay;
+  // adaptive schedule (schedule_kind 1) driven by the KL of THIS minibatch
+  int schedule_kind;       // 0 keep lr, 1 adaptive on *kl
+  const float* kl;         // device scalar (already averaged over ranks)
+  float kl_scale;          // 1/world_size when kl holds a cross-rank SUM
+  double kl_threshold, min_lr, max_lr, lr_multiplier;
+  float* stats_out;        // [4]: total_norm, clip_coef, lr used, lr next
+};
+
+__global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
+  __shared__ float sh_clip;
+  __shared__ float sh_norm;
+  if (threadIdx.x == 0) {
+    float coef = 1.0f, total_norm = 0.0f;
+    if (a.norm_partials) {
+      double s = 0.0;
+      for (int b = 0; b < a.norm_blocks; ++b) s += a.norm_partials[b];
+      total_norm = static_cast<float>(sqrt(s));
+      // clip_coef = max_norm / (total_norm + 1e-6); clamp(max=1.0)       torch clip_grad_norm_
+      coef = fminf(a.max_norm / (total_norm + 1e-6f), 1.0f);
+    }
+    sh_clip = coef;
+    sh_norm = total_norm;
+  }
+  __syncthreads();
+  const float clip = sh_clip;
+  const double lr = a.lr_slots[a.cur];
+
+  // torch.optim.Adam (single-tensor path) scalar prologue, evaluated in double like Python
+  const double bc1 = 1.0 - pow(a.beta1, static_cast<double>(a.step));
+  const double bc2 = 1.0 - pow(a.beta2, static_cast<double>(a.step));
+  const float step_size = static_cast<float>(lr / bc1);
+  const float bc2_sqrt = static_cast<float>(sqrt(bc2));
+  const float w1 = static_cast<float>(1.0 - a.beta1);
+  const float b2 = static_cast<float>(a.beta2);
+  const float w2 = static_cast<float>(1.0 - a.beta2);
+  const float eps = static_cast<float>(a.eps);
+  const float wd = static_cast<float>(a.weight_decay);
+
+  for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < a.n;
+       i += static_cast<long long>(gridDim.x) * kOptBlock) {
+    float g = (a.grads[i] * a.grad_scale) * clip;
+    a.grads[i] = g;
+    float p = a.params[i];
+    if (wd != 0.0f) g = g + wd * p;                              // grad.add(param, alpha=wd)
+    float m = a.exp_avg[i];
+    m = m + w1 * (g - m);                                        // exp_avg.lerp_(grad, 1-beta1)
+    float v = a.exp_avg_sq[i];
+    v = v * b2 + (w2 * g) * g;                                   // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);                             // addcdiv_(exp_avg, denom, -step_size)
+    a.exp_avg[i] = m;
+    a.exp_avg_sq[i] = v;
+    a.params[i] = p;
+  }
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double next = lr;
+    if (a.schedule_kind == 1) {
+      // AdaptiveScheduler.update, python-float arithmetic                 schedulers.py:27-33
+      const double kl = static_cast<double>(*a.kl * a.kl_scale);
+      if (kl > 2.0 * a.kl_threshold) next = fmax(lr / a.lr_multiplier, a.min_lr);
+      if (kl < 0.5 * a.kl_threshold) next = fmin(lr * a.lr_multiplier, a.max_lr);
+    }
+    a.lr_slots[a.cur ^ 1] = next;
+    if (a.stats_out) {
+      a.stats_out[0] = sh_norm;
+      a.stats_out[1] = clip;
+      a.stats_out[2] = static_cast<float>(lr);
+      a.stats_out[3] = static_cast<float>(next);
+    }
+  }
+}
+
+}  // namespace rlg
+
+extern "C" {
+
+int rlg_grad_norm_num_blocks(long long n) {
+  long long b = (n + rlg::kOptBlock * 8 - 1) / (rlg::kOptBlock * 8);
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return static_cast<int>(b);
+}
+
+int rlg_grad_sumsq(const float* grads, long long n, float grad_scale, double* partials,
+                   int num_blocks, void* stream) {
+  if (n <= 0) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::grad_sumsq_kernel, dim3(num_blocks), dim3(rlg::kOptBlock), 0,
+                     static_cast<hipStream_t>(stream), grads, n, grad_scale, partials);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  const double* norm_partials_or_null, int norm_blocks, float grad_scale,
+                  float max_norm, double* lr_slots, int cur_slot, long long step, double beta1,
+                  double beta2, double eps, double weight_decay, int schedule_kind,
+                  const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
+                  double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream) {
+  using namespace rlg;
+  if (n <= 0 || step < 1 || (cur_slot != 0 && cur_slot != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if (schedule_kind == 1 && !kl_or_null) return static_cast<int>(hipErrorInvalidValue);
+  AdamArgs a;
+  a.params = params;
+  a.grads = grads;
+  a.exp_avg = exp_avg;
+  a.exp_avg_sq = exp_avg_sq;
+  a.n = n;
+  a.norm_partials = norm_partials_or_null;
+  a.norm_blocks = norm_blocks;
+  a.grad_scale = grad_scale;
+  a.max_norm = max_norm;
+  a.lr_slots = lr_slots;
+  a.cur = cur_slot;
+  a.step = step;
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.weight_decay = weight_decay;
+  a.schedule_kind = schedule_kind;
+  a.kl = kl_or_null;
+  a.kl_scale = kl_scale;
+  a.kl_threshold = kl_threshold;
+  a.min_lr = min_lr;
+  a.max_lr = max_lr;
+  a.lr_multiplier = lr_multiplier;
+  a.stats_out = stats_out_or_null;
+  long long grid = (n + kOptBlock * kOptVec - 1) / (kOptBlock * kOptVec);
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(adam_step_kernel, dim3(static_cast<int>(grid)), dim3(kOptBlock), 0,
+                     static_cast<hipStream_t>(stream), a);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

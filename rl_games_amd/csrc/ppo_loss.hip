@@ -1,0 +1,395 @@
+// Fused clipped-PPO loss: distribution epilogue + losses + KL + analytic backward, gfx950.
+//
+// Replaces, per minibatch (continuous actions, fixed-sigma 'exp' parametrisation, value_size 1):
+//   * the Normal-distribution epilogue of ModelA2CContinuousLogStd.forward
+//     (rl_games/algos_torch/models.py:329-347: sigma = exp(logstd) :296, entropy :337,
+//     neglogp :361-364);
+//   * A2CAgent.calc_losses (rl_games/algos_torch/a2c_continuous.py:97-134) with
+//     common_losses.actor_loss / smoothed_actor_loss / default_critic_loss
+//     (rl_games/common/common_losses.py:64-82, :39-61, :16-29), bound_loss / reg_loss
+//     (a2c_continuous.py:241-257) and torch_ext.apply_masks (torch_ext.py:157-170);
+//   * loss.backward() down to the network outputs (a2c_continuous.py:211): d loss/d mu,
+//     d loss/d logstd, d loss/d value, reproducing torch.max's tie rule (equal branches split
+//     the gradient 1/2 + 1/2) and clamp's inclusive pass-through range;
+//   * torch_ext.policy_kl (torch_ext.py:27-36; masked mean a2c_continuous.py:215-221);
+//   * PPODataset.update_mu_sigma (rl_games/common/datasets.py:33-43): the new mu/sigma are
+//     written over the old ones in the same pass (the old values are read first for the KL).
+//
+// One block = 256 rows.  Phase 1 walks the block's [256, A] tile element-wise with coalesced
+// loads (mu, actions, old mu, old sigma), writes the per-element terms to LDS; phase 2 has one
+// thread per row reduce over A (odd LDS row stride -> conflict free), evaluate the scalar
+// losses and the row's gradient coefficient; phase 3 walks the tile again (mu/actions come
+// back from L2) to emit d mu coalesced and the per-column logstd gradient terms; phase 4
+// reduces those over rows.  Per-block fp64 partial sums go to global memory (no atomics);
+// ppo_loss_finalize_kernel folds them into the scalars and d logstd.
+//
+// Algorithmic HBM traffic per row: reads 4*A*4 + 5*4 (+4 mask), writes 3*A*4 + 4 bytes
+// (d mu, new mu, new sigma, d value) = 28*A + 24 bytes.
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+constexpr int kLossRows = 256;   // rows per block == threads per block
+constexpr int kLossScalars = 6;  // a_loss, c_loss, entropy, b_loss, kl, mask sum
+
+struct LossArgs {
+  // network outputs
+  const float* mu;         // [mb, A]
+  const float* logstd;     // [A]
+  const float* values;     // [mb]
+  // minibatch slices of the dataset
+  const float* actions;    // [mb, A]
+  const float* old_neglogp;  // [mb]
+  const float* advantages;   // [mb]
+  const float* old_values;   // [mb]
+  const float* returns;      // [mb]
+  float* old_mu;           // [mb, A]  read, then overwritten with mu     (update_mu_sigma)
+  float* old_sigma;        // [mb, A]  read, then overwritten with sigma
+  const float* mask;       // [mb] or nullptr (rnn_masks)
+  const float* mask_sum;   // device scalar sum(mask) for this minibatch, or nullptr
+  // outputs
+  float* d_mu;             // [mb, A]
+  float* d_values;         // [mb]
+  double* partials;        // [gridDim.x][kLossScalars + A]
+  int mb, A;
+  float e_clip, critic_coef, bounds_coef;
+  int clip_value;          // default_critic_loss clip flag
+  int smooth;              // use_smooth_clamp
+  int bound_kind;          // 0 none (coef None), 1 'bound', 2 'regularisation'
+  int write_back;          // overwrite old_mu/old_sigma with the new policy's
+};
+
+__device__ __forceinline__ float smooth_clamp_f(float x, float mi, float mx) {
+  // 1/(1 + exp((-(x-mi)/(mx-mi)+0.5)*4)) * (mx-mi) + mi          common_losses.py:32-36
+  const float t = ((-(x - mi) / (mx - mi)) + 0.5f) * 4.0f;
+  return (1.0f / (1.0f + expf(t))) * (mx - mi) + mi;
+}
+
+__device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) {
+  // d/dx of the above: s = 1/(1+e^t), ds/dt = -s(1-s), dt/dx = -4/(mx-mi)  ->  4 s (1-s)
+  const float t = ((-(x - mi) / (mx - mi)) + 0.5f) * 4.0f;
+  const float s = 1.0f / (1.0f + expf(t));
+  return 4.0f * s * (1.0f - s);
+}
+
+__global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int A = p.A;
+  const int AP = A | 1;                       // odd row stride: conflict-free row walks
+  float* t_z2 = lds;                          // [256][AP]  z^2, later g*(1-z^2)
+  float* t_kl = t_z2 + kLossRows * AP;        // [256][AP]
+  float* t_b = t_kl + kLossRows * AP;         // [256][AP]
+  float* row_g = t_b + kLossRows * AP;        // [256]  d loss / d neglogp of the row
+  float* row_w = row_g + kLossRows;           // [256]  inv_count * mask of the row
+  float* col_sigma = row_w + kLossRows;       // [A]
+  float* col_logstd = col_sigma + A;          // [A]
+  double* red = reinterpret_cast<double*>(col_logstd + A);  // float offset is even -> 8 B aligned
+
+  const int tid = threadIdx.x;
+  const long long row0 = static_cast<long long>(blockIdx.x) * kLossRows;
+  const int rows = static_cast<int>(min(static_cast<long long>(kLossRows), p.mb - row0));
+  const long long e0 = row0 * A;              // first element of the tile
+  const int tile_elems = rows * A;
+
+  for (int a = tid; a < A; a += kLossRows) {
+    const float ls = p.logstd[a];
+    col_logstd[a] = ls;
+    col_sigma[a] = expf(ls);                                                  // models.py:296
+  }
+  __syncthreads();
+
+  const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
+  float denom_count = static_cast<float>(p.mb);
+  if (p.mask) denom_count = fmaxf(*p.mask_sum, 1.0f);                         // torch_ext.py:165
+
+  // ------------------------------ phase 1: element-wise ------------------------------
+  {
+    int r = tid / A, a = tid - r * A;
+    const int dr = kLossRows / A, da = kLossRows - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossRows) {
+      const float mu = p.mu[e0 + e];
+      const float x = p.actions[e0 + e];
+      const float omu = p.old_mu[e0 + e];
+      const float osg = p.old_sigma[e0 + e];
+      const float sg = col_sigma[a];
+      const float z = (x - mu) / sg;                                          // models.py:362
+      t_z2[r * AP + a] = z * z;
+      // policy_kl(p0 = new, p1 = old)                                        torch_ext.py:28-31
+      const float c1 = logf(osg / sg + 1e-5f);
+      const float dm = omu - mu;
+      const float c2 = (sg * sg + dm * dm) / (2.0f * (osg * osg + 1e-5f));
+      t_kl[r * AP + a] = (c1 + c2) + (-0.5f);
+      float b = 0.0f;
+      if (p.bound_kind == 1) {                                                // a2c_continuous.py:248-253
+        const float hi_t = fmaxf(mu - 1.1f, 0.0f);
+        const float lo_t = fminf(mu + 1.1f, 0.0f);
+        b = lo_t * lo_t + hi_t * hi_t;
+      } else if (p.bound_kind == 2) {                                         // :241-246
+        b = mu * mu;
+      }
+      t_b[r * AP + a] = b;
+      if (p.write_back) {                                                     // datasets.py:42-43
+        p.old_mu[e0 + e] = mu;
+        p.old_sigma[e0 + e] = sg;
+      }
+      a += da;
+      r += dr;
+      if (a >= A) {
+        a -= A;
+        r += 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------ phase 2: one thread per row ------------------------
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (tid < rows) {
+    const long long i = row0 + tid;
+    float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      s_z2 += t_z2[tid * AP + a];
+      s_kl += t_kl[tid * AP + a];
+      s_b += t_b[tid * AP + a];
+      s_ls += col_logstd[a];
+      // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale)
+      s_ent += 1.4189385332046727f + logf(col_sigma[a]);
+    }
+    // neglogp                                                                models.py:361-364
+    const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
+    const float adv = p.advantages[i];
+    const float ratio = expf(p.old_neglogp[i] - nlp);                         // common_losses.py:75
+    const float surr1 = adv * ratio;
+    float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
+    if (p.smooth) {
+      l2 = adv * smooth_clamp_f(ratio, lo, hi);
+      dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
+    } else {
+      l2 = adv * fminf(fmaxf(ratio, lo), hi);
+      dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    }
+    const float n1 = -surr1, n2 = -l2;
+    const float a_loss = fmaxf(n1, n2);                                       // :78
+    // torch.max backward: the larger branch takes the gradient, equal branches split it
+    float w1, w2;
+    if (n1 > n2) {
+      w1 = 1.0f;
+      w2 = 0.0f;
+    } else if (n2 > n1) {
+      w1 = 0.0f;
+      w2 = 1.0f;
+    } else {
+      w1 = 0.5f;
+      w2 = 0.5f;
+    }
+    // d a_loss / d ratio = -adv*(w1 + w2*dl2) ; d ratio / d nlp = -ratio
+    const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
+
+    // critic                                                                 common_losses.py:20-27
+    const float v = p.values[i], vo = p.old_values[i], R = p.returns[i];
+    float c_loss, g_v;
+    if (p.clip_value) {
+      const float delta = v - vo;
+      const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+      const float d1 = v - R, d2 = vclip - R;
+      const float c1 = d1 * d1, c2 = d2 * d2;
+      c_loss = fmaxf(c1, c2);
+      const float in = (delta >= -p.e_clip && delta <= p.e_clip) ? 1.0f : 0.0f;
+      if (c1 > c2) {
+        g_v = 2.0f * d1;
+      } else if (c2 > c1) {
+        g_v = 2.0f * d2 * in;
+      } else {
+        g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
+      }
+    } else {
+      const float d = R - v;
+      c_loss = d * d;
+      g_v = -2.0f * d;
+    }
+
+    const float m = p.mask ? p.mask[i] : 1.0f;
+    const float w = m / denom_count;          // d(mean)/d(element)
+    row_g[tid] = g_nlp * w;
+    row_w[tid] = w;
+    p.d_values[i] = (0.5f * p.critic_coef) * g_v * w;                         // a2c_continuous.py:133
+    acc[0] = static_cast<double>(a_loss) * m;
+    acc[1] = static_cast<double>(c_loss) * m;
+    acc[2] = static_cast<double>(s_ent) * m;
+    acc[3] = static_cast<double>(s_b) * m;
+    acc[4] = static_cast<double>(s_kl) * m;
+    acc[5] = m;
+  }
+  block_sum<kLossScalars, kLossRows>(acc, red);
+  double* out = p.partials + static_cast<long long>(blockIdx.x) * (kLossScalars + A);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < kLossScalars; ++k) out[k] = acc[k];
+  }
+  __syncthreads();   // row_g / row_w visible; also fences the reuse of `red`
+
+  // ------------------------------ phase 3: d mu, logstd terms -------------------------
+  {
+    int r = tid / A, a = tid - r * A;
+    const int dr = kLossRows / A, da = kLossRows - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossRows) {
+      const float mu = p.mu[e0 + e];
+      const float x = p.actions[e0 + e];
+      const float sg = col_sigma[a];
+      const float z = (x - mu) / sg;
+      float db = 0.0f;
+      if (p.bound_kind == 1) {
+        db = 2.0f * fminf(mu + 1.1f, 0.0f) + 2.0f * fmaxf(mu - 1.1f, 0.0f);
+      } else if (p.bound_kind == 2) {
+        db = 2.0f * mu;
+      }
+      // d nlp / d mu = -z / sigma
+      p.d_mu[e0 + e] = row_g[r] * (-(z / sg)) + (row_w[r] * p.bounds_coef) * db;
+      // d nlp / d logstd = 1 - z^2
+      t_z2[r * AP + a] = row_g[r] * (1.0f - z * z);
+      a += da;
+      r += dr;
+      if (a >= A) {
+        a -= A;
+        r += 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------ phase 4: column sums over the block's rows ----------
+  // 8 row groups x A columns, then A threads fold the 8 partials (fixed order).
+  {
+    const int groups = 8;
+    const int per = (rows + groups - 1) / groups;
+    for (int j = tid; j < groups * A; j += kLossRows) {
+      const int g = j / A, a = j - g * A;
+      double s = 0.0;
+      const int r_end = min(rows, (g + 1) * per);
+      for (int r = g * per; r < r_end; ++r) s += static_cast<double>(t_z2[r * AP + a]);
+      red[j] = s;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += kLossRows) {
+      double s = 0.0;
+      for (int g = 0; g < groups; ++g) s += red[g * A + a];
+      out[kLossScalars + a] = s;
+    }
+  }
+}
+
+// Scalars written by the finalise kernel (fp32, read lazily by the host):
+//   [0] a_loss [1] c_loss [2] entropy [3] b_loss [4] kl [5] total loss [6] sum(mask) [7] unused
+constexpr int kLossOutScalars = 8;
+
+__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
+    const double* __restrict__ partials, int nblocks, int A, int mb, int masked,
+    float critic_coef, float entropy_coef, float bounds_coef, float* __restrict__ scalars,
+    float* __restrict__ d_logstd, float* __restrict__ kl_slot) {
+  __shared__ double sh[kLossScalars];
+  const int W = kLossScalars + A;
+  if (threadIdx.x < kLossScalars) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[static_cast<long long>(b) * W + threadIdx.x];
+    sh[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const double msum = sh[5];
+  const double denom = masked ? fmax(msum, 1.0) : static_cast<double>(mb);
+  // sum_i w_i = msum/denom : 1 unless every row is masked out
+  const float w_total = static_cast<float>(msum / denom);
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[static_cast<long long>(b) * W + kLossScalars + a];
+    // d loss / d logstd_a = sum_i g_i (1 - z^2)  -  entropy_coef * sum_i w_i * d ent/d logstd (=1)
+    d_logstd[a] = static_cast<float>(s) - entropy_coef * w_total;
+  }
+  if (threadIdx.x == 0) {
+    const float a_loss = static_cast<float>(sh[0] / denom);
+    const float c_loss = static_cast<float>(sh[1] / denom);
+    const float ent = static_cast<float>(sh[2] / denom);
+    const float b_loss = static_cast<float>(sh[3] / denom);
+    const float kl = static_cast<float>(sh[4] / denom);
+    // loss = a + 0.5*c*critic_coef - entropy*entropy_coef + b*bounds_coef   a2c_continuous.py:133
+    const float loss = ((a_loss + (0.5f * c_loss) * critic_coef) - ent * entropy_coef) + b_loss * bounds_coef;
+    scalars[0] = a_loss;
+    scalars[1] = c_loss;
+    scalars[2] = ent;
+    scalars[3] = b_loss;
+    scalars[4] = kl;
+    scalars[5] = loss;
+    scalars[6] = static_cast<float>(msum);
+    scalars[7] = 0.0f;
+    if (kl_slot) *kl_slot = kl;
+  }
+}
+
+}  // namespace rlg
+
+extern "C" {
+
+int rlg_ppo_loss_num_blocks(int minibatch) { return (minibatch + rlg::kLossRows - 1) / rlg::kLossRows; }
+
+int rlg_ppo_loss_partials_per_block(int actions) { return rlg::kLossScalars + actions; }
+
+int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values,
+                       const float* actions, const float* old_neglogp, const float* advantages,
+                       const float* old_values, const float* returns, float* old_mu,
+                       float* old_sigma, const float* mask_or_null, const float* mask_sum_or_null,
+                       float* d_mu, float* d_values, double* partials, int minibatch, int actions_num,
+                       float e_clip, float critic_coef, float bounds_coef, int clip_value,
+                       int use_smooth_clamp, int bound_kind, int write_back, void* stream) {
+  using namespace rlg;
+  if (minibatch <= 0 || actions_num <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
+  LossArgs p;
+  p.mu = mu;
+  p.logstd = logstd;
+  p.values = values;
+  p.actions = actions;
+  p.old_neglogp = old_neglogp;
+  p.advantages = advantages;
+  p.old_values = old_values;
+  p.returns = returns;
+  p.old_mu = old_mu;
+  p.old_sigma = old_sigma;
+  p.mask = mask_or_null;
+  p.mask_sum = mask_sum_or_null;
+  p.d_mu = d_mu;
+  p.d_values = d_values;
+  p.partials = partials;
+  p.mb = minibatch;
+  p.A = actions_num;
+  p.e_clip = e_clip;
+  p.critic_coef = critic_coef;
+  p.bounds_coef = bounds_coef;
+  p.clip_value = clip_value;
+  p.smooth = use_smooth_clamp;
+  p.bound_kind = bound_kind;
+  p.write_back = write_back;
+  const int AP = actions_num | 1;
+  size_t shm = (static_cast<size_t>(3) * kLossRows * AP + 2 * kLossRows + 2 * actions_num + 2) * sizeof(float);
+  shm = (shm + 7) & ~static_cast<size_t>(7);
+  const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossRows / kWave)
+                                 ? static_cast<size_t>(8) * actions_num
+                                 : kLossScalars * (kLossRows / kWave);
+  shm += red_doubles * sizeof(double);
+  if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+  const int grid = rlg_ppo_loss_num_blocks(minibatch);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossRows), shm,
+                     static_cast<hipStream_t>(stream), p);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_num, int minibatch,
+                          int masked, float critic_coef, float entropy_coef, float bounds_coef,
+                          float* scalars8, float* d_logstd, float* kl_slot_or_null, void* stream) {
+  hipLaunchKernelGGL(rlg::ppo_loss_finalize_kernel, dim3(1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), partials, num_blocks, actions_num, minibatch,
+                     masked, critic_coef, entropy_coef, bounds_coef, scalars8, d_logstd,
+                     kl_slot_or_null);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

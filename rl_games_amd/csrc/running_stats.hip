@@ -1,0 +1,475 @@
+// Running statistics and normalisation for gfx950 (MI355X).
+//
+// Replaces
+//   * RunningMeanStd.forward / _update_mean_var_count_from_moments
+//     (rl_games/algos_torch/running_mean_std.py:69-114, :55-67) for observations (every
+//     minibatch forward, models.py:54-56) and values/returns (a2c_common.py:1600-1620);
+//   * the batch advantage normalisation (a2c_common.py:1622-1634, torch.std is UNBIASED),
+//     its masked variant (torch_ext.py:172-191) and the EMA variant
+//     GeneralizedMovingStats 'mean_std' (rl_games/algos_torch/moving_mean_std.py:52-61,
+//     :83-134, :136-150).
+//
+// Structure: (1) a bandwidth-bound moments pass producing per-block fp64 partial sums
+// (sum x, sum x^2 per column, no atomics -> bit-reproducible), (2) a tiny finalise kernel
+// that folds the partials into the fp64/int64 running state with the reference's Chan
+// merge, (3) a bandwidth-bound element-wise normalise pass.  State dtypes match the
+// reference's registered buffers (running_mean/var float64, count int64) so checkpoints
+// are interchangeable.
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+// ---------------------------------------------------------------------------------
+// (1) column moments of a row-major [rows, C] fp32 matrix
+// ---------------------------------------------------------------------------------
+// Lane mapping: a row is `upr` units of UNIT floats; a wave covers rpp = 64/upr consecutive
+// rows per pass (upr <= 64) so that its 64 lanes read one contiguous span.  Each lane keeps
+// fp64 accumulators for its UNIT columns; lanes that share a column are combined through LDS.
+
+constexpr int kMomBlock = 256;
+constexpr int kMomWaves = kMomBlock / kWave;
+
+template <int UNIT>
+struct UnitLoad;
+template <>
+struct UnitLoad<4> {
+  static __device__ __forceinline__ void load(const float* p, float (&x)[4]) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+    x[0] = q[0];
+    x[1] = q[1];
+    x[2] = q[2];
+    x[3] = q[3];
+  }
+};
+template <>
+struct UnitLoad<1> {
+  static __device__ __forceinline__ void load(const float* p, float (&x)[1]) { x[0] = *p; }
+};
+
+// partials layout: [gridDim.x][2*C + 1]  = {sum[C], sumsq[C], count}
+template <int UNIT>
+__global__ __launch_bounds__(kMomBlock) void column_moments_kernel(
+    const float* __restrict__ x, const float* __restrict__ row_mask, long long rows, int C,
+    double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [kMomWaves][64][2*UNIT] + C*2+1
+  const int upr = C / UNIT;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const long long gwave = static_cast<long long>(blockIdx.x) * kMomWaves + wave;
+  const long long nwaves = static_cast<long long>(gridDim.x) * kMomWaves;
+  double* out = partials + static_cast<long long>(blockIdx.x) * (2 * C + 1);
+  double* block_acc = smem + kMomWaves * kWave * 2 * UNIT;       // [2*C + 1]
+  for (int i = threadIdx.x; i < 2 * C + 1; i += kMomBlock) block_acc[i] = 0.0;
+  __syncthreads();
+
+  double cnt = 0.0;
+  for (int cb = 0; cb < upr; cb += kWave) {        // column blocks of 64 units
+    const int w_upr = min(kWave, upr - cb);        // units of this column block
+    const int rpp = kWave / w_upr;                 // rows per wave pass
+    const int sub = lane / w_upr;
+    const int cu = lane - sub * w_upr;
+    const bool active = sub < rpp;
+    double s[UNIT], ss[UNIT];
+#pragma unroll
+    for (int u = 0; u < UNIT; ++u) s[u] = ss[u] = 0.0;
+    const long long groups = (rows + rpp - 1) / rpp;
+    for (long long g = gwave; g < groups; g += nwaves) {
+      const long long row = g * rpp + sub;
+      if (active && row < rows) {
+        float v[UNIT];
+        UnitLoad<UNIT>::load(x + row * C + static_cast<long long>(cb + cu) * UNIT, v);
+        float m = 1.0f;
+        if (row_mask) m = row_mask[row];
+        if (cb == 0 && cu == 0) cnt += static_cast<double>(m);
+#pragma unroll
+        for (int u = 0; u < UNIT; ++u) {
+          const double d = static_cast<double>(v[u]) * static_cast<double>(m);
+          s[u] += d;
+          ss[u] = fma(d, static_cast<double>(v[u]), ss[u]);
+        }
+      }
+    }
+    // combine lanes/waves that own the same columns (fixed order -> deterministic)
+    double* mine = smem + (wave * kWave + lane) * 2 * UNIT;
+#pragma unroll
+    for (int u = 0; u < UNIT; ++u) {
+      mine[u] = s[u];
+      mine[UNIT + u] = ss[u];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < w_upr * UNIT; j += kMomBlock) {
+      const int u_idx = j / UNIT, u = j - u_idx * UNIT;
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < kMomWaves; ++w) {
+        for (int sb = 0; sb < rpp; ++sb) {
+          const double* p = smem + (w * kWave + sb * w_upr + u_idx) * 2 * UNIT;
+          a += p[u];
+          b += p[UNIT + u];
+        }
+      }
+      const int col = (cb + u_idx) * UNIT + u;
+      block_acc[col] = a;
+      block_acc[C + col] = b;
+    }
+    __syncthreads();
+  }
+  // row count: every lane that owns column-unit 0 of column-block 0 counted its rows
+  cnt = wave_sum(cnt);
+  if (lane == 0) smem[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c = 0.0;
+    for (int w = 0; w < kMomWaves; ++w) c += smem[w];
+    block_acc[2 * C] = c;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C + 1; i += kMomBlock) out[i] = block_acc[i];
+}
+
+// ---------------------------------------------------------------------------------
+// (2) finalise: fold partial sums into the running state (Chan merge, fp64)
+// ---------------------------------------------------------------------------------
+
+// running_mean_std.py:55-67, operands promoted exactly as torch does: batch_mean / batch_var
+// are fp32 tensors (input.mean / input.var of an fp32 input), the state is fp64.
+__device__ __forceinline__ void chan_merge(double& mean, double& var, double count_f,
+                                           double batch_mean, double batch_var, double batch_count) {
+  const double tot = count_f + batch_count;
+  const double delta = batch_mean - mean;
+  const double new_mean = mean + delta * batch_count / tot;
+  const double m_a = var * count_f;
+  const double m_b = batch_var * batch_count;
+  const double M2 = m_a + m_b + delta * delta * count_f * batch_count / tot;
+  mean = new_mean;
+  var = M2 / tot;
+}
+
+// mode 0: unmasked  - population variance, batch_count = rows            (:74-75, :83)
+// mode 1: masked    - mean/var of get_mean_var_with_masks (unbiased, denominators clamped,
+//                     torch_ext.py:182-191), batch_count = total rows     (:72, :83)
+// mode 2: selected  - statistics of the rows with mask==1 only, batch_count = #selected
+//                     (the value normaliser's `values[valid]` path, a2c_common.py:1609-1611)
+__global__ __launch_bounds__(256) void rms_update_kernel(const double* __restrict__ partials,
+                                                         int nblocks, int C, long long total_rows,
+                                                         int mode, double* __restrict__ running_mean,
+                                                         double* __restrict__ running_var,
+                                                         long long* __restrict__ count,
+                                                         int update_count) {
+  const int W = 2 * C + 1;
+  double n_sum = 0.0;
+  for (int b = 0; b < nblocks; ++b) n_sum += partials[static_cast<long long>(b) * W + 2 * C];
+  const long long old_count = *count;
+  double batch_count;
+  if (mode == 2) {
+    batch_count = n_sum;
+  } else {
+    batch_count = static_cast<double>(total_rows);
+  }
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += partials[static_cast<long long>(b) * W + c];
+      ss += partials[static_cast<long long>(b) * W + C + c];
+    }
+    double bm, bv;
+    if (mode == 1) {
+      const double sm = fmax(n_sum, 1.0);
+      bm = s / sm;
+      const double min_sqr = ss / sm - (s / sm) * (s / sm);
+      bv = min_sqr * sm / fmax(sm - 1.0, 1.0);
+    } else {
+      const double n = fmax(n_sum, 1.0);
+      bm = s / n;
+      bv = fmax(ss / n - bm * bm, 0.0);
+    }
+    // the reference's batch moments are fp32 tensors: round once before the fp64 merge
+    bm = static_cast<double>(static_cast<float>(bm));
+    bv = static_cast<double>(static_cast<float>(bv));
+    double mean = running_mean[c], var = running_var[c];
+    if (batch_count > 0.0) chan_merge(mean, var, static_cast<double>(old_count), bm, bv, batch_count);
+    running_mean[c] = mean;
+    running_var[c] = var;
+  }
+  __syncthreads();
+  if (update_count && blockIdx.x == 0 && threadIdx.x == 0) {
+    *count = old_count + static_cast<long long>(batch_count);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// (3) element-wise normalise / de-normalise with the running state
+// ---------------------------------------------------------------------------------
+// mode 0: y = clamp((x - mean32) / sqrt(var32 + eps), -5, 5)            (:112-113)
+// mode 1: y = sqrt(var32 + eps) * clamp(x, -5, 5) + mean32   (denorm)    (:106-107)
+// mode 2: y = x / sqrt(var32 + eps)                          (norm_only) (:110)
+template <int UNIT>
+__global__ __launch_bounds__(256) void rms_apply_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ y, long long rows, int C,
+                                                        const double* __restrict__ running_mean,
+                                                        const double* __restrict__ running_var,
+                                                        float eps, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];  // mean32[C], denom[C]
+  float* mean32 = smem_f;
+  float* denom = smem_f + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    mean32[c] = static_cast<float>(running_mean[c]);
+    denom[c] = sqrtf(static_cast<float>(running_var[c]) + eps);
+  }
+  __syncthreads();
+  const long long total_units = rows * C / UNIT;
+  const int upr = C / UNIT;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total_units;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int c0 = static_cast<int>(i % upr) * UNIT;
+    float v[UNIT], o[UNIT];
+    UnitLoad<UNIT>::load(x + i * UNIT, v);
+#pragma unroll
+    for (int u = 0; u < UNIT; ++u) {
+      const float m = mean32[c0 + u], d = denom[c0 + u];
+      if (mode == 0) {
+        o[u] = fminf(fmaxf((v[u] - m) / d, -5.0f), 5.0f);
+      } else if (mode == 1) {
+        o[u] = d * fminf(fmaxf(v[u], -5.0f), 5.0f) + m;
+      } else {
+        o[u] = v[u] / d;
+      }
+    }
+    if constexpr (UNIT == 4) {
+      f32x4 q = {o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(y + i * 4) = q;
+    } else {
+      y[i] = o[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// prepare_dataset epilogue (value_size == 1): driven by the GAE kernel's partial moments
+// ---------------------------------------------------------------------------------
+
+struct PrepareStats {
+  // written by prepare_finalize_kernel, read by prepare_apply_kernel
+  float v_mean, v_denom;       // value normaliser after the `values` update
+  float r_mean, r_denom;       // ... after the `returns` update
+  float a_mean, a_denom;       // advantage mean, std + 1e-8 (or EMA mean / std)
+  float pad0, pad1;
+};
+
+// flags
+constexpr int kPrepNormValue = 1;      // normalize_value
+constexpr int kPrepNormAdv = 2;        // normalize_advantage (batch statistics)
+constexpr int kPrepFreezeCritic = 4;   // freeze_critic: normalise with frozen stats
+constexpr int kPrepEmaAdv = 8;         // normalize_rms_advantage (GeneralizedMovingStats mean_std)
+
+__global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials, int ntiles,
+                                        long long B, int flags, double* __restrict__ running_mean,
+                                        double* __restrict__ running_var,
+                                        long long* __restrict__ count, float eps,
+                                        float* __restrict__ ema_mean, float* __restrict__ ema_sqrs,
+                                        int* __restrict__ ema_step, float ema_decay, float ema_factor,
+                                        float ema_max, float ema_eps,
+                                        PrepareStats* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < ntiles; ++t) {
+    for (int k = 0; k < 6; ++k) m[k] += gae_partials[static_cast<long long>(t) * 6 + k];
+  }
+  const double n = static_cast<double>(B);
+  PrepareStats st = {0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f};
+  if (flags & kPrepNormValue) {
+    double mean = running_mean[0], var = running_var[0];
+    long long cnt = *count;
+    if (!(flags & kPrepFreezeCritic)) {
+      // values first (a2c_common.py:1617-1618) ...
+      double bm = static_cast<double>(static_cast<float>(m[2] / n));
+      double bv = static_cast<double>(static_cast<float>(fmax(m[3] / n - (m[2] / n) * (m[2] / n), 0.0)));
+      chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n);
+      cnt += B;
+    }
+    st.v_mean = static_cast<float>(mean);
+    st.v_denom = sqrtf(static_cast<float>(var) + eps);
+    if (!(flags & kPrepFreezeCritic)) {
+      // ... then returns (:1619), a second, separate merge
+      double bm = static_cast<double>(static_cast<float>(m[4] / n));
+      double bv = static_cast<double>(static_cast<float>(fmax(m[5] / n - (m[4] / n) * (m[4] / n), 0.0)));
+      chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n);
+      cnt += B;
+      running_mean[0] = mean;
+      running_var[0] = var;
+      *count = cnt;
+    }
+    st.r_mean = static_cast<float>(mean);
+    st.r_denom = sqrtf(static_cast<float>(var) + eps);
+  }
+  if (flags & kPrepEmaAdv) {
+    // moving_mean_std.py:119-122 (_update_stats 'mean_std'), :57-61 (_get_stats)
+    const float x_mean = static_cast<float>(m[0] / n);
+    const float x_sqr = static_cast<float>(m[1] / n);
+    *ema_step += 1;
+    const float factor = ema_factor;  // fp32(1 - decay), rounded from the Python double
+    float mean = ema_mean[0] * ema_decay;
+    mean = mean + factor * x_mean;
+    float sqrs = ema_sqrs[0] * ema_decay;
+    sqrs = sqrs + factor * x_sqr;
+    ema_mean[0] = mean;
+    ema_sqrs[0] = sqrs;
+    const float var = sqrs - mean * mean;
+    st.a_mean = mean;
+    st.a_denom = sqrtf(fmaxf(var, 1.0f / (ema_max * ema_max)) + ema_eps);
+  } else if (flags & kPrepNormAdv) {
+    // advantages.mean(), advantages.std() (unbiased) + 1e-8                  a2c_common.py:1634
+    const double mean = m[0] / n;
+    const double var = (n > 1.0) ? fmax(m[1] - n * mean * mean, 0.0) / (n - 1.0) : 0.0;
+    st.a_mean = static_cast<float>(mean);
+    st.a_denom = static_cast<float>(sqrt(var)) + 1e-8f;
+  }
+  *out = st;
+}
+
+// values <- norm(values), returns <- norm(returns), advantages <- (adv - mean)/denom, in place.
+__global__ __launch_bounds__(256) void prepare_apply_kernel(float* __restrict__ values,
+                                                            float* __restrict__ returns,
+                                                            float* __restrict__ advantages,
+                                                            long long B4, long long B, int flags,
+                                                            const PrepareStats* __restrict__ stp) {
+  const PrepareStats st = *stp;
+  const bool nv = flags & kPrepNormValue;
+  const bool na = (flags & (kPrepNormAdv | kPrepEmaAdv)) != 0;
+  const bool ema = flags & kPrepEmaAdv;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < B4;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    if (nv) {
+      f32x4 v = reinterpret_cast<f32x4*>(values)[i];
+      f32x4 r = reinterpret_cast<f32x4*>(returns)[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = fminf(fmaxf((v[u] - st.v_mean) / st.v_denom, -5.0f), 5.0f);
+        r[u] = fminf(fmaxf((r[u] - st.r_mean) / st.r_denom, -5.0f), 5.0f);
+      }
+      reinterpret_cast<f32x4*>(values)[i] = v;
+      reinterpret_cast<f32x4*>(returns)[i] = r;
+    }
+    if (na) {
+      f32x4 a = reinterpret_cast<f32x4*>(advantages)[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = (a[u] - st.a_mean) / st.a_denom;
+        if (ema) a[u] = fminf(fmaxf(a[u], -5.0f), 5.0f);
+      }
+      reinterpret_cast<f32x4*>(advantages)[i] = a;
+    }
+  }
+  // tail (B not a multiple of 4)
+  const long long tail0 = B4 * 4;
+  const long long i = tail0 + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < B) {
+    if (nv) {
+      values[i] = fminf(fmaxf((values[i] - st.v_mean) / st.v_denom, -5.0f), 5.0f);
+      returns[i] = fminf(fmaxf((returns[i] - st.r_mean) / st.r_denom, -5.0f), 5.0f);
+    }
+    if (na) {
+      float a = (advantages[i] - st.a_mean) / st.a_denom;
+      if (ema) a = fminf(fmaxf(a, -5.0f), 5.0f);
+      advantages[i] = a;
+    }
+  }
+}
+
+}  // namespace rlg
+
+extern "C" {
+
+int rlg_column_moments_num_blocks(long long rows, int cols) {
+  // enough waves to fill the chip, never more than one 4-wave block per 256 rows
+  long long need = (rows * cols + 256LL * 64 - 1) / (256LL * 64);
+  if (need < 1) need = 1;
+  if (need > 1024) need = 1024;
+  return static_cast<int>(need);
+}
+
+int rlg_column_moments(const float* x, const float* row_mask_or_null, long long rows, int cols,
+                       double* partials, int num_blocks, void* stream) {
+  using namespace rlg;
+  if (rows <= 0 || cols <= 0) return static_cast<int>(hipErrorInvalidValue);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (cols % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int unit = vec ? 4 : 1;
+  const size_t shm = (static_cast<size_t>(kMomWaves) * kWave * 2 * unit + 2 * cols + 1) * sizeof(double);
+  if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+  if (vec) {
+    hipLaunchKernelGGL((column_moments_kernel<4>), dim3(num_blocks), dim3(kMomBlock), shm, st, x,
+                       row_mask_or_null, rows, cols, partials);
+  } else {
+    hipLaunchKernelGGL((column_moments_kernel<1>), dim3(num_blocks), dim3(kMomBlock), shm, st, x,
+                       row_mask_or_null, rows, cols, partials);
+  }
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_rms_update(const double* partials, int num_blocks, int cols, long long total_rows,
+                   int mode, double* running_mean, double* running_var, long long* count,
+                   void* stream) {
+  if (cols <= 0 || mode < 0 || mode > 2) return static_cast<int>(hipErrorInvalidValue);
+  // single block: the count update must follow every column's read of the old count
+  hipLaunchKernelGGL(rlg::rms_update_kernel, dim3(1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), partials, num_blocks, cols, total_rows, mode,
+                     running_mean, running_var, count, 1);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_rms_apply(const float* x, float* y, long long rows, int cols, const double* running_mean,
+                  const double* running_var, float eps, int mode, void* stream) {
+  using namespace rlg;
+  if (rows <= 0 || cols <= 0) return 0;
+  if (mode < 0 || mode > 2) return static_cast<int>(hipErrorInvalidValue);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (cols % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+  const long long units = rows * cols / (vec ? 4 : 1);
+  long long grid = (units + 256 * 4 - 1) / (256 * 4);
+  if (grid < 1) grid = 1;
+  if (grid > 4096) grid = 4096;
+  const size_t shm = 2 * static_cast<size_t>(cols) * sizeof(float);
+  if (vec) {
+    hipLaunchKernelGGL((rms_apply_kernel<4>), dim3(static_cast<int>(grid)), dim3(256), shm, st, x,
+                       y, rows, cols, running_mean, running_var, eps, mode);
+  } else {
+    hipLaunchKernelGGL((rms_apply_kernel<1>), dim3(static_cast<int>(grid)), dim3(256), shm, st, x,
+                       y, rows, cols, running_mean, running_var, eps, mode);
+  }
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_prepare_stats_bytes(void) { return static_cast<int>(sizeof(rlg::PrepareStats)); }
+
+int rlg_prepare_finalize(const double* gae_partials, int num_tiles, long long batch, int flags,
+                         double* value_running_mean, double* value_running_var,
+                         long long* value_count, float eps, float* ema_mean, float* ema_sqrs,
+                         int* ema_step, float ema_decay, float ema_factor, float ema_max,
+                         float ema_eps, void* stats_out, void* stream) {
+  hipLaunchKernelGGL(rlg::prepare_finalize_kernel, dim3(1), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), gae_partials, num_tiles, batch, flags,
+                     value_running_mean, value_running_var, value_count, eps, ema_mean, ema_sqrs,
+                     ema_step, ema_decay, ema_factor, ema_max, ema_eps,
+                     static_cast<rlg::PrepareStats*>(stats_out));
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_prepare_apply(float* values, float* returns, float* advantages, long long batch, int flags,
+                      const void* stats, void* stream) {
+  if (batch <= 0) return 0;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(returns) |
+                         reinterpret_cast<uintptr_t>(advantages)) % 16) == 0;
+  const long long b4 = aligned ? batch / 4 : 0;
+  long long work = b4 > (batch - b4 * 4) ? b4 : (batch - b4 * 4);
+  long long grid = (work + 255) / 256;
+  if (grid < 1) grid = 1;
+  if (grid > 2048 && b4 * 4 == batch) grid = 2048;   // grid-stride when there is no scalar tail
+  hipLaunchKernelGGL(rlg::prepare_apply_kernel, dim3(static_cast<int>(grid)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), values, returns, advantages, b4, batch, flags,
+                     static_cast<const rlg::PrepareStats*>(stats));
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""Thin, typed wrappers over the C ABI (include/rlg_hip.h): one Python function per entry
+point, taking torch CUDA tensors, launching on torch's current stream.  No arithmetic
+happens here - shapes/dtypes are checked and raw pointers are handed to librlg_hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+F64 = torch.float64
+U8 = torch.uint8
+
+
+def _need(t, dtype, name, contiguous=True):
+    if t is None:
+        raise ValueError(f'{name} is None')
+    _lib.require_gpu(t, name)
+    if t.dtype != dtype:
+        raise ValueError(f'{name}: expected {dtype}, got {t.dtype}')
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f'{name}: expected a contiguous tensor, got strides {t.stride()}')
+    return t.data_ptr()
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _need(t, dtype, name)
+
+
+def _stream(t):
+    return _lib.stream_handle(t.device)
+
+
+# ------------------------------------------------------------------ rollout buffer
+
+def rollout_store_step(pairs, num_envs, horizon, step):
+    """pairs: list of (src [N, ...] contiguous, dst env-major storage [N, H, ...] contiguous).
+    Equivalent to `dst_view[step, :] = src` for every pair (experience.py:433-456)."""
+    lib = _lib.load()
+    n = len(pairs)
+    srcs = (ctypes.c_void_p * n)()
+    dsts = (ctypes.c_void_p * n)()
+    rows = (ctypes.c_int * n)()
+    for k, (src, dst) in enumerate(pairs):
+        _lib.require_gpu(src, 'rollout_store_step src')
+        if not src.is_contiguous() or not dst.is_contiguous():
+            raise ValueError('rollout_store_step needs contiguous src and env-major dst')
+        if src.dtype != dst.dtype:
+            raise ValueError(f'dtype mismatch {src.dtype} vs {dst.dtype}')
+        row_bytes = (src.numel() // num_envs) * src.element_size()
+        if src.shape[0] != num_envs or dst.numel() * dst.element_size() != num_envs * horizon * row_bytes:
+            raise ValueError(f'shape mismatch: src {tuple(src.shape)} dst {tuple(dst.shape)}')
+        srcs[k] = src.data_ptr()
+        dsts[k] = dst.data_ptr()
+        rows[k] = row_bytes
+    _lib.check(lib.rlg_rollout_store_step(n, srcs, dsts, rows, num_envs, horizon, step,
+                                          _stream(pairs[0][0])), 'rlg_rollout_store_step')
+
+
+def post_step_num_blocks(num_envs):
+    return _lib.load().rlg_rollout_post_step_num_blocks(int(num_envs))
+
+
+def rollout_post_step(rewards, dones, time_outs, values, live_rows, rewards_buf, cur_rewards,
+                      cur_shaped, cur_lengths, ep_partials, shaper, bootstrap, gamma, horizon, step):
+    """shaper = (shift, scale, min_val, max_val)."""
+    lib = _lib.load()
+    N, V = rewards.shape
+    shift, scale, rmin, rmax = shaper
+    clamp = 0 if (rmin == -np.inf and rmax == np.inf) else 1
+    kind, to_ptr = 0, None
+    if time_outs is not None:
+        if time_outs.dtype == F32:
+            kind, to_ptr = 2, _need(time_outs, F32, 'time_outs')
+        elif time_outs.dtype in (U8, torch.bool):
+            kind, to_ptr = 1, (time_outs.view(U8) if time_outs.dtype == torch.bool else time_outs).data_ptr()
+            _lib.require_gpu(time_outs, 'time_outs')
+        else:
+            raise ValueError(f'time_outs dtype {time_outs.dtype} unsupported')
+    _lib.check(lib.rlg_rollout_post_step(
+        _need(rewards, F32, 'rewards'), _need(dones, U8, 'dones'), to_ptr, kind,
+        _need(values, F32, 'values'), _opt(live_rows, F32, 'live_rows'),
+        _need(rewards_buf, F32, 'rewards_buf'), _need(cur_rewards, F32, 'cur_rewards'),
+        _need(cur_shaped, F32, 'cur_shaped'), _need(cur_lengths, F32, 'cur_lengths'),
+        _need(ep_partials, F64, 'ep_partials'), float(np.float32(shift)), float(np.float32(scale)),
+        float(np.float32(max(rmin, -3.0e38))), float(np.float32(min(rmax, 3.0e38))), clamp,
+        1 if bootstrap else 0, float(np.float32(gamma)), N, horizon, V, step, _stream(rewards)),
+        'rlg_rollout_post_step')
+
+
+def episode_meters_update(ep_partials, horizon, num_blocks, value_size, max_size, mean_rewards,
+                          mean_shaped, mean_lengths, current_sizes, finished_total):
+    lib = _lib.load()
+    _lib.check(lib.rlg_episode_meters_update(
+        _need(ep_partials, F64, 'ep_partials'), horizon, num_blocks, value_size, max_size,
+        _need(mean_rewards, F32, 'mean_rewards'), _need(mean_shaped, F32, 'mean_shaped'),
+        _need(mean_lengths, F32, 'mean_lengths'), _need(current_sizes, torch.int32, 'current_sizes'),
+        _need(finished_total, torch.int64, 'finished_total'), _stream(ep_partials)),
+        'rlg_episode_meters_update')
+
+
+def rnn_zero_done_states(states, dones):
+    lib = _lib.load()
+    L, N, U = states.shape
+    _lib.check(lib.rlg_rnn_zero_done_states(_need(states, F32, 'states'), _need(dones, U8, 'dones'),
+                                            L, N, U, _stream(states)), 'rlg_rnn_zero_done_states')
+
+
+# ------------------------------------------------------------------ running statistics
+
+def column_moments_blocks(rows, cols):
+    return _lib.load().rlg_column_moments_num_blocks(int(rows), int(cols))
+
+
+def column_moments(x, mask=None, partials=None):
+    """x [rows, C] fp32 -> partials [blocks, 2C+1] fp64."""
+    lib = _lib.load()
+    x2 = x.reshape(x.shape[0], -1)
+    rows, C = x2.shape
+    nb = column_moments_blocks(rows, C)
+    if partials is None:
+        partials = torch.empty((nb, 2 * C + 1), dtype=F64, device=x.device)
+    _lib.check(lib.rlg_column_moments(_need(x2, F32, 'x'), _opt(mask, F32, 'mask'), rows, C,
+                                      _need(partials, F64, 'partials'), nb, _stream(x)),
+               'rlg_column_moments')
+    return partials, nb
+
+
+def rms_update(partials, num_blocks, cols, total_rows, mode, running_mean, running_var, count):
+    lib = _lib.load()
+    _lib.check(lib.rlg_rms_update(_need(partials, F64, 'partials'), num_blocks, cols, total_rows, mode,
+                                  _need(running_mean, F64, 'running_mean'),
+                                  _need(running_var, F64, 'running_var'),
+                                  _need(count, torch.int64, 'count'), _stream(partials)),
+               'rlg_rms_update')
+
+
+def rms_apply(x, running_mean, running_var, eps, mode=0, out=None):
+    lib = _lib.load()
+    x2 = x.reshape(x.shape[0], -1) if x.dim() > 1 else x.reshape(-1, 1)
+    rows, C = x2.shape
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    _lib.check(lib.rlg_rms_apply(_need(x2, F32, 'x'), _need(out, F32, 'out'), rows, C,
+                                 _need(running_mean, F64, 'running_mean'),
+                                 _need(running_var, F64, 'running_var'), float(np.float32(eps)), mode,
+                                 _stream(x)), 'rlg_rms_apply')
+    return out
+
+
+PREP_NORM_VALUE = 1
+PREP_NORM_ADV = 2
+PREP_FREEZE_CRITIC = 4
+PREP_EMA_ADV = 8
+
+
+def prepare_stats_buffer(device):
+    n = _lib.load().rlg_prepare_stats_bytes()
+    return torch.zeros(n // 4, dtype=F32, device=device)
+
+
+def prepare_finalize(gae_partials, batch, flags, value_stats, eps, ema, stats_out):
+    """value_stats = (running_mean, running_var, count) or None; ema = dict(mean, sqrs, step,
+    decay, max, eps) or None."""
+    lib = _lib.load()
+    rm = rv = cnt = None
+    if value_stats is not None:
+        rm, rv, cnt = value_stats
+    em = es = est = None
+    decay = factor = 0.0
+    emax, eeps = 1e5, 0.0
+    if ema is not None:
+        em, es, est = ema['mean'], ema['sqrs'], ema['step']
+        decay = float(np.float32(ema['decay']))
+        factor = float(np.float32(1 - ema['decay']))
+        emax, eeps = float(ema['max']), float(ema['eps'])
+    _lib.check(lib.rlg_prepare_finalize(
+        _need(gae_partials, F64, 'gae_partials'), gae_partials.shape[0], batch, flags,
+        _opt(rm, F64, 'value running_mean'), _opt(rv, F64, 'value running_var'),
+        _opt(cnt, torch.int64, 'value count'), float(np.float32(eps)), _opt(em, F32, 'ema mean'),
+        _opt(es, F32, 'ema sqrs'), _opt(est, torch.int32, 'ema step'), decay, factor,
+        float(np.float32(emax)), float(np.float32(eeps)), _need(stats_out, F32, 'stats_out'),
+        _stream(gae_partials)), 'rlg_prepare_finalize')
+
+
+def prepare_apply(values, returns, advantages, flags, stats):
+    lib = _lib.load()
+    B = advantages.numel()
+    _lib.check(lib.rlg_prepare_apply(_need(values, F32, 'values'), _need(returns, F32, 'returns'),
+                                     _need(advantages, F32, 'advantages'), B, flags,
+                                     _need(stats, F32, 'stats'), _stream(values)), 'rlg_prepare_apply')
+
+
+# ------------------------------------------------------------------ PPO loss
+
+BOUND_KINDS = {None: 0, 'none': 0, 'bound': 1, 'regularisation': 2}
+
+
+def ppo_loss_blocks(minibatch):
+    return _lib.load().rlg_ppo_loss_num_blocks(int(minibatch))
+
+
+def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_values, returns,
+                   old_mu, old_sigma, d_mu, d_values, partials, e_clip, critic_coef, bounds_coef,
+                   clip_value=True, smooth=False, bound_kind=1, write_back=True, mask=None,
+                   mask_sum=None):
+    lib = _lib.load()
+    mb, A = mu.shape
+    _lib.check(lib.rlg_ppo_loss_fused(
+        _need(mu, F32, 'mu'), _need(logstd, F32, 'logstd'), _need(values, F32, 'values'),
+        _need(actions, F32, 'actions'), _need(old_neglogp, F32, 'old_neglogp'),
+        _need(advantages, F32, 'advantages'), _need(old_values, F32, 'old_values'),
+        _need(returns, F32, 'returns'), _need(old_mu, F32, 'old_mu'), _need(old_sigma, F32, 'old_sigma'),
+        _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), _need(d_mu, F32, 'd_mu'),
+        _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'), mb, A,
+        float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(bounds_coef)),
+        1 if clip_value else 0, 1 if smooth else 0, bound_kind, 1 if write_back else 0, _stream(mu)),
+        'rlg_ppo_loss_fused')
+
+
+def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, critic_coef,
+                      entropy_coef, bounds_coef, scalars, d_logstd, kl_slot=None):
+    lib = _lib.load()
+    _lib.check(lib.rlg_ppo_loss_finalize(
+        _need(partials, F64, 'partials'), num_blocks, actions_num, minibatch, 1 if masked else 0,
+        float(np.float32(critic_coef)), float(np.float32(entropy_coef)), float(np.float32(bounds_coef)),
+        _need(scalars, F32, 'scalars'), _need(d_logstd, F32, 'd_logstd'),
+        _opt(kl_slot, F32, 'kl_slot'), _stream(partials)), 'rlg_ppo_loss_finalize')
+
+
+# ------------------------------------------------------------------ optimiser
+
+def grad_norm_blocks(n):
+    return _lib.load().rlg_grad_norm_num_blocks(int(n))
+
+
+def grad_sumsq(grads, grad_scale, partials):
+    lib = _lib.load()
+    _lib.check(lib.rlg_grad_sumsq(_need(grads, F32, 'grads'), grads.numel(),
+                                  float(np.float32(grad_scale)), _need(partials, F64, 'partials'),
+                                  partials.numel(), _stream(grads)), 'rlg_grad_sumsq')
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max_norm, lr_slots,
+              cur_slot, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
+              kl=None, kl_scale=1.0, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2,
+              lr_multiplier=1.5, stats_out=None):
+    lib = _lib.load()
+    _lib.check(lib.rlg_adam_step(
+        _need(params, F32, 'params'), _need(grads, F32, 'grads'), _need(exp_avg, F32, 'exp_avg'),
+        _need(exp_avg_sq, F32, 'exp_avg_sq'), params.numel(), _opt(norm_partials, F64, 'norm_partials'),
+        0 if norm_partials is None else norm_partials.numel(), float(np.float32(grad_scale)),
+        float(np.float32(max_norm)), _need(lr_slots, F64, 'lr_slots'), cur_slot, step,
+        float(betas[0]), float(betas[1]), float(eps), float(weight_decay), schedule_kind,
+        _opt(kl, F32, 'kl'), float(np.float32(kl_scale)), float(kl_threshold), float(min_lr),
+        float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), _stream(params)),
+        'rlg_adam_step')

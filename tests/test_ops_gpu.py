@@ -1,0 +1,358 @@
+"""GPU parity of the rollout-buffer, running-statistics, PPO-loss and optimiser kernels
+(through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances: integer / index / copy semantics bit-exact; element-wise fp32 bit-exact where the
+kernel performs the same op chain; results that pass through a reduction (means, variances,
+norms) within rtol 1e-5 (north_star) - the kernels reduce in fp64, torch in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+RTOL = 1e-5
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ----------------------------------------------------------------------------- rollout buffer
+
+@pytest.mark.parametrize('N,H,O_,A', [(300, 8, 108, 21), (64, 4, 3, 1), (1000, 16, 60, 8)])
+def test_store_step_matches_indexed_assignment(N, H, O_, A):
+    from rl_games_amd import ops
+    gen = g(0)
+    fields = {'obses': (O_,), 'actions': (A,), 'mus': (A,), 'sigmas': (A,), 'neglogpacs': (),
+              'values': (1,)}
+    phys = {k: torch.zeros((N, H) + s, device=DEV) for k, s in fields.items()}
+    phys['dones'] = torch.zeros((N, H), dtype=torch.uint8, device=DEV)
+    ref = {k: torch.zeros((H, N) + s) for k, s in fields.items()}
+    ref['dones'] = torch.zeros((H, N), dtype=torch.uint8)
+    for step in (0, 3, H - 1):
+        vals = {k: torch.randn((N,) + s, generator=gen) for k, s in fields.items()}
+        vals['dones'] = (torch.rand(N, generator=gen) < 0.3).to(torch.uint8)
+        for k, v in vals.items():
+            ref[k][step, :] = v                                   # experience.py:456
+        ops.rollout_store_step([(v.to(DEV), phys[k]) for k, v in vals.items()], N, H, step)
+    for k in ref:
+        view = phys[k].transpose(0, 1)                            # the [H, N, ...] API view
+        assert torch.equal(view.cpu(), ref[k]), k
+        # swap_and_flatten01 of the view is the physical storage itself (no copy)
+        flat = O.flatten_env_major(view)
+        assert flat.data_ptr() == phys[k].data_ptr()
+        assert torch.equal(flat.cpu(), O.flatten_env_major(ref[k]))
+
+
+@pytest.mark.parametrize('V,masked,to_dtype', [(1, False, torch.bool), (2, False, torch.float32),
+                                                (1, True, torch.uint8), (1, False, None)])
+def test_post_step_matches_oracle(V, masked, to_dtype):
+    from rl_games_amd import ops
+    N, H, gamma = 777, 6, 0.99
+    gen = g(1)
+    shaper = (0.5, 2.0, -3.0, 3.0)
+    nb = ops.post_step_num_blocks(N)
+    rewards_buf = torch.zeros(N, H, V, device=DEV)
+    cur_r = torch.randn(N, V, generator=gen)
+    cur_s = torch.randn(N, V, generator=gen)
+    cur_l = torch.randint(0, 50, (N,), generator=gen).float()
+    d_cur = [t.clone().to(DEV) for t in (cur_r, cur_s, cur_l)]
+    ep_partials = torch.zeros(H, nb, 2 * V + 2, dtype=torch.float64, device=DEV)
+    ref_buf = torch.zeros(H, N, V)
+    meters = {'m': [torch.zeros(V), torch.zeros(V), torch.zeros(1)], 'n': [0, 0, 0]}
+    max_size = 100
+    for step in range(H):
+        rewards = torch.randn(N, V, generator=gen)
+        values = torch.randn(N, V, generator=gen)
+        dones = (torch.rand(N, generator=gen) < 0.2).to(torch.uint8)
+        time_outs = (torch.rand(N, generator=gen) < 0.5) & dones.bool()
+        live = (torch.rand(N, generator=gen) < 0.8).float() if masked else None
+        shaped = O.shape_rewards(rewards, scale=shaper[1], shift=shaper[0], min_val=shaper[2],
+                                 max_val=shaper[3])
+        if to_dtype is not None:
+            shaped = O.bootstrap_timeouts(shaped, values, time_outs, gamma)
+        ref_buf[step, :] = shaped
+        cur_r, cur_s, cur_l, fin = O.episode_bookkeeping(cur_r, cur_s, cur_l, rewards, shaped, dones,
+                                                         live_rows=live)
+        for j, vals in enumerate(fin[:3]):
+            vals = vals.reshape(vals.shape[0], -1) if j < 2 else vals.reshape(-1, 1)
+            meters['m'][j], meters['n'][j] = O.average_meter_update(meters['m'][j], meters['n'][j],
+                                                                    vals, max_size)
+        to = None if to_dtype is None else time_outs.to(to_dtype).to(DEV)
+        ops.rollout_post_step(rewards.to(DEV), dones.to(DEV), to, values.to(DEV),
+                              None if live is None else live.to(DEV), rewards_buf, d_cur[0], d_cur[1],
+                              d_cur[2], ep_partials, shaper, to_dtype is not None, gamma, H, step)
+        assert torch.equal(d_cur[0].cpu(), cur_r) and torch.equal(d_cur[1].cpu(), cur_s)
+        assert torch.equal(d_cur[2].cpu(), cur_l)
+    assert torch.equal(rewards_buf.transpose(0, 1).cpu(), ref_buf)
+    mr, ms, ml = torch.zeros(V, device=DEV), torch.zeros(V, device=DEV), torch.zeros(1, device=DEV)
+    sizes = torch.zeros(3, dtype=torch.int32, device=DEV)
+    fin_total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.episode_meters_update(ep_partials, H, nb, V, max_size, mr, ms, ml, sizes, fin_total)
+    assert sizes.tolist() == meters['n']
+    for dev_t, ref_t in zip((mr, ms, ml), meters['m']):
+        assert torch.allclose(dev_t.cpu(), ref_t.reshape(-1), rtol=RTOL, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- RunningMeanStd
+
+@pytest.mark.parametrize('rows,C', [(4096, 108), (1000, 60), (777, 3), (5000, 1), (300, 260), (64, 7)])
+def test_running_mean_std_update_and_normalise(rows, C):
+    from rl_games_amd import ops
+    gen = g(2)
+    state = O.new_running_stats(C)
+    dmean = state['running_mean'].clone().to(DEV)
+    dvar = state['running_var'].clone().to(DEV)
+    dcount = state['count'].clone().reshape(1).to(DEV)
+    for it in range(3):
+        x = torch.randn(rows, C, generator=gen) * (1 + it) + 3.0 * it - 1.0
+        y_ref, state = O.running_stats_forward(state, x, training=True)
+        xd = x.to(DEV)
+        part, nb = ops.column_moments(xd)
+        ops.rms_update(part, nb, C, rows, 0, dmean, dvar, dcount)
+        y = ops.rms_apply(xd, dmean, dvar, 1e-5, 0)
+        assert dcount.item() == state['count'].item()
+        assert torch.allclose(dmean.cpu(), state['running_mean'], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(dvar.cpu(), state['running_var'], rtol=2e-6, atol=1e-9)
+        assert torch.allclose(y.cpu(), y_ref, rtol=RTOL, atol=2e-6)
+    # eval-mode normalise and de-normalise use the state only: bit-exact given the same state
+    state_dev = {'running_mean': dmean.cpu(), 'running_var': dvar.cpu(), 'count': dcount.cpu()[0]}
+    x = torch.randn(rows, C, generator=gen) * 4
+    y_ref, _ = O.running_stats_forward(state_dev, x, training=False)
+    assert torch.equal(ops.rms_apply(x.to(DEV), dmean, dvar, 1e-5, 0).cpu(), y_ref)
+    y_ref, _ = O.running_stats_forward(state_dev, x, training=False, denorm=True)
+    assert torch.equal(ops.rms_apply(x.to(DEV), dmean, dvar, 1e-5, 1).cpu(), y_ref)
+
+
+def test_running_mean_std_masked_modes():
+    """mode 1 = forward(x, mask=...) (unbiased masked moments, count += rows); mode 2 = the
+    value normaliser's `x[valid]` path (a2c_common.py:1609-1611)."""
+    from rl_games_amd import ops
+    gen = g(3)
+    rows = 3000
+    x = torch.randn(rows, 1, generator=gen) * 2 + 1
+    mask = (torch.rand(rows, generator=gen) < 0.7).float()
+    for mode in (1, 2):
+        state = O.new_running_stats(1)
+        if mode == 1:
+            _, ref = O.running_stats_forward(state, x, training=True, mask=mask.unsqueeze(1))
+        else:
+            _, ref = O.running_stats_forward(state, x[mask.bool()], training=True)
+        dmean = state['running_mean'].clone().to(DEV)
+        dvar = state['running_var'].clone().to(DEV)
+        dcount = state['count'].clone().reshape(1).to(DEV)
+        part, nb = ops.column_moments(x.to(DEV), mask.to(DEV))
+        ops.rms_update(part, nb, 1, rows, mode, dmean, dvar, dcount)
+        assert dcount.item() == ref['count'].item()
+        assert torch.allclose(dmean.cpu(), ref['running_mean'], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(dvar.cpu(), ref['running_var'], rtol=2e-6)
+
+
+@pytest.mark.parametrize('N,H', [(1000, 32), (130, 8), (4096, 16)])
+@pytest.mark.parametrize('ema', [False, True])
+def test_prepare_dataset_from_gae_moments(N, H, ema):
+    """GAE kernel -> prepare_finalize -> prepare_apply == oracle prepare_dataset
+    (a2c_common.py:1586-1660) on the same rollout tensors."""
+    from oracle.seeded_inputs import gae_inputs
+    from rl_games_amd import ops
+    from rl_games_amd.gae import gae_returns_advantages
+    r, v, d, lv, ld = gae_inputs(H, N, 1, seed=4, p_done=0.05)
+    v = v * 2 + 5
+    advs = O.gae_scan(r, v, d, lv, ld, 0.99, 0.95)
+    returns = O.flatten_env_major(O.returns_from_advantages(advs, v))
+    values = O.flatten_env_major(v)
+    vstate = O.new_running_stats(1)
+    ema_state = O.new_moving_stats(1) if ema else None
+    ref = O.prepare_dataset(returns, values, vstate, adv_ema_state=ema_state, adv_ema_decay=0.5)
+
+    rp, vp = r[..., 0].t().contiguous().to(DEV), v[..., 0].t().contiguous().to(DEV)
+    dp = d.t().contiguous().to(torch.uint8).to(DEV)
+    ret, adv, part = gae_returns_advantages(rp, vp, dp, lv[:, 0].contiguous().to(DEV),
+                                            ld.to(torch.uint8).to(DEV), 0.99, 0.95)
+    vs = (vstate['running_mean'].clone().to(DEV), vstate['running_var'].clone().to(DEV),
+          vstate['count'].clone().reshape(1).to(DEV))
+    stats = ops.prepare_stats_buffer(DEV)
+    flags = ops.PREP_NORM_VALUE | (ops.PREP_EMA_ADV if ema else ops.PREP_NORM_ADV)
+    ema_dev = None
+    if ema:
+        ema_dev = {'mean': torch.zeros(1, device=DEV), 'sqrs': torch.zeros(1, device=DEV),
+                   'step': torch.ones(1, dtype=torch.int32, device=DEV), 'decay': 0.5, 'max': 1e5, 'eps': 0.0}
+    ops.prepare_finalize(part, N * H, flags, vs, 1e-5, ema_dev, stats)
+    vals_n = vp.clone()
+    ops.prepare_apply(vals_n, ret, adv, flags, stats)
+    assert vs[2].item() == ref['value_stats']['count'].item()
+    assert torch.allclose(vs[0].cpu(), ref['value_stats']['running_mean'], rtol=1e-6)
+    assert torch.allclose(vs[1].cpu(), ref['value_stats']['running_var'], rtol=2e-6)
+    assert torch.allclose(vals_n.reshape(-1, 1).cpu(), ref['old_values'], rtol=RTOL, atol=2e-6)
+    assert torch.allclose(ret.reshape(-1, 1).cpu(), ref['returns'], rtol=RTOL, atol=2e-6)
+    assert torch.allclose(adv.reshape(-1).cpu(), ref['advantages'], rtol=RTOL, atol=2e-6)
+    if ema:
+        assert ema_dev['step'].item() == ref['adv_ema_state']['step'].item()
+        assert torch.allclose(ema_dev['mean'].cpu(), ref['adv_ema_state']['mean'], rtol=RTOL, atol=1e-7)
+        assert torch.allclose(ema_dev['sqrs'].cpu(), ref['adv_ema_state']['sqrs'], rtol=RTOL)
+
+
+# ----------------------------------------------------------------------------- PPO loss
+
+def _loss_inputs(mb, A, seed):
+    """SURVEY 8d kernel-level inputs: both clip sides fire, bound loss active."""
+    gen = g(seed)
+    old_nlp = torch.randn(mb, generator=gen)
+    batch = {
+        'old_logp_actions': old_nlp,
+        'advantages': torch.randn(mb, generator=gen),
+        'old_values': torch.randn(mb, 1, generator=gen),
+        'returns': torch.randn(mb, 1, generator=gen),
+        'actions': torch.randn(mb, A, generator=gen),
+        'mu': 1.2 * torch.randn(mb, A, generator=gen),
+        'sigma': torch.exp(0.1 * torch.randn(mb, A, generator=gen)),
+    }
+    mu = batch['mu'] + 0.1 * torch.randn(mb, A, generator=gen)
+    logstd = 0.1 * torch.randn(A, generator=gen)
+    values = batch['old_values'] + 0.3 * torch.randn(mb, 1, generator=gen)
+    # make neglogp land near old_neglogp so that ratios straddle the clip range
+    with torch.no_grad():
+        sigma = torch.exp(logstd)
+        nlp = O.neglogp(batch['actions'], mu, mu * 0 + sigma, mu * 0 + logstd)
+        batch['old_logp_actions'] = nlp + 0.2 * torch.randn(mb, generator=gen)
+    return mu, logstd, values, batch
+
+
+@pytest.mark.parametrize('mb,A', [(4096, 21), (1000, 8), (300, 1), (257, 33), (32768, 21)])
+@pytest.mark.parametrize('variant', ['bound', 'smooth_reg', 'noclip_nobound', 'masked'])
+def test_ppo_loss_forward_backward_kl(mb, A, variant):
+    from rl_games_amd import ops
+    mu, logstd, values, batch = _loss_inputs(mb, A, seed=mb + A)
+    hp = {'e_clip': 0.2, 'critic_coef': 2.0, 'entropy_coef': 0.01, 'bounds_loss_coef': 1e-4,
+          'clip_value': True, 'use_smooth_clamp': False, 'bound_loss_type': 'bound'}
+    mask = None
+    if variant == 'smooth_reg':
+        hp.update(use_smooth_clamp=True, bound_loss_type='regularisation', bounds_loss_coef=0.01)
+    elif variant == 'noclip_nobound':
+        hp.update(clip_value=False, bounds_loss_coef=None)
+    elif variant == 'masked':
+        mask = (torch.rand(mb, generator=g(7)) < 0.8).float()
+    ref = O.distribution_loss_and_grads(mu, logstd, values, batch, hp, mask)
+
+    d = lambda t: t.contiguous().to(DEV)
+    old_mu, old_sigma = d(batch['mu']), d(batch['sigma'])
+    d_mu = torch.empty(mb, A, device=DEV)
+    d_val = torch.empty(mb, device=DEV)
+    nb = ops.ppo_loss_blocks(mb)
+    partials = torch.empty(nb, 6 + A, dtype=torch.float64, device=DEV)
+    scalars = torch.zeros(8, device=DEV)
+    d_logstd = torch.zeros(A, device=DEV)
+    kl_slot = torch.zeros(1, device=DEV)
+    coef_b = hp['bounds_loss_coef'] if hp['bounds_loss_coef'] is not None else 0.0
+    kind = 0 if hp['bounds_loss_coef'] is None else ops.BOUND_KINDS[hp['bound_loss_type']]
+    mask_d = None if mask is None else d(mask)
+    mask_sum = None if mask is None else mask_d.sum().reshape(1)
+    ops.ppo_loss_fused(d(mu), d(logstd), d(values.reshape(-1)), d(batch['actions']),
+                       d(batch['old_logp_actions']), d(batch['advantages']),
+                       d(batch['old_values'].reshape(-1)), d(batch['returns'].reshape(-1)), old_mu,
+                       old_sigma, d_mu, d_val, partials, hp['e_clip'], hp['critic_coef'], coef_b,
+                       hp['clip_value'], hp['use_smooth_clamp'], kind, True, mask_d, mask_sum)
+    ops.ppo_loss_finalize(partials, nb, A, mb, mask is not None, hp['critic_coef'], hp['entropy_coef'],
+                          coef_b, scalars, d_logstd, kl_slot)
+    s = scalars.cpu()
+    for k, name in enumerate(('a_loss', 'c_loss', 'entropy', 'b_loss', 'kl', 'loss')):
+        assert torch.allclose(s[k], ref[name], rtol=RTOL, atol=1e-7), (name, s[k].item(), ref[name].item())
+    assert kl_slot.item() == s[4].item()
+    scale = 1.0 / mb
+    assert torch.allclose(d_mu.cpu(), ref['d_mu'], rtol=RTOL, atol=1e-7 * scale)
+    assert torch.allclose(d_val.cpu(), ref['d_values'].reshape(-1), rtol=RTOL, atol=1e-7 * scale)
+    assert torch.allclose(d_logstd.cpu(), ref['d_logstd'], rtol=2e-5, atol=2e-7)
+    # update_mu_sigma write-back (datasets.py:42-43): bit-exact copies of the new policy
+    assert torch.equal(old_mu.cpu(), mu)
+    assert torch.equal(old_sigma.cpu(), ref['sigma'])
+
+
+def test_ppo_loss_max_tie_and_clip_edges():
+    """Rows constructed to sit exactly on the torch.max tie / clamp boundary."""
+    from rl_games_amd import ops
+    mb, A = 512, 4
+    mu, logstd, values, batch = _loss_inputs(mb, A, seed=99)
+    with torch.no_grad():
+        sigma = torch.exp(logstd)
+        nlp = O.neglogp(batch['actions'], mu, mu * 0 + sigma, mu * 0 + logstd)
+    batch['old_logp_actions'] = nlp.clone()            # ratio == 1 exactly: both branches tie
+    batch['advantages'][::7] = 0.0                     # zero advantage: both branches 0
+    values = batch['old_values'].clone()               # delta == 0: value branches tie
+    values[::5] += 0.2                                 # delta == e_clip (inclusive edge, in fp32 ~)
+    hp = {'e_clip': 0.2, 'critic_coef': 1.0, 'entropy_coef': 0.0, 'bounds_loss_coef': 1e-4,
+          'clip_value': True, 'use_smooth_clamp': False, 'bound_loss_type': 'bound'}
+    ref = O.distribution_loss_and_grads(mu, logstd, values, batch, hp, None)
+    d = lambda t: t.contiguous().to(DEV)
+    d_mu, d_val = torch.empty(mb, A, device=DEV), torch.empty(mb, device=DEV)
+    nb = ops.ppo_loss_blocks(mb)
+    partials = torch.empty(nb, 6 + A, dtype=torch.float64, device=DEV)
+    ops.ppo_loss_fused(d(mu), d(logstd), d(values.reshape(-1)), d(batch['actions']),
+                       d(batch['old_logp_actions']), d(batch['advantages']),
+                       d(batch['old_values'].reshape(-1)), d(batch['returns'].reshape(-1)),
+                       d(batch['mu']), d(batch['sigma']), d_mu, d_val, partials, 0.2, 1.0, 1e-4, True,
+                       False, 1, False)
+    assert torch.allclose(d_mu.cpu(), ref['d_mu'], rtol=RTOL, atol=1e-10)
+    assert torch.allclose(d_val.cpu(), ref['d_values'].reshape(-1), rtol=RTOL, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+@pytest.mark.parametrize('truncate', [True, False])
+def test_adam_step_matches_torch_adam(truncate):
+    from rl_games_amd import ops
+    gen = g(5)
+    shapes = [(400, 108), (400,), (200, 400), (200,), (21,), (1, 100)]
+    params = [torch.randn(s, generator=gen) * 0.1 for s in shapes]
+    exp_avg = [torch.randn(s, generator=gen) * 0.01 for s in shapes]
+    exp_avg_sq = [torch.rand(s, generator=gen) * 1e-3 for s in shapes]
+    n = sum(p.numel() for p in params)
+    flat = lambda ts: torch.cat([t.reshape(-1) for t in ts]).to(DEV)
+    fp, fm, fv = flat(params), flat(exp_avg), flat(exp_avg_sq)
+    lr_slots = torch.tensor([3e-4, 0.0], dtype=torch.float64, device=DEV)
+    stats = torch.zeros(4, device=DEV)
+    cur = 0
+    lr = 3e-4
+    for step in range(1, 4):
+        grads = [torch.randn(s, generator=gen) * (3.0 if step == 1 else 0.01) for s in shapes]
+        kl = 0.02 if step == 1 else (0.001 if step == 2 else 0.008)
+        p_ref, m_ref, v_ref, norm_ref = O.clip_and_adam_reference(params, grads, exp_avg, exp_avg_sq,
+                                                                 step - 1, lr, 1.0, truncate)
+        fg = flat(grads)
+        partials = None
+        if truncate:
+            partials = torch.empty(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
+            ops.grad_sumsq(fg, 1.0, partials)
+        ops.adam_step(fp, fg, fm, fv, partials, 1.0, 1.0, lr_slots, cur, step, schedule_kind=1,
+                      kl=torch.tensor([kl], device=DEV), stats_out=stats)
+        params, exp_avg, exp_avg_sq = p_ref, m_ref, v_ref
+        if truncate:
+            assert np.isclose(stats[0].item(), norm_ref.item(), rtol=1e-6)
+        assert np.isclose(stats[2].item(), lr, rtol=1e-7)
+        lr = O.adaptive_lr(lr, kl)
+        cur ^= 1
+        assert lr_slots[cur].item() == lr               # python-double arithmetic, bit-exact
+        assert torch.allclose(fp.cpu(), flat(params).cpu(), rtol=1e-6, atol=1e-8)
+        assert torch.allclose(fm.cpu(), flat(exp_avg).cpu(), rtol=1e-6, atol=1e-9)
+        assert torch.allclose(fv.cpu(), flat(exp_avg_sq).cpu(), rtol=1e-6, atol=1e-12)
+
+
+def test_adam_multi_gpu_average_and_kl_scale():
+    """grad_scale = 1/world (a2c_common.py:505-507) and kl_scale for a cross-rank KL sum."""
+    from rl_games_amd import ops
+    gen = g(6)
+    n = 5000
+    p0 = torch.randn(n, generator=gen)
+    g_sum = torch.randn(n, generator=gen)          # what all_reduce(SUM) over 4 ranks leaves
+    ref_p, _, _, _ = O.clip_and_adam_reference([p0], [g_sum / 4], [torch.zeros(n)], [torch.zeros(n)],
+                                               0, 1e-3, 1.0, True)
+    fp, fg = p0.clone().to(DEV), g_sum.clone().to(DEV)
+    fm, fv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    partials = torch.empty(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
+    ops.grad_sumsq(fg, 0.25, partials)
+    lr_slots = torch.tensor([1e-3, 0.0], dtype=torch.float64, device=DEV)
+    ops.adam_step(fp, fg, fm, fv, partials, 0.25, 1.0, lr_slots, 0, 1, schedule_kind=1,
+                  kl=torch.tensor([4 * 0.02], device=DEV), kl_scale=0.25)
+    assert torch.allclose(fp.cpu(), ref_p[0], rtol=1e-6, atol=1e-8)
+    assert lr_slots[1].item() == O.adaptive_lr(1e-3, float(np.float32(0.02 * 4) * np.float32(0.25)))

@@ -1,0 +1,199 @@
+// Development experiment (not part of the product library): A/B variants of the env-major
+// GAE kernel + a same-footprint copy kernel, timed with hipEvents over back-to-back launches
+// on rotating buffer sets (cold = 16 sets > 256 MB MALL, warm = 1 set).
+#include "../../rl_games_amd/csrc/gae.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace rlg;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// same bytes as the fused kernel: read r,v (f32) + d (u8), write ret, adv.
+__global__ __launch_bounds__(256) void copy_like_kernel(const f32x4* __restrict__ r, const f32x4* __restrict__ v,
+                                                        const u32x4* __restrict__ d, f32x4* __restrict__ o0,
+                                                        f32x4* __restrict__ o1, int n4) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int stride = gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    f32x4 a = r[i], b = v[i];
+    float s = 0.f;
+    if ((i & 3) == 0) { u32x4 q = d[i >> 2]; s = (float)(q[0] & 1); }
+    o0[i] = a + b + s;
+    o1[i] = a - b;
+  }
+}
+
+// Variant: MOM 0 none / 1 f64 per element / 2 f32 shifted sums per lane -> f64 merge
+template <int H, int MOM, int WAVES, int PW = 0>
+__global__ __launch_bounds__(64 * WAVES) void gae_var_kernel(
+    const float* __restrict__ rewards, const float* __restrict__ values, const uint8_t* __restrict__ dones,
+    const float* __restrict__ last_values, const uint8_t* __restrict__ last_dones, float* __restrict__ out0,
+    float* __restrict__ out1, double* __restrict__ partials, int N, float gamma, float gamma_tau) {
+  __shared__ __attribute__((aligned(16))) float lds[WAVES * 2 * TileGeom<H>::kTileFloats];
+  const int w = threadIdx.x >> 6;
+  float* tile_r = lds + w * 2 * TileGeom<H>::kTileFloats;
+  float* tile_v = tile_r + TileGeom<H>::kTileFloats;
+  const int tile = blockIdx.x * WAVES + w;
+  const int env0 = tile * kWave;
+  if (env0 >= N) return;
+  const int rows = min(kWave, N - env0);
+  const int lane = lane_id();
+  const int env = env0 + lane;
+  const bool live = lane < rows;
+  const long long base = (long long)env0 * H;
+  f32x4 rbuf[H / 4], vbuf[H / 4];
+  tile_load_issue<H>(rewards + base, rows, rbuf);
+  tile_load_issue<H>(values + base, rows, vbuf);
+  uint32_t dw[H / 4];
+  {
+    const uint8_t* drow = dones + (long long)(live ? env : env0) * H;
+#pragma unroll
+    for (int j = 0; j < H / 16; ++j) {
+      const u32x4 q = *reinterpret_cast<const u32x4*>(drow + 16 * j);
+      dw[4 * j + 0] = q[0]; dw[4 * j + 1] = q[1]; dw[4 * j + 2] = q[2]; dw[4 * j + 3] = q[3];
+    }
+  }
+  float nv = last_values[live ? env : env0];
+  float nnt = 1.0f - (float)last_dones[live ? env : env0];
+  tile_regs_to_lds<H>(rbuf, tile_r);
+  tile_regs_to_lds<H>(vbuf, tile_v);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float r[H], v[H];
+  row_from_lds<H>(tile_r, r);
+  row_from_lds<H>(tile_v, v);
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  float f[6] = {0, 0, 0, 0, 0, 0};
+  float a_[MOM >= 3 ? H : 1];
+  const float kv = v[H - 1];   // per-lane pivots for the shifted sums
+  float A = 0.0f;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int t = H - 1 - i;
+    const float vt = v[t];
+    const float delta = (r[t] + (gamma * nv) * nnt) - vt;
+    A = delta + (gamma_tau * nnt) * A;
+    const float ret = A + vt;
+    const float adv = ret - vt;
+    r[t] = ret;
+    if (MOM >= 3) { a_[t] = adv; } else { v[t] = adv; }
+    if (MOM == 1) {
+      const double da = adv, dv = vt, dr = ret;
+      m[0] += da; m[1] = fma(da, da, m[1]); m[2] += dv; m[3] = fma(dv, dv, m[3]); m[4] += dr; m[5] = fma(dr, dr, m[5]);
+    } else if (MOM == 2) {
+      const float sv = vt - kv, sr = ret - kv;
+      f[0] += adv; f[1] = fmaf(adv, adv, f[1]); f[2] += sv; f[3] = fmaf(sv, sv, f[3]); f[4] += sr; f[5] = fmaf(sr, sr, f[5]);
+    }
+    nv = vt;
+    const uint32_t dbyte = (dw[t >> 2] >> (8 * (t & 3))) & 0xffu;
+    nnt = 1.0f - (float)dbyte;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  row_to_lds<H>(tile_r, r);
+  if constexpr (MOM >= 3) row_to_lds<H>(tile_v, a_); else row_to_lds<H>(tile_v, v);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  tile_lds_to_global<H>(tile_r, out0 + base, rows);
+  tile_lds_to_global<H>(tile_v, out1 + base, rows);
+  if constexpr (MOM == 3) {
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+      const double da = a_[t], dv = v[t], dr = r[t];
+      m[0] += da; m[1] = fma(da, da, m[1]); m[2] += dv; m[3] = fma(dv, dv, m[3]); m[4] += dr; m[5] = fma(dr, dr, m[5]);
+    }
+  }
+  if constexpr (MOM == 4) {
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+      const float adv = a_[t], sv = v[t] - kv, sr = r[t] - kv;
+      f[0] += adv; f[1] = fmaf(adv, adv, f[1]); f[2] += sv; f[3] = fmaf(sv, sv, f[3]); f[4] += sr; f[5] = fmaf(sr, sr, f[5]);
+    }
+  }
+  if (MOM == 2 || MOM == 4) {
+    // un-shift per lane in fp64: sum x = s1 + n*k ; sum x^2 = s2 + 2k s1 + n k^2
+    const double k = kv, n = H;
+    m[0] = f[0]; m[1] = f[1];
+    m[2] = (double)f[2] + n * k; m[3] = (double)f[3] + 2.0 * k * (double)f[2] + n * k * k;
+    m[4] = (double)f[4] + n * k; m[5] = (double)f[5] + 2.0 * k * (double)f[4] + n * k * k;
+  }
+  if (MOM != 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[k] = wave_sum(live ? m[k] : 0.0);
+    if (PW == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) asm volatile("" :: "v"(m[k]));
+    } else if (lane == 0) {
+      const long long stride = (PW == 1) ? 16 : 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) partials[(long long)tile * stride + k] = m[k];
+    }
+  }
+  if (MOM == 0 && PW == 3 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) partials[(long long)tile * 6 + k] = (double)A;
+  }
+}
+
+struct Set { float *r, *v, *lv, *o0, *o1; uint8_t *d, *ld; double* part; };
+
+template <typename F>
+static float time_it(F launch, int iters) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) launch(i);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) launch(i);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+  const int N = 65536, H = 32; const int iters = 200;
+  const size_t nf = (size_t)N * H;
+  for (int nsets : {1, 16}) {
+    std::vector<Set> sets(nsets);
+    for (auto& s : sets) {
+      CK(hipMalloc(&s.r, nf * 4)); CK(hipMalloc(&s.v, nf * 4)); CK(hipMalloc(&s.o0, nf * 4)); CK(hipMalloc(&s.o1, nf * 4));
+      CK(hipMalloc(&s.d, nf)); CK(hipMalloc(&s.lv, N * 4)); CK(hipMalloc(&s.ld, N)); CK(hipMalloc(&s.part, 1024 * 16 * 8));
+      std::vector<float> h(nf); for (auto& x : h) x = (float)rand() / RAND_MAX - 0.5f;
+      CK(hipMemcpy(s.r, h.data(), nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(s.v, h.data(), nf * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(s.lv, h.data(), N * 4, hipMemcpyHostToDevice));
+      std::vector<uint8_t> hd(nf); for (auto& x : hd) x = (rand() % 20) == 0;
+      CK(hipMemcpy(s.d, hd.data(), nf, hipMemcpyHostToDevice)); CK(hipMemcpy(s.ld, hd.data(), N, hipMemcpyHostToDevice));
+    }
+    const double mb = nf * 17.0 / 1e6;
+    auto report = [&](const char* name, float us) {
+      printf("sets=%2d %-34s %7.2f us  %7.1f GB/s (%.1f%% of 8TB/s)\n", nsets, name, us, mb / us * 1e3, mb / us * 1e3 / 80.0);
+    };
+    report("copy_like 2048x256", time_it([&](int i) { auto& s = sets[i % nsets];
+      hipLaunchKernelGGL(copy_like_kernel, dim3(2048), dim3(256), 0, 0, (f32x4*)s.r, (f32x4*)s.v, (u32x4*)s.d, (f32x4*)s.o0, (f32x4*)s.o1, (int)(nf / 4)); }, iters));
+    report("copy_like 8192x256", time_it([&](int i) { auto& s = sets[i % nsets];
+      hipLaunchKernelGGL(copy_like_kernel, dim3(8192), dim3(256), 0, 0, (f32x4*)s.r, (f32x4*)s.v, (u32x4*)s.d, (f32x4*)s.o0, (f32x4*)s.o1, (int)(nf / 4)); }, iters));
+    report("product fused (f64 mom, 64thr)", time_it([&](int i) { auto& s = sets[i % nsets];
+      rlg_gae_envmajor_fused(s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, H, 0.99f, 0.9405f, nullptr); }, iters));
+#define RUNVARP(MOM, WAVES, PW, label) report(label, time_it([&](int i) { auto& s = sets[i % nsets]; \
+      hipLaunchKernelGGL((gae_var_kernel<32, MOM, WAVES, PW>), dim3((N / 64 + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
+#define RUNVAR(MOM, WAVES, label) report(label, time_it([&](int i) { auto& s = sets[i % nsets]; \
+      hipLaunchKernelGGL((gae_var_kernel<32, MOM, WAVES>), dim3((N / 64 + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
+    RUNVAR(0, 1, "var nomom 1wave/blk");
+    RUNVAR(1, 1, "var f64mom 1wave/blk");
+    RUNVAR(2, 1, "var f32mom 1wave/blk");
+    RUNVAR(0, 4, "var nomom 4wave/blk");
+    RUNVAR(2, 4, "var f32mom 4wave/blk");
+    RUNVARP(4, 4, 1, "f32mom-after 4w partial stride128B");
+    RUNVARP(4, 4, 2, "f32mom-after 4w NO partial write");
+    RUNVARP(0, 4, 3, "nomom 4w + const partial write");
+    RUNVAR(3, 1, "var f64mom-after-store 1w");
+    RUNVAR(4, 1, "var f32mom-after-store 1w");
+    RUNVAR(3, 4, "var f64mom-after-store 4w");
+    RUNVAR(4, 4, "var f32mom-after-store 4w");
+    for (auto& s : sets) { hipFree(s.r); hipFree(s.v); hipFree(s.o0); hipFree(s.o1); hipFree(s.d); hipFree(s.lv); hipFree(s.ld); hipFree(s.part); }
+  }
+  return 0;
+}
