@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
     m = m + w1 * (g - m);                                        // exp_avg.lerp_(grad, 1-beta1)
     float v = a.exp_avg_sq[i];
     v = v * b2 + (w2 * g) * g;                                   // mul_(beta2).addcmul_(g, g, 1-beta2)
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    const float denom = sqrt_rn(v) / bc2_sqrt + eps;
     p = p - step_size * (m / denom);                             // addcdiv_(exp_avg, denom, -step_size)
     a.exp_avg[i] = m;
     a.exp_avg_sq[i] = v;

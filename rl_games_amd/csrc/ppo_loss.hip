@@ -67,10 +67,12 @@ __device__ __forceinline__ float smooth_clamp_f(float x, float mi, float mx) {
 }
 
 __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) {
-  // d/dx of the above: s = 1/(1+e^t), ds/dt = -s(1-s), dt/dx = -4/(mx-mi)  ->  4 s (1-s)
+  // d/dx of the above: s = 1/(1+e^t), ds/dt = -e^t s^2, dt/dx = -4/(mx-mi)  ->  4 e^t s^2.
+  // (4 s (1-s) is the same number but cancels catastrophically once s -> 1.)
   const float t = ((-(x - mi) / (mx - mi)) + 0.5f) * 4.0f;
-  const float s = 1.0f / (1.0f + expf(t));
-  return 4.0f * s * (1.0f - s);
+  const float e = expf(t);
+  const float s = 1.0f / (1.0f + e);
+  return (4.0f * e) * (s * s);
 }
 
 __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {

@@ -58,6 +58,13 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* scratch) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Correctly rounded fp32 square root.  hipcc lowers sqrtf/__fsqrt_rn to the 1-ulp v_sqrt_f32;
+// the reference's CPU ops are IEEE.  sqrt in fp64 then one rounding to fp32 is exact for
+// sqrt (53 >= 2*24+2 bits), so this matches the CPU bit for bit.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  return static_cast<float>(sqrt(static_cast<double>(x)));
+}
+
 __device__ __forceinline__ bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }

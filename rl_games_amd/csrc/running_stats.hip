@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void rms_apply_kernel(const float* __restrict_
   float* denom = smem_f + C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     mean32[c] = static_cast<float>(running_mean[c]);
-    denom[c] = sqrtf(static_cast<float>(running_var[c]) + eps);
+    denom[c] = sqrt_rn(static_cast<float>(running_var[c]) + eps);
   }
   __syncthreads();
   const long long total_units = rows * C / UNIT;
@@ -288,7 +288,7 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
       cnt += B;
     }
     st.v_mean = static_cast<float>(mean);
-    st.v_denom = sqrtf(static_cast<float>(var) + eps);
+    st.v_denom = sqrt_rn(static_cast<float>(var) + eps);
     if (!(flags & kPrepFreezeCritic)) {
       // ... then returns (:1619), a second, separate merge
       double bm = static_cast<double>(static_cast<float>(m[4] / n));
@@ -300,7 +300,7 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
       *count = cnt;
     }
     st.r_mean = static_cast<float>(mean);
-    st.r_denom = sqrtf(static_cast<float>(var) + eps);
+    st.r_denom = sqrt_rn(static_cast<float>(var) + eps);
   }
   if (flags & kPrepEmaAdv) {
     // moving_mean_std.py:119-122 (_update_stats 'mean_std'), :57-61 (_get_stats)
@@ -316,7 +316,7 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
     ema_sqrs[0] = sqrs;
     const float var = sqrs - mean * mean;
     st.a_mean = mean;
-    st.a_denom = sqrtf(fmaxf(var, 1.0f / (ema_max * ema_max)) + ema_eps);
+    st.a_denom = sqrt_rn(fmaxf(var, 1.0f / (ema_max * ema_max)) + ema_eps);
   } else if (flags & kPrepNormAdv) {
     // advantages.mean(), advantages.std() (unbiased) + 1e-8                  a2c_common.py:1634
     const double mean = m[0] / n;
