@@ -148,16 +148,27 @@ int rlg_prepare_stats_bytes(void);
  * value RunningMeanStd with `values` then `returns` (a2c_common.py:1616-1619), computes the
  * advantage mean / unbiased std + 1e-8 (:1634) or the EMA statistics (moving_mean_std.py).
  * flags: 1 normalize_value, 2 normalize_advantage, 4 freeze_critic, 8 normalize_rms_advantage. */
-int rlg_prepare_finalize(const double* gae_partials, int num_tiles, long long batch, int flags,
+/* Same 6 sums as the GAE kernel's partials (7 with a mask: + sum mask, every term weighted
+ * by the mask) for batches that did not come out of rlg_gae_envmajor_fused. */
+int rlg_triple_moments_num_blocks(long long batch);
+int rlg_triple_moments(const float* advantages, const float* values, const float* returns,
+                       const float* mask_or_null, long long batch, double* partials, int num_blocks,
+                       void* stream);
+
+/* stride 6: unmasked partials; stride 7: masked (valid-row statistics, a2c_common.py:1605-1615,
+ * torch_ext.py:172-191). */
+int rlg_prepare_finalize(const double* gae_partials, int num_tiles, int stride, long long batch,
+                         int flags,
                          double* value_running_mean, double* value_running_var,
                          long long* value_count, float eps, float* ema_mean, float* ema_sqrs,
                          int* ema_step, float ema_decay, float ema_factor, float ema_max,
                          float ema_eps, void* stats_out, void* stream);
 
-/* In place: values/returns normalised with their respective statistics, advantages
- * normalised (a2c_common.py:1618-1619,:1634). */
-int rlg_prepare_apply(float* values, float* returns, float* advantages, long long batch, int flags,
-                      const void* stats, void* stream);
+/* values/returns normalised with their respective statistics, advantages normalised
+ * (a2c_common.py:1618-1619,:1634).  Outputs may alias the inputs. */
+int rlg_prepare_apply(const float* values, const float* returns, const float* advantages,
+                      float* values_out, float* returns_out, float* advantages_out, long long batch,
+                      int flags, const void* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused clipped-PPO loss forward + backward + KL

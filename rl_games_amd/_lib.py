@@ -44,9 +44,11 @@ _PROTOTYPES = {
     'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P],
     'rlg_rms_apply': [_P, _P, _c_ll, _c_int, _P, _P, _c_float, _c_int, _P],
     'rlg_prepare_stats_bytes': [],
-    'rlg_prepare_finalize': [_P, _c_int, _c_ll, _c_int, _P, _P, _P, _c_float, _P, _P, _P,
+    'rlg_triple_moments_num_blocks': [_c_ll],
+    'rlg_triple_moments': [_P, _P, _P, _P, _c_ll, _P, _c_int, _P],
+    'rlg_prepare_finalize': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _c_float, _P, _P, _P,
                              _c_float, _c_float, _c_float, _c_float, _P, _P],
-    'rlg_prepare_apply': [_P, _P, _P, _c_ll, _c_int, _P, _P],
+    'rlg_prepare_apply': [_P, _P, _P, _P, _P, _P, _c_ll, _c_int, _P, _P],
     # ppo_loss.hip
     'rlg_ppo_loss_num_blocks': [_c_int],
     'rlg_ppo_loss_partials_per_block': [_c_int],

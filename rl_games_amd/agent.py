@@ -1,0 +1,1058 @@
+"""A2CAgent: the rl_games continuous-PPO agent with the per-epoch hot path on MI355X kernels.
+
+Drop-in for `rl_games.algos_torch.a2c_continuous.A2CAgent` (rl_games/algos_torch/
+a2c_continuous.py:12-257) and its bases `ContinuousA2CBase` / `A2CBase`
+(rl_games/common/a2c_common.py:168-1202, :1482-1782) behind the same plugin seam:
+
+    runner.algo_factory.register_builder('a2c_continuous', lambda **kw: A2CAgent(**kw))
+    agent = A2CAgent(base_name='run', params=params);  agent.train()
+
+Same constructor (`base_name`, `params` dict with the reference's config keys), same public
+methods and attributes: init_tensors, env_reset, play_steps, play_steps_rnn,
+prepare_dataset, dataset[i], train_actor_critic, calc_gradients, train_epoch, train,
+get_action_values, get_values, update_lr, save/restore, get/set_weights, get/set_param,
+experience_buffer.tensor_dict, game_rewards/game_lengths, value_mean_std, ...
+
+What runs where (per epoch):
+  rollout   : model forward on rocBLAS/hipBLASLt via torch; every buffer write of a step is ONE
+              launch (csrc/experience.hip); reward shaping, time-out bootstrap, episode
+              accumulators and meters are one launch per step + one per rollout, with no host
+              sync (the reference syncs twice per step: a2c_common.py:1039, algo_observer.py:42)
+  GAE       : one launch -> returns, advantages, fp64 moments (csrc/gae.hip)
+  dataset   : 2 launches (statistics, normalise); swap_and_flatten01 is a view
+  minibatch : obs normaliser 3 launches, fused loss fwd+bwd+KL 2 launches, clip+Adam+adaptive-lr
+              2 launches, one all-reduce; learning rate and KL stay on the device.
+"""
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import distributed as rdist
+from . import ops
+from .flat_optim import FlatAdam
+from .gae import compute_gae, gae_returns_advantages
+from .lr_control import AdaptiveScheduler, IdentityScheduler, LinearScheduler
+from .minibatch import PPODataset
+from .normalizers import GeneralizedMovingStats
+from .policy import PolicyBuilder
+from .rollout_buffer import ExperienceBuffer
+
+
+def swap_and_flatten01(arr):
+    """[H, N, ...] -> [N*H, ...], flat index env*H + t (a2c_common.py:33-40).  On the env-major
+    buffer views this is a zero-copy reshape."""
+    if arr is None:
+        return arr
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+def rescale_actions(low, high, action):
+    d = (high - low) / 2.0
+    m = (high + low) / 2.0
+    return action * d + m
+
+
+class NullObserver:
+    """AlgoObserver interface (rl_games/common/algo_observer.py:6-26) with no-op hooks."""
+
+    def before_init(self, base_name, config, experiment_name):
+        pass
+
+    def after_init(self, algo):
+        pass
+
+    def process_infos(self, infos, done_indices):
+        pass
+
+    def after_steps(self):
+        pass
+
+    def after_clear_stats(self):
+        pass
+
+    def after_print_stats(self, frame, epoch_num, total_time):
+        pass
+
+
+class NullWriter:
+    def add_scalar(self, *args, **kwargs):
+        pass
+
+    def flush(self):
+        pass
+
+
+def _make_writer(summaries_dir):
+    try:
+        from tensorboardX import SummaryWriter  # optional, like the reference (a2c_common.py:21)
+        return SummaryWriter(summaries_dir)
+    except Exception:
+        return NullWriter()
+
+
+class DeviceAverageMeter:
+    """AverageMeter (rl_games/algos_torch/torch_ext.py:326-352) whose running mean and size
+    live on the device and are updated by rlg_episode_meters_update; host reads are lazy."""
+
+    def __init__(self, in_shape, max_size, device, sizes, slot):
+        self.max_size = max_size
+        self.mean = torch.zeros(in_shape, dtype=torch.float32, device=device)
+        self._sizes = sizes
+        self._slot = slot
+
+    @property
+    def current_size(self):
+        return int(self._sizes[self._slot].item())
+
+    def __len__(self):
+        return self.current_size
+
+    def clear(self):
+        self._sizes[self._slot] = 0
+        self.mean.fill_(0)
+
+    def get_mean(self):
+        return self.mean.squeeze(0).cpu().numpy()
+
+    def update(self, values):
+        size = values.size()[0]
+        if size == 0:
+            return
+        new_mean = torch.mean(values.float(), dim=0)
+        size = int(np.clip(size, 0, self.max_size))
+        old_size = min(self.max_size - size, self.current_size)
+        size_sum = old_size + size
+        self._sizes[self._slot] = size_sum
+        self.mean = (self.mean * old_size + new_mean * size) / size_sum
+
+
+class A2CAgent:
+    def __init__(self, base_name, params):
+        self.config = config = params['config']
+        self.params = params
+        self.name = base_name
+        full_name = config.get('full_experiment_name', None)
+        self.experiment_name = full_name or (config['name'] + datetime.now().strftime('_%d-%H-%M-%S'))
+        features = config.get('features') or {}
+        self.algo_observer = features.get('observer') or NullObserver()
+        self.algo_observer.before_init(base_name, config, self.experiment_name)
+        self.network = config['network'] = PolicyBuilder(params)          # load_networks :516-525
+        if config.get('central_value_config') is not None:
+            raise NotImplementedError('central_value_config is outside the MI355X hot path (SURVEY 2, row 16)')
+        if config.get('use_action_masks', False):
+            raise NotImplementedError('action masks are not implemented for continuous actions')
+
+        # ---- ranks / device (a2c_common.py:193-220) ----
+        self.multi_gpu = config.get('multi_gpu', False)
+        self.multi_gpu_sync_stats = config.get('multi_gpu_sync_stats', True)
+        self.multi_gpu_sync_stats_mode = rdist.resolve_stats_sync_mode(
+            config.get('multi_gpu_sync_stats_mode', 'pooled'))
+        self.local_rank = self.global_rank = 0
+        self.world_size = 1
+        if self.multi_gpu:
+            self.local_rank, self.global_rank, self.world_size = rdist.env_ranks()
+            config['device'] = 'cuda:' + str(self.local_rank)
+            torch.cuda.set_device(self.local_rank)
+            rdist.init_process_group(True)
+            if self.global_rank != 0:
+                config['print_stats'] = False
+        self.ppo_device = config.get('device', 'cuda:0')
+        if not str(self.ppo_device).startswith('cuda'):
+            raise RuntimeError(f"rl_games_amd.A2CAgent runs on an MI355X HIP device only, got device "
+                               f"'{self.ppo_device}' (there is no CPU fallback)")
+
+        # ---- environment (a2c_common.py:228-241) ----
+        self.env_config = config.get('env_config', {})
+        self.num_actors = config['num_actors']
+        self.env_name = config.get('env_name', 'synthetic')
+        self.env_info = config.get('env_info')
+        self.vec_env = config.get('vec_env', None)
+        if self.env_info is None:
+            if self.vec_env is None:
+                from .synthetic_env import SyntheticTensorEnv
+                self.vec_env = SyntheticTensorEnv(self.num_actors, device=self.ppo_device, **self.env_config)
+            self.env_info = self.vec_env.get_env_info()
+        self.value_size = self.env_info.get('value_size', 1)
+        self.observation_space = self.env_info['observation_space']
+        self.num_agents = self.env_info.get('agents', 1)
+        self.weight_decay = config.get('weight_decay', 0.0)
+        self.has_central_value = False
+        self.use_action_masks = False
+        self.is_train = config.get('is_train', True)
+
+        self.save_freq = config.get('save_frequency', 0)
+        self.save_best_after = config.get('save_best_after', 100)
+        self.print_stats = config.get('print_stats', True)
+        self.epochs_between_resets = config.get('epochs_between_resets', 0)
+        self.rnn_states = None
+        self.ppo = config.get('ppo', True)
+        if not self.ppo:
+            raise NotImplementedError('ppo: False (plain A2C loss) is not implemented')
+        self.max_epochs = config.get('max_epochs', -1)
+        self.max_frames = max(config.get('max_frames', -1), config.get('max_steps', -1))
+        self.stop_fn = config.get('stop_fn', None)
+        if self.stop_fn is not None and not callable(self.stop_fn):
+            raise ValueError(f"'stop_fn' must be callable, got {type(self.stop_fn).__name__}")
+
+        # ---- lr schedule (a2c_common.py:286-332) ----
+        lr_schedule = config.get('lr_schedule')
+        self.is_adaptive_lr = lr_schedule == 'adaptive'
+        self.linear_lr = lr_schedule == 'linear'
+        self.schedule_type = config.get('schedule_type', 'per_minibatch')
+        if self.schedule_type == 'legacy':
+            self.schedule_type = 'per_minibatch'
+        if self.is_adaptive_lr:
+            self.kl_threshold = config['kl_threshold']
+            self.scheduler = AdaptiveScheduler(self.kl_threshold, min_lr=config.get('min_lr', 1e-6),
+                                               max_lr=config.get('max_lr', 1e-2),
+                                               lr_multiplier=config.get('lr_multiplier', 1.5))
+        elif self.linear_lr:
+            if self.max_epochs == -1 and self.max_frames == -1:
+                self.scheduler = IdentityScheduler()
+            else:
+                use_epochs = self.max_epochs != -1
+                self.scheduler = LinearScheduler(
+                    float(config['learning_rate']), min_lr=config.get('min_lr', 1e-6),
+                    max_steps=self.max_epochs if use_epochs else self.max_frames, use_epochs=use_epochs,
+                    apply_to_entropy=config.get('schedule_entropy', False),
+                    start_entropy_coef=config.get('entropy_coef'))
+        else:
+            self.scheduler = IdentityScheduler()
+
+        self.e_clip = config['e_clip']
+        self.clip_value = config['clip_value']
+        self.rewards_shaper = config.get('reward_shaper', {})
+        self.autoreset_mode = (self.env_info or {}).get('autoreset_mode', 'same_step')
+        self.mask_autoreset_rows = self.autoreset_mode == 'next_step'
+        self._autoreset_prev_dones = None
+        if self.mask_autoreset_rows and self.num_agents > 1:
+            raise ValueError('PPO next_step autoreset masking does not support multi-agent envs; '
+                             'wrap the env with a same_step autoreset adapter instead')
+        self.horizon_length = config['horizon_length']
+        self.seq_length = config.get('seq_length', 4)
+        self.bptt_len = config.get('bptt_length', self.seq_length)
+        self.zero_rnn_on_done = config.get('zero_rnn_on_done', True)
+        self.normalize_advantage = config['normalize_advantage']
+        self.normalize_rms_advantage = config.get('normalize_rms_advantage', False)
+        self.normalize_input = config['normalize_input']
+        self.normalize_value = config.get('normalize_value', False)
+        self.truncate_grads = config.get('truncate_grads', False)
+        if type(self.observation_space).__name__ == 'Dict':
+            raise NotImplementedError('dict observations are not implemented on the MI355X hot path')
+        self.obs_shape = self.observation_space.shape
+        self.critic_coef = config['critic_coef']
+        self.grad_norm = config['grad_norm']
+        self.gamma = config['gamma']
+        self.tau = config['tau']
+        self.games_to_track = config.get('games_to_track', 100)
+
+        self.batch_size = self.horizon_length * self.num_actors * self.num_agents
+        self.batch_size_envs = self.horizon_length * self.num_actors
+        if 'minibatch_size' not in config and 'minibatch_size_per_env' not in config:
+            raise ValueError("Configuration must include either 'minibatch_size' or 'minibatch_size_per_env'. "
+                             'Neither was found in the provided config.')
+        self.minibatch_size_per_env = config.get('minibatch_size_per_env', 0)
+        self.minibatch_size = config.get('minibatch_size', self.num_actors * self.minibatch_size_per_env)
+        if self.minibatch_size <= 0:
+            raise ValueError(f"'minibatch_size' must be greater than 0. Calculated value: {self.minibatch_size}.")
+        self.games_num = self.minibatch_size // self.seq_length
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        if self.batch_size % self.minibatch_size != 0:
+            raise ValueError(f"'batch_size' ({self.batch_size}) must be divisible by 'minibatch_size' "
+                             f'({self.minibatch_size}).')
+        self.mini_epochs_num = config['mini_epochs']
+        self.mixed_precision = False
+        if config.get('mixed_precision', False):
+            print('rl_games_amd: mixed_precision requested - this path computes in fp32 (parity); ignoring')
+        self.last_lr = float(config['learning_rate'])
+        self.frame = 0
+        self.update_time = 0
+        self.mean_rewards = self.last_mean_rewards = -float('inf')
+        self.play_time = 0
+        self.epoch_num = 0
+        self.curr_frames = 0
+        self.train_dir = config.get('train_dir', 'runs')
+        self.experiment_dir = os.path.join(self.train_dir, self.experiment_name)
+        self.nn_dir = os.path.join(self.experiment_dir, 'nn')
+        self.summaries_dir = os.path.join(self.experiment_dir, 'summaries')
+        self._dirs_made = False
+        self.entropy_coef = config['entropy_coef']
+        self.writer = None
+        self.value_bootstrap = config.get('value_bootstrap', True)
+        self.use_smooth_clamp = config.get('use_smooth_clamp', False)
+        self.is_tensor_obses = False
+        self.aux_loss_dict = {}
+
+        # ---- ContinuousA2CBase.__init__ (a2c_common.py:1484-1498) ----
+        self.is_discrete = False
+        action_space = self.env_info['action_space']
+        self.actions_num = action_space.shape[0]
+        self.bounds_loss_coef = config.get('bounds_loss_coef', None)
+        self.clip_actions = config.get('clip_actions', True)
+        dev = self.ppo_device
+        self.actions_low = torch.from_numpy(np.asarray(action_space.low).copy()).float().to(dev)
+        self.actions_high = torch.from_numpy(np.asarray(action_space.high).copy()).float().to(dev)
+
+        # ---- A2CAgent.__init__ (a2c_continuous.py:18-76) ----
+        build_config = {
+            'actions_num': self.actions_num, 'input_shape': self.obs_shape,
+            'num_seqs': self.num_actors * self.num_agents, 'value_size': self.value_size,
+            'normalize_value': self.normalize_value, 'normalize_input': self.normalize_input,
+        }
+        self.model = self.network.build(build_config)
+        self.model.to(dev)
+        self.states = None
+        self.is_rnn = self.model.is_rnn()
+        self.bound_loss_type = config.get('bound_loss_type', 'bound')
+        self.optimizer = FlatAdam(self.model.parameters(), self.last_lr, eps=1e-08,
+                                  weight_decay=self.weight_decay)
+        self.dataset = PPODataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn,
+                                  dev, self.seq_length)
+        if self.normalize_value:
+            self.value_mean_std = self.model.value_mean_std
+        if self.normalize_advantage and self.normalize_rms_advantage:
+            momentum = config.get('adv_rms_momentum', 0.5)
+            self.advantage_mean_std = GeneralizedMovingStats((1,), decay=momentum).to(dev)
+        self.has_value_loss = True
+
+        # device-side episode meters (game_rewards / game_shaped_rewards / game_lengths)
+        self._meter_sizes = torch.zeros(3, dtype=torch.int32, device=dev)
+        self._finished_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.game_rewards = DeviceAverageMeter(self.value_size, self.games_to_track, dev, self._meter_sizes, 0)
+        self.game_shaped_rewards = DeviceAverageMeter(self.value_size, self.games_to_track, dev,
+                                                      self._meter_sizes, 1)
+        self.game_lengths = DeviceAverageMeter(1, self.games_to_track, dev, self._meter_sizes, 2)
+        self.obs = None
+
+        # per-minibatch scratch
+        A = self.actions_num
+        mb = self.minibatch_size
+        self._d_mu = torch.empty(mb, A, dtype=torch.float32, device=dev)
+        self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
+        self._loss_blocks = ops.ppo_loss_blocks(mb)
+        self._loss_partials = torch.empty(self._loss_blocks, 6 + A, dtype=torch.float64, device=dev)
+        self._mb_scalars = torch.zeros(max(1, self.mini_epochs_num * self.num_minibatches), 8,
+                                       dtype=torch.float32, device=dev)
+        self._mb_index = 0
+        self._prep_stats = ops.prepare_stats_buffer(dev)
+        self._obs_norm = None
+        self._host_lr = self.last_lr
+        self.train_result = None
+        self.algo_observer.after_init(self)
+
+    # ================================================================== small helpers
+    @property
+    def device(self):
+        return self.ppo_device
+
+    def _ensure_dirs(self):
+        if not self._dirs_made:
+            for d in (self.train_dir, self.experiment_dir, self.nn_dir, self.summaries_dir):
+                os.makedirs(d, exist_ok=True)
+            if self.global_rank == 0:
+                self.writer = _make_writer(self.summaries_dir)
+            self._dirs_made = True
+
+    def _shaper_params(self):
+        s = self.rewards_shaper
+        get = (lambda k, d: s.get(k, d)) if isinstance(s, dict) else (lambda k, d: getattr(s, k, d))
+        if get('log_val', False):
+            raise NotImplementedError('reward_shaper log_val is not implemented in the post-step kernel')
+        return (float(get('shift_value', 0)), float(get('scale_value', 1)),
+                float(get('min_val', -np.inf)), float(get('max_val', np.inf)))
+
+    def _uses_observer_infos(self):
+        fn = getattr(type(self.algo_observer), 'process_infos', None)
+        return fn is not None and fn is not NullObserver.process_infos and \
+            getattr(fn, '__qualname__', '').split('.')[0] != 'AlgoObserver'
+
+    def update_epoch(self):
+        self.epoch_num += 1
+        return self.epoch_num
+
+    def set_eval(self):
+        self.model.eval()
+        if self.normalize_rms_advantage:
+            self.advantage_mean_std.eval()
+        if self.epochs_between_resets > 0 and self.epoch_num % self.epochs_between_resets == 0:
+            self.reset_envs()
+            rows = self.num_agents * self.num_actors
+            self.init_current_rewards(rows, (rows, self.value_size))
+
+    def set_train(self):
+        self.model.train()
+        if self.normalize_rms_advantage:
+            self.advantage_mean_std.train()
+
+    def update_lr(self, lr):
+        """a2c_common.py:564-576.  The per-minibatch adaptive schedule never calls this (the lr
+        moves on the device); host-driven schedules and user code do."""
+        self.last_lr = lr
+        self._host_lr = lr
+        self.optimizer.set_lr(lr)
+
+    def _sync_lr_to_host(self):
+        self.last_lr = self.optimizer.current_lr()
+        return self.last_lr
+
+    # ================================================================== model queries
+    def _preproc_obs(self, obs_batch):
+        if obs_batch.dtype == torch.uint8:
+            obs_batch = obs_batch.float() / 255.0
+        return obs_batch
+
+    def get_action_values(self, obs):
+        processed_obs = self._preproc_obs(obs['obs'])
+        self.model.eval()
+        input_dict = {'is_train': False, 'prev_actions': None, 'obs': processed_obs,
+                      'rnn_states': self.rnn_states}
+        with torch.no_grad():
+            return self.model(input_dict)
+
+    def get_values(self, obs):
+        with torch.no_grad():
+            self.model.eval()
+            processed_obs = self._preproc_obs(obs['obs'])
+            input_dict = {'is_train': False, 'prev_actions': None, 'obs': processed_obs,
+                          'rnn_states': self.rnn_states}
+            return self.model(input_dict)['values']
+
+    def get_masked_action_values(self, obs, action_masks):
+        raise NotImplementedError('Masked action values are not implemented for continuous actions')
+
+    # ================================================================== env plumbing
+    def cast_obs(self, obs):
+        if isinstance(obs, torch.Tensor):
+            self.is_tensor_obses = True
+            if obs.device != torch.device(self.ppo_device):
+                obs = obs.to(self.ppo_device)
+        elif isinstance(obs, np.ndarray):
+            assert obs.dtype != np.int8
+            if obs.dtype == np.uint8:
+                obs = torch.from_numpy(obs).to(self.ppo_device)
+            else:
+                obs = torch.from_numpy(obs).float().to(self.ppo_device)
+        return obs
+
+    def obs_to_tensors(self, obs):
+        if isinstance(obs, dict):
+            upd = {k: self.cast_obs(v) for k, v in obs.items()}
+            return upd if 'obs' in obs else {'obs': upd}
+        return {'obs': self.cast_obs(obs)}
+
+    def preprocess_actions(self, actions):
+        if self.clip_actions:
+            clamped = torch.clamp(actions, -1.0, 1.0)
+            rescaled = rescale_actions(self.actions_low, self.actions_high, clamped)
+        else:
+            rescaled = actions
+        if not self.is_tensor_obses:
+            rescaled = rescaled.cpu().numpy()
+        return rescaled
+
+    def env_step(self, actions):
+        actions = self.preprocess_actions(actions)
+        obs, rewards, dones, infos = self.vec_env.step(actions)
+        dev = self.ppo_device
+        if not isinstance(rewards, torch.Tensor):
+            rewards = torch.from_numpy(np.asarray(rewards)).to(dev, dtype=torch.float32)
+            dones = torch.from_numpy(np.asarray(dones)).to(dev)
+        else:
+            rewards, dones = rewards.to(dev), dones.to(dev)
+        if self.value_size == 1 and rewards.dim() == 1:
+            rewards = rewards.unsqueeze(1)
+        return self.obs_to_tensors(obs), rewards, dones, infos
+
+    def env_reset(self):
+        obs = self.vec_env.reset()
+        obs = self.obs_to_tensors(obs)
+        self._autoreset_prev_dones = None
+        return obs
+
+    def reset_envs(self):
+        if self.is_rnn:
+            self.rnn_states = [s.to(self.ppo_device) for s in self.model.get_default_rnn_state()]
+        self.obs = self.env_reset()
+
+    # ================================================================== buffers
+    def init_tensors(self):
+        rows = self.num_agents * self.num_actors
+        algo_info = {'num_actors': self.num_actors, 'horizon_length': self.horizon_length,
+                     'has_central_value': False, 'use_action_masks': False}
+        self.experience_buffer = ExperienceBuffer(self.env_info, algo_info, self.ppo_device)
+        self.init_current_rewards(rows, (rows, self.value_size))
+        dev = self.ppo_device
+        self._post_blocks = ops.post_step_num_blocks(rows)
+        self._ep_partials = torch.zeros(self.horizon_length, self._post_blocks, 2 * self.value_size + 2,
+                                        dtype=torch.float64, device=dev)
+        B = self.batch_size
+        self._returns = torch.empty(rows, self.horizon_length, dtype=torch.float32, device=dev)
+        self._advantages = torch.empty(rows, self.horizon_length, dtype=torch.float32, device=dev)
+        self._norm_values = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        self._norm_returns = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        self._norm_advantages = torch.empty(B, dtype=torch.float32, device=dev)
+        from .gae import num_moment_partials
+        self._gae_partials = torch.empty(num_moment_partials(rows), 6, dtype=torch.float64, device=dev)
+        self.update_list = ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
+        self.tensor_list = self.update_list + ['obses', 'states', 'dones']
+        if self.is_rnn:
+            self.rnn_states = [s.to(dev) for s in self.model.get_default_rnn_state()]
+            num_seqs = self.horizon_length // self.seq_length
+            if (self.horizon_length * rows // self.num_minibatches) % self.seq_length != 0:
+                raise ValueError(f'Horizon length ({self.horizon_length}) times total agents ({rows}) divided by '
+                                 f'num minibatches ({self.num_minibatches}) must be divisible by sequence '
+                                 f'length ({self.seq_length})')
+            self.mb_rnn_states = [torch.zeros((num_seqs, s.size()[0], rows, s.size()[2]),
+                                              dtype=torch.float32, device=dev) for s in self.rnn_states]
+
+    def init_current_rewards(self, batch_size, current_rewards_shape):
+        dev = self.ppo_device
+        self.current_rewards = torch.zeros(current_rewards_shape, dtype=torch.float32, device=dev)
+        self.current_shaped_rewards = torch.zeros(current_rewards_shape, dtype=torch.float32, device=dev)
+        self.current_lengths = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        self.dones = torch.ones((batch_size,), dtype=torch.uint8, device=dev)
+
+    def discount_values(self, fdones, last_extrinsic_values, mb_fdones, mb_extrinsic_values, mb_rewards):
+        """a2c_common.py:729-734 (function seam kept for subclasses)."""
+        return compute_gae(mb_rewards, mb_extrinsic_values, mb_fdones, last_extrinsic_values, fdones,
+                           self.gamma, self.tau)
+
+    def clear_stats(self, clean_rewards=True):
+        self.game_rewards.clear()
+        self.game_shaped_rewards.clear()
+        self.game_lengths.clear()
+        if clean_rewards:
+            self.mean_rewards = self.last_mean_rewards = -float('inf')
+        self.algo_observer.after_clear_stats()
+
+    # ================================================================== rollout
+    def _as_u8(self, dones):
+        if dones.dtype == torch.uint8:
+            return dones
+        if dones.dtype == torch.bool:
+            return dones.view(torch.uint8)
+        return (dones != 0).to(torch.uint8)
+
+    def _rollout_step_tail(self, n, res_dict, rewards, infos, mb_valid):
+        """Everything after vec_env.step for step n (a2c_common.py:1021-1051)."""
+        buf = self.experience_buffer
+        time_outs = None
+        if self.value_bootstrap and isinstance(infos, dict) and 'time_outs' in infos:
+            time_outs = self.cast_obs(infos['time_outs'])
+            if time_outs.dtype not in (torch.uint8, torch.bool, torch.float32):
+                time_outs = time_outs.float()
+        values = res_dict['values']
+        if not values.is_contiguous():
+            values = values.contiguous()
+        if not rewards.is_contiguous():
+            rewards = rewards.contiguous()
+        live = None if mb_valid is None else mb_valid[n]
+        ops.rollout_post_step(rewards.float() if rewards.dtype != torch.float32 else rewards, self.dones,
+                              time_outs, values, live, buf.storage['rewards'], self.current_rewards,
+                              self.current_shaped_rewards, self.current_lengths, self._ep_partials,
+                              self._shaper, time_outs is not None, self.gamma, self.horizon_length, n)
+        if self._observer_needs_infos:
+            done_indices = self.dones.nonzero(as_tuple=False)[::self.num_agents]
+            self.algo_observer.process_infos(infos, done_indices)
+
+    def _finish_rollout(self, batch_dict, mb_valid, step_time):
+        buf = self.experience_buffer
+        H = self.horizon_length
+        rows = self.num_agents * self.num_actors
+        ops.episode_meters_update(self._ep_partials, H, self._post_blocks, self.value_size,
+                                  self.games_to_track, self.game_rewards.mean, self.game_shaped_rewards.mean,
+                                  self.game_lengths.mean, self._meter_sizes, self._finished_total)
+        last_values = self.get_values(self.obs)
+        if self.value_size == 1 and ops._lib.load().rlg_gae_envmajor_supported(H):
+            lv = last_values.reshape(-1).contiguous()
+            gae_returns_advantages(buf.storage['rewards'].view(rows, H), buf.storage['values'].view(rows, H),
+                                   buf.storage['dones'], lv, self.dones, self.gamma, self.tau,
+                                   out_returns=self._returns, out_advantages=self._advantages,
+                                   moment_partials=self._gae_partials)
+            batch_dict['returns'] = self._returns.view(rows * H, 1)
+            batch_dict['_fused'] = {'advantages': self._advantages.view(rows * H), 'partials': self._gae_partials}
+        else:
+            mb_advs = self.discount_values(self.dones, last_values, buf.tensor_dict['dones'],
+                                           buf.tensor_dict['values'], buf.tensor_dict['rewards'])
+            batch_dict['returns'] = swap_and_flatten01(mb_advs + buf.tensor_dict['values'])
+        batch_dict['played_frames'] = self.batch_size
+        batch_dict['step_time'] = step_time
+        if mb_valid is not None:
+            batch_dict['rnn_masks'] = swap_and_flatten01(mb_valid)
+        return batch_dict
+
+    def play_steps(self):
+        """a2c_common.py:985-1069."""
+        buf = self.experience_buffer
+        self._shaper = self._shaper_params()
+        self._observer_needs_infos = self._uses_observer_infos()
+        step_time = 0.0
+        mb_valid = None
+        if self.mask_autoreset_rows:
+            mb_valid = torch.ones((self.horizon_length, self.num_actors * self.num_agents),
+                                  dtype=torch.float32, device=self.ppo_device)
+        for n in range(self.horizon_length):
+            res_dict = self.get_action_values(self.obs)
+            fields = {'obses': self.obs['obs'], 'dones': self.dones}
+            for k in self.update_list:
+                fields[k] = res_dict[k]
+            buf.store_step(n, fields)
+            if mb_valid is not None:
+                prev = self._autoreset_prev_dones
+                if prev is None:
+                    prev = torch.zeros_like(self.dones)
+                mb_valid[n] = 1.0 - prev.float()
+            t0 = time.perf_counter()
+            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'])
+            self.dones = self._as_u8(dones)
+            if self.mask_autoreset_rows:
+                self._autoreset_prev_dones = self.dones.clone()
+            step_time += time.perf_counter() - t0
+            self._rollout_step_tail(n, res_dict, rewards, infos, mb_valid)
+        batch_dict = buf.get_transformed_list(swap_and_flatten01, self.tensor_list)
+        return self._finish_rollout(batch_dict, mb_valid, step_time)
+
+    def play_steps_rnn(self):
+        """a2c_common.py:1071-1202."""
+        buf = self.experience_buffer
+        self._shaper = self._shaper_params()
+        self._observer_needs_infos = self._uses_observer_infos()
+        step_time = 0.0
+        mb_valid = None
+        rows = self.num_actors * self.num_agents
+        if self.mask_autoreset_rows:
+            mb_valid = torch.ones((self.horizon_length, rows), dtype=torch.float32, device=self.ppo_device)
+        for n in range(self.horizon_length):
+            if n % self.seq_length == 0:
+                for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                    mb_s[n // self.seq_length, :, :, :] = s
+            res_dict = self.get_action_values(self.obs)
+            self.rnn_states = [s.contiguous() for s in res_dict['rnn_states']]
+            fields = {'obses': self.obs['obs'], 'dones': self.dones}
+            if mb_valid is not None:
+                prev = self._autoreset_prev_dones
+                if prev is None:
+                    prev = torch.zeros_like(self.dones)
+                mb_valid[n] = 1.0 - prev.float()
+                if self.zero_rnn_on_done:
+                    for s in self.rnn_states:
+                        ops.rnn_zero_done_states(s, prev)
+            for k in self.update_list:
+                fields[k] = res_dict[k]
+            buf.store_step(n, fields)
+            t0 = time.perf_counter()
+            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'])
+            self.dones = self._as_u8(dones)
+            if self.mask_autoreset_rows:
+                self._autoreset_prev_dones = self.dones.clone()
+            step_time += time.perf_counter() - t0
+            if self.zero_rnn_on_done:
+                for s in self.rnn_states:
+                    ops.rnn_zero_done_states(s, self.dones)
+            self._rollout_step_tail(n, res_dict, rewards, infos, mb_valid)
+        batch_dict = buf.get_transformed_list(swap_and_flatten01, self.tensor_list)
+        batch_dict = self._finish_rollout(batch_dict, mb_valid, step_time)
+        if mb_valid is not None and self.zero_rnn_on_done:
+            rnn_dones = buf.tensor_dict['dones'].clone()
+            garbage = (mb_valid == 0.0)
+            rnn_dones[1:] = torch.maximum(rnn_dones[1:], garbage[:-1].to(rnn_dones.dtype))
+            batch_dict['dones'] = swap_and_flatten01(rnn_dones)
+        states = []
+        for mb_s in self.mb_rnn_states:
+            t_size = mb_s.size()[0] * mb_s.size()[2]
+            h_size = mb_s.size()[3]
+            states.append(mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, h_size))
+        batch_dict['rnn_states'] = states
+        return batch_dict
+
+    # ================================================================== dataset
+    def prepare_dataset(self, batch_dict):
+        """a2c_common.py:1586-1660."""
+        returns = batch_dict['returns']
+        values = batch_dict['values']
+        rnn_masks = batch_dict.get('rnn_masks', None)
+        B = returns.shape[0]
+        if self.value_size != 1:
+            raise NotImplementedError('value_size > 1 is not implemented in prepare_dataset')
+        fused = batch_dict.get('_fused')
+        values_flat = values.reshape(-1)
+        returns_flat = returns.reshape(-1)
+        if not values_flat.is_contiguous():
+            values_flat = values_flat.contiguous()
+        if not returns_flat.is_contiguous():
+            returns_flat = returns_flat.contiguous()
+        mask = None
+        if rnn_masks is not None:
+            mask = rnn_masks.reshape(-1).float().contiguous()
+        if fused is not None and mask is None:
+            advantages, partials = fused['advantages'], fused['partials']
+        else:
+            advantages = returns_flat - values_flat                                     # :1598
+            partials = ops.triple_moments(advantages, values_flat, returns_flat, mask)
+        flags = 0
+        value_stats = None
+        if self.normalize_value:
+            flags |= ops.PREP_NORM_VALUE
+            if self.config.get('freeze_critic', False):
+                flags |= ops.PREP_FREEZE_CRITIC
+            m = self.value_mean_std
+            value_stats = (m.running_mean, m.running_var, m.count)
+        ema = None
+        if self.normalize_advantage:
+            if self.normalize_rms_advantage:
+                flags |= ops.PREP_EMA_ADV
+                ema = self.advantage_mean_std.kernel_state()
+            else:
+                flags |= ops.PREP_NORM_ADV
+        eps = self.value_mean_std.epsilon if self.normalize_value else 1e-5
+        if B > self._norm_values.shape[0]:
+            raise ValueError('batch larger than the allocated dataset buffers')
+        nv, nr, na = self._norm_values[:B], self._norm_returns[:B], self._norm_advantages[:B]
+        if flags:
+            ops.prepare_finalize(partials, B, flags, value_stats, eps, ema, self._prep_stats)
+        else:
+            self._prep_stats.zero_()
+        ops.prepare_apply(values_flat, returns_flat, advantages, flags, self._prep_stats,
+                          out=(nv.view(-1), nr.view(-1), na))
+        if self.normalize_value:
+            self.value_mean_std.eval()
+
+        dataset_dict = {
+            'old_values': nv, 'old_logp_actions': batch_dict['neglogpacs'], 'advantages': na,
+            'returns': nr, 'actions': batch_dict['actions'], 'obs': batch_dict['obses'],
+            'dones': batch_dict['dones'], 'rnn_states': batch_dict.get('rnn_states', None),
+            'rnn_masks': rnn_masks, 'mu': batch_dict['mus'], 'sigma': batch_dict['sigmas'],
+        }
+        self.dataset.update_values_dict(dataset_dict)
+
+    # ================================================================== update
+    def train_actor_critic(self, input_dict):
+        self.set_train()
+        self.calc_gradients(input_dict)
+        return self.train_result
+
+    def calc_gradients(self, input_dict):
+        """a2c_continuous.py:136-234 - forward, fused loss + analytic backward + KL, optimiser."""
+        opt = self.optimizer
+        net = self.model.a2c_network
+        obs_batch = self._preproc_obs(input_dict['obs'])
+        rnn_masks = input_dict.get('rnn_masks', None)
+        batch = {'is_train': True, 'prev_actions': input_dict['actions'], 'obs': obs_batch}
+        if self.is_rnn:
+            batch['rnn_states'] = input_dict['rnn_states']
+            batch['seq_length'] = self.seq_length
+            if self.zero_rnn_on_done:
+                batch['dones'] = input_dict['dones']
+
+        opt.zero_grad()
+        mu, logstd, values, _ = self.model.forward_heads(batch)
+        mb, A = mu.shape
+        row = self._mb_scalars[self._mb_index % self._mb_scalars.shape[0]]
+        self._mb_index += 1
+        mask = mask_sum = None
+        if rnn_masks is not None:
+            mask = rnn_masks.reshape(-1).float().contiguous()
+            mask_sum = mask.sum().reshape(1)
+        coef_b = self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0
+        kind = 0 if self.bounds_loss_coef is None else ops.BOUND_KINDS.get(self.bound_loss_type, 0)
+        d_mu, d_val = self._d_mu[:mb], self._d_val[:mb]
+        with torch.no_grad():
+            ops.ppo_loss_fused(
+                mu.detach(), logstd.detach(), values.detach().reshape(-1), input_dict['actions'],
+                input_dict['old_logp_actions'], input_dict['advantages'],
+                input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
+                input_dict['mu'], input_dict['sigma'], d_mu, d_val, self._loss_partials,
+                self.e_clip, self.critic_coef, coef_b, self.clip_value, self.use_smooth_clamp, kind,
+                True, mask, mask_sum)
+            ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
+                                  self.critic_coef, self.entropy_coef, coef_b, row, net.sigma.grad,
+                                  opt.kl_slot)
+        torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
+        self.trancate_gradients_and_step()
+        # dataset.update_mu_sigma happened inside the loss kernel (write_back)
+        self.train_result = (row[0], row[1], row[2], row[4], self._host_lr, 1.0,
+                             input_dict['mu'], input_dict['sigma'], row[3])
+
+    def trancate_gradients_and_step(self):
+        """a2c_common.py:493-514 (+ the per-minibatch lr control of :1557-1563)."""
+        opt = self.optimizer
+        scale = 1.0
+        if self.multi_gpu:
+            rdist.all_reduce_sum(opt.flat_grads)       # gradients + KL slot, one collective
+            scale = 1.0 / self.world_size
+        schedule = None
+        if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
+            s = self.scheduler
+            schedule = dict(kl_threshold=s.kl_threshold, min_lr=s.min_lr, max_lr=s.max_lr,
+                            lr_multiplier=s.lr_multiplier)
+        opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
+                 schedule=schedule, kl_scale=scale)
+
+    def _host_schedule(self, kl_value):
+        lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,
+                                                      self.frame, kl_value)
+        if lr != self._host_lr:
+            self.update_lr(lr)
+
+    def train_epoch(self):
+        """a2c_common.py:1517-1584."""
+        self.vec_env.set_train_info(self.frame, self)
+        self.set_eval()
+        play_time_start = time.perf_counter()
+        with torch.no_grad():
+            batch_dict = self.play_steps_rnn() if self.is_rnn else self.play_steps()
+        play_time_end = time.perf_counter()
+        update_time_start = time.perf_counter()
+        self.set_train()
+        self.curr_frames = batch_dict.pop('played_frames')
+        self.prepare_dataset(batch_dict)
+        self.algo_observer.after_steps()
+
+        a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
+        self._mb_index = 0
+        device_schedule = self.is_adaptive_lr and self.schedule_type == 'per_minibatch'
+        last_lr, lr_mul = self.last_lr, 1.0
+        for mini_ep in range(self.mini_epochs_num):
+            first = self._mb_index
+            for i in range(len(self.dataset)):
+                a_loss, c_loss, entropy, kl, last_lr, lr_mul, cmu, csigma, b_loss = \
+                    self.train_actor_critic(self.dataset[i])
+                a_losses.append(a_loss)
+                c_losses.append(c_loss)
+                entropies.append(entropy)
+                if self.bounds_loss_coef is not None:
+                    b_losses.append(b_loss)
+                if self.schedule_type == 'per_minibatch' and not device_schedule:
+                    self._host_schedule(None if not self.is_adaptive_lr else float(kl.item()))
+            av_kls = self._mb_scalars[first:self._mb_index, 4].mean()
+            if self.multi_gpu:
+                rdist.all_reduce_sum(av_kls)
+                av_kls /= self.world_size
+            if self.schedule_type == 'standard':
+                self._host_schedule(float(av_kls.item()))
+            kls.append(av_kls)
+            if self.normalize_input:
+                self.model.running_mean_std.eval()
+        if self.schedule_type == 'standard_epoch':
+            self._host_schedule(float(torch.stack(kls).mean().item()))
+        self.sync_running_stats()
+        if device_schedule:
+            last_lr = self._sync_lr_to_host()
+            self._host_lr = last_lr
+        else:
+            last_lr = self._host_lr
+        update_time_end = time.perf_counter()
+        play_time = play_time_end - play_time_start
+        update_time = update_time_end - update_time_start
+        total_time = update_time_end - play_time_start
+        return (batch_dict['step_time'], play_time, update_time, total_time, a_losses, c_losses, b_losses,
+                entropies, kls, last_lr, lr_mul)
+
+    # ================================================================== multi-GPU stats
+    def _stats_sync_modules(self):
+        mods = []
+        if self.normalize_input and hasattr(self.model, 'running_mean_std'):
+            mods.append(self.model.running_mean_std)
+        if self.normalize_value and getattr(self.model, 'value_mean_std', None) is not None:
+            mods.append(self.model.value_mean_std)
+        return mods
+
+    def _seed_stats_sync_snapshots(self):
+        if not self.multi_gpu or not self.multi_gpu_sync_stats or self.multi_gpu_sync_stats_mode == 'broadcast':
+            return
+        for m in self._stats_sync_modules():
+            rdist.seed_stats_sync_snapshot(m)
+
+    def sync_running_stats(self):
+        """a2c_common.py:782-808."""
+        if not self.multi_gpu or not self.multi_gpu_sync_stats:
+            return
+        import torch.distributed as dist
+        if self.multi_gpu_sync_stats_mode == 'broadcast':
+            for m in self._stats_sync_modules():
+                rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+            return
+        for m in self._stats_sync_modules():
+            rdist.merge_rank_stats(m, rdist.all_reduce_sum)
+
+    # ================================================================== weights / checkpoints
+    def get_stats_weights(self, model_stats=False):
+        state = {}
+        if self.normalize_rms_advantage:
+            state['advantage_mean_std'] = self.advantage_mean_std.state_dict()
+        if model_stats:
+            if self.normalize_input:
+                state['running_mean_std'] = self.model.running_mean_std.state_dict()
+            if self.normalize_value:
+                state['reward_mean_std'] = self.model.value_mean_std.state_dict()
+        return state
+
+    def set_stats_weights(self, weights):
+        if self.normalize_rms_advantage and 'advantage_mean_std' in weights:
+            self.advantage_mean_std.load_state_dict(weights['advantage_mean_std'])
+        if self.normalize_input and 'running_mean_std' in weights:
+            self.model.running_mean_std.load_state_dict(weights['running_mean_std'])
+        if self.normalize_value and 'reward_mean_std' in weights:
+            self.model.value_mean_std.load_state_dict(weights['reward_mean_std'])
+
+    def get_weights(self):
+        state = self.get_stats_weights()
+        state['model'] = self.model.state_dict()
+        return state
+
+    def set_weights(self, weights):
+        model_state = {k.replace('_orig_mod.', ''): v for k, v in weights['model'].items()}
+        self.model.load_state_dict(model_state)      # copy_ into the arena views: params stay flat
+        self.set_stats_weights(weights)
+        self._seed_stats_sync_snapshots()
+
+    def get_full_state_weights(self):
+        state = self.get_weights()
+        state['epoch'] = self.epoch_num
+        state['frame'] = self.frame
+        state['optimizer'] = self.optimizer.state_dict()
+        state['last_mean_rewards'] = self.last_mean_rewards
+        if self.vec_env is not None:
+            state['env_state'] = self.vec_env.get_env_state()
+        manifest = self.config.get('capability_manifest')
+        if manifest is not None:
+            state['capability_manifest'] = manifest
+        return state
+
+    def set_full_state_weights(self, weights, set_epoch=True):
+        self.set_weights(weights)
+        if set_epoch:
+            self.epoch_num = weights['epoch']
+            self.frame = weights['frame']
+        self.optimizer.load_state_dict(weights['optimizer'])
+        self._host_lr = self.last_lr = self.optimizer.param_groups[0]['lr']
+        self.last_mean_rewards = weights.get('last_mean_rewards', -float('inf'))
+        if self.vec_env is not None:
+            self.vec_env.set_env_state(weights.get('env_state', None))
+        if 'capability_manifest' in weights and self.config.get('capability_manifest') is None:
+            self.config['capability_manifest'] = weights['capability_manifest']
+        self._seed_stats_sync_snapshots()
+
+    def save(self, fn):
+        state = self.get_full_state_weights()
+        path = fn if fn.endswith('.pth') else fn + '.pth'
+        torch.save(state, path)                              # torch_ext.save_checkpoint :73-92
+        return path
+
+    def restore(self, fn, set_epoch=True):
+        checkpoint = torch.load(fn, map_location=self.ppo_device, weights_only=False)
+        self.set_full_state_weights(checkpoint, set_epoch=set_epoch)
+
+    def restore_central_value_function(self, fn):
+        raise NotImplementedError('central value function is outside the MI355X hot path')
+
+    def get_param(self, param_name):
+        if param_name in ('grad_norm', 'critic_coef', 'bounds_loss_coef', 'entropy_coef', 'kl_threshold',
+                          'gamma', 'tau', 'mini_epochs_num', 'e_clip'):
+            return getattr(self, param_name)
+        if param_name == 'learning_rate':
+            return self._sync_lr_to_host()
+        raise NotImplementedError(f"Can't get param {param_name}")
+
+    def set_param(self, param_name, param_value):
+        if param_name in ('grad_norm', 'critic_coef', 'bounds_loss_coef', 'entropy_coef', 'gamma', 'tau',
+                          'mini_epochs_num', 'e_clip'):
+            setattr(self, param_name, param_value)
+        elif param_name == 'learning_rate':
+            if self.is_adaptive_lr:
+                raise NotImplementedError("Can't directly mutate LR on this schedule")
+            self.update_lr(param_value)
+        elif param_name == 'kl_threshold':
+            if not self.is_adaptive_lr:
+                raise NotImplementedError("Can't directly mutate kl threshold")
+            self.kl_threshold = param_value
+            self.scheduler.kl_threshold = param_value
+        else:
+            raise NotImplementedError(f'No param found for {param_value}')
+
+    # ================================================================== training loop
+    def train(self):
+        """a2c_common.py:1662-1782.  Returns (last_mean_rewards, epoch_num)."""
+        self._ensure_dirs()
+        self.init_tensors()
+        total_time = 0
+        self.obs = self.env_reset()
+        self.curr_frames = self.batch_size_envs
+        if self.multi_gpu:
+            import torch.distributed as dist
+            dist.broadcast(self.optimizer.flat_params, 0)                 # C2 without pickling
+            for m in self._stats_sync_modules():
+                rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+        while True:
+            epoch_num = self.update_epoch()
+            (step_time, play_time, update_time, sum_time, a_losses, c_losses, b_losses, entropies, kls,
+             last_lr, lr_mul) = self.train_epoch()
+            total_time += sum_time
+            curr_frames = self.curr_frames * self.world_size if self.multi_gpu else self.curr_frames
+            self.frame += curr_frames
+            frame = self.frame // self.num_agents
+            self.dataset.update_values_dict(None)
+            should_exit = False
+            if self.global_rank == 0:
+                if self.print_stats:
+                    fps_step = curr_frames / max(step_time, 1e-9)
+                    fps_inf = curr_frames / (self.num_agents * play_time)
+                    fps_total = curr_frames / (self.num_agents * sum_time)
+                    print(f'fps step: {fps_step:.0f} fps step and policy inference: {fps_inf:.0f} '
+                          f'fps total: {fps_total:.0f} epoch: {epoch_num:.0f}/{self.max_epochs:.0f} '
+                          f'frames: {frame:.0f}/{self.max_frames:.0f}')
+                w = self.writer
+                w.add_scalar('performance/step_inference_rl_update_fps', curr_frames / sum_time, frame)
+                w.add_scalar('performance/step_inference_fps', curr_frames / play_time, frame)
+                w.add_scalar('performance/rl_update_time', update_time, frame)
+                w.add_scalar('performance/step_inference_time', play_time, frame)
+                if not isinstance(w, NullWriter):
+                    w.add_scalar('losses/a_loss', torch.stack(a_losses).mean().item(), frame)
+                    w.add_scalar('losses/c_loss', torch.stack(c_losses).mean().item(), frame)
+                    w.add_scalar('losses/entropy', torch.stack(entropies).mean().item(), frame)
+                    w.add_scalar('info/kl', torch.stack(kls).mean().item(), frame)
+                    if len(b_losses) > 0:
+                        w.add_scalar('losses/bounds_loss', torch.stack(b_losses).mean().item(), frame)
+                w.add_scalar('info/last_lr', last_lr * lr_mul, frame)
+                w.add_scalar('info/e_clip', self.e_clip * lr_mul, frame)
+                w.add_scalar('info/epochs', epoch_num, frame)
+                self.algo_observer.after_print_stats(frame, epoch_num, total_time)
+                mean_rewards = -np.inf
+                if self.game_rewards.current_size > 0:
+                    mean_rewards = self.game_rewards.get_mean()
+                    mean_lengths = self.game_lengths.get_mean()
+                    mean_rewards = np.atleast_1d(mean_rewards)
+                    self.mean_rewards = mean_rewards[0]
+                    w.add_scalar('rewards/step', mean_rewards[0], frame)
+                    w.add_scalar('rewards/iter', mean_rewards[0], epoch_num)
+                    w.add_scalar('episode_lengths/step', float(np.atleast_1d(mean_lengths)[0]), frame)
+                    checkpoint_name = self.config['name'] + '_ep_' + str(epoch_num) + '_rew_' + str(mean_rewards[0])
+                    if self.save_freq > 0 and epoch_num % self.save_freq == 0:
+                        self.save(os.path.join(self.nn_dir, 'last_' + checkpoint_name))
+                    if mean_rewards[0] > self.last_mean_rewards and epoch_num >= self.save_best_after:
+                        self.last_mean_rewards = mean_rewards[0]
+                        self.save(os.path.join(self.nn_dir, self.config['name']))
+                        if 'score_to_win' in self.config and self.last_mean_rewards > self.config['score_to_win']:
+                            self.save(os.path.join(self.nn_dir, checkpoint_name))
+                            should_exit = True
+                if epoch_num >= self.max_epochs and self.max_epochs != -1:
+                    self.save(os.path.join(self.nn_dir, 'last_' + self.config['name'] + '_ep_' + str(epoch_num)))
+                    should_exit = True
+                if self.frame >= self.max_frames and self.max_frames != -1:
+                    self.save(os.path.join(self.nn_dir, 'last_' + self.config['name'] + '_frame_' + str(self.frame)))
+                    should_exit = True
+                if not should_exit and self.stop_fn is not None and self.stop_fn(self):
+                    self.save(os.path.join(self.nn_dir, 'last_' + self.config['name'] + '_custom_stop_ep_'
+                                           + str(epoch_num)))
+                    should_exit = True
+            if self.multi_gpu:
+                import torch.distributed as dist
+                flag = torch.tensor(float(should_exit), device=self.ppo_device)
+                dist.broadcast(flag, 0)                                                   # C8
+                should_exit = bool(flag.item())
+            if should_exit:
+                return self.last_mean_rewards, epoch_num

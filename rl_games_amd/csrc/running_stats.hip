@@ -248,6 +248,34 @@ __global__ __launch_bounds__(256) void rms_apply_kernel(const float* __restrict_
 // prepare_dataset epilogue (value_size == 1): driven by the GAE kernel's partial moments
 // ---------------------------------------------------------------------------------
 
+// Generic producer of the {sum adv, sum adv^2, sum v, sum v^2, sum ret, sum ret^2[, sum mask]}
+// partials that prepare_finalize_kernel consumes, for batches that did not come out of the
+// fused GAE kernel (user-built batch_dict, masked rows).  With a mask every term is weighted
+// by it (binary masks: the moments of the valid rows).
+__global__ __launch_bounds__(256) void triple_moments_kernel(
+    const float* __restrict__ adv, const float* __restrict__ values,
+    const float* __restrict__ returns, const float* __restrict__ mask, long long B,
+    double* __restrict__ partials, int stride) {
+  __shared__ double scratch[7 * 4];
+  double m[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < B;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const double w = mask ? static_cast<double>(mask[i]) : 1.0;
+    const double a = adv[i], v = values[i], r = returns[i];
+    m[0] += a * w;
+    m[1] += a * a * w;
+    m[2] += v * w;
+    m[3] += v * v * w;
+    m[4] += r * w;
+    m[5] += r * r * w;
+    m[6] += w;
+  }
+  block_sum<7, 256>(m, scratch);
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < stride; ++k) partials[static_cast<long long>(blockIdx.x) * stride + k] = m[k];
+  }
+}
+
 struct PrepareStats {
   // written by prepare_finalize_kernel, read by prepare_apply_kernel
   float v_mean, v_denom;       // value normaliser after the `values` update
@@ -263,7 +291,8 @@ constexpr int kPrepFreezeCritic = 4;   // freeze_critic: normalise with frozen s
 constexpr int kPrepEmaAdv = 8;         // normalize_rms_advantage (GeneralizedMovingStats mean_std)
 
 __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials, int ntiles,
-                                        long long B, int flags, double* __restrict__ running_mean,
+                                        int stride, long long B, int flags,
+                                        double* __restrict__ running_mean,
                                         double* __restrict__ running_var,
                                         long long* __restrict__ count, float eps,
                                         float* __restrict__ ema_mean, float* __restrict__ ema_sqrs,
@@ -271,11 +300,16 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
                                         float ema_max, float ema_eps,
                                         PrepareStats* __restrict__ out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  double m[6] = {0, 0, 0, 0, 0, 0};
+  double m[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int t = 0; t < ntiles; ++t) {
-    for (int k = 0; k < 6; ++k) m[k] += gae_partials[static_cast<long long>(t) * 6 + k];
+    for (int k = 0; k < stride; ++k) m[k] += gae_partials[static_cast<long long>(t) * stride + k];
   }
-  const double n = static_cast<double>(B);
+  // stride 7 = masked batch: statistics of the valid rows only (a2c_common.py:1605-1615,
+  // torch_ext.py:172-191); n_valid rows feed the value normaliser's count.
+  const bool masked = stride == 7;
+  const double n_rows = masked ? m[6] : static_cast<double>(B);
+  const double n = masked ? fmax(m[6], 1.0) : static_cast<double>(B);
+  const long long n_count = masked ? static_cast<long long>(m[6]) : B;
   PrepareStats st = {0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f};
   if (flags & kPrepNormValue) {
     double mean = running_mean[0], var = running_var[0];
@@ -284,8 +318,8 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
       // values first (a2c_common.py:1617-1618) ...
       double bm = static_cast<double>(static_cast<float>(m[2] / n));
       double bv = static_cast<double>(static_cast<float>(fmax(m[3] / n - (m[2] / n) * (m[2] / n), 0.0)));
-      chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n);
-      cnt += B;
+      if (n_rows > 0.0) chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n_rows);
+      cnt += n_count;
     }
     st.v_mean = static_cast<float>(mean);
     st.v_denom = sqrt_rn(static_cast<float>(var) + eps);
@@ -293,8 +327,8 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
       // ... then returns (:1619), a second, separate merge
       double bm = static_cast<double>(static_cast<float>(m[4] / n));
       double bv = static_cast<double>(static_cast<float>(fmax(m[5] / n - (m[4] / n) * (m[4] / n), 0.0)));
-      chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n);
-      cnt += B;
+      if (n_rows > 0.0) chan_merge(mean, var, static_cast<double>(cnt), bm, bv, n_rows);
+      cnt += n_count;
       running_mean[0] = mean;
       running_var[0] = var;
       *count = cnt;
@@ -304,75 +338,84 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
   }
   if (flags & kPrepEmaAdv) {
     // moving_mean_std.py:119-122 (_update_stats 'mean_std'), :57-61 (_get_stats)
-    const float x_mean = static_cast<float>(m[0] / n);
-    const float x_sqr = static_cast<float>(m[1] / n);
-    *ema_step += 1;
-    const float factor = ema_factor;  // fp32(1 - decay), rounded from the Python double
-    float mean = ema_mean[0] * ema_decay;
-    mean = mean + factor * x_mean;
-    float sqrs = ema_sqrs[0] * ema_decay;
-    sqrs = sqrs + factor * x_sqr;
-    ema_mean[0] = mean;
-    ema_sqrs[0] = sqrs;
+    float mean = ema_mean[0], sqrs = ema_sqrs[0];
+    if (n_rows > 0.0) {   // an all-masked batch leaves the statistics untouched (:108-112)
+      const float x_mean = static_cast<float>(m[0] / n);
+      const float x_sqr = static_cast<float>(m[1] / n);
+      *ema_step += 1;
+      const float factor = ema_factor;  // fp32(1 - decay), rounded from the Python double
+      mean = mean * ema_decay;
+      mean = mean + factor * x_mean;
+      sqrs = sqrs * ema_decay;
+      sqrs = sqrs + factor * x_sqr;
+      ema_mean[0] = mean;
+      ema_sqrs[0] = sqrs;
+    }
     const float var = sqrs - mean * mean;
     st.a_mean = mean;
     st.a_denom = sqrt_rn(fmaxf(var, 1.0f / (ema_max * ema_max)) + ema_eps);
   } else if (flags & kPrepNormAdv) {
     // advantages.mean(), advantages.std() (unbiased) + 1e-8                  a2c_common.py:1634
     const double mean = m[0] / n;
-    const double var = (n > 1.0) ? fmax(m[1] - n * mean * mean, 0.0) / (n - 1.0) : 0.0;
+    double var;
+    if (masked) {
+      // get_mean_var_with_masks: (sum (a m)^2/sm - mean^2) * sm / max(sm - 1, 1)
+      var = fmax(m[1] / n - mean * mean, 0.0) * n / fmax(n - 1.0, 1.0);
+    } else {
+      var = (n > 1.0) ? fmax(m[1] - n * mean * mean, 0.0) / (n - 1.0) : 0.0;
+    }
     st.a_mean = static_cast<float>(mean);
     st.a_denom = static_cast<float>(sqrt(var)) + 1e-8f;
   }
   *out = st;
 }
 
-// values <- norm(values), returns <- norm(returns), advantages <- (adv - mean)/denom, in place.
-__global__ __launch_bounds__(256) void prepare_apply_kernel(float* __restrict__ values,
-                                                            float* __restrict__ returns,
-                                                            float* __restrict__ advantages,
-                                                            long long B4, long long B, int flags,
-                                                            const PrepareStats* __restrict__ stp) {
+// values_out = norm(values), returns_out = norm(returns), adv_out = (adv - mean)/denom.
+// Outputs may alias the inputs (in place).
+__global__ __launch_bounds__(256) void prepare_apply_kernel(
+    const float* __restrict__ values, const float* __restrict__ returns,
+    const float* __restrict__ advantages, float* __restrict__ values_out,
+    float* __restrict__ returns_out, float* __restrict__ adv_out, long long B4, long long B,
+    int flags, const PrepareStats* __restrict__ stp) {
   const PrepareStats st = *stp;
   const bool nv = flags & kPrepNormValue;
   const bool na = (flags & (kPrepNormAdv | kPrepEmaAdv)) != 0;
   const bool ema = flags & kPrepEmaAdv;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < B4;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    if (nv) {
-      f32x4 v = reinterpret_cast<f32x4*>(values)[i];
-      f32x4 r = reinterpret_cast<f32x4*>(returns)[i];
+    f32x4 v = reinterpret_cast<const f32x4*>(values)[i];
+    f32x4 r = reinterpret_cast<const f32x4*>(returns)[i];
+    f32x4 a = reinterpret_cast<const f32x4*>(advantages)[i];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 4; ++u) {
+      if (nv) {
         v[u] = fminf(fmaxf((v[u] - st.v_mean) / st.v_denom, -5.0f), 5.0f);
         r[u] = fminf(fmaxf((r[u] - st.r_mean) / st.r_denom, -5.0f), 5.0f);
       }
-      reinterpret_cast<f32x4*>(values)[i] = v;
-      reinterpret_cast<f32x4*>(returns)[i] = r;
-    }
-    if (na) {
-      f32x4 a = reinterpret_cast<f32x4*>(advantages)[i];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      if (na) {
         a[u] = (a[u] - st.a_mean) / st.a_denom;
         if (ema) a[u] = fminf(fmaxf(a[u], -5.0f), 5.0f);
       }
-      reinterpret_cast<f32x4*>(advantages)[i] = a;
     }
+    reinterpret_cast<f32x4*>(values_out)[i] = v;
+    reinterpret_cast<f32x4*>(returns_out)[i] = r;
+    reinterpret_cast<f32x4*>(adv_out)[i] = a;
   }
-  // tail (B not a multiple of 4)
-  const long long tail0 = B4 * 4;
-  const long long i = tail0 + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // tail (B not a multiple of 4, or unaligned bases)
+  const long long i = B4 * 4 + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < B) {
+    float v = values[i], r = returns[i], a = advantages[i];
     if (nv) {
-      values[i] = fminf(fmaxf((values[i] - st.v_mean) / st.v_denom, -5.0f), 5.0f);
-      returns[i] = fminf(fmaxf((returns[i] - st.r_mean) / st.r_denom, -5.0f), 5.0f);
+      v = fminf(fmaxf((v - st.v_mean) / st.v_denom, -5.0f), 5.0f);
+      r = fminf(fmaxf((r - st.r_mean) / st.r_denom, -5.0f), 5.0f);
     }
     if (na) {
-      float a = (advantages[i] - st.a_mean) / st.a_denom;
+      a = (a - st.a_mean) / st.a_denom;
       if (ema) a = fminf(fmaxf(a, -5.0f), 5.0f);
-      advantages[i] = a;
     }
+    values_out[i] = v;
+    returns_out[i] = r;
+    adv_out[i] = a;
   }
 }
 
@@ -443,31 +486,61 @@ int rlg_rms_apply(const float* x, float* y, long long rows, int cols, const doub
 
 int rlg_prepare_stats_bytes(void) { return static_cast<int>(sizeof(rlg::PrepareStats)); }
 
-int rlg_prepare_finalize(const double* gae_partials, int num_tiles, long long batch, int flags,
+int rlg_triple_moments_num_blocks(long long batch) {
+  long long b = (batch + 256 * 8 - 1) / (256 * 8);
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  return static_cast<int>(b);
+}
+
+int rlg_triple_moments(const float* advantages, const float* values, const float* returns,
+                       const float* mask_or_null, long long batch, double* partials, int num_blocks,
+                       void* stream) {
+  if (batch <= 0) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::triple_moments_kernel, dim3(num_blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), advantages, values, returns, mask_or_null,
+                     batch, partials, mask_or_null ? 7 : 6);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_prepare_finalize(const double* gae_partials, int num_tiles, int stride, long long batch,
+                         int flags,
                          double* value_running_mean, double* value_running_var,
                          long long* value_count, float eps, float* ema_mean, float* ema_sqrs,
                          int* ema_step, float ema_decay, float ema_factor, float ema_max,
                          float ema_eps, void* stats_out, void* stream) {
+  if (stride != 6 && stride != 7) return static_cast<int>(hipErrorInvalidValue);
   hipLaunchKernelGGL(rlg::prepare_finalize_kernel, dim3(1), dim3(64), 0,
-                     static_cast<hipStream_t>(stream), gae_partials, num_tiles, batch, flags,
+                     static_cast<hipStream_t>(stream), gae_partials, num_tiles, stride, batch, flags,
                      value_running_mean, value_running_var, value_count, eps, ema_mean, ema_sqrs,
                      ema_step, ema_decay, ema_factor, ema_max, ema_eps,
                      static_cast<rlg::PrepareStats*>(stats_out));
   RLG_RETURN_LAUNCH_STATUS();
 }
 
-int rlg_prepare_apply(float* values, float* returns, float* advantages, long long batch, int flags,
-                      const void* stats, void* stream) {
+int rlg_prepare_apply(const float* values, const float* returns, const float* advantages,
+                      float* values_out, float* returns_out, float* advantages_out, long long batch,
+                      int flags, const void* stats, void* stream) {
   if (batch <= 0) return 0;
-  const bool aligned = ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(returns) |
-                         reinterpret_cast<uintptr_t>(advantages)) % 16) == 0;
-  const long long b4 = aligned ? batch / 4 : 0;
-  long long work = b4 > (batch - b4 * 4) ? b4 : (batch - b4 * 4);
-  long long grid = (work + 255) / 256;
+  const uintptr_t all = reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(returns) |
+                        reinterpret_cast<uintptr_t>(advantages) |
+                        reinterpret_cast<uintptr_t>(values_out) |
+                        reinterpret_cast<uintptr_t>(returns_out) |
+                        reinterpret_cast<uintptr_t>(advantages_out);
+  const long long b4 = (all % 16 == 0) ? batch / 4 : 0;
+  const long long tail = batch - b4 * 4;
+  long long grid;
+  if (tail == 0) {
+    grid = (b4 + 255) / 256;
+    if (grid > 2048) grid = 2048;          // grid-stride over the vector part
+  } else {
+    const long long work = b4 > tail ? b4 : tail;
+    grid = (work + 255) / 256;             // the scalar tail needs one thread per element
+  }
   if (grid < 1) grid = 1;
-  if (grid > 2048 && b4 * 4 == batch) grid = 2048;   // grid-stride when there is no scalar tail
   hipLaunchKernelGGL(rlg::prepare_apply_kernel, dim3(static_cast<int>(grid)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), values, returns, advantages, b4, batch, flags,
+                     static_cast<hipStream_t>(stream), values, returns, advantages, values_out,
+                     returns_out, advantages_out, b4, batch, flags,
                      static_cast<const rlg::PrepareStats*>(stats));
   RLG_RETURN_LAUNCH_STATUS();
 }

@@ -1,0 +1,122 @@
+"""Flat parameter arena + fused clip/Adam step (csrc/optim.hip).
+
+Replaces the optimiser side of A2CBase.trancate_gradients_and_step
+(rl_games/common/a2c_common.py:493-514): the reference concatenates every `.grad` into a
+fresh buffer for the all-reduce and scatters it back, then runs clip_grad_norm_ and a foreach
+Adam.  Here parameters, gradients and both Adam moments are *views* of four contiguous fp32
+arenas created once, so
+  * the multi-GPU all-reduce runs in place on `flat_grads` (one collective, no cat/copy; one
+    extra tail slot carries the minibatch KL so the separate scalar all-reduce of
+    a2c_common.py:1560 and the lr broadcast of :569 are folded into it),
+  * clipping + Adam + the KL-adaptive learning-rate update are two launches.
+
+`state_dict()` / `load_state_dict()` use torch.optim.Adam's format, so the 'optimizer' entry
+of a checkpoint (a2c_common.py:829, :862) is interchangeable with the reference's.
+"""
+import torch
+
+from . import ops
+
+_TAIL = 4   # extra fp32 slots at the end of the gradient arena: [0] = minibatch KL
+
+
+class FlatAdam:
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError('no parameters')
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam runs on the MI355X only (no CPU fallback)')
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(self.numel + _TAIL, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            n = p.numel()
+            self.flat_params[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_params[off:off + n].view(p.shape)
+            p.grad = self.flat_grads[off:off + n].view(p.shape)
+            self.offsets.append((off, n))
+            off += n
+        self.grads = self.flat_grads[:self.numel]
+        self.kl_slot = self.flat_grads[self.numel:self.numel + 1]
+        self.step_count = 0
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        # two fp64 lr slots, ping-pong by step parity (see csrc/optim.hip)
+        self.lr_slots = torch.tensor([float(lr), float(lr)], dtype=torch.float64, device=dev)
+        self.cur = 0
+        self.norm_partials = torch.zeros(ops.grad_norm_blocks(self.numel), dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.param_groups = [{'params': self.params, 'lr': float(lr), 'betas': betas, 'eps': eps,
+                              'weight_decay': weight_decay}]
+
+    # ------------------------------------------------------------------ learning rate
+    def set_lr(self, lr):
+        """Host-driven lr (linear / identity schedules, restore): overwrites the live slot."""
+        self.lr_slots[self.cur] = float(lr)
+        self.param_groups[0]['lr'] = float(lr)
+
+    def current_lr(self):
+        """Reads the live lr back (one device->host sync; call once per epoch, not per step)."""
+        lr = float(self.lr_slots[self.cur].item())
+        self.param_groups[0]['lr'] = lr
+        return lr
+
+    # ------------------------------------------------------------------ step
+    def zero_grad(self, set_to_none=False):
+        self.flat_grads.zero_()
+
+    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
+        """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
+        schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
+        driven by the KL in `kl_slot` (times kl_scale)."""
+        self.step_count += 1
+        partials = None
+        if max_norm is not None:
+            partials = self.norm_partials
+            ops.grad_sumsq(self.grads, grad_scale, partials)
+        kw = {}
+        kind = 0
+        if schedule is not None:
+            kind = 1
+            kw = dict(kl_threshold=schedule['kl_threshold'], min_lr=schedule['min_lr'],
+                      max_lr=schedule['max_lr'], lr_multiplier=schedule['lr_multiplier'])
+        ops.adam_step(self.flat_params, self.grads, self.exp_avg, self.exp_avg_sq, partials,
+                      grad_scale, 0.0 if max_norm is None else max_norm, self.lr_slots, self.cur,
+                      self.step_count, betas=self.betas, eps=self.eps,
+                      weight_decay=self.weight_decay, schedule_kind=kind,
+                      kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats, **kw)
+        self.cur ^= 1
+
+    # ------------------------------------------------------------------ checkpoint format
+    def state_dict(self):
+        state = {}
+        for i, (off, n) in enumerate(self.offsets):
+            shape = self.params[i].shape
+            state[i] = {'step': torch.tensor(float(self.step_count)),
+                        'exp_avg': self.exp_avg[off:off + n].view(shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(shape).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        group.update(lr=self.current_lr(), amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=True, decoupled_weight_decay=False,
+                     params=list(range(len(self.params))))
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        st = sd.get('state', {})
+        steps = []
+        for i, (off, n) in enumerate(self.offsets):
+            if i not in st:
+                continue
+            self.exp_avg[off:off + n].copy_(st[i]['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st[i]['exp_avg_sq'].reshape(-1))
+            steps.append(int(float(st[i]['step'])))
+        if steps:
+            self.step_count = max(steps)
+        groups = sd.get('param_groups') or []
+        if groups:
+            self.set_lr(groups[0].get('lr', self.param_groups[0]['lr']))

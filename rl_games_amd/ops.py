@@ -177,7 +177,7 @@ def prepare_finalize(gae_partials, batch, flags, value_stats, eps, ema, stats_ou
         factor = float(np.float32(1 - ema['decay']))
         emax, eeps = float(ema['max']), float(ema['eps'])
     _lib.check(lib.rlg_prepare_finalize(
-        _need(gae_partials, F64, 'gae_partials'), gae_partials.shape[0], batch, flags,
+        _need(gae_partials, F64, 'gae_partials'), gae_partials.shape[0], gae_partials.shape[1], batch, flags,
         _opt(rm, F64, 'value running_mean'), _opt(rv, F64, 'value running_var'),
         _opt(cnt, torch.int64, 'value count'), float(np.float32(eps)), _opt(em, F32, 'ema mean'),
         _opt(es, F32, 'ema sqrs'), _opt(est, torch.int32, 'ema step'), decay, factor,
@@ -185,12 +185,28 @@ def prepare_finalize(gae_partials, batch, flags, value_stats, eps, ema, stats_ou
         _stream(gae_partials)), 'rlg_prepare_finalize')
 
 
-def prepare_apply(values, returns, advantages, flags, stats):
+def triple_moments(advantages, values, returns, mask=None):
+    """[blocks, 6 or 7] fp64 partial sums in the GAE-partials format."""
     lib = _lib.load()
     B = advantages.numel()
+    nb = lib.rlg_triple_moments_num_blocks(B)
+    part = torch.empty((nb, 7 if mask is not None else 6), dtype=F64, device=advantages.device)
+    _lib.check(lib.rlg_triple_moments(_need(advantages, F32, 'advantages'), _need(values, F32, 'values'),
+                                      _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'), B,
+                                      part.data_ptr(), nb, _stream(advantages)), 'rlg_triple_moments')
+    return part
+
+
+def prepare_apply(values, returns, advantages, flags, stats, out=None):
+    """out = (values_out, returns_out, advantages_out) or None for in place."""
+    lib = _lib.load()
+    B = advantages.numel()
+    vo, ro, ao = (values, returns, advantages) if out is None else out
     _lib.check(lib.rlg_prepare_apply(_need(values, F32, 'values'), _need(returns, F32, 'returns'),
-                                     _need(advantages, F32, 'advantages'), B, flags,
-                                     _need(stats, F32, 'stats'), _stream(values)), 'rlg_prepare_apply')
+                                     _need(advantages, F32, 'advantages'), _need(vo, F32, 'values_out'),
+                                     _need(ro, F32, 'returns_out'), _need(ao, F32, 'advantages_out'),
+                                     B, flags, _need(stats, F32, 'stats'), _stream(values)),
+               'rlg_prepare_apply')
 
 
 # ------------------------------------------------------------------ PPO loss

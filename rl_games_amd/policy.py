@@ -1,0 +1,295 @@
+"""Actor-critic policy used by the MI355X PPO agent.
+
+Host-side mirror of the part of the reference's model zoo that the BASELINE configs use:
+`ModelA2CContinuousLogStd` (rl_games/algos_torch/models.py:305-364) over the `actor_critic`
+network of `A2CBuilder` (rl_games/algos_torch/network_builder.py:218-589) - shared MLP trunk,
+`mu` / `value` heads, fixed-sigma parameter, optional LSTM/GRU after the MLP.  Module and
+parameter names match the reference (`a2c_network.actor_mlp.<2i>.weight`, `a2c_network.mu`,
+`a2c_network.value`, `a2c_network.sigma`, `running_mean_std.*`, `value_mean_std.*`), so
+`state_dict()`s are interchangeable with reference checkpoints.
+
+The GEMMs stay on rocBLAS/hipBLASLt through `torch.nn.Linear`; the
+normalisers and - in training - the whole distribution/loss epilogue run in the HIP kernels.
+`forward(input_dict)` keeps the reference's dict-in/dict-out contract; `forward_heads` is the
+raw (mu, logstd, value) path the fused loss kernel consumes.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .normalizers import RunningMeanStd
+
+_ACTIVATIONS = {
+    'relu': nn.ReLU, 'tanh': nn.Tanh, 'sigmoid': nn.Sigmoid, 'elu': nn.ELU, 'selu': nn.SELU,
+    'swish': nn.SiLU, 'gelu': nn.GELU, 'softplus': nn.Softplus, 'None': nn.Identity, None: nn.Identity,
+}
+
+
+def _activation(name):
+    if name not in _ACTIVATIONS:
+        raise ValueError(f'unknown activation {name}')
+    return _ACTIVATIONS[name]()
+
+
+def _initializer(spec):
+    """network_builder.py:60-70: name -> in-place init function."""
+    spec = dict(spec or {'name': 'default'})
+    name = spec.pop('name', 'default')
+    if name == 'default':
+        return lambda t: t
+    if name == 'const_initializer':
+        val = spec.get('val', spec.get('value', 0))
+        return lambda t: nn.init.constant_(t, val)
+    table = {
+        'orthogonal_initializer': nn.init.orthogonal_, 'orthogonal': nn.init.orthogonal_,
+        'glorot_normal_initializer': nn.init.xavier_normal_,
+        'glorot_uniform_initializer': nn.init.xavier_uniform_,
+        'random_uniform_initializer': nn.init.uniform_, 'kaiming_normal': nn.init.kaiming_normal_,
+    }
+    if name not in table:
+        raise NotImplementedError(f'initializer {name}')
+    fn = table[name]
+    return lambda t: fn(t, **spec)
+
+
+class RnnWithDones(nn.Module):
+    """LSTM/GRU that resets its state where `dones` is set, without the per-call `.cpu()`
+    done search of the reference (rl_games/common/layers/recurrent.py:26-58): the state is
+    multiplied by (1 - done) before every timestep, which yields the same outputs as running
+    the fused RNN between done positions.  Parameter names follow torch.nn.LSTM (`rnn.rnn.*`),
+    like the reference's wrapper."""
+
+    def __init__(self, kind, input_size, hidden_size, num_layers):
+        super().__init__()
+        self.kind = kind
+        cls = nn.LSTM if kind == 'lstm' else nn.GRU
+        self.rnn = cls(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+
+    def forward(self, x, states, dones=None, bptt_len=0):
+        # x: [T, B, F]; states: tuple (h, c) or (h,) / tensor
+        if self.kind == 'lstm':
+            st = tuple(states) if isinstance(states, (tuple, list)) else states
+        else:
+            st = states[0] if isinstance(states, (tuple, list)) else states
+        if dones is None:
+            return self.rnn(x, st)
+        outs = []
+        T = x.shape[0]
+        for t in range(T):
+            keep = (1.0 - dones[t].float()).reshape(1, -1, 1)
+            if self.kind == 'lstm':
+                st = (st[0] * keep, st[1] * keep)
+            else:
+                st = st * keep
+            o, st = self.rnn(x[t:t + 1], st)
+            outs.append(o)
+        return torch.cat(outs, dim=0), st
+
+
+class ActorCriticNetwork(nn.Module):
+    """`a2c_network`: MLP trunk (+ optional RNN after it) with mu / value heads."""
+
+    def __init__(self, net_params, actions_num, input_shape, value_size=1, num_seqs=1):
+        super().__init__()
+        if 'cnn' in net_params:
+            raise NotImplementedError('CNN encoders are outside the MI355X PPO hot path (SURVEY 2, row 15)')
+        self.separate = net_params.get('separate', False)
+        if self.separate:
+            raise NotImplementedError('separate actor/critic trunks are not implemented on this path')
+        space = net_params.get('space', {})
+        if 'continuous' not in space:
+            raise NotImplementedError('only continuous action spaces run on the fused HIP loss path')
+        self.space_config = space['continuous']
+        self.fixed_sigma = self.space_config['fixed_sigma']
+        if not self.fixed_sigma:
+            raise NotImplementedError('state-dependent sigma (fixed_sigma: False) is not implemented')
+        if self.space_config.get('sigma_parametrization', 'exp') != 'exp' or \
+                self.space_config.get('logstd_bounds') is not None or \
+                float(self.space_config.get('min_sigma', 0.0)) > 0:
+            raise NotImplementedError('only the plain exp sigma parametrisation is implemented')
+        mlp = net_params['mlp']
+        if mlp.get('d2rl', False) or net_params.get('normalization'):
+            raise NotImplementedError('d2rl / normalisation layers are not implemented on this path')
+        self.units = list(mlp['units'])
+        self.value_size = value_size
+        self.num_seqs = num_seqs
+        self.actions_num = actions_num
+        assert len(input_shape) == 1, 'flat observations only'
+        in_size = input_shape[0]
+
+        self.has_rnn = 'rnn' in net_params
+        layers = []
+        last = in_size
+        for u in self.units:
+            layers.append(nn.Linear(last, u))
+            layers.append(_activation(mlp['activation']))
+            last = u
+        self.actor_mlp = nn.Sequential(*layers)
+        out_size = last
+        if self.has_rnn:
+            rnn = net_params['rnn']
+            if rnn.get('before_mlp', False) or rnn.get('concat_input', False) or \
+                    rnn.get('concat_output', False) or rnn.get('layer_norm', False):
+                raise NotImplementedError('only the plain RNN-after-MLP layout is implemented')
+            self.rnn_name = rnn['name']
+            self.rnn_units = rnn['units']
+            self.rnn_layers = rnn['layers']
+            self.rnn = RnnWithDones(self.rnn_name, out_size, self.rnn_units, self.rnn_layers)
+            out_size = self.rnn_units
+        self.value = nn.Linear(out_size, value_size)
+        self.value_act = _activation(net_params.get('value_activation', 'None'))
+        self.mu = nn.Linear(out_size, actions_num)
+        self.mu_act = _activation(self.space_config['mu_activation'])
+        self.sigma_act = _activation(self.space_config['sigma_activation'])
+        self.sigma = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
+
+        mlp_init = _initializer(mlp['initializer'])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                mlp_init(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        _initializer(self.space_config['mu_init'])(self.mu.weight)
+        _initializer(self.space_config['sigma_init'])(self.sigma)
+
+    def is_rnn(self):
+        return self.has_rnn
+
+    def is_separate_critic(self):
+        return False
+
+    def get_value_layer(self):
+        return self.value
+
+    def get_aux_loss(self):
+        return None
+
+    def get_default_rnn_state(self):
+        if not self.has_rnn:
+            return None
+        z = lambda: torch.zeros((self.rnn_layers, self.num_seqs, self.rnn_units))
+        return (z(), z()) if self.rnn_name == 'lstm' else (z(),)
+
+    def trunk(self, obs, states=None, dones=None, seq_length=1):
+        out = self.actor_mlp(obs)
+        if not self.has_rnn:
+            return out, states
+        batch = out.shape[0]
+        num_seqs = batch // seq_length
+        out = out.reshape(num_seqs, seq_length, -1).transpose(0, 1)
+        if dones is not None:
+            dones = dones.reshape(num_seqs, seq_length, -1).transpose(0, 1)
+        if states is None:
+            states = tuple()
+        out, states = self.rnn(out, states, dones)
+        out = out.transpose(0, 1).contiguous().reshape(batch, -1)
+        if not isinstance(states, tuple):
+            states = (states,)
+        return out, states
+
+    def forward(self, obs_dict):
+        """(mu, logstd_broadcast, value, states) - network_builder.py:447-512."""
+        out, states = self.trunk(obs_dict['obs'], obs_dict.get('rnn_states'), obs_dict.get('dones'),
+                                 obs_dict.get('seq_length', 1))
+        value = self.value_act(self.value(out))
+        mu = self.mu_act(self.mu(out))
+        sigma = self.sigma_act(self.sigma)
+        return mu, mu * 0 + sigma, value, states
+
+
+class ContinuousA2CLogStdModel(nn.Module):
+    """The reference's `ModelA2CContinuousLogStd.Network` contract (models.py:311-364)."""
+
+    def __init__(self, a2c_network, obs_shape, normalize_value, normalize_input, value_size):
+        super().__init__()
+        self.obs_shape = obs_shape
+        self.normalize_value = normalize_value
+        self.normalize_input = normalize_input
+        self.value_size = value_size
+        self.a2c_network = a2c_network
+        if normalize_value:
+            self.value_mean_std = RunningMeanStd((value_size,))
+        if normalize_input:
+            if isinstance(obs_shape, dict):
+                raise NotImplementedError('dict observations are not implemented on this path')
+            self.running_mean_std = RunningMeanStd(obs_shape)
+
+    # -- reference API ---------------------------------------------------------------
+    def is_rnn(self):
+        return self.a2c_network.is_rnn()
+
+    def get_default_rnn_state(self):
+        return self.a2c_network.get_default_rnn_state()
+
+    def get_value_layer(self):
+        return self.a2c_network.get_value_layer()
+
+    def get_aux_loss(self):
+        return None
+
+    def norm_obs(self, observation):
+        with torch.no_grad():
+            return self.running_mean_std(observation) if self.normalize_input else observation
+
+    def denorm_value(self, value):
+        with torch.no_grad():
+            return self.value_mean_std(value, denorm=True) if self.normalize_value else value
+
+    @staticmethod
+    def neglogp(x, mean, std, logstd):
+        return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) \
+            + 0.5 * np.log(2.0 * np.pi) * x.size(-1) + logstd.sum(dim=-1)
+
+    def forward_heads(self, input_dict):
+        """Training fast path: normalise (and update) observations, run the trunk, return the
+        raw heads (mu [B,A], logstd parameter [A], value [B,V], rnn states)."""
+        obs = self.norm_obs(input_dict['obs'])
+        net = self.a2c_network
+        out, states = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
+                                input_dict.get('seq_length', 1))
+        value = net.value_act(net.value(out))
+        mu = net.mu_act(net.mu(out))
+        return mu, net.sigma_act(net.sigma), value, states
+
+    def forward(self, input_dict):
+        is_train = input_dict.get('is_train', True)
+        prev_actions = input_dict.get('prev_actions', None)
+        input_dict = dict(input_dict)
+        input_dict['obs'] = self.norm_obs(input_dict['obs'])
+        mu, logstd, value, states = self.a2c_network(input_dict)
+        sigma = torch.exp(logstd)
+        if is_train:
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(sigma)).sum(dim=-1)
+            prev_neglogp = self.neglogp(prev_actions, mu, sigma, logstd)
+            return {'prev_neglogp': torch.squeeze(prev_neglogp), 'values': value, 'entropy': entropy,
+                    'rnn_states': states, 'mus': mu, 'sigmas': sigma}
+        selected_action = torch.normal(mu, sigma)
+        neglogp = self.neglogp(selected_action, mu, sigma, logstd)
+        return {'neglogpacs': torch.squeeze(neglogp), 'values': self.denorm_value(value),
+                'actions': selected_action, 'rnn_states': states, 'mus': mu, 'sigmas': sigma}
+
+
+class PolicyBuilder:
+    """Stands in for `model_builder.ModelBuilder().load(params)` (rl_games/algos_torch/
+    model_builder.py:56-60): `.build(config)` returns the model for one agent."""
+
+    def __init__(self, params):
+        model_name = params.get('model', {}).get('name', 'continuous_a2c_logstd')
+        net_name = params.get('network', {}).get('name', 'actor_critic')
+        if model_name != 'continuous_a2c_logstd':
+            raise NotImplementedError(f"model '{model_name}' is not implemented on the MI355X PPO path")
+        if net_name != 'actor_critic':
+            raise NotImplementedError(f"network '{net_name}' is not implemented on the MI355X PPO path")
+        self.net_params = params['network']
+
+    def build(self, config):
+        net = ActorCriticNetwork(self.net_params, actions_num=config['actions_num'],
+                                 input_shape=config['input_shape'],
+                                 value_size=config.get('value_size', 1),
+                                 num_seqs=config.get('num_seqs', 1))
+        return ContinuousA2CLogStdModel(net, obs_shape=config['input_shape'],
+                                        normalize_value=config.get('normalize_value', False),
+                                        normalize_input=config.get('normalize_input', False),
+                                        value_size=config.get('value_size', 1))

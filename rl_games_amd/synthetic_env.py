@@ -1,0 +1,64 @@
+"""Device-resident synthetic vector environment (the `IVecEnv` data-source seam,
+rl_games/common/ivecenv.py:1-36) producing the shapes of BASELINE.json's configs.
+
+SURVEY 8(d): obs = 3*randn(N,O)+1, rewards = randn(N), dones = rand(N) < 0.05,
+time_outs = dones & (rand(N) < 0.5); `autoreset_mode: 'same_step'` (Isaac-style), torch-tensor
+observations (zero-copy mode of the agent, a2c_common.py:672-673,:712-715).  Works on any
+torch device so that the CPU baseline drives the very same environment."""
+import numpy as np
+import torch
+
+from .spaces import Box
+
+
+class SyntheticTensorEnv:
+    def __init__(self, num_envs, obs_dim, act_dim, device='cuda:0', seed=1234, p_done=0.05,
+                 value_size=1):
+        self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
+        self.device = torch.device(device)
+        self.p_done = p_done
+        self.value_size = value_size
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
+        self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
+
+    def _obs(self):
+        return torch.randn(self.num_envs, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, actions):
+        n = self.num_envs
+        obs = self._obs()
+        if self.value_size == 1:
+            rewards = torch.randn(n, device=self.device, generator=self.gen)
+        else:
+            rewards = torch.randn(n, self.value_size, device=self.device, generator=self.gen)
+        u = torch.rand(2, n, device=self.device, generator=self.gen)
+        dones = u[0] < self.p_done
+        time_outs = dones & (u[1] < 0.5)
+        return obs, rewards, dones.to(torch.uint8), {'time_outs': time_outs}
+
+    def get_env_info(self):
+        return {'observation_space': self.observation_space, 'action_space': self.action_space,
+                'agents': 1, 'value_size': self.value_size, 'autoreset_mode': 'same_step'}
+
+    def has_action_masks(self):
+        return False
+
+    def get_number_of_agents(self):
+        return 1
+
+    def set_train_info(self, env_frames, *args, **kwargs):
+        pass
+
+    def get_env_state(self):
+        return None
+
+    def set_env_state(self, env_state):
+        pass
+
+    def seed(self, seed):
+        self.gen.manual_seed(seed)
