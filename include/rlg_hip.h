@@ -132,10 +132,11 @@ int rlg_column_moments(const float* x, const float* row_mask_or_null, long long 
 /* Chan merge of the batch moments into the fp64/int64 running state (running_mean_std.py:
  * 55-67).  mode 0: population variance, count += rows (:74-75,:83); mode 1: masked moments
  * of get_mean_var_with_masks, count += rows (:72,:83); mode 2: moments of the selected rows
- * only, count += #selected (values[valid], a2c_common.py:1609-1611). */
+ * only, count += #selected (values[valid], a2c_common.py:1609-1611).  `ticket` is a zero-initialised
+ * device word owned by the caller (self-resetting arrival counter of the per-column blocks). */
 int rlg_rms_update(const double* partials, int num_blocks, int cols, long long total_rows,
                    int mode, double* running_mean, double* running_var, long long* count,
-                   void* stream);
+                   unsigned int* ticket, void* stream);
 
 /* y = clamp((x-mean)/sqrt(var+eps),-5,5) (mode 0, :112-113); denorm (mode 1, :106-107);
  * norm_only (mode 2, :110).  mean/var are the fp64 buffers, cast to fp32 like `.float()`. */

@@ -41,7 +41,7 @@ _PROTOTYPES = {
     # running_stats.hip
     'rlg_column_moments_num_blocks': [_c_ll, _c_int],
     'rlg_column_moments': [_P, _P, _c_ll, _c_int, _P, _c_int, _P],
-    'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P],
+    'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P, _P],
     'rlg_rms_apply': [_P, _P, _c_ll, _c_int, _P, _P, _c_float, _c_int, _P],
     'rlg_prepare_stats_bytes': [],
     'rlg_triple_moments_num_blocks': [_c_ll],

@@ -841,8 +841,10 @@ class A2CAgent:
             self._host_schedule(float(torch.stack(kls).mean().item()))
         self.sync_running_stats()
         if device_schedule:
-            last_lr = self._sync_lr_to_host()
-            self._host_lr = last_lr
+            # one host read per epoch: [lr the last minibatch was stepped with, lr for the next one]
+            used, nxt = self.optimizer.last_and_next_lr()
+            last_lr = used                  # what the reference returns (train_result[4])
+            self.last_lr = self._host_lr = nxt
         else:
             last_lr = self._host_lr
         update_time_end = time.perf_counter()

@@ -171,45 +171,71 @@ __global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepA
 }
 
 // Replays AverageMeter.update for steps 0..H-1 (game_rewards, game_shaped_rewards,
-// game_lengths) from the per-step partial sums.  One thread: the state is a handful of floats.
+// game_lengths) from the per-step partial sums.  One block: per step a parallel sum over the
+// post-step blocks, then thread 0 applies the meter recurrence.
 //   size = clip(count, 0, max); old = min(max - size, cur); mean = (mean*old + new*size)/(old+size)
-__global__ void episode_meters_kernel(const double* __restrict__ ep_partials, int H, int nblocks,
-                                      int V, int max_size, float* __restrict__ mean_rewards,
-                                      float* __restrict__ mean_shaped,
-                                      float* __restrict__ mean_lengths,
-                                      int* __restrict__ current_sizes /* [3] */,
-                                      long long* __restrict__ finished_total) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void episode_meters_kernel(
+    const double* __restrict__ ep_partials, int H, int nblocks, int V, int max_size,
+    float* __restrict__ mean_rewards, float* __restrict__ mean_shaped,
+    float* __restrict__ mean_lengths, int* __restrict__ current_sizes /* [3] */,
+    long long* __restrict__ finished_total) {
+  __shared__ double scratch[(2 * kMaxV + 2) * 4];
   const int W = 2 * V + 2;
   for (int t = 0; t < H; ++t) {
     double s[2 * kMaxV + 2];
-    for (int k = 0; k < W; ++k) s[k] = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+#pragma unroll
+    for (int k = 0; k < 2 * kMaxV + 2; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
       const double* p = ep_partials + (static_cast<long long>(t) * nblocks + b) * W;
-      for (int k = 0; k < W; ++k) s[k] += p[k];
-    }
-    const long long count = static_cast<long long>(s[2 * V + 1]);
-    if (count == 0) continue;                                     // torch_ext.py:334-336
-    *finished_total += count;
-    const int size = static_cast<int>(count < max_size ? count : max_size);
-    for (int m = 0; m < 3; ++m) {
-      const int old_size = min(max_size - size, current_sizes[m]);
-      const int size_sum = old_size + size;
-      current_sizes[m] = size_sum;
-      if (m < 2) {
-        float* mean = (m == 0) ? mean_rewards : mean_shaped;
-        for (int k = 0; k < V; ++k) {
-          const float new_mean = static_cast<float>(s[m * V + k] / static_cast<double>(count));
-          mean[k] = (mean[k] * static_cast<float>(old_size) + new_mean * static_cast<float>(size)) /
-                    static_cast<float>(size_sum);
-        }
-      } else {
-        const float new_mean = static_cast<float>(s[2 * V] / static_cast<double>(count));
-        mean_lengths[0] = (mean_lengths[0] * static_cast<float>(old_size) +
-                           new_mean * static_cast<float>(size)) /
-                          static_cast<float>(size_sum);
+#pragma unroll
+      for (int k = 0; k < 2 * kMaxV + 2; ++k) {
+        if (k < W) s[k] += p[k];
       }
     }
+    block_sum<2 * kMaxV + 2, 256>(s, scratch);
+    if (threadIdx.x == 0) {
+      double sv[2 * kMaxV + 2];
+#pragma unroll
+      for (int k = 0; k < 2 * kMaxV + 2; ++k) sv[k] = s[k];
+      double cnt_d = 0.0, len_d = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2 * kMaxV + 2; ++k) {
+        if (k == 2 * V + 1) cnt_d = sv[k];
+        if (k == 2 * V) len_d = sv[k];
+      }
+      const long long count = static_cast<long long>(cnt_d);
+      if (count != 0) {                                           // torch_ext.py:334-336
+        *finished_total += count;
+        const int size = static_cast<int>(count < max_size ? count : max_size);
+        for (int m = 0; m < 3; ++m) {
+          const int old_size = min(max_size - size, current_sizes[m]);
+          const int size_sum = old_size + size;
+          current_sizes[m] = size_sum;
+          if (m < 2) {
+            float* mean = (m == 0) ? mean_rewards : mean_shaped;
+#pragma unroll
+            for (int k = 0; k < kMaxV; ++k) {
+              if (k < V) {
+                double tot = 0.0;
+#pragma unroll
+                for (int q = 0; q < 2 * kMaxV; ++q) {
+                  if (q == m * V + k) tot = sv[q];
+                }
+                const float new_mean = static_cast<float>(tot / static_cast<double>(count));
+                mean[k] = (mean[k] * static_cast<float>(old_size) + new_mean * static_cast<float>(size)) /
+                          static_cast<float>(size_sum);
+              }
+            }
+          } else {
+            const float new_mean = static_cast<float>(len_d / static_cast<double>(count));
+            mean_lengths[0] = (mean_lengths[0] * static_cast<float>(old_size) +
+                               new_mean * static_cast<float>(size)) /
+                              static_cast<float>(size_sum);
+          }
+        }
+      }
+    }
+    __syncthreads();   // scratch is reused by the next step's block_sum
   }
 }
 
@@ -308,7 +334,7 @@ int rlg_episode_meters_update(const double* ep_partials, int horizon, int num_bl
                               float* mean_shaped, float* mean_lengths, int* current_sizes,
                               long long* finished_total, void* stream) {
   if (value_size < 1 || value_size > rlg::kMaxV) return static_cast<int>(hipErrorInvalidValue);
-  hipLaunchKernelGGL(rlg::episode_meters_kernel, dim3(1), dim3(64), 0,
+  hipLaunchKernelGGL(rlg::episode_meters_kernel, dim3(1), dim3(256), 0,
                      static_cast<hipStream_t>(stream), ep_partials, horizon, num_blocks, value_size,
                      max_size, mean_rewards, mean_shaped, mean_lengths, current_sizes,
                      finished_total);

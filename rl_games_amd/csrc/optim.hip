@@ -61,11 +61,16 @@ struct AdamArgs {
 __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   __shared__ float sh_clip;
   __shared__ float sh_norm;
+  __shared__ double scratch[kOptBlock / kWave];
+  double sq[1] = {0.0};
+  if (a.norm_partials) {
+    for (int b = threadIdx.x; b < a.norm_blocks; b += kOptBlock) sq[0] += a.norm_partials[b];
+    block_sum<1, kOptBlock>(sq, scratch);
+  }
   if (threadIdx.x == 0) {
     float coef = 1.0f, total_norm = 0.0f;
     if (a.norm_partials) {
-      double s = 0.0;
-      for (int b = 0; b < a.norm_blocks; ++b) s += a.norm_partials[b];
+      const double s = sq[0];
       total_norm = static_cast<float>(sqrt(s));
       // clip_coef = max_norm / (total_norm + 1e-6); clamp(max=1.0)       torch clip_grad_norm_
       coef = fminf(a.max_norm / (total_norm + 1e-6f), 1.0f);

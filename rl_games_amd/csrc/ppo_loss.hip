@@ -281,33 +281,50 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   }
 }
 
-// Scalars written by the finalise kernel (fp32, read lazily by the host):
+// Scalars written by the finalise kernel (fp32[8], read lazily by the host):
 //   [0] a_loss [1] c_loss [2] entropy [3] b_loss [4] kl [5] total loss [6] sum(mask) [7] unused
-constexpr int kLossOutScalars = 8;
 
 __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
     const double* __restrict__ partials, int nblocks, int A, int mb, int masked,
     float critic_coef, float entropy_coef, float bounds_coef, float* __restrict__ scalars,
     float* __restrict__ d_logstd, float* __restrict__ kl_slot) {
+  // 8 block-slices x 32 columns per pass; slices are folded through LDS in a fixed order.
+  __shared__ double part[8][32];
   __shared__ double sh[kLossScalars];
   const int W = kLossScalars + A;
-  if (threadIdx.x < kLossScalars) {
+  const int col_in_pass = threadIdx.x & 31;
+  const int slice = threadIdx.x >> 5;
+  for (int c0 = 0; c0 < W; c0 += 32) {
+    const int c = c0 + col_in_pass;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[static_cast<long long>(b) * W + threadIdx.x];
-    sh[threadIdx.x] = s;
-  }
-  __syncthreads();
-  const double msum = sh[5];
-  const double denom = masked ? fmax(msum, 1.0) : static_cast<double>(mb);
-  // sum_i w_i = msum/denom : 1 unless every row is masked out
-  const float w_total = static_cast<float>(msum / denom);
-  for (int a = threadIdx.x; a < A; a += blockDim.x) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[static_cast<long long>(b) * W + kLossScalars + a];
-    // d loss / d logstd_a = sum_i g_i (1 - z^2)  -  entropy_coef * sum_i w_i * d ent/d logstd (=1)
-    d_logstd[a] = static_cast<float>(s) - entropy_coef * w_total;
+    if (c < W) {
+      for (int b = slice; b < nblocks; b += 8) s += partials[static_cast<long long>(b) * W + c];
+    }
+    part[slice][col_in_pass] = s;
+    __syncthreads();
+    if (slice == 0 && c < W) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][col_in_pass];
+      if (c < kLossScalars) {
+        sh[c] = t;
+      } else {
+        part[0][col_in_pass] = t;   // keep the column total for the d_logstd pass below
+      }
+    }
+    __syncthreads();
+    // d loss / d logstd_a = sum_i g_i (1 - z^2)  -  entropy_coef * sum_i w_i   (d ent/d logstd = 1)
+    if (slice == 0 && c < W && c >= kLossScalars) {
+      const double msum0 = sh[5];
+      const double denom0 = masked ? fmax(msum0, 1.0) : static_cast<double>(mb);
+      const float w_total = static_cast<float>(msum0 / denom0);
+      d_logstd[c - kLossScalars] = static_cast<float>(part[0][col_in_pass]) - entropy_coef * w_total;
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
+    const double msum = sh[5];
+    const double denom = masked ? fmax(msum, 1.0) : static_cast<double>(mb);
     const float a_loss = static_cast<float>(sh[0] / denom);
     const float c_loss = static_cast<float>(sh[1] / denom);
     const float ent = static_cast<float>(sh[2] / denom);

@@ -150,49 +150,55 @@ __device__ __forceinline__ void chan_merge(double& mean, double& var, double cou
 //                     torch_ext.py:182-191), batch_count = total rows     (:72, :83)
 // mode 2: selected  - statistics of the rows with mask==1 only, batch_count = #selected
 //                     (the value normaliser's `values[valid]` path, a2c_common.py:1609-1611)
-__global__ __launch_bounds__(256) void rms_update_kernel(const double* __restrict__ partials,
-                                                         int nblocks, int C, long long total_rows,
-                                                         int mode, double* __restrict__ running_mean,
-                                                         double* __restrict__ running_var,
-                                                         long long* __restrict__ count,
-                                                         int update_count) {
+//
+// One 64-lane block per column: lanes stride over the per-block partials, wave-reduce, lane 0
+// merges.  The shared `count` is bumped by whichever block finishes last (ticket), i.e. after
+// every block has read the old value.
+__global__ __launch_bounds__(64) void rms_update_kernel(const double* __restrict__ partials,
+                                                        int nblocks, int C, long long total_rows,
+                                                        int mode, double* __restrict__ running_mean,
+                                                        double* __restrict__ running_var,
+                                                        long long* __restrict__ count,
+                                                        unsigned int* __restrict__ ticket) {
   const int W = 2 * C + 1;
-  double n_sum = 0.0;
-  for (int b = 0; b < nblocks; ++b) n_sum += partials[static_cast<long long>(b) * W + 2 * C];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  double s = 0.0, ss = 0.0, n_sum = 0.0;
+  for (int b = lane; b < nblocks; b += kWave) {
+    const double* p = partials + static_cast<long long>(b) * W;
+    s += p[c];
+    ss += p[C + c];
+    n_sum += p[2 * C];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  n_sum = wave_sum(n_sum);
+  if (lane != 0) return;
   const long long old_count = *count;
-  double batch_count;
-  if (mode == 2) {
-    batch_count = n_sum;
+  const double batch_count = (mode == 2) ? n_sum : static_cast<double>(total_rows);
+  double bm, bv;
+  if (mode == 1) {
+    const double sm = fmax(n_sum, 1.0);
+    bm = s / sm;
+    const double min_sqr = ss / sm - (s / sm) * (s / sm);
+    bv = min_sqr * sm / fmax(sm - 1.0, 1.0);
   } else {
-    batch_count = static_cast<double>(total_rows);
+    const double n = fmax(n_sum, 1.0);
+    bm = s / n;
+    bv = fmax(ss / n - bm * bm, 0.0);
   }
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-      s += partials[static_cast<long long>(b) * W + c];
-      ss += partials[static_cast<long long>(b) * W + C + c];
-    }
-    double bm, bv;
-    if (mode == 1) {
-      const double sm = fmax(n_sum, 1.0);
-      bm = s / sm;
-      const double min_sqr = ss / sm - (s / sm) * (s / sm);
-      bv = min_sqr * sm / fmax(sm - 1.0, 1.0);
-    } else {
-      const double n = fmax(n_sum, 1.0);
-      bm = s / n;
-      bv = fmax(ss / n - bm * bm, 0.0);
-    }
-    // the reference's batch moments are fp32 tensors: round once before the fp64 merge
-    bm = static_cast<double>(static_cast<float>(bm));
-    bv = static_cast<double>(static_cast<float>(bv));
-    double mean = running_mean[c], var = running_var[c];
-    if (batch_count > 0.0) chan_merge(mean, var, static_cast<double>(old_count), bm, bv, batch_count);
-    running_mean[c] = mean;
-    running_var[c] = var;
-  }
-  __syncthreads();
-  if (update_count && blockIdx.x == 0 && threadIdx.x == 0) {
+  // the reference's batch moments are fp32 tensors: round once before the fp64 merge
+  bm = static_cast<double>(static_cast<float>(bm));
+  bv = static_cast<double>(static_cast<float>(bv));
+  double mean = running_mean[c], var = running_var[c];
+  if (batch_count > 0.0) chan_merge(mean, var, static_cast<double>(old_count), bm, bv, batch_count);
+  running_mean[c] = mean;
+  running_var[c] = var;
+  // every block read `count` above; the last one to arrive publishes the new count.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  const unsigned int t = atomicAdd(ticket, 1u);
+  if (t == static_cast<unsigned int>(C) - 1u) {
+    *ticket = 0u;
     *count = old_count + static_cast<long long>(batch_count);
   }
 }
@@ -290,7 +296,7 @@ constexpr int kPrepNormAdv = 2;        // normalize_advantage (batch statistics)
 constexpr int kPrepFreezeCritic = 4;   // freeze_critic: normalise with frozen stats
 constexpr int kPrepEmaAdv = 8;         // normalize_rms_advantage (GeneralizedMovingStats mean_std)
 
-__global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials, int ntiles,
+__global__ __launch_bounds__(256) void prepare_finalize_kernel(const double* __restrict__ gae_partials, int ntiles,
                                         int stride, long long B, int flags,
                                         double* __restrict__ running_mean,
                                         double* __restrict__ running_var,
@@ -299,11 +305,16 @@ __global__ void prepare_finalize_kernel(const double* __restrict__ gae_partials,
                                         int* __restrict__ ema_step, float ema_decay, float ema_factor,
                                         float ema_max, float ema_eps,
                                         PrepareStats* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  __shared__ double scratch[7 * 4];
   double m[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < ntiles; ++t) {
-    for (int k = 0; k < stride; ++k) m[k] += gae_partials[static_cast<long long>(t) * stride + k];
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      if (k < stride) m[k] += gae_partials[static_cast<long long>(t) * stride + k];
+    }
   }
+  block_sum<7, 256>(m, scratch);
+  if (threadIdx.x != 0) return;
   // stride 7 = masked batch: statistics of the valid rows only (a2c_common.py:1605-1615,
   // torch_ext.py:172-191); n_valid rows feed the value normaliser's count.
   const bool masked = stride == 7;
@@ -452,12 +463,11 @@ int rlg_column_moments(const float* x, const float* row_mask_or_null, long long 
 
 int rlg_rms_update(const double* partials, int num_blocks, int cols, long long total_rows,
                    int mode, double* running_mean, double* running_var, long long* count,
-                   void* stream) {
-  if (cols <= 0 || mode < 0 || mode > 2) return static_cast<int>(hipErrorInvalidValue);
-  // single block: the count update must follow every column's read of the old count
-  hipLaunchKernelGGL(rlg::rms_update_kernel, dim3(1), dim3(256), 0,
+                   unsigned int* ticket, void* stream) {
+  if (cols <= 0 || mode < 0 || mode > 2 || !ticket) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::rms_update_kernel, dim3(cols), dim3(rlg::kWave), 0,
                      static_cast<hipStream_t>(stream), partials, num_blocks, cols, total_rows, mode,
-                     running_mean, running_var, count, 1);
+                     running_mean, running_var, count, ticket);
   RLG_RETURN_LAUNCH_STATUS();
 }
 
@@ -510,7 +520,7 @@ int rlg_prepare_finalize(const double* gae_partials, int num_tiles, int stride, 
                          int* ema_step, float ema_decay, float ema_factor, float ema_max,
                          float ema_eps, void* stats_out, void* stream) {
   if (stride != 6 && stride != 7) return static_cast<int>(hipErrorInvalidValue);
-  hipLaunchKernelGGL(rlg::prepare_finalize_kernel, dim3(1), dim3(64), 0,
+  hipLaunchKernelGGL(rlg::prepare_finalize_kernel, dim3(1), dim3(256), 0,
                      static_cast<hipStream_t>(stream), gae_partials, num_tiles, stride, batch, flags,
                      value_running_mean, value_running_var, value_count, eps, ema_mean, ema_sqrs,
                      ema_step, ema_decay, ema_factor, ema_max, ema_eps,

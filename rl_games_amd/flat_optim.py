@@ -66,6 +66,15 @@ class FlatAdam:
         self.param_groups[0]['lr'] = lr
         return lr
 
+    def last_and_next_lr(self):
+        """(lr used by the most recent step, lr the next step will use) - one host sync."""
+        both = self.lr_slots.tolist()
+        nxt, used = both[self.cur], both[self.cur ^ 1]
+        if self.step_count == 0:
+            used = nxt
+        self.param_groups[0]['lr'] = nxt
+        return used, nxt
+
     # ------------------------------------------------------------------ step
     def zero_grad(self, set_to_none=False):
         self.flat_grads.zero_()

@@ -128,12 +128,25 @@ def column_moments(x, mask=None, partials=None):
     return partials, nb
 
 
+_tickets = {}
+
+
+def _ticket(device):
+    """Zero-initialised arrival counter shared by all rms_update launches of a device (the
+    launches are stream-ordered and the kernel resets it)."""
+    key = str(device)
+    if key not in _tickets:
+        _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _tickets[key]
+
+
 def rms_update(partials, num_blocks, cols, total_rows, mode, running_mean, running_var, count):
     lib = _lib.load()
     _lib.check(lib.rlg_rms_update(_need(partials, F64, 'partials'), num_blocks, cols, total_rows, mode,
                                   _need(running_mean, F64, 'running_mean'),
                                   _need(running_var, F64, 'running_var'),
-                                  _need(count, torch.int64, 'count'), _stream(partials)),
+                                  _need(count, torch.int64, 'count'),
+                                  _ticket(partials.device).data_ptr(), _stream(partials)),
                'rlg_rms_update')
 
 

@@ -1,0 +1,174 @@
+"""GPU: the A2CAgent (rl_games_amd/agent.py) against golden vectors recorded from the REAL
+reference agent's train_epoch, and against the CPU oracle epoch, on identical rollout tensors.
+
+Comparison granularity follows SURVEY 8a' pitfall 12: minibatches are contiguous env blocks and
+never shuffled, so per-minibatch scalars are compared in order."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+from oracle.ppo_epoch_oracle import OracleAgent
+from rl_games_amd.synthetic_env import SyntheticTensorEnv
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _make_agent(cap, **over):
+    from rl_games_amd.agent import A2CAgent
+    params = copy.deepcopy(cap['params'])
+    params['config'].update(device=DEV, **over)
+    env = SyntheticTensorEnv(cap['env']['num_envs'], cap['env']['obs_dim'], cap['env']['act_dim'],
+                             device=DEV, seed=cap['env']['seed'])
+    params['config']['vec_env'] = env
+    params['config']['env_info'] = env.get_env_info()
+    agent = A2CAgent('test', params)
+    agent.init_tensors()
+    return agent
+
+
+def _to_dev(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema'])
+def test_update_matches_reference_epoch(golden, variant):
+    cap = golden('epoch.pt')[variant]
+    agent = _make_agent(cap)
+    agent.model.load_state_dict(cap['state_after_rollout'])
+    batch = _to_dev(cap['batch'])
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    ds = cap['dataset']
+    vd = agent.dataset.values_dict
+    assert torch.allclose(vd['old_values'].cpu(), ds['old_values'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(vd['returns'].cpu(), ds['returns'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(vd['advantages'].cpu(), ds['advantages'], rtol=1e-5, atol=1e-6)
+    rows = []
+    for mini_ep in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            rows.append(torch.stack([a, c, e, kl, b]).clone())
+    rows = torch.stack(rows).cpu()
+    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
+    if cap['b_losses'] is not None:
+        assert torch.allclose(rows[:, 4], cap['b_losses'], rtol=1e-5, atol=1e-7)
+    nmb = len(agent.dataset)
+    kls = rows[:, 3].reshape(agent.mini_epochs_num, nmb).mean(1)
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-4, atol=1e-7)
+    # device-side adaptive learning rate == the reference's python-float trajectory, bit for bit
+    used, nxt = agent.optimizer.last_and_next_lr()
+    assert nxt == cap['lrs'][-1]
+    assert used == cap['last_lr']
+    final = agent.model.state_dict()
+    for k, v in cap['final_state'].items():
+        tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
+        assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+    assert torch.allclose(vd['mu'].cpu(), ds['mu'], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(vd['sigma'].cpu(), ds['sigma'], rtol=1e-5, atol=1e-6)
+    # optimiser moments in torch.optim.Adam's state_dict format
+    opt = agent.optimizer.state_dict()['state']
+    for i, st in cap['opt_state'].items():
+        assert torch.allclose(opt[i]['exp_avg'].cpu(), st['exp_avg'], rtol=1e-3, atol=1e-6), i
+        assert int(float(opt[i]['step'])) == int(float(st['step']))
+    if 'adv_ema' in cap:
+        ema = agent.advantage_mean_std
+        assert ema.step.item() == cap['adv_ema']['step'].item()
+        assert torch.allclose(ema.mean.cpu(), cap['adv_ema']['mean'], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(ema.sqrs.cpu(), cap['adv_ema']['sqrs'], rtol=1e-5)
+
+
+def test_rollout_epilogue_matches_reference_buffers(golden):
+    """Reference rollout buffers -> env-major storage -> fused GAE == the reference's returns,
+    bit for bit; values view unchanged."""
+    from rl_games_amd.gae import gae_returns_advantages
+    cap = golden('epoch.pt')['default']
+    buf = cap['buffers']
+    H, N = buf['dones'].shape
+    rp = buf['rewards'][..., 0].t().contiguous().to(DEV)
+    vp = buf['values'][..., 0].t().contiguous().to(DEV)
+    dp = buf['dones'].t().contiguous().to(DEV)
+    cfg = cap['params']['config']
+    ret, adv, _ = gae_returns_advantages(rp, vp, dp, cap['last_values'].reshape(-1).to(DEV),
+                                         cap['last_dones'].to(DEV), cfg['gamma'], cfg['tau'])
+    assert torch.equal(ret.reshape(-1, 1).cpu(), cap['batch']['returns'])
+    assert torch.equal(adv.reshape(-1).cpu(), (cap['batch']['returns'] - cap['batch']['values']).reshape(-1))
+
+
+def test_full_train_epoch_runs_and_matches_oracle_on_same_rollout():
+    """End to end on the device: play_steps -> (copy the rollout to the CPU oracle) -> both update;
+    per-minibatch losses agree.  Also checks counts, meters and buffer/index layout."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=128, horizon=8, obs_dim=10, act_dim=4)
+    agent = A2CAgent('test', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps()
+    N, H = 128, 8
+    # env-major flat index: row env*H + t of the flat batch == buffer[t, env]
+    tb = agent.experience_buffer.tensor_dict
+    for key, flat in (('obses', batch['obses']), ('actions', batch['actions']), ('dones', batch['dones'])):
+        assert flat.data_ptr() == agent.experience_buffer.storage[key].data_ptr()      # zero copy
+        assert torch.equal(flat.reshape((N, H) + flat.shape[1:]).transpose(0, 1), tb[key])
+    assert torch.equal(tb['dones'][0], torch.ones(N, dtype=torch.uint8, device=DEV))      # :666
+    # oracle on the same rollout
+    cpu_params = copy.deepcopy(params)
+    env = SyntheticTensorEnv(N, 10, 4, device='cpu', seed=1)
+    oracle = OracleAgent(cpu_params, env)
+    sd = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+    oracle.model.load_full_state_dict(sd)
+    cpu_batch = {k: v.detach().cpu().clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    # GAE consistency of the device rollout with the oracle scan
+    advs = O.gae_scan(tb['rewards'].cpu(), tb['values'].cpu(), tb['dones'].cpu().float(),
+                      agent.get_values(agent.obs).cpu(), agent.dones.cpu().float(), 0.99, 0.95)
+    assert torch.equal(cpu_batch['returns'], O.flatten_env_major(advs + tb['values'].cpu()))
+    ref = oracle.update(cpu_batch)
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    k = 0
+    for mini_ep in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            r = ref[k]
+            for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
+                assert np.isclose(got.item(), r[key].item(), rtol=1e-4, atol=5e-6), (k, key, got.item(), r[key].item())
+            k += 1
+    assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
+    # a complete train_epoch through the public entry point
+    agent.update_epoch()
+    out = agent.train_epoch()
+    assert len(out[4]) == agent.mini_epochs_num * agent.num_minibatches
+    assert agent.model.running_mean_std.count.item() == 1 + 2 * agent.mini_epochs_num * N * H
+    assert agent.model.value_mean_std.count.item() == 1 + 2 * 2 * N * H
+    assert agent.game_lengths.current_size > 0
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=64, horizon=8)
+    a1 = A2CAgent('t', copy.deepcopy(params))
+    a1.init_tensors()
+    a1.obs = a1.env_reset()
+    a1.update_epoch()
+    a1.train_epoch()
+    path = a1.save(str(tmp_path / 'ckpt'))
+    a2 = A2CAgent('t', copy.deepcopy(params))
+    a2.restore(path)
+    for (k1, v1), (k2, v2) in zip(a1.model.state_dict().items(), a2.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert a2.epoch_num == a1.epoch_num
+    assert torch.equal(a1.optimizer.exp_avg, a2.optimizer.exp_avg)
+    assert a2.optimizer.step_count == a1.optimizer.step_count
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ck) >= {'model', 'optimizer', 'epoch', 'frame', 'last_mean_rewards'}
+    assert ck['model']['running_mean_std.running_mean'].dtype == torch.float64
+    assert ck['model']['running_mean_std.count'].dtype == torch.int64

@@ -1,0 +1,91 @@
+"""CPU: pins the full-epoch oracle (oracle/ppo_epoch_oracle.py) to golden vectors recorded from
+the REAL reference A2CAgent.train_epoch (tests/golden/make_golden.py, section `epoch`), fed with
+the identical rollout tensors."""
+import copy
+
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+from oracle.ppo_epoch_oracle import OracleAgent
+from rl_games_amd.synthetic_env import SyntheticTensorEnv
+
+
+def _agent(cap):
+    params = copy.deepcopy(cap['params'])
+    env = SyntheticTensorEnv(cap['env']['num_envs'], cap['env']['obs_dim'], cap['env']['act_dim'],
+                             device='cpu', seed=cap['env']['seed'])
+    agent = OracleAgent(params, env)
+    return agent
+
+
+@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema'])
+def test_oracle_update_matches_reference_epoch(golden, variant):
+    cap = golden('epoch.pt')[variant]
+    agent = _agent(cap)
+    agent.model.load_full_state_dict(cap['state_after_rollout'])
+    batch = {k: v.clone() for k, v in cap['batch'].items()}
+    results = agent.update(batch)
+    ds = cap['dataset']
+    # prepare_dataset (a2c_common.py:1586-1660)
+    assert torch.allclose(agent.dataset['old_values'], ds['old_values'], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(agent.dataset['returns'], ds['returns'], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(agent.dataset['advantages'], ds['advantages'], rtol=1e-6, atol=1e-7)
+    # per-minibatch scalars, in order (minibatches are contiguous env blocks, never shuffled)
+    a = torch.stack([r['a_loss'] for r in results])
+    c = torch.stack([r['c_loss'] for r in results])
+    e = torch.stack([r['entropy'] for r in results])
+    assert torch.allclose(a, cap['a_losses'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(c, cap['c_losses'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(e, cap['entropies'], rtol=1e-5, atol=1e-6)
+    if cap['b_losses'] is not None:
+        b = torch.stack([r['b_loss'] for r in results])
+        assert torch.allclose(b, cap['b_losses'], rtol=1e-5, atol=1e-7)
+    nmb = len(results) // agent.mini_epochs
+    kls = torch.stack([torch.stack([r['kl'] for r in results[i * nmb:(i + 1) * nmb]]).mean()
+                       for i in range(agent.mini_epochs)])
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-4, atol=1e-7)
+    # learning-rate trajectory of the adaptive schedule: python floats, exact
+    assert [r['lr'] for r in results][1:] == cap['lrs'][:len(results) - 1]
+    assert agent.lr == cap['lrs'][len(results) - 1]
+    # train_epoch returns the lr the LAST minibatch was stepped with (train_result[4])
+    assert results[-1]['lr'] == cap['last_lr']
+    # final parameters and statistics
+    final = agent.model.full_state_dict()
+    for k, v in cap['final_state'].items():
+        tol = dict(rtol=1e-4, atol=1e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
+        assert torch.allclose(final[k].to(v.dtype), v, **tol), k
+    assert torch.allclose(agent.dataset['mu'], ds['mu'], rtol=1e-4, atol=1e-5)
+    if 'adv_ema' in cap:
+        for k in ('mean', 'sqrs', 'step'):
+            assert torch.allclose(agent.ema_state[k].float(), cap['adv_ema'][k].float(), rtol=1e-6)
+
+
+def test_oracle_gae_and_returns_match_reference_rollout(golden):
+    """The recorded rollout buffers -> oracle GAE/returns == the reference's batch_dict['returns']."""
+    cap = golden('epoch.pt')['default']
+    buf = cap['buffers']
+    advs = O.gae_scan(buf['rewards'], buf['values'], buf['dones'].float(), cap['last_values'],
+                      cap['last_dones'].float(), cap['params']['config']['gamma'], cap['params']['config']['tau'])
+    ret = O.flatten_env_major(O.returns_from_advantages(advs, buf['values']))
+    assert torch.equal(ret, cap['batch']['returns'])
+    assert torch.equal(O.flatten_env_major(buf['values']), cap['batch']['values'])
+
+
+def test_oracle_rollout_is_self_consistent():
+    """play_steps of the oracle: buffer layout, done bookkeeping and GAE agree with the leaf
+    functions (the reference's rollout RNG stream is not reproducible across implementations, so
+    the rollout itself is checked structurally; its tensors are pinned through the update test)."""
+    from rl_games_amd import configs
+    params = configs.tiny(num_actors=32, horizon=8, obs_dim=5, act_dim=2, device='cpu')
+    env = SyntheticTensorEnv(32, 5, 2, device='cpu', seed=3)
+    agent = OracleAgent(params, env, seed=0)
+    agent.obs = env.reset()
+    batch = agent.play_steps()
+    buf = agent.last_buffers
+    assert batch['obses'].shape == (32 * 8, 5)
+    assert torch.equal(batch['dones'].reshape(32, 8)[:, 0], torch.ones(32, dtype=torch.uint8))
+    assert torch.equal(batch['dones'].reshape(32, 8).t(), buf['dones'])
+    advs = O.gae_scan(buf['rewards'], buf['values'], buf['dones'].float(), agent.last_values,
+                      agent.last_dones.float(), 0.99, 0.95)
+    assert torch.equal(batch['returns'], O.flatten_env_major(advs + buf['values']))
