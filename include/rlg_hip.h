@@ -65,6 +65,17 @@ int rlg_gae_envmajor_fused(const float* rewards, const float* values, const uint
                            float* advantages, double* moment_partials, int num_envs, int horizon,
                            float gamma, float gamma_tau, void* stream);
 
+/* Profiling hooks used by bench.py (not part of the reference surface): hipEvent handles as
+ * void*, and the fused GAE launch bracketed by event records on the same stream inside one call. */
+int rlg_event_create(void** event_out);
+int rlg_event_destroy(void* event);
+int rlg_event_elapsed_us(void* start, void* stop, float* us_out);   /* synchronises on `stop` */
+int rlg_gae_envmajor_fused_timed(const float* rewards, const float* values, const uint8_t* dones,
+                                 const float* last_values, const uint8_t* last_dones, float* returns,
+                                 float* advantages, double* moment_partials, int num_envs,
+                                 int horizon, float gamma, float gamma_tau, void* stream,
+                                 void* ev_start, void* ev_stop);
+
 /* Raw A_t only (the compute_gae return value) on the env-major layout. */
 int rlg_gae_envmajor_raw(const float* rewards, const float* values, const uint8_t* dones,
                          const float* last_values, const uint8_t* last_dones, float* gae_out,

@@ -29,6 +29,11 @@ _PROTOTYPES = {
     'rlg_gae_envmajor_fused': [_P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float,
                                _c_float, _P],
     'rlg_gae_envmajor_raw': [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float, _c_float, _P],
+    'rlg_event_create': [ctypes.POINTER(_P)],
+    'rlg_event_destroy': [_P],
+    'rlg_event_elapsed_us': [_P, _P, ctypes.POINTER(_c_float)],
+    'rlg_gae_envmajor_fused_timed': [_P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_float,
+                                     _c_float, _P, _P, _P],
     # experience.hip
     'rlg_rollout_store_step': [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_P),
                                ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _P],

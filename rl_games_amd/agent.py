@@ -342,6 +342,7 @@ class A2CAgent:
         self._obs_norm = None
         self._host_lr = self.last_lr
         self.train_result = None
+        self.kernel_timers = None
         self.algo_observer.after_init(self)
 
     # ================================================================== small helpers
@@ -569,10 +570,16 @@ class A2CAgent:
         last_values = self.get_values(self.obs)
         if self.value_size == 1 and ops._lib.load().rlg_gae_envmajor_supported(H):
             lv = last_values.reshape(-1).contiguous()
+            timers = self.kernel_timers
+            ev = None
+            if timers is not None:      # bench.py: HIP events on the launch stream around the kernel
+                from .gae import HipEventPair
+                ev = HipEventPair()
+                timers.setdefault('gae_envmajor_fused', []).append(ev)
             gae_returns_advantages(buf.storage['rewards'].view(rows, H), buf.storage['values'].view(rows, H),
                                    buf.storage['dones'], lv, self.dones, self.gamma, self.tau,
                                    out_returns=self._returns, out_advantages=self._advantages,
-                                   moment_partials=self._gae_partials)
+                                   moment_partials=self._gae_partials, events=ev)
             batch_dict['returns'] = self._returns.view(rows * H, 1)
             batch_dict['_fused'] = {'advantages': self._advantages.view(rows * H), 'partials': self._gae_partials}
         else:
@@ -976,6 +983,17 @@ class A2CAgent:
         else:
             raise NotImplementedError(f'No param found for {param_value}')
 
+    def broadcast_parameters(self):
+        """Rank 0's parameters and normaliser state to every rank (a2c_common.py:1670-1680, C2) -
+        one broadcast of the flat arena instead of a pickled state_dict."""
+        if not self.multi_gpu:
+            return
+        import torch.distributed as dist
+        dist.broadcast(self.optimizer.flat_params, 0)
+        for m in self._stats_sync_modules():
+            rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+        self._seed_stats_sync_snapshots()
+
     # ================================================================== training loop
     def train(self):
         """a2c_common.py:1662-1782.  Returns (last_mean_rewards, epoch_num)."""
@@ -984,11 +1002,7 @@ class A2CAgent:
         total_time = 0
         self.obs = self.env_reset()
         self.curr_frames = self.batch_size_envs
-        if self.multi_gpu:
-            import torch.distributed as dist
-            dist.broadcast(self.optimizer.flat_params, 0)                 # C2 without pickling
-            for m in self._stats_sync_modules():
-                rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+        self.broadcast_parameters()
         while True:
             epoch_num = self.update_epoch()
             (step_time, play_time, update_time, sum_time, a_losses, c_losses, b_losses, entropies, kls,

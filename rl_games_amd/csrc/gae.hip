@@ -410,6 +410,41 @@ int rlg_gae_envmajor_fused(const float* rewards, const float* values, const uint
                                        gamma_tau, static_cast<hipStream_t>(stream));
 }
 
+// Profiling hooks (bench.py): HIP events recorded on the launch stream immediately around the
+// kernel, inside one C call, so that no host-side Python latency sits between the markers.
+int rlg_event_create(void** event_out) {
+  hipEvent_t ev;
+  const hipError_t e = hipEventCreate(&ev);
+  *event_out = static_cast<void*>(ev);
+  return static_cast<int>(e);
+}
+
+int rlg_event_destroy(void* event) { return static_cast<int>(hipEventDestroy(static_cast<hipEvent_t>(event))); }
+
+int rlg_event_elapsed_us(void* start, void* stop, float* us_out) {
+  hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(stop));
+  if (e != hipSuccess) return static_cast<int>(e);
+  float ms = 0.0f;
+  e = hipEventElapsedTime(&ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
+  *us_out = ms * 1000.0f;
+  return static_cast<int>(e);
+}
+
+int rlg_gae_envmajor_fused_timed(const float* rewards, const float* values, const uint8_t* dones,
+                                 const float* last_values, const uint8_t* last_dones, float* returns,
+                                 float* advantages, double* moment_partials, int num_envs,
+                                 int horizon, float gamma, float gamma_tau, void* stream,
+                                 void* ev_start, void* ev_stop) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipEventRecord(static_cast<hipEvent_t>(ev_start), st);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const int rc = rlg_gae_envmajor_fused(rewards, values, dones, last_values, last_dones, returns,
+                                        advantages, moment_partials, num_envs, horizon, gamma,
+                                        gamma_tau, stream);
+  if (rc != 0) return rc;
+  return static_cast<int>(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
+}
+
 int rlg_gae_envmajor_raw(const float* rewards, const float* values, const uint8_t* dones,
                          const float* last_values, const uint8_t* last_dones, float* gae_out,
                          int num_envs, int horizon, float gamma, float gamma_tau, void* stream) {

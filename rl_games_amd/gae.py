@@ -91,8 +91,32 @@ def num_moment_partials(num_envs):
     return _lib.load().rlg_gae_envmajor_num_partials(int(num_envs))
 
 
+class HipEventPair:
+    """Two raw hipEvents bracketing one launch (bench.py's roofline timing)."""
+
+    def __init__(self):
+        lib = _lib.load()
+        self.start, self.stop = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.rlg_event_create(ctypes.byref(self.start)), 'rlg_event_create')
+        _lib.check(lib.rlg_event_create(ctypes.byref(self.stop)), 'rlg_event_create')
+
+    def elapsed_us(self):
+        out = ctypes.c_float()
+        _lib.check(_lib.load().rlg_event_elapsed_us(self.start, self.stop, ctypes.byref(out)),
+                   'rlg_event_elapsed_us')
+        return float(out.value)
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            lib.rlg_event_destroy(self.start)
+            lib.rlg_event_destroy(self.stop)
+        except Exception:
+            pass
+
+
 def gae_returns_advantages(rewards, values, dones, last_values, last_dones, gamma, tau,
-                           out_returns=None, out_advantages=None, moment_partials=None):
+                           out_returns=None, out_advantages=None, moment_partials=None, events=None):
     """Fused rollout epilogue on the buffer's physical layout.
 
     rewards/values: [N, H] fp32 contiguous, dones: [N, H] uint8, last_values: [N] or [N,1],
@@ -120,9 +144,12 @@ def gae_returns_advantages(rewards, values, dones, last_values, last_dones, gamm
     if moment_partials is None:
         moment_partials = torch.empty((num_moment_partials(N), 6), dtype=torch.float64, device=dev)
     g, gt = _f32_scalars(gamma, tau)
-    _lib.check(lib.rlg_gae_envmajor_fused(
-        rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), last_values.data_ptr(),
-        last_dones.data_ptr(), out_returns.data_ptr(), out_advantages.data_ptr(),
-        moment_partials.data_ptr(), N, H, g, gt, _lib.stream_handle(dev)),
-        'rlg_gae_envmajor_fused')
+    args = (rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), last_values.data_ptr(),
+            last_dones.data_ptr(), out_returns.data_ptr(), out_advantages.data_ptr(),
+            moment_partials.data_ptr(), N, H, g, gt, _lib.stream_handle(dev))
+    if events is None:
+        _lib.check(lib.rlg_gae_envmajor_fused(*args), 'rlg_gae_envmajor_fused')
+    else:
+        _lib.check(lib.rlg_gae_envmajor_fused_timed(*args, events.start, events.stop),
+                   'rlg_gae_envmajor_fused_timed')
     return out_returns, out_advantages, moment_partials
