@@ -98,6 +98,9 @@ def main():
     params = configs.humanoid_65536(num_actors=envs, minibatch_size=GLOBAL_MINIBATCH // world, device=device,
                                     multi_gpu=multi)
     params['config']['env_config']['seed'] = 1234 + rank
+    # GEMM solution selection: shipped TunableOp file; shapes missing from it (other library
+    # versions) are tuned during the untimed warm-up epochs.
+    params['config']['gemm_tuning_online'] = args.warmup >= 1
     torch.manual_seed(42 + rank)
     agent = A2CAgent('bench', params)
     agent.init_tensors()

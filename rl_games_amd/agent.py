@@ -161,6 +161,9 @@ class A2CAgent:
             if self.global_rank != 0:
                 config['print_stats'] = False
         self.ppo_device = config.get('device', 'cuda:0')
+        if config.get('gemm_tuning', True):
+            from . import gemm_tuning
+            gemm_tuning.enable(allow_tuning=bool(config.get('gemm_tuning_online', False)))
         if not str(self.ppo_device).startswith('cuda'):
             raise RuntimeError(f"rl_games_amd.A2CAgent runs on an MI355X HIP device only, got device "
                                f"'{self.ppo_device}' (there is no CPU fallback)")
