@@ -20,19 +20,18 @@ from . import ops
 _TAIL = 4   # extra fp32 slots at the end of the gradient arena: [0] = minibatch KL
 
 
-class FlatAdam:
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+class FlatArena:
+    """Rebinds every parameter's `.data` and `.grad` to views of two contiguous fp32 buffers.
+    Pure tensor plumbing (works on any device - the multi-process gloo tests use it on CPU)."""
+
+    def __init__(self, params):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError('no parameters')
         dev = self.params[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('FlatAdam runs on the MI355X only (no CPU fallback)')
         self.numel = sum(p.numel() for p in self.params)
         self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.flat_grads = torch.zeros(self.numel + _TAIL, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         off = 0
         self.offsets = []
         for p in self.params:
@@ -44,6 +43,19 @@ class FlatAdam:
             off += n
         self.grads = self.flat_grads[:self.numel]
         self.kl_slot = self.flat_grads[self.numel:self.numel + 1]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grads.zero_()
+
+
+class FlatAdam(FlatArena):
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params)
+        dev = self.flat_params.device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam runs on the MI355X only (no CPU fallback)')
+        self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         # two fp64 lr slots, ping-pong by step parity (see csrc/optim.hip)
@@ -76,9 +88,6 @@ class FlatAdam:
         return used, nxt
 
     # ------------------------------------------------------------------ step
-    def zero_grad(self, set_to_none=False):
-        self.flat_grads.zero_()
-
     def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
         """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
