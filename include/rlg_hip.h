@@ -198,21 +198,26 @@ int rlg_ppo_loss_partials_per_block(int actions);
 /* mu [mb,A], logstd [A] (fixed sigma, 'exp'), values [mb]; dataset slices actions [mb,A],
  * old_neglogp/advantages/old_values/returns [mb], old_mu/old_sigma [mb,A] (overwritten with
  * the new mu/sigma when write_back).  Emits d_mu [mb,A], d_values [mb] (already scaled by
- * 1/mb or mask/sum(mask)) and fp64 partials [blocks][6+A].  bound_kind 0 none / 1 'bound' /
- * 2 'regularisation'. */
+ * 1/mb or mask/sum(mask)) and fp64 partials [blocks][rlg_ppo_loss_partials_per_block(A)].
+ * mu/values/d_mu/d_values take row strides ld_* (elements) so they can be column views of a fused
+ * [mb, 1+A] head buffer.  bound_kind 0 none / 1 'bound' / 2 'regularisation'. */
 int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values,
                        const float* actions, const float* old_neglogp, const float* advantages,
                        const float* old_values, const float* returns, float* old_mu,
                        float* old_sigma, const float* mask_or_null, const float* mask_sum_or_null,
                        float* d_mu, float* d_values, double* partials, int minibatch, int actions_num,
-                       float e_clip, float critic_coef, float bounds_coef, int clip_value,
-                       int use_smooth_clamp, int bound_kind, int write_back, void* stream);
+                       int ld_mu, int ld_values, int ld_d_mu, int ld_d_values, float e_clip,
+                       float critic_coef, float bounds_coef, int clip_value, int use_smooth_clamp,
+                       int bound_kind, int write_back, void* stream);
 
 /* scalars8 = {a_loss, c_loss, entropy, b_loss, kl, loss, sum(mask), 0}; d_logstd [A];
- * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena). */
+ * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena);
+ * d_mu_bias_or_null [A] / d_value_bias_or_null [1] receive sum_rows d_mu / d_values, i.e. the
+ * bias gradients of the mu and value heads (what nn.Linear's backward computes with sum(0)). */
 int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_num, int minibatch,
                           int masked, float critic_coef, float entropy_coef, float bounds_coef,
-                          float* scalars8, float* d_logstd, float* kl_slot_or_null, void* stream);
+                          float* scalars8, float* d_logstd, float* kl_slot_or_null,
+                          float* d_mu_bias_or_null, float* d_value_bias_or_null, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Gradient truncation + Adam + adaptive learning rate on a flat arena
@@ -236,6 +241,25 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   double beta2, double eps, double weight_decay, int schedule_kind,
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
                   double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Manual MLP backward helpers
+ *   replace, per hidden layer of A2CBuilder's MLP (rl_games/algos_torch/network_builder.py:
+ *   118-147, forward :498), aten's activation backward + the bias-gradient sum(0) of
+ *   nn.Linear's backward that loss.backward() (a2c_continuous.py:211) runs.
+ * ---------------------------------------------------------------------------------- */
+
+int rlg_act_bwd_num_blocks(long long rows, int cols);
+
+/* d_pre = d_out * act'(pre_act) (may alias d_out), partials[block][cols] = column sums of d_pre.
+ * act_kind 0 identity, 1 elu(alpha 1), 2 relu, 3 tanh.  cols % 4 == 0, ld = row stride. */
+int rlg_act_bwd_colsum(const float* d_out, const float* pre_act, float* d_pre, long long rows,
+                       int cols, long long ld, int act_kind, double* partials, int num_blocks,
+                       void* stream);
+
+/* out[c] (+)= sum_b partials[b][c]: the bias gradient. */
+int rlg_colsum_finalize(const double* partials, int num_blocks, int cols, float* out, int accumulate,
+                        void* stream);
 
 #ifdef __cplusplus
 }

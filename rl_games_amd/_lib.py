@@ -57,10 +57,14 @@ _PROTOTYPES = {
     # ppo_loss.hip
     'rlg_ppo_loss_num_blocks': [_c_int],
     'rlg_ppo_loss_partials_per_block': [_c_int],
-    'rlg_ppo_loss_fused': [_P] * 15 + [_c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int,
-                                       _c_int, _c_int, _P],
+    'rlg_ppo_loss_fused': [_P] * 15 + [_c_int] * 6 + [_c_float, _c_float, _c_float, _c_int, _c_int,
+                                                      _c_int, _c_int, _P],
     'rlg_ppo_loss_finalize': [_P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _P,
-                              _P, _P, _P],
+                              _P, _P, _P, _P, _P],
+    # mlp_fused.hip
+    'rlg_act_bwd_num_blocks': [_c_ll, _c_int],
+    'rlg_act_bwd_colsum': [_P, _P, _P, _c_ll, _c_int, _c_ll, _c_int, _P, _c_int, _P],
+    'rlg_colsum_finalize': [_P, _c_int, _c_int, _P, _c_int, _P],
     # optim.hip
     'rlg_grad_norm_num_blocks': [_c_ll],
     'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P],

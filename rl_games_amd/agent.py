@@ -311,8 +311,23 @@ class A2CAgent:
         self.states = None
         self.is_rnn = self.model.is_rnn()
         self.bound_loss_type = config.get('bound_loss_type', 'bound')
+        layout = None
+        self._use_engine = (not self.is_rnn) and config.get('manual_mlp', True)
+        if self._use_engine:
+            from .mlp_engine import ManualMLP
+            net = self.model.a2c_network
+            rest = [p for p in self.model.parameters() if all(p is not q for q in net.parameters())]
+            layout = ManualMLP.layout(net) + rest
         self.optimizer = FlatAdam(self.model.parameters(), self.last_lr, eps=1e-08,
-                                  weight_decay=self.weight_decay)
+                                  weight_decay=self.weight_decay, layout=layout)
+        self._engine = None
+        if self._use_engine:
+            try:
+                self._engine = ManualMLP(self.model.a2c_network, self.optimizer,
+                                         max(self.minibatch_size, self.num_actors * self.num_agents))
+            except NotImplementedError as e:
+                print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
+                self._engine = None
         self.dataset = PPODataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn,
                                   dev, self.seq_length)
         if self.normalize_value:
@@ -337,7 +352,8 @@ class A2CAgent:
         self._d_mu = torch.empty(mb, A, dtype=torch.float32, device=dev)
         self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
         self._loss_blocks = ops.ppo_loss_blocks(mb)
-        self._loss_partials = torch.empty(self._loss_blocks, 6 + A, dtype=torch.float64, device=dev)
+        self._loss_partials = torch.empty(self._loss_blocks, ops.ppo_loss_partials_per_block(A),
+                                          dtype=torch.float64, device=dev)
         self._mb_scalars = torch.zeros(max(1, self.mini_epochs_num * self.num_minibatches), 8,
                                        dtype=torch.float32, device=dev)
         self._mb_index = 0
@@ -759,7 +775,15 @@ class A2CAgent:
                 batch['dones'] = input_dict['dones']
 
         opt.zero_grad()
-        mu, logstd, values, _ = self.model.forward_heads(batch)
+        eng = self._engine
+        if eng is not None:
+            with torch.no_grad():
+                obs_n = self.model.norm_obs(obs_batch)                  # updates the obs statistics
+                heads = eng.forward(obs_n)
+            mu, values = eng.mu_view(heads), eng.values_view(heads)
+            logstd = net.sigma
+        else:
+            mu, logstd, values, _ = self.model.forward_heads(batch)
         mb, A = mu.shape
         row = self._mb_scalars[self._mb_index % self._mb_scalars.shape[0]]
         self._mb_index += 1
@@ -769,19 +793,29 @@ class A2CAgent:
             mask_sum = mask.sum().reshape(1)
         coef_b = self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0
         kind = 0 if self.bounds_loss_coef is None else ops.BOUND_KINDS.get(self.bound_loss_type, 0)
-        d_mu, d_val = self._d_mu[:mb], self._d_val[:mb]
+        if eng is not None:
+            d_heads = eng.d_heads[:mb]
+            d_mu, d_val = eng.mu_view(d_heads), eng.values_view(d_heads)
+            mu_bias_grad, value_bias_grad = eng.net.mu.bias.grad, eng.net.value.bias.grad
+        else:
+            d_mu, d_val = self._d_mu[:mb], self._d_val[:mb]
+            mu_bias_grad = value_bias_grad = None
         with torch.no_grad():
             ops.ppo_loss_fused(
-                mu.detach(), logstd.detach(), values.detach().reshape(-1), input_dict['actions'],
+                mu.detach(), logstd.detach(), values.detach().reshape(mb, -1)[:, 0] if eng is not None
+                else values.detach().reshape(-1), input_dict['actions'],
                 input_dict['old_logp_actions'], input_dict['advantages'],
                 input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
-                input_dict['mu'], input_dict['sigma'], d_mu, d_val, self._loss_partials,
-                self.e_clip, self.critic_coef, coef_b, self.clip_value, self.use_smooth_clamp, kind,
-                True, mask, mask_sum)
+                input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
+                self._loss_partials, self.e_clip, self.critic_coef, coef_b, self.clip_value,
+                self.use_smooth_clamp, kind, True, mask, mask_sum)
             ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
                                   self.critic_coef, self.entropy_coef, coef_b, row, net.sigma.grad,
-                                  opt.kl_slot)
-        torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
+                                  opt.kl_slot, mu_bias_grad, value_bias_grad)
+            if eng is not None:
+                eng.backward(d_heads)
+        if eng is None:
+            torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
         self.trancate_gradients_and_step()
         # dataset.update_mu_sigma happened inside the loss kernel (write_back)
         self.train_result = (row[0], row[1], row[2], row[4], self._host_lr, 1.0,

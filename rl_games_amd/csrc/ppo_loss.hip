@@ -24,14 +24,16 @@
 // ppo_loss_finalize_kernel folds them into the scalars and d logstd.
 //
 // Algorithmic HBM traffic per row: reads 4*A*4 + 5*4 (+4 mask), writes 3*A*4 + 4 bytes
-// (d mu, new mu, new sigma, d value) = 28*A + 24 bytes.
+// (d mu, new mu, new sigma, d value) = 28*A + 24 bytes.  mu / values / d mu / d values may be
+// strided views (columns of a fused [mb, 1+A] head buffer); the column sums of d mu and the sum
+// of d value (= the head biases' gradients) ride along in the block partials.
 
 #include "rlg_device.hpp"
 
 namespace rlg {
 
 constexpr int kLossRows = 256;   // rows per block == threads per block
-constexpr int kLossScalars = 6;  // a_loss, c_loss, entropy, b_loss, kl, mask sum
+constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
 
 struct LossArgs {
   // network outputs
@@ -51,8 +53,9 @@ struct LossArgs {
   // outputs
   float* d_mu;             // [mb, A]
   float* d_values;         // [mb]
-  double* partials;        // [gridDim.x][kLossScalars + A]
+  double* partials;        // [gridDim.x][kLossScalars + 2A]: scalars | d logstd terms | sum_rows d_mu
   int mb, A;
+  int ld_mu, ld_val, ld_dmu, ld_dval;   // row strides (elements) of mu / values / d_mu / d_values
   float e_clip, critic_coef, bounds_coef;
   int clip_value;          // default_critic_loss clip flag
   int smooth;              // use_smooth_clamp
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     int r = tid / A, a = tid - r * A;
     const int dr = kLossRows / A, da = kLossRows - dr * A;
     for (int e = tid; e < tile_elems; e += kLossRows) {
-      const float mu = p.mu[e0 + e];
+      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float omu = p.old_mu[e0 + e];
       const float osg = p.old_sigma[e0 + e];
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   __syncthreads();
 
   // ------------------------------ phase 2: one thread per row ------------------------
-  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (tid < rows) {
     const long long i = row0 + tid;
     float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
 
     // critic                                                                 common_losses.py:20-27
-    const float v = p.values[i], vo = p.old_values[i], R = p.returns[i];
+    const float v = p.values[i * p.ld_val], vo = p.old_values[i], R = p.returns[i];
     float c_loss, g_v;
     if (p.clip_value) {
       const float delta = v - vo;
@@ -215,7 +218,9 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     const float w = m / denom_count;          // d(mean)/d(element)
     row_g[tid] = g_nlp * w;
     row_w[tid] = w;
-    p.d_values[i] = (0.5f * p.critic_coef) * g_v * w;                         // a2c_continuous.py:133
+    const float dv = (0.5f * p.critic_coef) * g_v * w;                        // a2c_continuous.py:133
+    p.d_values[i * p.ld_dval] = dv;
+    acc[6] = static_cast<double>(dv);
     acc[0] = static_cast<double>(a_loss) * m;
     acc[1] = static_cast<double>(c_loss) * m;
     acc[2] = static_cast<double>(s_ent) * m;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     acc[5] = m;
   }
   block_sum<kLossScalars, kLossRows>(acc, red);
-  double* out = p.partials + static_cast<long long>(blockIdx.x) * (kLossScalars + A);
+  double* out = p.partials + static_cast<long long>(blockIdx.x) * (kLossScalars + 2 * A);
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < kLossScalars; ++k) out[k] = acc[k];
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     int r = tid / A, a = tid - r * A;
     const int dr = kLossRows / A, da = kLossRows - dr * A;
     for (int e = tid; e < tile_elems; e += kLossRows) {
-      const float mu = p.mu[e0 + e];
+      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float sg = col_sigma[a];
       const float z = (x - mu) / sg;
@@ -247,7 +252,9 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
         db = 2.0f * mu;
       }
       // d nlp / d mu = -z / sigma
-      p.d_mu[e0 + e] = row_g[r] * (-(z / sg)) + (row_w[r] * p.bounds_coef) * db;
+      const float dmu = row_g[r] * (-(z / sg)) + (row_w[r] * p.bounds_coef) * db;
+      p.d_mu[(row0 + r) * p.ld_dmu + a] = dmu;
+      t_kl[r * AP + a] = dmu;                     // column sums -> bias gradient of the mu head
       // d nlp / d logstd = 1 - z^2
       t_z2[r * AP + a] = row_g[r] * (1.0f - z * z);
       a += da;
@@ -261,23 +268,26 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   __syncthreads();
 
   // ------------------------------ phase 4: column sums over the block's rows ----------
-  // 8 row groups x A columns, then A threads fold the 8 partials (fixed order).
-  {
+  // two column sets (d logstd terms in t_z2, d mu in t_kl); 8 row groups x A columns each, then
+  // A threads fold the 8 partials (fixed order).
+  for (int set = 0; set < 2; ++set) {
+    const float* tile = set == 0 ? t_z2 : t_kl;
     const int groups = 8;
     const int per = (rows + groups - 1) / groups;
     for (int j = tid; j < groups * A; j += kLossRows) {
       const int g = j / A, a = j - g * A;
       double s = 0.0;
       const int r_end = min(rows, (g + 1) * per);
-      for (int r = g * per; r < r_end; ++r) s += static_cast<double>(t_z2[r * AP + a]);
+      for (int r = g * per; r < r_end; ++r) s += static_cast<double>(tile[r * AP + a]);
       red[j] = s;
     }
     __syncthreads();
     for (int a = tid; a < A; a += kLossRows) {
       double s = 0.0;
       for (int g = 0; g < groups; ++g) s += red[g * A + a];
-      out[kLossScalars + a] = s;
+      out[kLossScalars + set * A + a] = s;
     }
+    __syncthreads();
   }
 }
 
@@ -287,11 +297,12 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
 __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
     const double* __restrict__ partials, int nblocks, int A, int mb, int masked,
     float critic_coef, float entropy_coef, float bounds_coef, float* __restrict__ scalars,
-    float* __restrict__ d_logstd, float* __restrict__ kl_slot) {
+    float* __restrict__ d_logstd, float* __restrict__ kl_slot, float* __restrict__ d_mu_bias,
+    float* __restrict__ d_value_bias) {
   // 8 block-slices x 32 columns per pass; slices are folded through LDS in a fixed order.
   __shared__ double part[8][32];
   __shared__ double sh[kLossScalars];
-  const int W = kLossScalars + A;
+  const int W = kLossScalars + 2 * A;
   const int col_in_pass = threadIdx.x & 31;
   const int slice = threadIdx.x >> 5;
   for (int c0 = 0; c0 < W; c0 += 32) {
@@ -318,7 +329,12 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
       const double msum0 = sh[5];
       const double denom0 = masked ? fmax(msum0, 1.0) : static_cast<double>(mb);
       const float w_total = static_cast<float>(msum0 / denom0);
-      d_logstd[c - kLossScalars] = static_cast<float>(part[0][col_in_pass]) - entropy_coef * w_total;
+      const int a = c - kLossScalars;
+      if (a < A) {
+        d_logstd[a] = static_cast<float>(part[0][col_in_pass]) - entropy_coef * w_total;
+      } else if (d_mu_bias) {
+        d_mu_bias[a - A] = static_cast<float>(part[0][col_in_pass]);   // bias grad of the mu head
+      }
     }
     __syncthreads();
   }
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
     scalars[6] = static_cast<float>(msum);
     scalars[7] = 0.0f;
     if (kl_slot) *kl_slot = kl;
+    if (d_value_bias) *d_value_bias = static_cast<float>(sh[6]);       // bias grad of the value head
   }
 }
 
@@ -350,15 +367,16 @@ extern "C" {
 
 int rlg_ppo_loss_num_blocks(int minibatch) { return (minibatch + rlg::kLossRows - 1) / rlg::kLossRows; }
 
-int rlg_ppo_loss_partials_per_block(int actions) { return rlg::kLossScalars + actions; }
+int rlg_ppo_loss_partials_per_block(int actions) { return rlg::kLossScalars + 2 * actions; }
 
 int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values,
                        const float* actions, const float* old_neglogp, const float* advantages,
                        const float* old_values, const float* returns, float* old_mu,
                        float* old_sigma, const float* mask_or_null, const float* mask_sum_or_null,
                        float* d_mu, float* d_values, double* partials, int minibatch, int actions_num,
-                       float e_clip, float critic_coef, float bounds_coef, int clip_value,
-                       int use_smooth_clamp, int bound_kind, int write_back, void* stream) {
+                       int ld_mu, int ld_values, int ld_d_mu, int ld_d_values, float e_clip,
+                       float critic_coef, float bounds_coef, int clip_value, int use_smooth_clamp,
+                       int bound_kind, int write_back, void* stream) {
   using namespace rlg;
   if (minibatch <= 0 || actions_num <= 0) return static_cast<int>(hipErrorInvalidValue);
   if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
@@ -380,6 +398,10 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   p.partials = partials;
   p.mb = minibatch;
   p.A = actions_num;
+  p.ld_mu = ld_mu;
+  p.ld_val = ld_values;
+  p.ld_dmu = ld_d_mu;
+  p.ld_dval = ld_d_values;
   p.e_clip = e_clip;
   p.critic_coef = critic_coef;
   p.bounds_coef = bounds_coef;
@@ -403,11 +425,12 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
 
 int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_num, int minibatch,
                           int masked, float critic_coef, float entropy_coef, float bounds_coef,
-                          float* scalars8, float* d_logstd, float* kl_slot_or_null, void* stream) {
+                          float* scalars8, float* d_logstd, float* kl_slot_or_null,
+                          float* d_mu_bias_or_null, float* d_value_bias_or_null, void* stream) {
   hipLaunchKernelGGL(rlg::ppo_loss_finalize_kernel, dim3(1), dim3(256), 0,
                      static_cast<hipStream_t>(stream), partials, num_blocks, actions_num, minibatch,
                      masked, critic_coef, entropy_coef, bounds_coef, scalars8, d_logstd,
-                     kl_slot_or_null);
+                     kl_slot_or_null, d_mu_bias_or_null, d_value_bias_or_null);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

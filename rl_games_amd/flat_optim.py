@@ -24,33 +24,50 @@ class FlatArena:
     """Rebinds every parameter's `.data` and `.grad` to views of two contiguous fp32 buffers.
     Pure tensor plumbing (works on any device - the multi-process gloo tests use it on CPU)."""
 
-    def __init__(self, params):
+    def __init__(self, params, layout=None):
+        """`params`: logical order (= model.parameters(), the order torch.optim indexes its
+        state by).  `layout`: optional physical order of the same tensors inside the arena, used
+        to make e.g. the value and mu head weights adjacent so that they form one GEMM operand."""
         self.params = [p for p in params]
         if not self.params:
             raise ValueError('no parameters')
+        physical = list(layout) if layout is not None else self.params
+        if sorted(id(p) for p in physical) != sorted(id(p) for p in self.params):
+            raise ValueError('layout must be a permutation of params')
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.flat_grads = torch.zeros(self.numel + _TAIL, dtype=torch.float32, device=dev)
         off = 0
-        self.offsets = []
-        for p in self.params:
+        where = {}
+        for p in physical:
             n = p.numel()
             self.flat_params[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_params[off:off + n].view(p.shape)
             p.grad = self.flat_grads[off:off + n].view(p.shape)
-            self.offsets.append((off, n))
+            where[id(p)] = (off, n)
             off += n
+        self.offsets = [where[id(p)] for p in self.params]
         self.grads = self.flat_grads[:self.numel]
         self.kl_slot = self.flat_grads[self.numel:self.numel + 1]
 
     def zero_grad(self, set_to_none=False):
         self.flat_grads.zero_()
 
+    def span(self, first, last):
+        """(params view, grads view) of the contiguous arena range covering parameters `first`
+        .. `last` (which must be physically adjacent, in that order)."""
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        o0, n0 = self.offsets[ids[id(first)]]
+        o1, n1 = self.offsets[ids[id(last)]]
+        if o1 != o0 + n0:
+            raise ValueError('parameters are not adjacent in the arena')
+        return self.flat_params[o0:o1 + n1], self.flat_grads[o0:o1 + n1]
+
 
 class FlatAdam(FlatArena):
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        super().__init__(params)
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, layout=None):
+        super().__init__(params, layout)
         dev = self.flat_params.device
         if dev.type != 'cuda':
             raise RuntimeError('FlatAdam runs on the MI355X only (no CPU fallback)')

@@ -1,0 +1,123 @@
+"""Manual forward/backward of the actor-critic MLP (no autograd graph).
+
+For the plain-MLP policies of the BASELINE configs the training step is a fixed chain
+    obs -> [Linear -> act] x L -> fused (value | mu) head -> fused PPO loss kernel
+so the backward pass is written out explicitly instead of being recorded by autograd:
+  * the GEMMs are the same rocBLAS/hipBLASLt calls nn.Linear's autograd issues
+    (forward addmm; dX = dZ W; dW = dZ^T A), written straight into preallocated buffers and
+    into the gradient arena (no AccumulateGrad adds, no per-step allocations);
+  * activation backward + bias-gradient column sum is ONE pass (csrc/mlp_fused.hip) instead of
+    aten's elu_backward followed by a separate sum(0) reduction;
+  * the value and mu heads (`a2c_network.value`, `a2c_network.mu`,
+    rl_games/algos_torch/network_builder.py:295-311) are adjacent in the parameter arena and
+    run as one [1+A, K] GEMM operand; their bias gradients come out of the loss kernel.
+Numerics: identical formulas (elu'(z) = exp(z) from the pre-activation, like aten); GEMM
+results are the library's, as before.  Parameters keep their reference names and shapes.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class ManualMLP:
+    def __init__(self, net, arena, max_rows):
+        """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`."""
+        self.net = net
+        self.arena = arena
+        self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
+        acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
+        if len(acts) != len(self.linears):
+            raise NotImplementedError('unexpected MLP structure')
+        name = {nn.ELU: 'elu', nn.ReLU: 'relu', nn.Tanh: 'tanh', nn.Identity: 'None'}.get(type(acts[0]))
+        if name is None or any(type(a) is not type(acts[0]) for a in acts):
+            raise NotImplementedError('manual MLP engine supports elu / relu / tanh / identity trunks')
+        if isinstance(acts[0], nn.ELU) and acts[0].alpha != 1.0:
+            raise NotImplementedError('elu alpha != 1')
+        self.act_name = name
+        self.act_kind = ops.ACT_KINDS[name]
+        self.act_module = acts[0]
+        if not isinstance(net.value_act, nn.Identity) or not isinstance(net.mu_act, nn.Identity):
+            raise NotImplementedError('head activations are not supported by the manual MLP engine')
+        if any(l.out_features % 4 for l in self.linears):
+            raise NotImplementedError('hidden widths must be multiples of 4')
+        self.A = net.mu.out_features
+        self.V = net.value.out_features
+        K = net.mu.in_features
+        wp, wg = arena.span(net.value.weight, net.mu.weight)
+        bp, bg = arena.span(net.value.bias, net.mu.bias)
+        self.head_w, self.head_w_grad = wp.view(self.V + self.A, K), wg.view(self.V + self.A, K)
+        self.head_b, self.head_b_grad = bp, bg
+        dev = wp.device
+        self.max_rows = max_rows
+        widths = [l.out_features for l in self.linears]
+        self.Z = [torch.empty(max_rows, w, device=dev) for w in widths]       # pre-activations
+        self.Hs = [torch.empty(max_rows, w, device=dev) for w in widths]      # activations
+        self.dA = [torch.empty(max_rows, w, device=dev) for w in widths]      # d activation / d pre-act
+        self.heads = torch.empty(max_rows, self.V + self.A, device=dev)
+        self.d_heads = torch.empty(max_rows, self.V + self.A, device=dev)
+        self.nb = [ops.act_bwd_blocks(max_rows, w) for w in widths]
+        self.partials = [torch.empty(nb * w, dtype=torch.float64, device=dev) for nb, w in zip(self.nb, widths)]
+
+    @staticmethod
+    def layout(net):
+        """Physical arena order: everything in parameters() order except that the head weights
+        (value, mu) and head biases (value, mu) are made adjacent."""
+        heads = [net.value.weight, net.mu.weight, net.value.bias, net.mu.bias]
+        skip = {id(p) for p in heads}
+        rest = [p for p in net.parameters() if id(p) not in skip]
+        return rest + heads
+
+    # ------------------------------------------------------------------
+    def forward(self, x, keep=True):
+        """x: [rows, in] normalised observations.  Returns heads [rows, V+A] (col 0..V-1 value,
+        then mu).  `keep` retains the pre-activations for backward()."""
+        rows = x.shape[0]
+        a = x
+        for l, lin in enumerate(self.linears):
+            z = self.Z[l][:rows]
+            torch.addmm(lin.bias, a, lin.weight.t(), out=z)
+            h = self.Hs[l][:rows]
+            if self.act_kind == 1:
+                torch.ops.aten.elu.out(z, out=h)
+            elif self.act_kind == 2:
+                torch.relu(z, out=h) if False else torch.clamp_min(z, 0.0, out=h)
+            elif self.act_kind == 3:
+                torch.tanh(z, out=h)
+            else:
+                h = z
+            a = h
+        heads = self.heads[:rows]
+        torch.addmm(self.head_b, a, self.head_w.t(), out=heads)
+        self._x, self._rows, self._last = x, rows, a
+        return heads
+
+    def values_view(self, heads):
+        return heads[:, :self.V]
+
+    def mu_view(self, heads):
+        return heads[:, self.V:]
+
+    def backward(self, d_heads):
+        """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
+        and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
+        finalise kernel)."""
+        rows = self._rows
+        L = len(self.linears)
+        a_last = self._last
+        torch.mm(d_heads.t(), a_last, out=self.head_w_grad)
+        d = self.dA[L - 1][:rows]
+        torch.mm(d_heads, self.head_w, out=d)
+        for l in range(L - 1, -1, -1):
+            lin = self.linears[l]
+            w = lin.out_features
+            nb = ops.act_bwd_blocks(rows, w)
+            part = self.partials[l][:nb * w]
+            ops.act_bwd_colsum(d, self.Z[l][:rows], d, self.act_kind, part, nb)
+            ops.colsum_finalize(part, nb, w, lin.bias.grad)
+            a_prev = self.Hs[l - 1][:rows] if l > 0 else self._x
+            torch.mm(d.t(), a_prev, out=lin.weight.grad)
+            if l > 0:
+                d_prev = self.dA[l - 1][:rows]
+                torch.mm(d, lin.weight, out=d_prev)
+                d = d_prev

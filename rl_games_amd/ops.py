@@ -231,32 +231,83 @@ def ppo_loss_blocks(minibatch):
     return _lib.load().rlg_ppo_loss_num_blocks(int(minibatch))
 
 
+def ppo_loss_partials_per_block(actions):
+    return _lib.load().rlg_ppo_loss_partials_per_block(int(actions))
+
+
+def _rows_view(t, name):
+    """(pointer, row stride) of a [rows, cols] / [rows] fp32 view whose inner stride is 1."""
+    _lib.require_gpu(t, name)
+    if t.dtype != F32:
+        raise ValueError(f'{name}: expected fp32')
+    if t.dim() == 2:
+        if t.shape[1] != 1 and t.stride(1) != 1:
+            raise ValueError(f'{name}: inner stride must be 1, got {t.stride()}')
+        return t.data_ptr(), t.stride(0)
+    if t.dim() == 1:
+        return t.data_ptr(), t.stride(0)
+    raise ValueError(f'{name}: expected 1-D or 2-D')
+
+
 def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_values, returns,
                    old_mu, old_sigma, d_mu, d_values, partials, e_clip, critic_coef, bounds_coef,
                    clip_value=True, smooth=False, bound_kind=1, write_back=True, mask=None,
                    mask_sum=None):
+    """mu/d_mu [mb, A] and values/d_values [mb] may be strided row views (fused head buffer)."""
     lib = _lib.load()
     mb, A = mu.shape
+    mu_p, ld_mu = _rows_view(mu, 'mu')
+    val_p, ld_val = _rows_view(values, 'values')
+    dmu_p, ld_dmu = _rows_view(d_mu, 'd_mu')
+    dval_p, ld_dval = _rows_view(d_values, 'd_values')
     _lib.check(lib.rlg_ppo_loss_fused(
-        _need(mu, F32, 'mu'), _need(logstd, F32, 'logstd'), _need(values, F32, 'values'),
+        mu_p, _need(logstd, F32, 'logstd'), val_p,
         _need(actions, F32, 'actions'), _need(old_neglogp, F32, 'old_neglogp'),
         _need(advantages, F32, 'advantages'), _need(old_values, F32, 'old_values'),
         _need(returns, F32, 'returns'), _need(old_mu, F32, 'old_mu'), _need(old_sigma, F32, 'old_sigma'),
-        _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), _need(d_mu, F32, 'd_mu'),
-        _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'), mb, A,
+        _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), dmu_p,
+        dval_p, _need(partials, F64, 'partials'), mb, A, ld_mu, ld_val, ld_dmu, ld_dval,
         float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(bounds_coef)),
         1 if clip_value else 0, 1 if smooth else 0, bound_kind, 1 if write_back else 0, _stream(mu)),
         'rlg_ppo_loss_fused')
 
 
 def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, critic_coef,
-                      entropy_coef, bounds_coef, scalars, d_logstd, kl_slot=None):
+                      entropy_coef, bounds_coef, scalars, d_logstd, kl_slot=None, d_mu_bias=None,
+                      d_value_bias=None):
     lib = _lib.load()
     _lib.check(lib.rlg_ppo_loss_finalize(
         _need(partials, F64, 'partials'), num_blocks, actions_num, minibatch, 1 if masked else 0,
         float(np.float32(critic_coef)), float(np.float32(entropy_coef)), float(np.float32(bounds_coef)),
         _need(scalars, F32, 'scalars'), _need(d_logstd, F32, 'd_logstd'),
-        _opt(kl_slot, F32, 'kl_slot'), _stream(partials)), 'rlg_ppo_loss_finalize')
+        _opt(kl_slot, F32, 'kl_slot'), _opt(d_mu_bias, F32, 'd_mu_bias'),
+        _opt(d_value_bias, F32, 'd_value_bias'), _stream(partials)), 'rlg_ppo_loss_finalize')
+
+
+# ------------------------------------------------------------------ manual MLP backward
+
+ACT_KINDS = {'None': 0, None: 0, 'elu': 1, 'relu': 2, 'tanh': 3}
+
+
+def act_bwd_blocks(rows, cols):
+    return _lib.load().rlg_act_bwd_num_blocks(int(rows), int(cols))
+
+
+def act_bwd_colsum(d_out, pre_act, d_pre, act_kind, partials, num_blocks):
+    """d_pre = d_out * act'(pre_act) (d_pre may be d_out); partials[blocks, C] column sums."""
+    lib = _lib.load()
+    rows, C = d_out.shape
+    _lib.check(lib.rlg_act_bwd_colsum(_need(d_out, F32, 'd_out'), _opt(pre_act, F32, 'pre_act'),
+                                      _need(d_pre, F32, 'd_pre'), rows, C, d_out.stride(0), act_kind,
+                                      _need(partials, F64, 'partials'), num_blocks, _stream(d_out)),
+               'rlg_act_bwd_colsum')
+
+
+def colsum_finalize(partials, num_blocks, cols, out, accumulate=False):
+    lib = _lib.load()
+    _lib.check(lib.rlg_colsum_finalize(_need(partials, F64, 'partials'), num_blocks, cols,
+                                       _need(out, F32, 'out'), 1 if accumulate else 0,
+                                       _stream(partials)), 'rlg_colsum_finalize')
 
 
 # ------------------------------------------------------------------ optimiser

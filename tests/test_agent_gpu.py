@@ -172,3 +172,42 @@ def test_checkpoint_round_trip(tmp_path):
     assert set(ck) >= {'model', 'optimizer', 'epoch', 'frame', 'last_mean_rewards'}
     assert ck['model']['running_mean_std.running_mean'].dtype == torch.float64
     assert ck['model']['running_mean_std.count'].dtype == torch.int64
+
+
+def test_manual_mlp_engine_matches_autograd_gradients():
+    """Same parameters, same minibatch: the hand-written backward (mlp_engine.ManualMLP + fused
+    act-backward/colsum kernel + head-bias sums from the loss kernel) produces the gradients
+    torch autograd produces through nn.Linear / ELU."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    base = configs.humanoid_65536(num_actors=512, minibatch_size=4096, grad_norm=1e9, lr_schedule=None,
+                                  learning_rate=0.0)
+    torch.manual_seed(0)
+    a1 = A2CAgent('eng', copy.deepcopy(base))
+    p2 = copy.deepcopy(base)
+    p2['config']['manual_mlp'] = False
+    a2 = A2CAgent('auto', p2)
+    assert a1._engine is not None and a2._engine is None
+    a2.model.load_state_dict(a1.model.state_dict())
+    a1.init_tensors()
+    a1.obs = a1.env_reset()
+    a1.set_eval()
+    with torch.no_grad():
+        batch = a1.play_steps()
+    a2.init_tensors()
+    snapshot = {k: v.detach().clone() for k, v in a1.model.state_dict().items()}
+    grads = []
+    for ag in (a1, a2):
+        b = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != '_fused'}
+        ag.model.load_state_dict(snapshot)
+        ag.set_train()
+        ag.prepare_dataset(b)
+        ag.train_actor_critic(ag.dataset[1])
+        grads.append({n: p.grad.detach().clone() for n, p in ag.model.named_parameters()})
+        res = ag.train_result
+        grads[-1]['_scalars'] = torch.stack([res[0], res[1], res[2], res[3], res[8]])
+    g1, g2 = grads
+    assert torch.allclose(g1.pop('_scalars'), g2.pop('_scalars'), rtol=1e-6, atol=1e-8)
+    for n in g2:
+        scale = g2[n].abs().max().item() + 1e-12
+        assert torch.allclose(g1[n], g2[n], rtol=1e-4, atol=2e-6 * scale), (n, (g1[n] - g2[n]).abs().max().item(), scale)

@@ -250,7 +250,7 @@ def test_ppo_loss_forward_backward_kl(mb, A, variant):
     d_mu = torch.empty(mb, A, device=DEV)
     d_val = torch.empty(mb, device=DEV)
     nb = ops.ppo_loss_blocks(mb)
-    partials = torch.empty(nb, 6 + A, dtype=torch.float64, device=DEV)
+    partials = torch.empty(nb, ops.ppo_loss_partials_per_block(A), dtype=torch.float64, device=DEV)
     scalars = torch.zeros(8, device=DEV)
     d_logstd = torch.zeros(A, device=DEV)
     kl_slot = torch.zeros(1, device=DEV)
@@ -320,7 +320,7 @@ def test_ppo_loss_max_tie_and_clip_edges():
     d = lambda t: t.contiguous().to(DEV)
     d_mu, d_val = torch.empty(mb, A, device=DEV), torch.empty(mb, device=DEV)
     nb = ops.ppo_loss_blocks(mb)
-    partials = torch.empty(nb, 6 + A, dtype=torch.float64, device=DEV)
+    partials = torch.empty(nb, ops.ppo_loss_partials_per_block(A), dtype=torch.float64, device=DEV)
     ops.ppo_loss_fused(d(mu), d(logstd), d(values.reshape(-1)), d(batch['actions']),
                        d(batch['old_logp_actions']), d(batch['advantages']),
                        d(batch['old_values'].reshape(-1)), d(batch['returns'].reshape(-1)),
@@ -389,3 +389,61 @@ def test_adam_multi_gpu_average_and_kl_scale():
                   kl=torch.tensor([4 * 0.02], device=DEV), kl_scale=0.25)
     assert torch.allclose(fp.cpu(), ref_p[0], rtol=1e-6, atol=1e-8)
     assert lr_slots[1].item() == O.adaptive_lr(1e-3, float(np.float32(0.02 * 4) * np.float32(0.25)))
+
+
+# ----------------------------------------------------------------------------- manual MLP backward
+
+@pytest.mark.parametrize('rows,C', [(32768, 400), (1000, 200), (777, 100), (64, 8), (5000, 68)])
+@pytest.mark.parametrize('act', ['elu', 'relu', 'tanh', 'None'])
+def test_act_bwd_colsum_matches_autograd(rows, C, act):
+    """d_pre = d_out * act'(z), db = sum_rows d_pre  ==  aten's activation backward followed by the
+    bias-gradient sum(0) of nn.Linear's backward."""
+    from rl_games_amd import ops
+    gen = g(rows + C)
+    z = torch.randn(rows, C, generator=gen) * 2
+    d_out = torch.randn(rows, C, generator=gen)
+    fn = {'elu': torch.nn.functional.elu, 'relu': torch.relu, 'tanh': torch.tanh, 'None': lambda t: t}[act]
+    zz = z.clone().requires_grad_(True)
+    fn(zz).backward(d_out)
+    ref = zz.grad
+    dz = d_out.clone().to(DEV)
+    nb = ops.act_bwd_blocks(rows, C)
+    part = torch.empty(nb * C, dtype=torch.float64, device=DEV)
+    ops.act_bwd_colsum(dz, z.to(DEV), dz, ops.ACT_KINDS[act], part, nb)
+    db = torch.zeros(C, device=DEV)
+    ops.colsum_finalize(part, nb, C, db)
+    # exp / tanh differ in the last bits between the device and the host libm
+    assert torch.allclose(dz.cpu(), ref, rtol=2e-5 if act == 'tanh' else 3e-7, atol=2e-6 if act == 'tanh' else 1e-7)
+    truth = ref.double().sum(0)
+    scale = ref.abs().double().sum(0)
+    assert ((db.cpu().double() - truth).abs() <= 1e-6 * scale + 1e-9).all()
+
+
+def test_ppo_loss_on_strided_head_views_and_bias_grads():
+    """mu / values / d_mu / d_values as column views of one fused [mb, 1+A] buffer give the same
+    results as the contiguous call; the extra partial columns are the head-bias gradients."""
+    from rl_games_amd import ops
+    mb, A = 3000, 21
+    mu, logstd, values, batch = _loss_inputs(mb, A, seed=5)
+    d = lambda t: t.contiguous().to(DEV)
+    args = (d(batch['actions']), d(batch['old_logp_actions']), d(batch['advantages']),
+            d(batch['old_values'].reshape(-1)), d(batch['returns'].reshape(-1)))
+    nb, W = ops.ppo_loss_blocks(mb), ops.ppo_loss_partials_per_block(A)
+    # contiguous
+    d_mu, d_val = torch.empty(mb, A, device=DEV), torch.empty(mb, device=DEV)
+    p1 = torch.empty(nb, W, dtype=torch.float64, device=DEV)
+    ops.ppo_loss_fused(d(mu), d(logstd), d(values.reshape(-1)), *args, d(batch['mu']), d(batch['sigma']),
+                       d_mu, d_val, p1, 0.2, 2.0, 1e-4, True, False, 1, False)
+    # fused head buffer
+    heads = torch.cat([values, mu], dim=1).to(DEV)
+    d_heads = torch.zeros(mb, 1 + A, device=DEV)
+    p2 = torch.empty(nb, W, dtype=torch.float64, device=DEV)
+    ops.ppo_loss_fused(heads[:, 1:], d(logstd), heads[:, 0], *args, d(batch['mu']), d(batch['sigma']),
+                       d_heads[:, 1:], d_heads[:, 0], p2, 0.2, 2.0, 1e-4, True, False, 1, False)
+    assert torch.equal(d_heads[:, 1:], d_mu) and torch.equal(d_heads[:, 0], d_val)
+    assert torch.equal(p1, p2)
+    scal, dls = torch.zeros(8, device=DEV), torch.zeros(A, device=DEV)
+    bmu, bval = torch.zeros(A, device=DEV), torch.zeros(1, device=DEV)
+    ops.ppo_loss_finalize(p2, nb, A, mb, False, 2.0, 0.0, 1e-4, scal, dls, None, bmu, bval)
+    assert torch.allclose(bmu.cpu(), d_mu.cpu().double().sum(0).float(), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(bval.cpu(), d_val.cpu().double().sum().float().reshape(1), rtol=1e-5, atol=1e-9)
