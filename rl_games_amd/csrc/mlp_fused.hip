@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __re
 extern "C" {
 
 int rlg_act_bwd_num_blocks(long long rows, int cols) {
-  long long need = (rows * cols + 256LL * 32 - 1) / (256LL * 32);
+  long long need = (rows * cols + 256LL * 64 - 1) / (256LL * 64);
   if (need < 1) need = 1;
-  if (need > 512) need = 512;
+  if (need > 256) need = 256;      // one block per CU; fewer partial rows for the finalise pass
   return static_cast<int>(need);
 }
 
