@@ -98,24 +98,27 @@ __global__ __launch_bounds__(kActBlock) void act_bwd_colsum_kernel(
 }
 
 // db[c] (+)= sum over blocks of partials[b][c]
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ partials,
-                                                              int nblocks, int C,
-                                                              float* __restrict__ out, int accumulate) {
-  __shared__ double part[8][32];
+// 1024 threads = 32 row-slices x 32 columns: each thread sums <= nblocks/32 partial rows, so the
+// dependent-load chain stays short (this kernel is pure latency).
+constexpr int kFinSlices = 32;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const double* __restrict__ partials,
+                                                               int nblocks, int C,
+                                                               float* __restrict__ out, int accumulate) {
+  __shared__ double part[kFinSlices][33];
   const int col_in_pass = threadIdx.x & 31;
   const int slice = threadIdx.x >> 5;
   for (int c0 = blockIdx.x * 32; c0 < C; c0 += gridDim.x * 32) {
     const int c = c0 + col_in_pass;
     double s = 0.0;
     if (c < C) {
-      for (int b = slice; b < nblocks; b += 8) s += partials[static_cast<long long>(b) * C + c];
+      for (int b = slice; b < nblocks; b += kFinSlices) s += partials[static_cast<long long>(b) * C + c];
     }
     part[slice][col_in_pass] = s;
     __syncthreads();
     if (slice == 0 && c < C) {
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += part[k][col_in_pass];
+      for (int k = 0; k < kFinSlices; ++k) t += part[k][col_in_pass];
       const float v = static_cast<float>(t);
       out[c] = accumulate ? out[c] + v : v;
     }
@@ -173,7 +176,7 @@ int rlg_colsum_finalize(const double* partials, int num_blocks, int cols, float*
                         void* stream) {
   int grid = (cols + 31) / 32;
   if (grid > 64) grid = 64;
-  hipLaunchKernelGGL(rlg::colsum_finalize_kernel, dim3(grid), dim3(256), 0,
+  hipLaunchKernelGGL(rlg::colsum_finalize_kernel, dim3(grid), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), partials, num_blocks, cols, out, accumulate);
   RLG_RETURN_LAUNCH_STATUS();
 }

@@ -15,7 +15,7 @@
 //   * PPODataset.update_mu_sigma (rl_games/common/datasets.py:33-43): the new mu/sigma are
 //     written over the old ones in the same pass (the old values are read first for the KL).
 //
-// One block = 256 rows.  Phase 1 walks the block's [256, A] tile element-wise with coalesced
+// One block = 64 rows, 256 threads.  Phase 1 walks the block's [256, A] tile element-wise with coalesced
 // loads (mu, actions, old mu, old sigma), writes the per-element terms to LDS; phase 2 has one
 // thread per row reduce over A (odd LDS row stride -> conflict free), evaluate the scalar
 // losses and the row's gradient coefficient; phase 3 walks the tile again (mu/actions come
@@ -32,7 +32,8 @@
 
 namespace rlg {
 
-constexpr int kLossRows = 256;   // rows per block == threads per block
+constexpr int kLossRows = 64;      // rows per block (one LDS tile set)
+constexpr int kLossThreads = 256;  // threads per block: all walk the tile, the first kLossRows own a row
 constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
 
 struct LossArgs {
@@ -78,7 +79,7 @@ __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) 
   return (4.0f * e) * (s * s);
 }
 
-__global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
+__global__ __launch_bounds__(kLossThreads) void ppo_loss_kernel(LossArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int A = p.A;
   const int AP = A | 1;                       // odd row stride: conflict-free row walks
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   const long long e0 = row0 * A;              // first element of the tile
   const int tile_elems = rows * A;
 
-  for (int a = tid; a < A; a += kLossRows) {
+  for (int a = tid; a < A; a += kLossThreads) {
     const float ls = p.logstd[a];
     col_logstd[a] = ls;
     col_sigma[a] = expf(ls);                                                  // models.py:296
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   // ------------------------------ phase 1: element-wise ------------------------------
   {
     int r = tid / A, a = tid - r * A;
-    const int dr = kLossRows / A, da = kLossRows - dr * A;
-    for (int e = tid; e < tile_elems; e += kLossRows) {
+    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossThreads) {
       const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float omu = p.old_mu[e0 + e];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     acc[4] = static_cast<double>(s_kl) * m;
     acc[5] = m;
   }
-  block_sum<kLossScalars, kLossRows>(acc, red);
+  block_sum<kLossScalars, kLossThreads>(acc, red);
   double* out = p.partials + static_cast<long long>(blockIdx.x) * (kLossScalars + 2 * A);
   if (tid == 0) {
 #pragma unroll
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
   // ------------------------------ phase 3: d mu, logstd terms -------------------------
   {
     int r = tid / A, a = tid - r * A;
-    const int dr = kLossRows / A, da = kLossRows - dr * A;
-    for (int e = tid; e < tile_elems; e += kLossRows) {
+    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossThreads) {
       const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float sg = col_sigma[a];
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
     const float* tile = set == 0 ? t_z2 : t_kl;
     const int groups = 8;
     const int per = (rows + groups - 1) / groups;
-    for (int j = tid; j < groups * A; j += kLossRows) {
+    for (int j = tid; j < groups * A; j += kLossThreads) {
       const int g = j / A, a = j - g * A;
       double s = 0.0;
       const int r_end = min(rows, (g + 1) * per);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
       red[j] = s;
     }
     __syncthreads();
-    for (int a = tid; a < A; a += kLossRows) {
+    for (int a = tid; a < A; a += kLossThreads) {
       double s = 0.0;
       for (int g = 0; g < groups; ++g) s += red[g * A + a];
       out[kLossScalars + set * A + a] = s;
@@ -294,13 +295,13 @@ __global__ __launch_bounds__(kLossRows) void ppo_loss_kernel(LossArgs p) {
 // Scalars written by the finalise kernel (fp32[8], read lazily by the host):
 //   [0] a_loss [1] c_loss [2] entropy [3] b_loss [4] kl [5] total loss [6] sum(mask) [7] unused
 
-__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
+__global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(
     const double* __restrict__ partials, int nblocks, int A, int mb, int masked,
     float critic_coef, float entropy_coef, float bounds_coef, float* __restrict__ scalars,
     float* __restrict__ d_logstd, float* __restrict__ kl_slot, float* __restrict__ d_mu_bias,
     float* __restrict__ d_value_bias) {
-  // 8 block-slices x 32 columns per pass; slices are folded through LDS in a fixed order.
-  __shared__ double part[8][32];
+  // 32 block-slices x 32 columns per pass; slices are folded through LDS in a fixed order.
+  __shared__ double part[32][33];
   __shared__ double sh[kLossScalars];
   const int W = kLossScalars + 2 * A;
   const int col_in_pass = threadIdx.x & 31;
@@ -309,14 +310,14 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(
     const int c = c0 + col_in_pass;
     double s = 0.0;
     if (c < W) {
-      for (int b = slice; b < nblocks; b += 8) s += partials[static_cast<long long>(b) * W + c];
+      for (int b = slice; b < nblocks; b += 32) s += partials[static_cast<long long>(b) * W + c];
     }
     part[slice][col_in_pass] = s;
     __syncthreads();
     if (slice == 0 && c < W) {
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += part[k][col_in_pass];
+      for (int k = 0; k < 32; ++k) t += part[k][col_in_pass];
       if (c < kLossScalars) {
         sh[c] = t;
       } else {
@@ -412,13 +413,13 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   const int AP = actions_num | 1;
   size_t shm = (static_cast<size_t>(3) * kLossRows * AP + 2 * kLossRows + 2 * actions_num + 2) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
-  const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossRows / kWave)
+  const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossThreads / kWave)
                                  ? static_cast<size_t>(8) * actions_num
-                                 : kLossScalars * (kLossRows / kWave);
+                                 : kLossScalars * (kLossThreads / kWave);
   shm += red_doubles * sizeof(double);
   if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const int grid = rlg_ppo_loss_num_blocks(minibatch);
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossRows), shm,
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossThreads), shm,
                      static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();
 }
@@ -427,7 +428,7 @@ int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_nu
                           int masked, float critic_coef, float entropy_coef, float bounds_coef,
                           float* scalars8, float* d_logstd, float* kl_slot_or_null,
                           float* d_mu_bias_or_null, float* d_value_bias_or_null, void* stream) {
-  hipLaunchKernelGGL(rlg::ppo_loss_finalize_kernel, dim3(1), dim3(256), 0,
+  hipLaunchKernelGGL(rlg::ppo_loss_finalize_kernel, dim3(1), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), partials, num_blocks, actions_num, minibatch,
                      masked, critic_coef, entropy_coef, bounds_coef, scalars8, d_logstd,
                      kl_slot_or_null, d_mu_bias_or_null, d_value_bias_or_null);

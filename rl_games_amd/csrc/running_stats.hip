@@ -74,19 +74,30 @@ __global__ __launch_bounds__(kMomBlock) void column_moments_kernel(
 #pragma unroll
     for (int u = 0; u < UNIT; ++u) s[u] = ss[u] = 0.0;
     const long long groups = (rows + rpp - 1) / rpp;
-    for (long long g = gwave; g < groups; g += nwaves) {
-      const long long row = g * rpp + sub;
-      if (active && row < rows) {
-        float v[UNIT];
-        UnitLoad<UNIT>::load(x + row * C + static_cast<long long>(cb + cu) * UNIT, v);
-        float m = 1.0f;
-        if (row_mask) m = row_mask[row];
-        if (cb == 0 && cu == 0) cnt += static_cast<double>(m);
+    constexpr int kU = 4;   // independent row groups in flight per lane
+    for (long long g0 = gwave; g0 < groups; g0 += nwaves * kU) {
+      float v[kU][UNIT];
+      float m[kU];
+      bool ok[kU];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const long long g = g0 + q * nwaves;
+        const long long row = g * rpp + sub;
+        ok[q] = active && g < groups && row < rows;
+        const long long r_safe = ok[q] ? row : 0;
+        UnitLoad<UNIT>::load(x + r_safe * C + static_cast<long long>(cb + cu) * UNIT, v[q]);
+        m[q] = 1.0f;
+        if (row_mask) m[q] = row_mask[r_safe];
+      }
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        if (!ok[q]) continue;
+        if (cb == 0 && cu == 0) cnt += static_cast<double>(m[q]);
 #pragma unroll
         for (int u = 0; u < UNIT; ++u) {
-          const double d = static_cast<double>(v[u]) * static_cast<double>(m);
+          const double d = static_cast<double>(v[q][u]) * static_cast<double>(m[q]);
           s[u] += d;
-          ss[u] = fma(d, static_cast<double>(v[u]), ss[u]);
+          ss[u] = fma(d, static_cast<double>(v[q][u]), ss[u]);
         }
       }
     }
