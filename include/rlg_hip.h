@@ -119,6 +119,17 @@ int rlg_episode_meters_update(const double* ep_partials, int horizon, int num_bl
                               float* mean_shaped, float* mean_lengths, int* current_sizes,
                               long long* finished_total, void* stream);
 
+/* Rollout policy head (rl_games/algos_torch/models.py:348-364, denorm_value :58-60) fused with
+ * the update_data writes of its outputs (a2c_common.py:1008-1009).  heads [N, ld]: column 0 the
+ * critic value, columns 1..A the action means; noise [N, A] ~ N(0,1).  Writes actions/mus/
+ * sigmas/neglogpacs/values of step `step` into the env-major buffer fields and the contiguous
+ * actions [N, A] / de-normalised values [N] the env step and the post-step kernel consume. */
+int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logstd, const float* noise,
+                            const double* value_mean_or_null, const double* value_var_or_null,
+                            float eps, float* actions_out, float* values_out, float* buf_actions,
+                            float* buf_mus, float* buf_sigmas, float* buf_neglogp, float* buf_values,
+                            int num_envs, int horizon, int actions_num, int step, void* stream);
+
 /* play_steps_rnn zero-on-done: s[:, done_envs, :] = 0 (a2c_common.py:1150-1153).
  * states [layers][num_envs][units] contiguous. */
 int rlg_rnn_zero_done_states(float* states, const uint8_t* dones, int layers, int num_envs,

@@ -519,6 +519,11 @@ class A2CAgent:
         self._gae_partials = torch.empty(num_moment_partials(rows), 6, dtype=torch.float64, device=dev)
         self.update_list = ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
         self.tensor_list = self.update_list + ['obses', 'states', 'dones']
+        if self._engine is not None:
+            self._roll_obs_norm = torch.empty((rows,) + tuple(self.obs_shape), dtype=torch.float32, device=dev)
+            self._roll_noise = torch.empty(rows, self.actions_num, dtype=torch.float32, device=dev)
+            self._roll_actions = torch.empty(rows, self.actions_num, dtype=torch.float32, device=dev)
+            self._roll_values = torch.empty(rows, dtype=torch.float32, device=dev)
         if self.is_rnn:
             self.rnn_states = [s.to(dev) for s in self.model.get_default_rnn_state()]
             num_seqs = self.horizon_length // self.seq_length
@@ -586,7 +591,10 @@ class A2CAgent:
         ops.episode_meters_update(self._ep_partials, H, self._post_blocks, self.value_size,
                                   self.games_to_track, self.game_rewards.mean, self.game_shaped_rewards.mean,
                                   self.game_lengths.mean, self._meter_sizes, self._finished_total)
-        last_values = self.get_values(self.obs)
+        if self._fast_rollout_ok():
+            last_values = self._fast_values(self.obs)
+        else:
+            last_values = self.get_values(self.obs)
         if self.value_size == 1 and ops._lib.load().rlg_gae_envmajor_supported(H):
             lv = last_values.reshape(-1).contiguous()
             timers = self.kernel_timers
@@ -611,6 +619,52 @@ class A2CAgent:
             batch_dict['rnn_masks'] = swap_and_flatten01(mb_valid)
         return batch_dict
 
+    def _fast_policy_step(self, n):
+        """Rollout forward of step n without autograd or torch element-wise ops: obs normalise ->
+        engine GEMMs -> fused policy-head kernel that also writes actions/mus/sigmas/neglogpacs/
+        values of the step into the buffer.  Same maths as get_action_values + update_data."""
+        eng, buf = self._engine, self.experience_buffer
+        obs = self._preproc_obs(self.obs['obs'])
+        if not obs.is_contiguous():
+            obs = obs.contiguous()
+        rows = obs.shape[0]
+        if self.normalize_input:
+            m = self.model.running_mean_std
+            obs_n = ops.rms_apply(obs, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
+        else:
+            obs_n = obs
+        heads = eng.forward(obs_n)
+        torch.randn(self._roll_noise.shape, device=self._roll_noise.device, out=self._roll_noise)
+        vs = None
+        eps = 1e-5
+        if self.normalize_value:
+            vm = self.model.value_mean_std
+            vs, eps = (vm.running_mean, vm.running_var), vm.epsilon
+        ops.rollout_policy_head(heads, self.model.a2c_network.sigma.data, self._roll_noise, vs, eps,
+                                self._roll_actions, self._roll_values, buf.storage, self.horizon_length, n)
+        buf.store_step(n, {'obses': obs, 'dones': self.dones})
+        return {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
+
+    def _fast_values(self, obs):
+        """get_values on the engine: de-normalised critic values [N] of `obs`."""
+        eng = self._engine
+        x = self._preproc_obs(obs['obs'])
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if self.normalize_input:
+            m = self.model.running_mean_std
+            x = ops.rms_apply(x, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
+        heads = eng.forward(x)
+        v = heads[:, 0].contiguous()
+        if self.normalize_value:
+            vm = self.model.value_mean_std
+            v = ops.rms_apply(v.view(-1, 1), vm.running_mean, vm.running_var, vm.epsilon, 1).view(-1)
+        return v
+
+    def _fast_rollout_ok(self):
+        return (self._engine is not None and self.value_size == 1 and not self.is_rnn
+                and self.config.get('fused_rollout', True))
+
     def play_steps(self):
         """a2c_common.py:985-1069."""
         buf = self.experience_buffer
@@ -618,15 +672,19 @@ class A2CAgent:
         self._observer_needs_infos = self._uses_observer_infos()
         step_time = 0.0
         mb_valid = None
+        fast = self._fast_rollout_ok()
         if self.mask_autoreset_rows:
             mb_valid = torch.ones((self.horizon_length, self.num_actors * self.num_agents),
                                   dtype=torch.float32, device=self.ppo_device)
         for n in range(self.horizon_length):
-            res_dict = self.get_action_values(self.obs)
-            fields = {'obses': self.obs['obs'], 'dones': self.dones}
-            for k in self.update_list:
-                fields[k] = res_dict[k]
-            buf.store_step(n, fields)
+            if fast:
+                res_dict = self._fast_policy_step(n)
+            else:
+                res_dict = self.get_action_values(self.obs)
+                fields = {'obses': self.obs['obs'], 'dones': self.dones}
+                for k in self.update_list:
+                    fields[k] = res_dict[k]
+                buf.store_step(n, fields)
             if mb_valid is not None:
                 prev = self._autoreset_prev_dones
                 if prev is None:

@@ -239,6 +239,65 @@ __global__ __launch_bounds__(256) void episode_meters_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Policy head of a rollout step (is_train = False branch of ModelA2CContinuousLogStd.forward,
+// rl_games/algos_torch/models.py:348-359 + neglogp :361-364 + denorm_value :58-60), fused with
+// the buffer writes of its outputs (update_data for actions/mus/sigmas/neglogpacs/values,
+// a2c_common.py:1008-1009):
+//   sigma = exp(logstd);  action = mu + sigma * noise   (= Normal(mu, sigma).sample())
+//   neglogp = 0.5*sum(((action-mu)/sigma)^2) + 0.5*log(2pi)*A + sum(logstd)
+//   value   = sqrt(var+eps)*clamp(v,-5,5) + mean        (running_mean_std.py:106-107)
+// heads: [N, 1+A] fused (value | mu) output of the MLP.  One thread per env.
+struct PolicyHeadArgs {
+  const float* heads;      // [N, ld]
+  int ld;
+  const float* logstd;     // [A]
+  const float* noise;      // [N, A] standard normal
+  const double* v_mean;    // value RunningMeanStd (fp64) or nullptr when normalize_value is off
+  const double* v_var;
+  float eps;
+  float* actions_out;      // [N, A] contiguous (goes to the env)
+  float* values_out;       // [N]    de-normalised values (time-out bootstrap needs them)
+  float* buf_actions;      // env-major [N][H][A]
+  float* buf_mus;
+  float* buf_sigmas;
+  float* buf_neglogp;      // [N][H]
+  float* buf_values;       // [N][H]
+  int N, H, A, step;
+};
+
+__global__ __launch_bounds__(256) void rollout_policy_head_kernel(PolicyHeadArgs p) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.N) return;
+  const float* h = p.heads + static_cast<long long>(env) * p.ld;
+  const float* nz = p.noise + static_cast<long long>(env) * p.A;
+  const long long slot = static_cast<long long>(env) * p.H + p.step;
+  float s_z2 = 0.0f, s_ls = 0.0f;
+  for (int a = 0; a < p.A; ++a) {
+    const float mu = h[1 + a];
+    const float ls = p.logstd[a];
+    const float sg = expf(ls);
+    const float act = mu + sg * nz[a];
+    const float z = (act - mu) / sg;
+    s_z2 += z * z;
+    s_ls += ls;
+    p.actions_out[static_cast<long long>(env) * p.A + a] = act;
+    p.buf_actions[slot * p.A + a] = act;
+    p.buf_mus[slot * p.A + a] = mu;
+    p.buf_sigmas[slot * p.A + a] = sg;
+  }
+  const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * p.A)) + s_ls;
+  p.buf_neglogp[slot] = nlp;
+  float v = h[0];
+  if (p.v_mean) {
+    const float m = static_cast<float>(p.v_mean[0]);
+    const float d = sqrt_rn(static_cast<float>(p.v_var[0]) + p.eps);
+    v = d * fminf(fmaxf(v, -5.0f), 5.0f) + m;
+  }
+  p.values_out[env] = v;
+  p.buf_values[slot] = v;
+}
+
 // RNN rollout helpers (a2c_common.py:1081-1083 snapshot, :1150-1153 zero-on-done).
 // states: [L, N, U] contiguous.  snapshot dst: [num_seqs, L, N, U] slice `seq`.
 __global__ __launch_bounds__(256) void rnn_zero_done_kernel(float* __restrict__ states,
@@ -338,6 +397,37 @@ int rlg_episode_meters_update(const double* ep_partials, int horizon, int num_bl
                      static_cast<hipStream_t>(stream), ep_partials, horizon, num_blocks, value_size,
                      max_size, mean_rewards, mean_shaped, mean_lengths, current_sizes,
                      finished_total);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logstd, const float* noise,
+                            const double* value_mean_or_null, const double* value_var_or_null,
+                            float eps, float* actions_out, float* values_out, float* buf_actions,
+                            float* buf_mus, float* buf_sigmas, float* buf_neglogp, float* buf_values,
+                            int num_envs, int horizon, int actions_num, int step, void* stream) {
+  if (num_envs <= 0) return 0;
+  if (step < 0 || step >= horizon || actions_num <= 0) return static_cast<int>(hipErrorInvalidValue);
+  rlg::PolicyHeadArgs p;
+  p.heads = heads;
+  p.ld = ld_heads;
+  p.logstd = logstd;
+  p.noise = noise;
+  p.v_mean = value_mean_or_null;
+  p.v_var = value_var_or_null;
+  p.eps = eps;
+  p.actions_out = actions_out;
+  p.values_out = values_out;
+  p.buf_actions = buf_actions;
+  p.buf_mus = buf_mus;
+  p.buf_sigmas = buf_sigmas;
+  p.buf_neglogp = buf_neglogp;
+  p.buf_values = buf_values;
+  p.N = num_envs;
+  p.H = horizon;
+  p.A = actions_num;
+  p.step = step;
+  hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -69,6 +69,7 @@ class ManualMLP:
         return rest + heads
 
     # ------------------------------------------------------------------
+    @torch.no_grad()
     def forward(self, x, keep=True):
         """x: [rows, in] normalised observations.  Returns heads [rows, V+A] (col 0..V-1 value,
         then mu).  `keep` retains the pre-activations for backward()."""
@@ -98,6 +99,7 @@ class ManualMLP:
     def mu_view(self, heads):
         return heads[:, self.V:]
 
+    @torch.no_grad()
     def backward(self, d_heads):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss

@@ -101,6 +101,23 @@ def episode_meters_update(ep_partials, horizon, num_blocks, value_size, max_size
         'rlg_episode_meters_update')
 
 
+def rollout_policy_head(heads, logstd, noise, value_stats, eps, actions_out, values_out, storage, horizon,
+                        step):
+    """storage: ExperienceBuffer.storage (env-major fields).  value_stats = (mean, var) or None."""
+    lib = _lib.load()
+    N, A = noise.shape
+    vm = vv = None
+    if value_stats is not None:
+        vm, vv = _need(value_stats[0], F64, 'value mean'), _need(value_stats[1], F64, 'value var')
+    _lib.check(lib.rlg_rollout_policy_head(
+        _need(heads, F32, 'heads'), heads.stride(0), _need(logstd, F32, 'logstd'), _need(noise, F32, 'noise'),
+        vm, vv, float(np.float32(eps)), _need(actions_out, F32, 'actions_out'),
+        _need(values_out, F32, 'values_out'), _need(storage['actions'], F32, 'actions'),
+        _need(storage['mus'], F32, 'mus'), _need(storage['sigmas'], F32, 'sigmas'),
+        _need(storage['neglogpacs'], F32, 'neglogpacs'), _need(storage['values'], F32, 'values'),
+        N, horizon, A, step, _stream(heads)), 'rlg_rollout_policy_head')
+
+
 def rnn_zero_done_states(states, dones):
     lib = _lib.load()
     L, N, U = states.shape

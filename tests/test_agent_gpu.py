@@ -211,3 +211,36 @@ def test_manual_mlp_engine_matches_autograd_gradients():
     for n in g2:
         scale = g2[n].abs().max().item() + 1e-12
         assert torch.allclose(g1[n], g2[n], rtol=1e-4, atol=2e-6 * scale), (n, (g1[n] - g2[n]).abs().max().item(), scale)
+
+
+def test_fused_rollout_step_matches_model_forward():
+    """The fused rollout path (obs normalise -> engine GEMMs -> policy-head kernel writing into the
+    buffer) stores exactly what model(eval) + update_data would store for the same noise."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=300, horizon=4, obs_dim=10, act_dim=5)
+    agent = A2CAgent('t', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    # make the statistics non-trivial
+    agent.model.running_mean_std.running_mean.normal_()
+    agent.model.running_mean_std.running_var.uniform_(0.5, 2.0)
+    agent.model.value_mean_std.running_mean.fill_(3.0)
+    agent.model.value_mean_std.running_var.fill_(4.0)
+    agent.set_eval()
+    with torch.no_grad():
+        res = agent._fast_policy_step(2)
+        noise = agent._roll_noise.clone()
+        ref = agent.model({'is_train': False, 'prev_actions': None, 'obs': agent.obs['obs'], 'rnn_states': None})
+        mu, sigma = ref['mus'], ref['sigmas']
+        action = mu + sigma * noise
+        nlp = agent.model.neglogp(action, mu, sigma, torch.log(sigma))
+    tb = agent.experience_buffer.tensor_dict
+    assert torch.allclose(tb['mus'][2], mu, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(tb['sigmas'][2], sigma, rtol=1e-6)
+    assert torch.allclose(tb['actions'][2], action, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(tb['neglogpacs'][2], nlp, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(tb['values'][2], ref['values'], rtol=1e-5, atol=1e-5)
+    assert torch.equal(tb['obses'][2], agent.obs['obs'])
+    assert torch.equal(res['actions'], tb['actions'][2]) and torch.equal(res['values'], tb['values'][2])
+    assert torch.allclose(agent._fast_values(agent.obs).view(-1, 1), agent.get_values(agent.obs), rtol=1e-5, atol=1e-5)
