@@ -134,6 +134,13 @@ def main():
     gae_bytes = envs * HORIZON * GAE_BYTES_PER_ENV_STEP
     achieved = gae_bytes / (gae_us * 1e-6) / 1e9 if gae_us > 0 else 0.0
 
+    traffic = None
+    try:   # PMC counters cannot be read inside a normal run: measured offline, see profiles/r1_gae_pmc.txt
+        with open(os.path.join(ROOT, 'profiles', 'gae_pmc_traffic.json')) as f:
+            traffic = json.load(f).get(f'{envs}x{HORIZON}', {}).get('traffic_bytes')
+    except Exception:
+        traffic = None
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -153,7 +160,8 @@ def main():
             'roofline': {
                 'kernel': 'rlg::gae_envmajor_kernel<32,false> (GAE + returns + advantages + fp64 moments)',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'traffic_note': 'HBM bytes/launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r1_gae_pmc.txt',
                 'algorithmic_bytes_per_launch': gae_bytes, 'avg_launch_us': gae_us, 'launches': len(pairs),
                 'timing': 'HIP events on the launch stream around each in-epoch launch (timed region)',
             },

@@ -154,9 +154,11 @@ static float time_it(F launch, int iters) {
 }
 
 int main(int argc, char** argv) {
-  const int N = 65536, H = 32; const int iters = 200;
+  const bool pmc = argc > 1;   // short mode for rocprofv3 --pmc runs: few launches, cold sets only
+  const int N = 65536, H = 32; const int iters = pmc ? 6 : 200;
   const size_t nf = (size_t)N * H;
   for (int nsets : {1, 16}) {
+    if (pmc && nsets == 1) continue;
     std::vector<Set> sets(nsets);
     for (auto& s : sets) {
       CK(hipMalloc(&s.r, nf * 4)); CK(hipMalloc(&s.v, nf * 4)); CK(hipMalloc(&s.o0, nf * 4)); CK(hipMalloc(&s.o1, nf * 4));
