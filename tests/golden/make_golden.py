@@ -97,12 +97,18 @@ def make_epoch():
         'default': dict(),
         'smooth_reg_ema': dict(use_smooth_clamp=True, bound_loss_type='regularisation', bounds_loss_coef=0.01,
                                normalize_rms_advantage=True, entropy_coef=0.01, critic_coef=1.0),
+        # BASELINE.json config #5 in miniature: LSTM policy, play_steps_rnn, seq_length chunks
+        'lstm': dict(seq_length=4, _rnn={'name': 'lstm', 'units': 16, 'layers': 1}),
     }
     out = {}
     for name, over in variants.items():
         N, H, O_, A = 64, 8, 12, 3
+        over = dict(over)
+        rnn = over.pop('_rnn', None)
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', games_to_track=100, **over)
+        if rnn is not None:
+            params['network']['rnn'] = rnn
         params['seed'] = 7
         env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=1234)
         params['config']['env_info'] = env.get_env_info()
@@ -117,11 +123,14 @@ def make_epoch():
         agent.init_tensors()
         agent.obs = agent.env_reset()
         cap = {'init_state': _clone(agent.model.state_dict()), 'lrs': []}
-        orig_play = agent.play_steps
+        play_name = 'play_steps_rnn' if agent.is_rnn else 'play_steps'
+        orig_play = getattr(agent, play_name)
 
         def play():
             b = orig_play()
             cap['batch'] = _clone({k: v for k, v in b.items() if isinstance(v, torch.Tensor)})
+            if 'rnn_states' in b:
+                cap['batch']['rnn_states'] = _clone(b['rnn_states'])
             cap['buffers'] = _clone({k: agent.experience_buffer.tensor_dict[k]
                                      for k in ('rewards', 'values', 'dones')})
             cap['last_dones'] = agent.dones.clone()
@@ -133,7 +142,7 @@ def make_epoch():
                                    agent.game_lengths.current_size]}
             cap['state_after_rollout'] = _clone(agent.model.state_dict())
             return b
-        agent.play_steps = play
+        setattr(agent, play_name, play)
         orig_update_lr = agent.update_lr
 
         def update_lr(lr):
