@@ -238,17 +238,19 @@ int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_nu
  * ---------------------------------------------------------------------------------- */
 
 int rlg_grad_norm_num_blocks(long long n);
+/* Also increments *step_counter_or_null (the device-resident Adam step count) by one. */
 int rlg_grad_sumsq(const float* grads, long long n, float grad_scale, double* partials,
-                   int num_blocks, void* stream);
+                   int num_blocks, long long* step_counter_or_null, void* stream);
 
 /* One optimiser step over n contiguous parameters.  grads are first scaled by grad_scale
  * (1/world_size) and by the clip coefficient min(1, max_norm/(norm+1e-6)) when
- * norm_partials is given.  lr_slots[cur_slot] is the lr of this step; lr_slots[cur_slot^1]
- * receives the next lr (schedule_kind 1: KL-adaptive on *kl * kl_scale).  stats_out[4] =
- * {total_norm, clip_coef, lr_used, lr_next}. */
+ * norm_partials is given.  step = *step_counter is the 1-based Adam step (device word, advanced
+ * by rlg_grad_sumsq); lr_slots[(step-1)&1] is the lr of this step, the other slot receives the next
+ * lr (schedule_kind 1: KL-adaptive on *kl * kl_scale).  stats_out[4] = {total_norm, clip_coef,
+ * lr_used, lr_next}.  No per-call host scalars: the pair replays from a captured HIP graph. */
 int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                   const double* norm_partials_or_null, int norm_blocks, float grad_scale,
-                  float max_norm, double* lr_slots, int cur_slot, long long step, double beta1,
+                  float max_norm, double* lr_slots, const long long* step_counter, double beta1,
                   double beta2, double eps, double weight_decay, int schedule_kind,
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
                   double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream);

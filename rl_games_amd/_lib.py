@@ -69,8 +69,8 @@ _PROTOTYPES = {
     'rlg_colsum_finalize': [_P, _c_int, _c_int, _P, _c_int, _P],
     # optim.hip
     'rlg_grad_norm_num_blocks': [_c_ll],
-    'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P],
-    'rlg_adam_step': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _c_int, _c_ll,
+    'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P, _P],
+    'rlg_adam_step': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
                       _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
                       _c_double, _c_double, _c_double, _P, _P],
 }

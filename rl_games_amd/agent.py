@@ -362,6 +362,15 @@ class A2CAgent:
         self._host_lr = self.last_lr
         self.train_result = None
         self.kernel_timers = None
+        # HIP graphs: one captured graph per minibatch index (forward/loss/backward) + one for the
+        # optimiser kernels; the first epoch always runs eagerly (allocations, GEMM selection).
+        self._hip_graphs = bool(config.get('hip_graphs', True))
+        self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
+        self._graph_failed = False
+        self._eager_epochs = 0
+        self._graph_rows = torch.zeros(max(1, self.num_minibatches), 8, dtype=torch.float32, device=dev)
+        self._obs_norm_mb = (torch.empty((mb,) + tuple(self.obs_shape), dtype=torch.float32, device=dev)
+                             if self.normalize_input else None)
         self.algo_observer.after_init(self)
 
     # ================================================================== small helpers
@@ -821,6 +830,18 @@ class A2CAgent:
 
     def calc_gradients(self, input_dict):
         """a2c_continuous.py:136-234 - forward, fused loss + analytic backward + KL, optimiser."""
+        row = self._mb_scalars[self._mb_index % self._mb_scalars.shape[0]]
+        self._mb_index += 1
+        self._forward_loss_backward(input_dict, row)
+        self.trancate_gradients_and_step()
+        # dataset.update_mu_sigma happened inside the loss kernel (write_back)
+        self.train_result = (row[0], row[1], row[2], row[4], self._host_lr, 1.0,
+                             input_dict['mu'], input_dict['sigma'], row[3])
+
+    def _forward_loss_backward(self, input_dict, row):
+        """Everything of calc_gradients up to (and including) the gradients in the arena.  No
+        host-side scalars change between calls for a given minibatch slice, so this body is what
+        gets captured into a HIP graph per minibatch index."""
         opt = self.optimizer
         net = self.model.a2c_network
         obs_batch = self._preproc_obs(input_dict['obs'])
@@ -836,15 +857,17 @@ class A2CAgent:
         eng = self._engine
         if eng is not None:
             with torch.no_grad():
-                obs_n = self.model.norm_obs(obs_batch)                  # updates the obs statistics
+                if self.normalize_input:                                # updates the obs statistics
+                    out = self._obs_norm_mb[:obs_batch.shape[0]] if self._obs_norm_mb is not None else None
+                    obs_n = self.model.running_mean_std(obs_batch, out=out)
+                else:
+                    obs_n = obs_batch
                 heads = eng.forward(obs_n)
             mu, values = eng.mu_view(heads), eng.values_view(heads)
             logstd = net.sigma
         else:
             mu, logstd, values, _ = self.model.forward_heads(batch)
         mb, A = mu.shape
-        row = self._mb_scalars[self._mb_index % self._mb_scalars.shape[0]]
-        self._mb_index += 1
         mask = mask_sum = None
         if rnn_masks is not None:
             mask = rnn_masks.reshape(-1).float().contiguous()
@@ -874,18 +897,17 @@ class A2CAgent:
                 eng.backward(d_heads)
         if eng is None:
             torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
-        self.trancate_gradients_and_step()
-        # dataset.update_mu_sigma happened inside the loss kernel (write_back)
-        self.train_result = (row[0], row[1], row[2], row[4], self._host_lr, 1.0,
-                             input_dict['mu'], input_dict['sigma'], row[3])
 
     def trancate_gradients_and_step(self):
         """a2c_common.py:493-514 (+ the per-minibatch lr control of :1557-1563)."""
         opt = self.optimizer
-        scale = 1.0
         if self.multi_gpu:
             rdist.all_reduce_sum(opt.flat_grads)       # gradients + KL slot, one collective
-            scale = 1.0 / self.world_size
+        self._optimizer_kernels()
+
+    def _optimizer_kernels(self):
+        opt = self.optimizer
+        scale = 1.0 / self.world_size if self.multi_gpu else 1.0
         schedule = None
         if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
             s = self.scheduler
@@ -893,6 +915,53 @@ class A2CAgent:
                             lr_multiplier=s.lr_multiplier)
         opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
                  schedule=schedule, kl_scale=scale)
+
+    # ------------------------------------------------------------------ HIP graphs
+    def _graph_signature(self):
+        """Everything a captured minibatch graph bakes in: dataset storage addresses and the
+        scalar hyper-parameters passed by value to the kernels."""
+        vd = self.dataset.values_dict
+        ptrs = tuple(vd[k].data_ptr() for k in ('obs', 'actions', 'old_logp_actions', 'advantages',
+                                               'old_values', 'returns', 'mu', 'sigma'))
+        s = self.scheduler
+        sched = (getattr(s, 'kl_threshold', None), getattr(s, 'min_lr', None), getattr(s, 'max_lr', None),
+                 getattr(s, 'lr_multiplier', None))
+        return (ptrs, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
+                self.bound_loss_type, self.clip_value, self.use_smooth_clamp, self.grad_norm,
+                self.truncate_grads, self.schedule_type, self.is_adaptive_lr, sched, self.world_size)
+
+    def _graphs_usable(self):
+        return (self._hip_graphs and self._engine is not None and self._eager_epochs >= 1
+                and self.dataset.values_dict.get('rnn_masks') is None and not self._graph_failed)
+
+    def _graph_minibatch(self, i):
+        """Replay (capturing on first use) the forward/loss/backward graph of minibatch i, run the
+        gradient all-reduce eagerly, then replay the (norm, Adam, lr) graph."""
+        sig = self._graph_signature()
+        if sig != self._graph_sig:
+            self._graphs.clear()
+            self._graph_opt = None
+            self._graph_sig = sig
+        g = self._graphs.get(i)
+        if g is None:
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            item = self.dataset[i]
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                self._forward_loss_backward(item, self._graph_rows[i])
+            self._graphs[i] = g
+        if self._graph_opt is None:
+            go = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(go, pool=self._graph_pool):
+                self._optimizer_kernels()
+            self.optimizer.step_count -= 1        # capture advanced the host mirror, not the device
+            self._graph_opt = go
+        g.replay()
+        if self.multi_gpu:
+            rdist.all_reduce_sum(self.optimizer.flat_grads)
+        self._graph_opt.replay()
+        self.optimizer.step_count += 1
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,
@@ -918,18 +987,42 @@ class A2CAgent:
         self._mb_index = 0
         device_schedule = self.is_adaptive_lr and self.schedule_type == 'per_minibatch'
         last_lr, lr_mul = self.last_lr, 1.0
+        use_graphs = self._graphs_usable() and (device_schedule or self.schedule_type != 'per_minibatch'
+                                                or not self.is_adaptive_lr)
+        nmb = len(self.dataset)
         for mini_ep in range(self.mini_epochs_num):
             first = self._mb_index
-            for i in range(len(self.dataset)):
-                a_loss, c_loss, entropy, kl, last_lr, lr_mul, cmu, csigma, b_loss = \
-                    self.train_actor_critic(self.dataset[i])
-                a_losses.append(a_loss)
-                c_losses.append(c_loss)
-                entropies.append(entropy)
-                if self.bounds_loss_coef is not None:
-                    b_losses.append(b_loss)
-                if self.schedule_type == 'per_minibatch' and not device_schedule:
-                    self._host_schedule(None if not self.is_adaptive_lr else float(kl.item()))
+            if use_graphs:
+                try:
+                    self.set_train()
+                    for i in range(nmb):
+                        self._graph_minibatch(i)
+                        if self.schedule_type == 'per_minibatch' and not device_schedule:
+                            self._host_schedule(None)
+                    self._mb_scalars[first:first + nmb].copy_(self._graph_rows[:nmb])
+                    self._mb_index += nmb
+                    for i in range(nmb):
+                        row = self._mb_scalars[first + i]
+                        a_losses.append(row[0])
+                        c_losses.append(row[1])
+                        entropies.append(row[2])
+                        if self.bounds_loss_coef is not None:
+                            b_losses.append(row[3])
+                except Exception as e:        # pragma: no cover - capture problems fall back to eager
+                    print(f'rl_games_amd: HIP graph path disabled ({type(e).__name__}: {e})')
+                    self._graph_failed = True
+                    raise
+            else:
+                for i in range(nmb):
+                    a_loss, c_loss, entropy, kl, last_lr, lr_mul, cmu, csigma, b_loss = \
+                        self.train_actor_critic(self.dataset[i])
+                    a_losses.append(a_loss)
+                    c_losses.append(c_loss)
+                    entropies.append(entropy)
+                    if self.bounds_loss_coef is not None:
+                        b_losses.append(b_loss)
+                    if self.schedule_type == 'per_minibatch' and not device_schedule:
+                        self._host_schedule(None if not self.is_adaptive_lr else float(kl.item()))
             av_kls = self._mb_scalars[first:self._mb_index, 4].mean()
             if self.multi_gpu:
                 rdist.all_reduce_sum(av_kls)
@@ -942,6 +1035,7 @@ class A2CAgent:
         if self.schedule_type == 'standard_epoch':
             self._host_schedule(float(torch.stack(kls).mean().item()))
         self.sync_running_stats()
+        self._eager_epochs += 0 if use_graphs else 1
         if device_schedule:
             # one host read per epoch: [lr the last minibatch was stepped with, lr for the next one]
             used, nxt = self.optimizer.last_and_next_lr()

@@ -7,7 +7,9 @@
 // and the per-minibatch learning-rate control: AdaptiveScheduler.update
 // (rl_games/common/schedulers.py:27-33) + update_lr (a2c_common.py:564-576, :1557-1563)
 // without the `.item()` host sync: the learning rate lives in device memory (two fp64 slots,
-// ping-pong by step parity) and is read lazily by the host.
+// ping-pong by step parity) and is read lazily by the host; the Adam step counter is a device
+// word too, so a (norm, Adam) launch pair has no per-call host arguments and can be replayed from a
+// captured HIP graph.
 //
 // All parameters (and their gradients / Adam moments) are views of contiguous fp32 arenas, so
 // one launch covers the whole model (~0.2 M parameters) instead of ~10 foreach kernels.
@@ -21,11 +23,15 @@ namespace rlg {
 constexpr int kOptBlock = 256;
 constexpr int kOptVec = 4;
 
-// partial sum of squares of (grad * grad_scale), fp64, one value per block
+// partial sum of squares of (grad * grad_scale), fp64, one value per block.  Also advances the
+// device-resident optimiser step counter (read by adam_step_kernel, which always follows on the
+// same stream): keeping the counter on the device makes the pair replayable from a HIP graph.
 __global__ __launch_bounds__(kOptBlock) void grad_sumsq_kernel(const float* __restrict__ grads,
                                                                long long n, float grad_scale,
-                                                               double* __restrict__ partials) {
+                                                               double* __restrict__ partials,
+                                                               long long* __restrict__ step_counter) {
   __shared__ double scratch[kOptBlock / kWave];
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
   double s[1] = {0.0};
   for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * kOptBlock) {
@@ -46,9 +52,8 @@ struct AdamArgs {
   int norm_blocks;
   float grad_scale;        // 1/world_size (multi-GPU average), 1 otherwise
   float max_norm;          // grad_norm
-  double* lr_slots;        // [2] fp64; slot `cur` is read, slot cur^1 receives the next lr
-  int cur;
-  long long step;          // Adam step count AFTER this update (1-based)
+  double* lr_slots;        // [2] fp64; slot (step-1)&1 is read, the other receives the next lr
+  const long long* step_counter;  // device: Adam step count AFTER this update (1-based)
   double beta1, beta2, eps, weight_decay;
   // adaptive schedule (schedule_kind 1) driven by the KL of THIS minibatch
   int schedule_kind;       // 0 keep lr, 1 adaptive on *kl
@@ -80,11 +85,13 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   }
   __syncthreads();
   const float clip = sh_clip;
-  const double lr = a.lr_slots[a.cur];
+  const long long step = *a.step_counter;
+  const int cur = static_cast<int>((step - 1) & 1);
+  const double lr = a.lr_slots[cur];
 
   // torch.optim.Adam (single-tensor path) scalar prologue, evaluated in double like Python
-  const double bc1 = 1.0 - pow(a.beta1, static_cast<double>(a.step));
-  const double bc2 = 1.0 - pow(a.beta2, static_cast<double>(a.step));
+  const double bc1 = 1.0 - pow(a.beta1, static_cast<double>(step));
+  const double bc2 = 1.0 - pow(a.beta2, static_cast<double>(step));
   const float step_size = static_cast<float>(lr / bc1);
   const float bc2_sqrt = static_cast<float>(sqrt(bc2));
   const float w1 = static_cast<float>(1.0 - a.beta1);
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
       if (kl > 2.0 * a.kl_threshold) next = fmax(lr / a.lr_multiplier, a.min_lr);
       if (kl < 0.5 * a.kl_threshold) next = fmin(lr * a.lr_multiplier, a.max_lr);
     }
-    a.lr_slots[a.cur ^ 1] = next;
+    a.lr_slots[cur ^ 1] = next;
     if (a.stats_out) {
       a.stats_out[0] = sh_norm;
       a.stats_out[1] = clip;
@@ -140,21 +147,22 @@ int rlg_grad_norm_num_blocks(long long n) {
 }
 
 int rlg_grad_sumsq(const float* grads, long long n, float grad_scale, double* partials,
-                   int num_blocks, void* stream) {
+                   int num_blocks, long long* step_counter_or_null, void* stream) {
   if (n <= 0) return static_cast<int>(hipErrorInvalidValue);
   hipLaunchKernelGGL(rlg::grad_sumsq_kernel, dim3(num_blocks), dim3(rlg::kOptBlock), 0,
-                     static_cast<hipStream_t>(stream), grads, n, grad_scale, partials);
+                     static_cast<hipStream_t>(stream), grads, n, grad_scale, partials,
+                     step_counter_or_null);
   RLG_RETURN_LAUNCH_STATUS();
 }
 
 int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                   const double* norm_partials_or_null, int norm_blocks, float grad_scale,
-                  float max_norm, double* lr_slots, int cur_slot, long long step, double beta1,
+                  float max_norm, double* lr_slots, const long long* step_counter, double beta1,
                   double beta2, double eps, double weight_decay, int schedule_kind,
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
                   double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream) {
   using namespace rlg;
-  if (n <= 0 || step < 1 || (cur_slot != 0 && cur_slot != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if (n <= 0 || !step_counter) return static_cast<int>(hipErrorInvalidValue);
   if (schedule_kind == 1 && !kl_or_null) return static_cast<int>(hipErrorInvalidValue);
   AdamArgs a;
   a.params = params;
@@ -167,8 +175,7 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
   a.grad_scale = grad_scale;
   a.max_norm = max_norm;
   a.lr_slots = lr_slots;
-  a.cur = cur_slot;
-  a.step = step;
+  a.step_counter = step_counter;
   a.beta1 = beta1;
   a.beta2 = beta2;
   a.eps = eps;

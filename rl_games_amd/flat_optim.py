@@ -73,17 +73,22 @@ class FlatAdam(FlatArena):
             raise RuntimeError('FlatAdam runs on the MI355X only (no CPU fallback)')
         self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self.step_count = 0                     # host mirror of the device counter below
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         # two fp64 lr slots, ping-pong by step parity (see csrc/optim.hip)
         self.lr_slots = torch.tensor([float(lr), float(lr)], dtype=torch.float64, device=dev)
-        self.cur = 0
         self.norm_partials = torch.zeros(ops.grad_norm_blocks(self.numel), dtype=torch.float64, device=dev)
         self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
         self.param_groups = [{'params': self.params, 'lr': float(lr), 'betas': betas, 'eps': eps,
                               'weight_decay': weight_decay}]
 
     # ------------------------------------------------------------------ learning rate
+    @property
+    def cur(self):
+        """Slot the NEXT step reads: step s (1-based) reads slot (s-1)&1."""
+        return self.step_count & 1
+
     def set_lr(self, lr):
         """Host-driven lr (linear / identity schedules, restore): overwrites the live slot."""
         self.lr_slots[self.cur] = float(lr)
@@ -110,10 +115,9 @@ class FlatAdam(FlatArena):
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
         driven by the KL in `kl_slot` (times kl_scale)."""
         self.step_count += 1
-        partials = None
-        if max_norm is not None:
-            partials = self.norm_partials
-            ops.grad_sumsq(self.grads, grad_scale, partials)
+        # always launched: it also advances the device step counter the Adam kernel reads
+        ops.grad_sumsq(self.grads, grad_scale, self.norm_partials, self.step_counter)
+        partials = self.norm_partials if max_norm is not None else None
         kw = {}
         kind = 0
         if schedule is not None:
@@ -121,11 +125,10 @@ class FlatAdam(FlatArena):
             kw = dict(kl_threshold=schedule['kl_threshold'], min_lr=schedule['min_lr'],
                       max_lr=schedule['max_lr'], lr_multiplier=schedule['lr_multiplier'])
         ops.adam_step(self.flat_params, self.grads, self.exp_avg, self.exp_avg_sq, partials,
-                      grad_scale, 0.0 if max_norm is None else max_norm, self.lr_slots, self.cur,
-                      self.step_count, betas=self.betas, eps=self.eps,
+                      grad_scale, 0.0 if max_norm is None else max_norm, self.lr_slots,
+                      self.step_counter, betas=self.betas, eps=self.eps,
                       weight_decay=self.weight_decay, schedule_kind=kind,
                       kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats, **kw)
-        self.cur ^= 1
 
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):
@@ -152,6 +155,9 @@ class FlatAdam(FlatArena):
             steps.append(int(float(st[i]['step'])))
         if steps:
             self.step_count = max(steps)
+            self.step_counter.fill_(self.step_count)
+            both = self.lr_slots.tolist()
+            self.lr_slots.fill_(both[0])
         groups = sd.get('param_groups') or []
         if groups:
             self.set_lr(groups[0].get('lr', self.param_groups[0]['lr']))

@@ -333,15 +333,17 @@ def grad_norm_blocks(n):
     return _lib.load().rlg_grad_norm_num_blocks(int(n))
 
 
-def grad_sumsq(grads, grad_scale, partials):
+def grad_sumsq(grads, grad_scale, partials, step_counter=None):
+    """Also advances the device-resident Adam step counter when given."""
     lib = _lib.load()
     _lib.check(lib.rlg_grad_sumsq(_need(grads, F32, 'grads'), grads.numel(),
                                   float(np.float32(grad_scale)), _need(partials, F64, 'partials'),
-                                  partials.numel(), _stream(grads)), 'rlg_grad_sumsq')
+                                  partials.numel(), _opt(step_counter, torch.int64, 'step_counter'),
+                                  _stream(grads)), 'rlg_grad_sumsq')
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max_norm, lr_slots,
-              cur_slot, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
+              step_counter, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
               kl=None, kl_scale=1.0, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2,
               lr_multiplier=1.5, stats_out=None):
     lib = _lib.load()
@@ -349,7 +351,8 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
         _need(params, F32, 'params'), _need(grads, F32, 'grads'), _need(exp_avg, F32, 'exp_avg'),
         _need(exp_avg_sq, F32, 'exp_avg_sq'), params.numel(), _opt(norm_partials, F64, 'norm_partials'),
         0 if norm_partials is None else norm_partials.numel(), float(np.float32(grad_scale)),
-        float(np.float32(max_norm)), _need(lr_slots, F64, 'lr_slots'), cur_slot, step,
+        float(np.float32(max_norm)), _need(lr_slots, F64, 'lr_slots'),
+        _need(step_counter, torch.int64, 'step_counter'),
         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), schedule_kind,
         _opt(kl, F32, 'kl'), float(np.float32(kl_scale)), float(kl_threshold), float(min_lr),
         float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), _stream(params)),

@@ -345,6 +345,7 @@ def test_adam_step_matches_torch_adam(truncate):
     fp, fm, fv = flat(params), flat(exp_avg), flat(exp_avg_sq)
     lr_slots = torch.tensor([3e-4, 0.0], dtype=torch.float64, device=DEV)
     stats = torch.zeros(4, device=DEV)
+    step_counter = torch.zeros(1, dtype=torch.int64, device=DEV)
     cur = 0
     lr = 3e-4
     for step in range(1, 4):
@@ -353,12 +354,11 @@ def test_adam_step_matches_torch_adam(truncate):
         p_ref, m_ref, v_ref, norm_ref = O.clip_and_adam_reference(params, grads, exp_avg, exp_avg_sq,
                                                                  step - 1, lr, 1.0, truncate)
         fg = flat(grads)
-        partials = None
-        if truncate:
-            partials = torch.empty(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
-            ops.grad_sumsq(fg, 1.0, partials)
-        ops.adam_step(fp, fg, fm, fv, partials, 1.0, 1.0, lr_slots, cur, step, schedule_kind=1,
-                      kl=torch.tensor([kl], device=DEV), stats_out=stats)
+        partials = torch.empty(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
+        ops.grad_sumsq(fg, 1.0, partials, step_counter)          # advances the device step counter
+        assert step_counter.item() == step
+        ops.adam_step(fp, fg, fm, fv, partials if truncate else None, 1.0, 1.0, lr_slots, step_counter,
+                      schedule_kind=1, kl=torch.tensor([kl], device=DEV), stats_out=stats)
         params, exp_avg, exp_avg_sq = p_ref, m_ref, v_ref
         if truncate:
             assert np.isclose(stats[0].item(), norm_ref.item(), rtol=1e-6)
@@ -383,9 +383,10 @@ def test_adam_multi_gpu_average_and_kl_scale():
     fp, fg = p0.clone().to(DEV), g_sum.clone().to(DEV)
     fm, fv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     partials = torch.empty(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
-    ops.grad_sumsq(fg, 0.25, partials)
+    step_counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.grad_sumsq(fg, 0.25, partials, step_counter)
     lr_slots = torch.tensor([1e-3, 0.0], dtype=torch.float64, device=DEV)
-    ops.adam_step(fp, fg, fm, fv, partials, 0.25, 1.0, lr_slots, 0, 1, schedule_kind=1,
+    ops.adam_step(fp, fg, fm, fv, partials, 0.25, 1.0, lr_slots, step_counter, schedule_kind=1,
                   kl=torch.tensor([4 * 0.02], device=DEV), kl_scale=0.25)
     assert torch.allclose(fp.cpu(), ref_p[0], rtol=1e-6, atol=1e-8)
     assert lr_slots[1].item() == O.adaptive_lr(1e-3, float(np.float32(0.02 * 4) * np.float32(0.25)))
