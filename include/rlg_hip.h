@@ -274,6 +274,22 @@ int rlg_act_bwd_colsum(const float* d_out, const float* pre_act, float* d_pre, l
 int rlg_colsum_finalize(const double* partials, int num_blocks, int cols, float* out, int accumulate,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * fp32-MFMA MLP layer kernels (fused epilogues)
+ *   replace torch.addmm + activation of every nn.Linear/activation pair built by
+ *   A2CBuilder._build_sequential_mlp (rl_games/algos_torch/network_builder.py:118-147, forward
+ *   :498) and the mu/value heads (:295-311).
+ * ---------------------------------------------------------------------------------- */
+
+/* out = act(x @ weight^T + bias) [rows, out_features]; pre_act_or_null additionally receives
+ * x @ weight^T + bias (kept for the backward pass).  x [rows, in_features] row stride ldx,
+ * weight [out_features, in_features] row stride ldw (nn.Linear layout).  act_kind 0 identity,
+ * 1 elu(alpha 1), 2 relu, 3 tanh. */
+int rlg_mlp_forward_layer(const float* x, long long ldx, const float* weight, long long ldw,
+                          const float* bias_or_null, float* pre_act_or_null, long long ldz, float* out,
+                          long long ldh, int rows, int out_features, int in_features, int act_kind,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
