@@ -357,6 +357,12 @@ __global__ __launch_bounds__(256) void prepare_finalize_kernel(const double* __r
     }
     st.r_mean = static_cast<float>(mean);
     st.r_denom = sqrt_rn(static_cast<float>(var) + eps);
+    if (masked) {
+      // masked branch (a2c_common.py:1605-1615): both updates happen first, then values AND
+      // returns are normalised in eval mode with the final statistics
+      st.v_mean = st.r_mean;
+      st.v_denom = st.r_denom;
+    }
   }
   if (flags & kPrepEmaAdv) {
     // moving_mean_std.py:119-122 (_update_stats 'mean_std'), :57-61 (_get_stats)

@@ -288,3 +288,47 @@ def test_lstm_config_train_epoch_runs():
     assert all(torch.isfinite(x).item() for x in out[4])
     st = agent.dataset.values_dict
     assert st is not None and st['rnn_states'][0].shape == (1, 256 * (16 // 16), 64)
+
+
+def test_masked_rows_path_matches_oracle():
+    """next_step-autoreset masking (SURVEY 8a' pitfall 9; a2c_common.py:1605-1615, torch_ext.py:157-191):
+    rnn_masks in the batch -> valid-row value statistics, masked advantage normalisation, masked
+    loss / KL means.  Same rollout tensors + mask through the device agent and the CPU oracle."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=96, horizon=8, obs_dim=9, act_dim=3, hip_graphs=False)
+    agent = A2CAgent('m', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps()
+    B = 96 * 8
+    mask = (torch.rand(B, generator=torch.Generator().manual_seed(3)) < 0.75).float()
+    batch = {k: v for k, v in batch.items() if k != '_fused'}
+    batch['rnn_masks'] = mask.to(DEV)
+    env = SyntheticTensorEnv(96, 9, 3, device='cpu', seed=1)
+    oracle = OracleAgent(copy.deepcopy(params), env)
+    oracle.model.load_full_state_dict({k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()})
+    cpu_batch = {k: v.detach().cpu().clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    ref = oracle.update(cpu_batch)
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    vd = agent.dataset.values_dict
+    assert torch.allclose(vd['old_values'].cpu(), oracle_ds(oracle, 'old_values'), rtol=1e-5, atol=2e-6)
+    assert torch.allclose(vd['returns'].cpu(), oracle_ds(oracle, 'returns'), rtol=1e-5, atol=2e-6)
+    k = 0
+    for mini_ep in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            r = ref[k]
+            for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
+                assert np.isclose(got.item(), r[key].item(), rtol=1e-4, atol=5e-6), (k, key, got.item(), r[key].item())
+            k += 1
+    assert agent.model.value_mean_std.count.item() == oracle.model.value_stats['count'].item()
+    assert agent.model.value_mean_std.count.item() == 1 + 2 * int(mask.sum().item())
+
+
+def oracle_ds(oracle, key):
+    # the oracle keeps the first-epoch dataset tensors; mu/sigma are updated in place, the rest is static
+    return oracle.dataset[key]
