@@ -221,6 +221,20 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
                        float critic_coef, float bounds_coef, int clip_value, int use_smooth_clamp,
                        int bound_kind, int write_back, void* stream);
 
+/* Discrete (Categorical) variant - replaces rl_games/algos_torch/a2c_discrete.py:
+ * DiscreteA2CAgent.calc_gradients :121-209 with the ModelA2C epilogue (models.py:95-111): logits
+ * [mb, n] (row stride ld), actions int64 [mb]; emits d_logits [mb, n] (actor + entropy terms,
+ * scaled) and d_values [mb]; partials [blocks][7] feed rlg_ppo_loss_finalize with actions_num = 0
+ * (kl = 0.5 (old_nlp - nlp)^2, :192-198). */
+int rlg_ppo_loss_discrete_num_blocks(int minibatch);
+int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
+                          const long long* actions, const float* old_neglogp, const float* advantages,
+                          const float* old_values, const float* returns, const float* mask_or_null,
+                          const float* mask_sum_or_null, float* d_logits, float* d_values,
+                          double* partials, int minibatch, int num_actions, float e_clip,
+                          float critic_coef, float entropy_coef, int clip_value, int use_smooth_clamp,
+                          void* stream);
+
 /* scalars8 = {a_loss, c_loss, entropy, b_loss, kl, loss, sum(mask), 0}; d_logstd [A];
  * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena);
  * d_mu_bias_or_null [A] / d_value_bias_or_null [1] receive sum_rows d_mu / d_values, i.e. the

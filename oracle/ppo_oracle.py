@@ -349,6 +349,28 @@ def distribution_loss_and_grads(mu, logstd, values, batch, hp, mask=None):
             'd_values': values.grad}
 
 
+def categorical_loss_and_grads(logits, values, batch, hp, mask=None):
+    """Discrete agent: ModelA2C epilogue (rl_games/algos_torch/models.py:95-111, Categorical(logits):
+    neglogp, entropy) + DiscreteA2CAgent.calc_gradients losses and KL
+    (rl_games/algos_torch/a2c_discrete.py:166-198), backward by autograd."""
+    logits = logits.detach().clone().requires_grad_(True)
+    values = values.detach().clone().requires_grad_(True)
+    cat = torch.distributions.Categorical(logits=logits)
+    nlp = torch.squeeze(-cat.log_prob(batch['actions']))
+    ent = cat.entropy()
+    a = actor_loss(batch['old_logp_actions'], nlp, batch['advantages'], hp['e_clip'], True,
+                   hp.get('use_smooth_clamp', False))
+    c = critic_loss(batch['old_values'], values, hp['e_clip'], batch['returns'], hp.get('clip_value', True))
+    (a_m, c_m, e_m), _ = masked_means([a.unsqueeze(1), c, ent.unsqueeze(1)], mask)
+    loss = a_m + 0.5 * c_m * hp['critic_coef'] - e_m * hp['entropy_coef']
+    loss.backward()
+    with torch.no_grad():
+        kl = 0.5 * ((batch['old_logp_actions'] - nlp) ** 2)
+        kl = kl.mean() if mask is None else (kl * mask).sum() / mask.sum().clamp(min=1.0)
+    return {'loss': loss.detach(), 'a_loss': a_m.detach(), 'c_loss': c_m.detach(), 'entropy': e_m.detach(),
+            'kl': kl, 'neglogp': nlp.detach(), 'd_logits': logits.grad, 'd_values': values.grad}
+
+
 # --------------------------------------------------------------------------------------
 # a15 - learning-rate control
 # --------------------------------------------------------------------------------------

@@ -290,15 +290,8 @@ class A2CAgent:
         self.is_tensor_obses = False
         self.aux_loss_dict = {}
 
-        # ---- ContinuousA2CBase.__init__ (a2c_common.py:1484-1498) ----
-        self.is_discrete = False
-        action_space = self.env_info['action_space']
-        self.actions_num = action_space.shape[0]
-        self.bounds_loss_coef = config.get('bounds_loss_coef', None)
-        self.clip_actions = config.get('clip_actions', True)
+        self._init_action_space(config)
         dev = self.ppo_device
-        self.actions_low = torch.from_numpy(np.asarray(action_space.low).copy()).float().to(dev)
-        self.actions_high = torch.from_numpy(np.asarray(action_space.high).copy()).float().to(dev)
 
         # ---- A2CAgent.__init__ (a2c_continuous.py:18-76) ----
         build_config = {
@@ -312,7 +305,8 @@ class A2CAgent:
         self.is_rnn = self.model.is_rnn()
         self.bound_loss_type = config.get('bound_loss_type', 'bound')
         layout = None
-        self._use_engine = (not self.is_rnn) and config.get('manual_mlp', True)
+        self._use_engine = ((not self.is_rnn) and (not self.is_discrete) and config.get('manual_mlp', True)
+                            and not self.model.a2c_network.is_separate_critic())
         if self._use_engine:
             from .mlp_engine import ManualMLP
             net = self.model.a2c_network
@@ -347,13 +341,8 @@ class A2CAgent:
         self.obs = None
 
         # per-minibatch scratch
-        A = self.actions_num
         mb = self.minibatch_size
-        self._d_mu = torch.empty(mb, A, dtype=torch.float32, device=dev)
-        self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
-        self._loss_blocks = ops.ppo_loss_blocks(mb)
-        self._loss_partials = torch.empty(self._loss_blocks, ops.ppo_loss_partials_per_block(A),
-                                          dtype=torch.float64, device=dev)
+        self._alloc_loss_scratch(mb, dev)
         self._mb_scalars = torch.zeros(max(1, self.mini_epochs_num * self.num_minibatches), 8,
                                        dtype=torch.float32, device=dev)
         self._mb_index = 0
@@ -372,6 +361,31 @@ class A2CAgent:
         self._obs_norm_mb = (torch.empty((mb,) + tuple(self.obs_shape), dtype=torch.float32, device=dev)
                              if self.normalize_input else None)
         self.algo_observer.after_init(self)
+
+    def _init_action_space(self, config):
+        """ContinuousA2CBase.__init__ (a2c_common.py:1484-1498)."""
+        self.is_discrete = False
+        action_space = self.env_info['action_space']
+        if type(action_space).__name__ != 'Box':
+            raise ValueError(f'A2CAgent (a2c_continuous) needs a Box action space, got '
+                             f'{type(action_space).__name__}; use DiscreteA2CAgent for a2c_discrete')
+        self.actions_num = action_space.shape[0]
+        self.bounds_loss_coef = config.get('bounds_loss_coef', None)
+        self.clip_actions = config.get('clip_actions', True)
+        dev = self.ppo_device
+        self.actions_low = torch.from_numpy(np.asarray(action_space.low).copy()).float().to(dev)
+        self.actions_high = torch.from_numpy(np.asarray(action_space.high).copy()).float().to(dev)
+
+    def _alloc_loss_scratch(self, mb, dev):
+        A = self.actions_num
+        self._d_mu = torch.empty(mb, A, dtype=torch.float32, device=dev)
+        self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
+        self._loss_blocks = ops.ppo_loss_blocks(mb)
+        self._loss_partials = torch.empty(self._loss_blocks, ops.ppo_loss_partials_per_block(A),
+                                          dtype=torch.float64, device=dev)
+
+    def _rollout_fields(self):
+        return ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
 
     # ================================================================== small helpers
     @property
@@ -526,7 +540,7 @@ class A2CAgent:
         self._norm_advantages = torch.empty(B, dtype=torch.float32, device=dev)
         from .gae import num_moment_partials
         self._gae_partials = torch.empty(num_moment_partials(rows), 6, dtype=torch.float64, device=dev)
-        self.update_list = ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
+        self.update_list = self._rollout_fields()
         self.tensor_list = self.update_list + ['obses', 'states', 'dones']
         if self._engine is not None:
             self._roll_obs_norm = torch.empty((rows,) + tuple(self.obs_shape), dtype=torch.float32, device=dev)
@@ -818,8 +832,10 @@ class A2CAgent:
             'old_values': nv, 'old_logp_actions': batch_dict['neglogpacs'], 'advantages': na,
             'returns': nr, 'actions': batch_dict['actions'], 'obs': batch_dict['obses'],
             'dones': batch_dict['dones'], 'rnn_states': batch_dict.get('rnn_states', None),
-            'rnn_masks': rnn_masks, 'mu': batch_dict['mus'], 'sigma': batch_dict['sigmas'],
+            'rnn_masks': rnn_masks,
         }
+        if not self.is_discrete:
+            dataset_dict['mu'], dataset_dict['sigma'] = batch_dict['mus'], batch_dict['sigmas']
         self.dataset.update_values_dict(dataset_dict)
 
     # ================================================================== update
@@ -1013,9 +1029,12 @@ class A2CAgent:
                     self._graph_failed = True
                     raise
             else:
+                if self.is_discrete:                  # a2c_common.py:1263 (no-op unless `permute`)
+                    self.dataset.apply_permutation()
                 for i in range(nmb):
-                    a_loss, c_loss, entropy, kl, last_lr, lr_mul, cmu, csigma, b_loss = \
-                        self.train_actor_critic(self.dataset[i])
+                    res = self.train_actor_critic(self.dataset[i])
+                    a_loss, c_loss, entropy, kl, last_lr, lr_mul = res[:6]
+                    b_loss = res[8] if len(res) > 8 else None
                     a_losses.append(a_loss)
                     c_losses.append(c_loss)
                     entropies.append(entropy)
@@ -1194,8 +1213,11 @@ class A2CAgent:
         self.broadcast_parameters()
         while True:
             epoch_num = self.update_epoch()
+            res = self.train_epoch()
+            if len(res) == 10:                     # discrete agents report no bound losses
+                res = res[:6] + ([],) + res[6:]
             (step_time, play_time, update_time, sum_time, a_losses, c_losses, b_losses, entropies, kls,
-             last_lr, lr_mul) = self.train_epoch()
+             last_lr, lr_mul) = res
             total_time += sum_time
             curr_frames = self.curr_frames * self.world_size if self.multi_gpu else self.curr_frames
             self.frame += curr_frames

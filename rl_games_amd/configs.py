@@ -70,5 +70,20 @@ def tiny(num_actors=256, horizon=8, obs_dim=12, act_dim=3, **over):
                               {'obs_dim': obs_dim, 'act_dim': act_dim}, **over)}
 
 
+def cartpole_discrete(num_actors=16, **over):
+    """BASELINE.json config #1 (rl_games/configs/ppo_cartpole.yaml): discrete PPO, CartPole-shaped
+    obs 4 / 2 actions, separate actor/critic MLPs [32,32] relu, next_step autoreset (masked rows)."""
+    net = {'name': 'actor_critic', 'separate': True, 'space': {'discrete': None},
+           'mlp': {'units': [32, 32], 'activation': 'relu', 'initializer': {'name': 'default'}}}
+    cfg = _config('cartpole_shaped', num_actors, 32, 64, 4,
+                  {'obs_dim': 4, 'discrete_actions': 2, 'autoreset_mode': 'next_step'},
+                  normalize_input=False, normalize_value=False, learning_rate=2e-4, lr_schedule=None,
+                  entropy_coef=0.01, critic_coef=1, tau=0.9, reward_shaper={'scale_value': 0.1})
+    cfg.pop('bounds_loss_coef')
+    cfg.pop('bound_loss_type')
+    cfg.update(over)
+    return {'algo': {'name': 'a2c_discrete'}, 'model': {'name': 'discrete_a2c'}, 'network': net, 'config': cfg}
+
+
 def clone(params):
     return copy.deepcopy(params)

@@ -362,6 +362,112 @@ __global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Discrete (Categorical) PPO loss - DiscreteA2CAgent.calc_gradients
+// (rl_games/algos_torch/a2c_discrete.py:121-209) with the ModelA2C epilogue
+// (rl_games/algos_torch/models.py:95-111: Categorical(logits) -> neglogp, entropy):
+//   nlp = logsumexp(z) - z[a] ;  p = softmax(z) ;  H = -sum p log p
+//   a_loss / c_loss as in the continuous case; loss = a + 0.5 c critic_coef - H entropy_coef
+//   kl  = 0.5 (old_nlp - nlp)^2                                   (:192-198)
+// backward: d nlp/d z_j = p_j - [j == a] ;  d H/d z_j = -p_j (log p_j + H).
+// One thread per row (the number of actions is small: 2 for config #1's CartPole).
+// ---------------------------------------------------------------------------------
+struct DiscreteLossArgs {
+  const float* logits;       // [mb, n] row stride ld
+  long long ld;
+  const float* values;       // [mb]
+  const long long* actions;  // [mb] int64
+  const float* old_neglogp;
+  const float* advantages;
+  const float* old_values;
+  const float* returns;
+  const float* mask;         // or nullptr
+  const float* mask_sum;
+  float* d_logits;           // [mb, n] contiguous
+  float* d_values;           // [mb]
+  double* partials;          // [gridDim.x][kLossScalars]
+  int mb, n;
+  float e_clip, critic_coef, entropy_coef;
+  int clip_value, smooth;
+};
+
+__global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs p) {
+  __shared__ double red[kLossScalars * 4];
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (i < p.mb) {
+    const float* z = p.logits + i * p.ld;
+    float zmax = z[0];
+    for (int j = 1; j < p.n; ++j) zmax = fmaxf(zmax, z[j]);
+    float se = 0.0f;
+    for (int j = 0; j < p.n; ++j) se += expf(z[j] - zmax);
+    const float lse = zmax + logf(se);                       // logits - logsumexp (Categorical.__init__)
+    const int a = static_cast<int>(p.actions[i]);
+    const float nlp = -(z[a] - lse);
+    float H = 0.0f;
+    for (int j = 0; j < p.n; ++j) {
+      const float lp = z[j] - lse;
+      H -= expf(lp) * lp;
+    }
+    const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
+    const float adv = p.advantages[i];
+    const float old_nlp = p.old_neglogp[i];
+    const float ratio = expf(old_nlp - nlp);
+    float l2, dl2;
+    if (p.smooth) {
+      l2 = adv * smooth_clamp_f(ratio, lo, hi);
+      dl2 = smooth_clamp_grad(ratio, lo, hi);
+    } else {
+      l2 = adv * fminf(fmaxf(ratio, lo), hi);
+      dl2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    }
+    const float n1 = -(adv * ratio), n2 = -l2;
+    const float a_loss = fmaxf(n1, n2);
+    float w1, w2;
+    if (n1 > n2) { w1 = 1.0f; w2 = 0.0f; } else if (n2 > n1) { w1 = 0.0f; w2 = 1.0f; } else { w1 = w2 = 0.5f; }
+    const float g_nlp = adv * (w1 + w2 * dl2) * ratio;
+    const float v = p.values[i], vo = p.old_values[i], R = p.returns[i];
+    float c_loss, g_v;
+    if (p.clip_value) {
+      const float delta = v - vo;
+      const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+      const float d1 = v - R, d2 = vclip - R;
+      const float c1 = d1 * d1, c2 = d2 * d2;
+      c_loss = fmaxf(c1, c2);
+      const float in = (delta >= -p.e_clip && delta <= p.e_clip) ? 1.0f : 0.0f;
+      if (c1 > c2) g_v = 2.0f * d1; else if (c2 > c1) g_v = 2.0f * d2 * in;
+      else g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
+    } else {
+      const float d = R - v;
+      c_loss = d * d;
+      g_v = -2.0f * d;
+    }
+    const float m = p.mask ? p.mask[i] : 1.0f;
+    const float denom = p.mask ? fmaxf(*p.mask_sum, 1.0f) : static_cast<float>(p.mb);
+    const float w = m / denom;
+    for (int j = 0; j < p.n; ++j) {
+      const float lp = z[j] - lse;
+      const float pj = expf(lp);
+      const float dnlp = pj - (j == a ? 1.0f : 0.0f);
+      const float dH = -pj * (lp + H);
+      p.d_logits[i * p.n + j] = w * (g_nlp * dnlp - p.entropy_coef * dH);
+    }
+    p.d_values[i] = (0.5f * p.critic_coef) * g_v * w;
+    const float dk = old_nlp - nlp;
+    acc[0] = static_cast<double>(a_loss) * m;
+    acc[1] = static_cast<double>(c_loss) * m;
+    acc[2] = static_cast<double>(H) * m;
+    acc[4] = static_cast<double>(0.5f * (dk * dk)) * m;
+    acc[5] = m;
+  }
+  block_sum<kLossScalars, 256>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kLossScalars; ++k) p.partials[static_cast<long long>(blockIdx.x) * kLossScalars + k] = acc[k];
+  }
+}
+
 }  // namespace rlg
 
 extern "C" {
@@ -420,6 +526,44 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const int grid = rlg_ppo_loss_num_blocks(minibatch);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossThreads), shm,
+                     static_cast<hipStream_t>(stream), p);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_ppo_loss_discrete_num_blocks(int minibatch) { return (minibatch + 255) / 256; }
+
+int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
+                          const long long* actions, const float* old_neglogp, const float* advantages,
+                          const float* old_values, const float* returns, const float* mask_or_null,
+                          const float* mask_sum_or_null, float* d_logits, float* d_values,
+                          double* partials, int minibatch, int num_actions, float e_clip,
+                          float critic_coef, float entropy_coef, int clip_value, int use_smooth_clamp,
+                          void* stream) {
+  using namespace rlg;
+  if (minibatch <= 0 || num_actions <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
+  DiscreteLossArgs p;
+  p.logits = logits;
+  p.ld = ld_logits;
+  p.values = values;
+  p.actions = actions;
+  p.old_neglogp = old_neglogp;
+  p.advantages = advantages;
+  p.old_values = old_values;
+  p.returns = returns;
+  p.mask = mask_or_null;
+  p.mask_sum = mask_sum_or_null;
+  p.d_logits = d_logits;
+  p.d_values = d_values;
+  p.partials = partials;
+  p.mb = minibatch;
+  p.n = num_actions;
+  p.e_clip = e_clip;
+  p.critic_coef = critic_coef;
+  p.entropy_coef = entropy_coef;
+  p.clip_value = clip_value;
+  p.smooth = use_smooth_clamp;
+  hipLaunchKernelGGL(ppo_loss_discrete_kernel, dim3(rlg_ppo_loss_discrete_num_blocks(minibatch)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();
 }

@@ -289,6 +289,28 @@ def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_val
         'rlg_ppo_loss_fused')
 
 
+def ppo_loss_discrete_blocks(minibatch):
+    return _lib.load().rlg_ppo_loss_discrete_num_blocks(int(minibatch))
+
+
+def ppo_loss_discrete(logits, values, actions, old_neglogp, advantages, old_values, returns, d_logits,
+                      d_values, partials, e_clip, critic_coef, entropy_coef, clip_value=True,
+                      smooth=False, mask=None, mask_sum=None):
+    lib = _lib.load()
+    mb, n = logits.shape
+    _lib.require_gpu(logits, 'logits')
+    if logits.dtype != F32 or logits.stride(1) != 1:
+        raise ValueError('logits: fp32 with unit inner stride expected')
+    _lib.check(lib.rlg_ppo_loss_discrete(
+        logits.data_ptr(), logits.stride(0), _need(values, F32, 'values'),
+        _need(actions, torch.int64, 'actions'), _need(old_neglogp, F32, 'old_neglogp'),
+        _need(advantages, F32, 'advantages'), _need(old_values, F32, 'old_values'),
+        _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'),
+        _need(d_logits, F32, 'd_logits'), _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'),
+        mb, n, float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(entropy_coef)),
+        1 if clip_value else 0, 1 if smooth else 0, _stream(logits)), 'rlg_ppo_loss_discrete')
+
+
 def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, critic_coef,
                       entropy_coef, bounds_coef, scalars, d_logstd, kl_slot=None, d_mu_bias=None,
                       d_value_bias=None):

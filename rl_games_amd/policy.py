@@ -95,12 +95,18 @@ class ActorCriticNetwork(nn.Module):
         super().__init__()
         if 'cnn' in net_params:
             raise NotImplementedError('CNN encoders are outside the MI355X PPO hot path (SURVEY 2, row 15)')
-        self.separate = net_params.get('separate', False)
-        if self.separate:
-            raise NotImplementedError('separate actor/critic trunks are not implemented on this path')
+        self.separate = bool(net_params.get('separate', False))
+        if self.separate and 'rnn' in net_params:
+            raise NotImplementedError('separate actor/critic trunks with an RNN are not implemented')
         space = net_params.get('space', {})
+        self.is_discrete = 'discrete' in space
+        if 'multi_discrete' in space:
+            raise NotImplementedError('multi-discrete action spaces are not implemented on this path')
+        if self.is_discrete:
+            self._init_discrete(net_params, actions_num, input_shape, value_size, num_seqs)
+            return
         if 'continuous' not in space:
-            raise NotImplementedError('only continuous action spaces run on the fused HIP loss path')
+            raise NotImplementedError("network 'space' must be continuous or discrete")
         self.space_config = space['continuous']
         self.fixed_sigma = self.space_config['fixed_sigma']
         if not self.fixed_sigma:
@@ -127,6 +133,8 @@ class ActorCriticNetwork(nn.Module):
             layers.append(_activation(mlp['activation']))
             last = u
         self.actor_mlp = nn.Sequential(*layers)
+        if self.separate:                                      # network_builder.py:292-293
+            self.critic_mlp = self._mlp_like(in_size, mlp['activation'])
         out_size = last
         if self.has_rnn:
             rnn = net_params['rnn']
@@ -154,11 +162,45 @@ class ActorCriticNetwork(nn.Module):
         _initializer(self.space_config['mu_init'])(self.mu.weight)
         _initializer(self.space_config['sigma_init'])(self.sigma)
 
+    def _init_discrete(self, net_params, actions_num, input_shape, value_size, num_seqs):
+        """Categorical head (network_builder.py:298-299): `logits` Linear in place of mu/sigma."""
+        mlp = net_params['mlp']
+        if mlp.get('d2rl', False) or net_params.get('normalization'):
+            raise NotImplementedError('d2rl / normalisation layers are not implemented on this path')
+        if 'rnn' in net_params:
+            raise NotImplementedError('recurrent discrete policies are not implemented on this path')
+        self.units = list(mlp['units'])
+        self.value_size, self.num_seqs, self.actions_num = value_size, num_seqs, actions_num
+        self.has_rnn = False
+        assert len(input_shape) == 1, 'flat observations only'
+        layers, last = [], input_shape[0]
+        for u in self.units:
+            layers += [nn.Linear(last, u), _activation(mlp['activation'])]
+            last = u
+        self.actor_mlp = nn.Sequential(*layers)
+        if self.separate:
+            self.critic_mlp = self._mlp_like(input_shape[0], mlp['activation'])
+        self.value = nn.Linear(last, value_size)
+        self.value_act = _activation(net_params.get('value_activation', 'None'))
+        self.logits = nn.Linear(last, actions_num)
+        mlp_init = _initializer(mlp['initializer'])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                mlp_init(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _mlp_like(self, in_size, activation):
+        layers, last = [], in_size
+        for u in self.units:
+            layers += [nn.Linear(last, u), _activation(activation)]
+            last = u
+        return nn.Sequential(*layers)
+
     def is_rnn(self):
         return self.has_rnn
 
     def is_separate_critic(self):
-        return False
+        return self.separate
 
     def get_value_layer(self):
         return self.value
@@ -171,6 +213,11 @@ class ActorCriticNetwork(nn.Module):
             return None
         z = lambda: torch.zeros((self.rnn_layers, self.num_seqs, self.rnn_units))
         return (z(), z()) if self.rnn_name == 'lstm' else (z(),)
+
+    def critic_features(self, obs, actor_out):
+        """Input of the value head: the separate critic trunk of `obs`, or the shared features
+        (network_builder.py:424-429 vs :447-500)."""
+        return self.critic_mlp(obs) if self.separate else actor_out
 
     def trunk(self, obs, states=None, dones=None, seq_length=1):
         out = self.actor_mlp(obs)
@@ -193,7 +240,9 @@ class ActorCriticNetwork(nn.Module):
         """(mu, logstd_broadcast, value, states) - network_builder.py:447-512."""
         out, states = self.trunk(obs_dict['obs'], obs_dict.get('rnn_states'), obs_dict.get('dones'),
                                  obs_dict.get('seq_length', 1))
-        value = self.value_act(self.value(out))
+        value = self.value_act(self.value(self.critic_features(obs_dict['obs'], out)))
+        if self.is_discrete:                                   # (logits, value, states) :431-433,:500-502
+            return self.logits(out), value, states
         mu = self.mu_act(self.mu(out))
         sigma = self.sigma_act(self.sigma)
         return mu, mu * 0 + sigma, value, states
@@ -208,13 +257,13 @@ class ContinuousA2CLogStdModel(nn.Module):
         self.normalize_value = normalize_value
         self.normalize_input = normalize_input
         self.value_size = value_size
-        self.a2c_network = a2c_network
         if normalize_value:
             self.value_mean_std = RunningMeanStd((value_size,))
         if normalize_input:
             if isinstance(obs_shape, dict):
                 raise NotImplementedError('dict observations are not implemented on this path')
             self.running_mean_std = RunningMeanStd(obs_shape)
+        self.a2c_network = a2c_network        # after the normalisers, as in models.py:27-45,:311-316
 
     # -- reference API ---------------------------------------------------------------
     def is_rnn(self):
@@ -249,7 +298,7 @@ class ContinuousA2CLogStdModel(nn.Module):
         net = self.a2c_network
         out, states = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
                                 input_dict.get('seq_length', 1))
-        value = net.value_act(net.value(out))
+        value = net.value_act(net.value(net.critic_features(obs, out)))
         mu = net.mu_act(net.mu(out))
         return mu, net.sigma_act(net.sigma), value, states
 
@@ -271,6 +320,36 @@ class ContinuousA2CLogStdModel(nn.Module):
                 'actions': selected_action, 'rnn_states': states, 'mus': mu, 'sigmas': sigma}
 
 
+class DiscreteA2CModel(ContinuousA2CLogStdModel):
+    """The reference's `ModelA2C.Network` contract (models.py:66-125) without action masks:
+    Categorical(logits) sampling in rollout, neglogp/entropy in training."""
+
+    def forward_heads(self, input_dict):
+        """Training fast path: (logits [B,n], value [B,V]) for the fused categorical loss kernel."""
+        obs = self.norm_obs(input_dict['obs'])
+        net = self.a2c_network
+        out, _ = net.trunk(obs)
+        return net.logits(out), net.value_act(net.value(net.critic_features(obs, out)))
+
+    def forward(self, input_dict):
+        is_train = input_dict.get('is_train', True)
+        if input_dict.get('action_masks', None) is not None:
+            raise NotImplementedError('action masks are not implemented on this path')
+        prev_actions = input_dict.get('prev_actions', None)
+        input_dict = dict(input_dict)
+        input_dict['obs'] = self.norm_obs(input_dict['obs'])
+        logits, value, states = self.a2c_network(input_dict)
+        categorical = torch.distributions.Categorical(logits=logits)
+        if is_train:
+            prev_neglogp = -categorical.log_prob(prev_actions)
+            return {'prev_neglogp': torch.squeeze(prev_neglogp), 'logits': categorical.logits,
+                    'values': value, 'entropy': categorical.entropy(), 'rnn_states': states}
+        selected_action = categorical.sample().long()
+        neglogp = -categorical.log_prob(selected_action)
+        return {'neglogpacs': torch.squeeze(neglogp), 'values': self.denorm_value(value),
+                'actions': selected_action, 'logits': categorical.logits, 'rnn_states': states}
+
+
 class PolicyBuilder:
     """Stands in for `model_builder.ModelBuilder().load(params)` (rl_games/algos_torch/
     model_builder.py:56-60): `.build(config)` returns the model for one agent."""
@@ -278,8 +357,9 @@ class PolicyBuilder:
     def __init__(self, params):
         model_name = params.get('model', {}).get('name', 'continuous_a2c_logstd')
         net_name = params.get('network', {}).get('name', 'actor_critic')
-        if model_name != 'continuous_a2c_logstd':
+        if model_name not in ('continuous_a2c_logstd', 'discrete_a2c'):
             raise NotImplementedError(f"model '{model_name}' is not implemented on the MI355X PPO path")
+        self.model_name = model_name
         if net_name != 'actor_critic':
             raise NotImplementedError(f"network '{net_name}' is not implemented on the MI355X PPO path")
         self.net_params = params['network']
@@ -289,7 +369,10 @@ class PolicyBuilder:
                                  input_shape=config['input_shape'],
                                  value_size=config.get('value_size', 1),
                                  num_seqs=config.get('num_seqs', 1))
-        return ContinuousA2CLogStdModel(net, obs_shape=config['input_shape'],
+        cls = DiscreteA2CModel if self.model_name == 'discrete_a2c' else ContinuousA2CLogStdModel
+        if (self.model_name == 'discrete_a2c') != net.is_discrete:
+            raise ValueError(f"model '{self.model_name}' does not match the network's action space")
+        return cls(net, obs_shape=config['input_shape'],
                                         normalize_value=config.get('normalize_value', False),
                                         normalize_input=config.get('normalize_input', False),
                                         value_size=config.get('value_size', 1))

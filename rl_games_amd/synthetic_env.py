@@ -8,20 +8,24 @@ torch device so that the CPU baseline drives the very same environment."""
 import numpy as np
 import torch
 
-from .spaces import Box
+from .spaces import Box, Discrete
 
 
 class SyntheticTensorEnv:
-    def __init__(self, num_envs, obs_dim, act_dim, device='cuda:0', seed=1234, p_done=0.05,
-                 value_size=1):
+    def __init__(self, num_envs, obs_dim, act_dim=0, device='cuda:0', seed=1234, p_done=0.05,
+                 value_size=1, discrete_actions=None, autoreset_mode='same_step'):
         self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
+        self.autoreset_mode = autoreset_mode
         self.device = torch.device(device)
         self.p_done = p_done
         self.value_size = value_size
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
-        self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
+        if discrete_actions is not None:          # CartPole-like (BASELINE config #1)
+            self.action_space = Discrete(discrete_actions)
+        else:
+            self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
 
     def _obs(self):
         return torch.randn(self.num_envs, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
@@ -43,7 +47,7 @@ class SyntheticTensorEnv:
 
     def get_env_info(self):
         return {'observation_space': self.observation_space, 'action_space': self.action_space,
-                'agents': 1, 'value_size': self.value_size, 'autoreset_mode': 'same_step'}
+                'agents': 1, 'value_size': self.value_size, 'autoreset_mode': self.autoreset_mode}
 
     def has_action_masks(self):
         return False

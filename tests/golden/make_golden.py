@@ -173,7 +173,92 @@ def make_epoch():
     print('epoch.pt written', os.path.getsize(os.path.join(HERE, 'epoch.pt')) // 1024, 'KiB')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch}
+def make_discrete():
+    """One train_epoch of the REAL reference DiscreteA2CAgent (a2c_discrete.py) on CPU: CartPole-like
+    shapes (BASELINE.json config #1 in miniature), separate actor/critic MLPs, next_step autoreset
+    (masked filler rows), adaptive lr stepped once per mini-epoch."""
+    import copy
+    import ref_import
+    ref_import.enable()
+    from rl_games.torch_runner import Runner
+    from rl_games_amd import configs
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+
+    variants = {
+        'masked_adaptive': dict(normalize_input=True, normalize_value=True, lr_schedule='adaptive',
+                                learning_rate=3e-4, kl_threshold=0.002, p_done=0.15),
+        'plain': dict(_autoreset='same_step', entropy_coef=0.02, p_done=0.05),
+    }
+    out = {}
+    for name, over in variants.items():
+        over = dict(over)
+        N, H, O_, n_act = 16, 8, 4, 3
+        p_done = over.pop('p_done')
+        mode = over.pop('_autoreset', 'next_step')
+        params = configs.cartpole_discrete(num_actors=N, horizon_length=H, minibatch_size=32, mini_epochs=2,
+                                           device='cpu', train_dir='/tmp/rlg_golden_runs', **over)
+        env_kw = dict(obs_dim=O_, discrete_actions=n_act, autoreset_mode=mode, p_done=p_done, seed=99)
+        params['config']['env_config'] = dict(env_kw)
+        params['seed'] = 5
+        env = SyntheticTensorEnv(N, device='cpu', **env_kw)
+        stored_params = copy.deepcopy(params)
+        runner = Runner()
+        runner.load({'params': copy.deepcopy(params)})
+        runner.params['config']['vec_env'] = env
+        runner.params['config']['env_info'] = env.get_env_info()
+        agent = runner.algo_factory.create(runner.algo_name, base_name='golden', params=runner.params)
+        assert type(agent).__name__ == 'DiscreteA2CAgent'
+        torch.manual_seed(13)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        cap = {'init_state': _clone(agent.model.state_dict()), 'lrs': []}
+        orig_play = agent.play_steps
+
+        def play():
+            b = orig_play()
+            cap['batch'] = _clone({k: v for k, v in b.items() if isinstance(v, torch.Tensor)})
+            cap['buffers'] = _clone({k: agent.experience_buffer.tensor_dict[k]
+                                     for k in ('rewards', 'values', 'dones')})
+            cap['state_after_rollout'] = _clone(agent.model.state_dict())
+            return b
+        agent.play_steps = play
+        orig_update_lr = agent.update_lr
+
+        def update_lr(lr):
+            cap['lrs'].append(float(lr))
+            return orig_update_lr(lr)
+        agent.update_lr = update_lr
+        mb_results = []
+        orig_calc = agent.calc_gradients
+
+        def calc(input_dict):
+            orig_calc(input_dict)
+            mb_results.append([x.detach().clone() for x in agent.train_result[:4]])
+        agent.calc_gradients = calc
+        agent.epoch_num = 1
+        res = agent.train_epoch()
+        (_, _, _, _, a_losses, c_losses, entropies, kls, last_lr, lr_mul) = res
+        cap['a_losses'] = torch.stack([x.detach() for x in a_losses])
+        cap['c_losses'] = torch.stack([x.detach() for x in c_losses])
+        cap['entropies'] = torch.stack([x.detach() for x in entropies])
+        cap['mb_kls'] = torch.stack([r[3] for r in mb_results])
+        cap['mini_epoch_kls'] = torch.stack([x.detach() for x in kls])
+        cap['last_lr'] = float(last_lr)
+        vd = agent.dataset.values_dict
+        cap['dataset'] = _clone({k: vd[k] for k in ('old_values', 'returns', 'advantages', 'actions',
+                                                      'old_logp_actions')})
+        cap['final_state'] = _clone(agent.model.state_dict())
+        cap['params'] = stored_params
+        cap['num_envs'] = N
+        out[name] = cap
+        print('discrete', name, 'minibatches', len(a_losses), 'masked rows',
+              None if 'rnn_masks' not in cap['batch'] else int((cap['batch']['rnn_masks'] == 0).sum()),
+              'lrs', cap['lrs'], 'kl', cap['mini_epoch_kls'].tolist())
+    torch.save(out, os.path.join(HERE, 'discrete.pt'))
+    print('discrete.pt written', os.path.getsize(os.path.join(HERE, 'discrete.pt')) // 1024, 'KiB')
+
+
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete}
 
 if __name__ == '__main__':
     only = sys.argv[1:] or list(SECTIONS)

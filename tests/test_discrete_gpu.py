@@ -1,0 +1,141 @@
+"""GPU: the discrete (categorical) PPO path - fused loss kernel vs the CPU oracle, and
+DiscreteA2CAgent vs golden vectors recorded from the REAL reference DiscreteA2CAgent."""
+import copy
+
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+from rl_games_amd.synthetic_env import SyntheticTensorEnv
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('mb,n', [(64, 2), (1000, 5), (4096, 18), (7, 3)])
+@pytest.mark.parametrize('masked', [False, True])
+@pytest.mark.parametrize('smooth', [False, True])
+def test_discrete_loss_kernel_matches_oracle(mb, n, masked, smooth):
+    from rl_games_amd import ops
+    g = torch.Generator().manual_seed(mb * 31 + n)
+    logits = torch.randn(mb, n, generator=g) * 1.5
+    values = torch.randn(mb, 1, generator=g)
+    batch = {'actions': torch.randint(0, n, (mb,), generator=g),
+             'old_logp_actions': -torch.log_softmax(torch.randn(mb, n, generator=g), 1)[:, 0],
+             'advantages': torch.randn(mb, generator=g), 'old_values': torch.randn(mb, 1, generator=g),
+             'returns': torch.randn(mb, 1, generator=g)}
+    # keep the importance ratio in a sane range (as PPO does): old_nlp near the new one
+    with torch.no_grad():
+        nlp = -torch.log_softmax(logits, 1).gather(1, batch['actions'].view(-1, 1)).view(-1)
+        batch['old_logp_actions'] = nlp + 0.3 * torch.randn(mb, generator=g)
+    mask = (torch.rand(mb, generator=g) > 0.3).float() if masked else None
+    hp = dict(e_clip=0.2, clip_value=True, critic_coef=2.0, entropy_coef=0.01, use_smooth_clamp=smooth)
+    ref = O.categorical_loss_and_grads(logits, values, batch, hp, mask.view(-1, 1) if masked else None)
+    hp64 = dict(hp)
+    ref64 = O.categorical_loss_and_grads(logits.double(), values.double(),
+                                         {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()},
+                                         hp64, mask.double().view(-1, 1) if masked else None)
+
+    d_logits = torch.empty(mb, n, device=DEV)
+    d_val = torch.empty(mb, device=DEV)
+    partials = torch.empty(ops.ppo_loss_discrete_blocks(mb), ops.ppo_loss_partials_per_block(0),
+                           dtype=torch.float64, device=DEV)
+    row = torch.zeros(8, device=DEV)
+    kl_slot = torch.zeros(1, device=DEV)
+    dm = mask.to(DEV) if masked else None
+    ops.ppo_loss_discrete(logits.to(DEV), values.to(DEV).reshape(-1), batch['actions'].to(DEV),
+                          batch['old_logp_actions'].to(DEV), batch['advantages'].to(DEV),
+                          batch['old_values'].to(DEV).reshape(-1), batch['returns'].to(DEV).reshape(-1),
+                          d_logits, d_val, partials, 0.2, 2.0, 0.01, True, smooth, dm,
+                          dm.sum().reshape(1) if masked else None)
+    ops.ppo_loss_finalize(partials, partials.shape[0], 0, mb, masked, 2.0, 0.01, 0.0, row,
+                          torch.zeros(1, device=DEV), kl_slot)
+    row = row.cpu()
+    # scalars: fp32 tolerance of north_star (1e-5 rtol) against the oracle
+    for i, k in ((0, 'a_loss'), (1, 'c_loss'), (2, 'entropy'), (4, 'kl'), (5, 'loss')):
+        assert torch.allclose(row[i], ref[k].float(), rtol=2e-5, atol=2e-6), (k, row[i], ref[k])
+    assert torch.allclose(kl_slot.cpu()[0], ref['kl'].float(), rtol=2e-5, atol=1e-7)
+    # gradients: both implementations are fp32; judge each by its distance to the fp64 evaluation
+    t_l, t_v = ref64['d_logits'], ref64['d_values']
+    err_k = (d_logits.cpu().double() - t_l).abs().max()
+    err_o = (ref['d_logits'].double() - t_l).abs().max()
+    scale = t_l.abs().max()
+    assert err_k <= max(8 * err_o, 2e-6 * scale), (err_k, err_o, scale)
+    err_kv = (d_val.cpu().double().view(-1, 1) - t_v).abs().max()
+    assert err_kv <= max(8 * (ref['d_values'].double() - t_v).abs().max(), 2e-6 * t_v.abs().max())
+
+
+def _make_agent(cap, **over):
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    params = copy.deepcopy(cap['params'])
+    params['config'].update(device=DEV, **over)
+    env = SyntheticTensorEnv(cap['num_envs'], device=DEV, **params['config']['env_config'])
+    params['config']['vec_env'] = env
+    params['config']['env_info'] = env.get_env_info()
+    agent = DiscreteA2CAgent('test', params)
+    agent.init_tensors()
+    return agent
+
+
+@pytest.mark.parametrize('variant', ['masked_adaptive', 'plain'])
+def test_discrete_update_matches_reference_epoch(golden, variant):
+    cap = golden('discrete.pt')[variant]
+    agent = _make_agent(cap)
+    agent.model.load_state_dict(cap['state_after_rollout'])
+    batch = {k: v.to(DEV) for k, v in cap['batch'].items()}
+    agent.set_train()
+    agent.epoch_num = 1
+    agent.prepare_dataset(batch)
+    ds, vd = cap['dataset'], agent.dataset.values_dict
+    for k in ('old_values', 'returns', 'advantages'):
+        assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
+    assert torch.equal(vd['actions'].cpu(), ds['actions'])
+    rows, lrs = [], []
+    nmb = len(agent.dataset)
+    for mini_ep in range(agent.mini_epochs_num):
+        first = len(rows)
+        for i in range(nmb):
+            a, c, e, kl, lr, lr_mul = agent.train_actor_critic(agent.dataset[i])
+            rows.append(torch.stack([a, c, e, kl]).clone())
+        av_kl = torch.stack([r[3] for r in rows[first:]]).mean()
+        agent._host_schedule(float(av_kl.item()))          # what train_epoch does per mini-epoch
+        lrs.append(agent._host_lr)
+        if agent.normalize_input:
+            agent.model.running_mean_std.eval()
+    rows = torch.stack(rows).cpu()
+    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 3], cap['mb_kls'], rtol=1e-4, atol=1e-8)
+    assert lrs == cap['lrs']                                # python-double schedule, exact
+    final = agent.model.state_dict()
+    for k, v in cap['final_state'].items():
+        tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
+        assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+
+
+def test_discrete_train_epoch_runs_on_cartpole_shaped_config():
+    """BASELINE.json config #1 shapes end to end (rollout with categorical sampling, masked
+    next_step-autoreset rows, 4 mini-epochs): finite losses, 10-tuple result, weights move."""
+    from rl_games_amd import configs
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    params = configs.cartpole_discrete(num_actors=16, device=DEV)
+    agent = DiscreteA2CAgent('cartpole', params)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    before = {k: v.clone() for k, v in agent.model.state_dict().items()}
+    for _ in range(2):
+        agent.epoch_num += 1
+        res = agent.train_epoch()
+    assert len(res) == 10
+    a_losses, c_losses, entropies, kls = res[4:8]
+    assert len(a_losses) == agent.mini_epochs_num * agent.num_minibatches
+    for x in a_losses + c_losses + entropies + kls:
+        assert torch.isfinite(x).all()
+    ent = torch.stack(entropies).cpu()
+    assert (ent > 0).all() and (ent <= torch.log(torch.tensor(2.0)) + 1e-6).all()
+    vd = agent.dataset.values_dict
+    assert vd['actions'].dtype == torch.int64 and int(vd['actions'].max()) <= 1
+    assert vd['rnn_masks'] is not None
+    moved = [k for k, v in agent.model.state_dict().items() if not torch.equal(v, before[k])]
+    assert any('logits' in k for k in moved) and any('critic_mlp' in k for k in moved)
