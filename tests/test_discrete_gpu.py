@@ -30,11 +30,11 @@ def test_discrete_loss_kernel_matches_oracle(mb, n, masked, smooth):
         batch['old_logp_actions'] = nlp + 0.3 * torch.randn(mb, generator=g)
     mask = (torch.rand(mb, generator=g) > 0.3).float() if masked else None
     hp = dict(e_clip=0.2, clip_value=True, critic_coef=2.0, entropy_coef=0.01, use_smooth_clamp=smooth)
-    ref = O.categorical_loss_and_grads(logits, values, batch, hp, mask.view(-1, 1) if masked else None)
+    ref = O.categorical_loss_and_grads(logits, values, batch, hp, mask)
     hp64 = dict(hp)
     ref64 = O.categorical_loss_and_grads(logits.double(), values.double(),
                                          {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()},
-                                         hp64, mask.double().view(-1, 1) if masked else None)
+                                         hp64, mask.double() if masked else None)
 
     d_logits = torch.empty(mb, n, device=DEV)
     d_val = torch.empty(mb, device=DEV)
