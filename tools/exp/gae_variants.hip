@@ -4,11 +4,201 @@
 #include "../../rl_games_amd/csrc/gae.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <vector>
 
 using namespace rlg;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// EXPERIMENT (measured slower than the wave-private product kernel: 12.4 vs 11.7 us cold, 9.2 vs 8.3 us
+// warm, outputs bit-identical - profiles/r1_gae_variants.txt).  Kept here for the record only.
+namespace rlg {
+// ---------------------------------------------------------------------------------
+// Cooperative env-major kernel (horizons that are multiples of 16).
+//
+// The wave-private kernel above runs exactly one wave per SIMD at 65,536 envs (1,024 tiles on
+// 1,024 SIMDs), so every ALU/LDS phase of a wave - transposes, the 32-step chain, the fp64
+// moments - is exposed time in which that SIMD issues no memory traffic.  Here one 256-thread
+// block owns a 64-env tile and each of its 4 waves owns a QUARTER OF THE HORIZON of all 64 envs:
+//   1. all 256 threads load the tile with fully contiguous 16-byte accesses into a shared,
+//      padded LDS tile (one barrier);
+//   2. wave q reads its H/4 steps of every env (lane = env), pre-computes the terms that do not
+//      depend on the carry (delta_t and gamma*tau*nnt_t), then the four waves run their chain
+//      segments back to back, handing A_t over through LDS (wave 3 first; 4 short barriers).
+//      The chain itself is evaluated in exactly the sequential order of gae_kernel.py:63-80, so
+//      the results are bit-identical to the wave-private kernel;
+//   3. all threads store returns / (returns - values) coalesced from LDS and accumulate the fp64
+//      moments on the way out.
+// 4 blocks are resident per CU (16 waves), so one block's ALU phases hide behind the others'
+// loads and stores.
+// ---------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void gae_envmajor_coop_kernel(
+    const float* __restrict__ rewards,      // [N, H]
+    const float* __restrict__ values,       // [N, H]
+    const uint8_t* __restrict__ dones,      // [N, H]
+    const float* __restrict__ last_values,  // [N]
+    const uint8_t* __restrict__ last_dones, // [N]
+    float* __restrict__ out_ret,            // [N, H]
+    float* __restrict__ out_adv,            // [N, H]
+    double* __restrict__ partials,          // [num_tiles, 6] or nullptr
+    int N, float gamma, float gamma_tau) {
+  static_assert(H % 16 == 0 && H >= 16 && H <= 64, "cooperative kernel: horizon multiple of 16");
+  constexpr int Q = H / 4;            // steps per wave
+  constexpr int RS = H + 4;           // padded row stride (floats): conflict-free b128 row reads
+  constexpr int C = H / 4;            // 16-byte chunks per row
+  constexpr int DSW = H / 4 + 1;      // dones row stride in dwords (odd: conflict-free b32 reads)
+  constexpr int kPer = (kWave * C) / 256;   // chunks per thread per array (= H/16)
+  __shared__ __attribute__((aligned(16))) float tr[kWave * RS];
+  __shared__ __attribute__((aligned(16))) float tv[kWave * RS];
+  __shared__ uint32_t td[kWave * DSW];
+  __shared__ float carry[kWave];
+  __shared__ double red[6 * 4];
+
+  const int tid = threadIdx.x;
+  const int q = tid >> 6;
+  const int lane = tid & 63;
+  const int env0 = blockIdx.x * kWave;
+  const int rows = min(kWave, N - env0);
+  const int live_chunks = rows * C;
+  const long long base4 = static_cast<long long>(env0) * C;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(rewards) + base4;
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(values) + base4;
+
+  // ---- 1. coalesced loads, all issued before the first LDS write ----
+  f32x4 rb[kPer], vb[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = min(tid + 256 * k, live_chunks - 1);   // ragged last tile: clamp, never predicate
+    rb[k] = r4[c];
+    vb[k] = v4[c];
+  }
+  constexpr int kDoneChunks = (kWave * H) / 16;          // <= 256
+  u32x4 db = {0u, 0u, 0u, 0u};
+  if (tid < kDoneChunks) {
+    const int c = min(tid, (rows * H) / 16 - 1);
+    db = reinterpret_cast<const u32x4*>(dones + static_cast<long long>(env0) * H)[c];
+  }
+  const int env_c = env0 + min(lane, rows - 1);
+  float lv = 0.0f;
+  uint32_t ld = 0u;
+  if (q == 3) {
+    lv = last_values[env_c];
+    ld = last_dones[env_c];
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = tid + 256 * k;
+    const int row = c / C;
+    const int col = (c - row * C) * 4;
+    *reinterpret_cast<f32x4*>(tr + row * RS + col) = rb[k];
+    *reinterpret_cast<f32x4*>(tv + row * RS + col) = vb[k];
+  }
+  if (tid < kDoneChunks) {
+    const int byte = tid * 16;
+    const int row = byte / H;
+    const int off = (byte - row * H) >> 2;
+    uint32_t* dst = td + row * DSW + off;
+    dst[0] = db[0];
+    dst[1] = db[1];
+    dst[2] = db[2];
+    dst[3] = db[3];
+  }
+  __syncthreads();
+
+  // ---- 2. this wave's quarter of every env row ----
+  float r[Q], v[Q], delta[Q], coef[Q];
+  uint32_t dw[Q / 4 + 1];
+  {
+    const float* rrow = tr + lane * RS + q * Q;
+    const float* vrow = tv + lane * RS + q * Q;
+#pragma unroll
+    for (int j = 0; j < Q / 4; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(rrow + 4 * j);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(vrow + 4 * j);
+      r[4 * j + 0] = a[0]; r[4 * j + 1] = a[1]; r[4 * j + 2] = a[2]; r[4 * j + 3] = a[3];
+      v[4 * j + 0] = b[0]; v[4 * j + 1] = b[1]; v[4 * j + 2] = b[2]; v[4 * j + 3] = b[3];
+    }
+#pragma unroll
+    for (int j = 0; j < Q / 4 + 1; ++j) dw[j] = td[lane * DSW + q * (Q / 4) + j];   // last: pad (q == 3)
+    float nv, nnt;
+    if (q == 3) {
+      nv = lv;
+      nnt = 1.0f - static_cast<float>(ld);
+    } else {
+      nv = vrow[Q];
+      nnt = 1.0f - static_cast<float>(dw[Q / 4] & 0xffu);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const int k = Q - 1 - i;
+      const float vt = v[k];
+      delta[k] = (r[k] + (gamma * nv) * nnt) - vt;     // gae_kernel.py:78, op for op
+      coef[k] = gamma_tau * nnt;                        // :79
+      nv = vt;
+      nnt = 1.0f - static_cast<float>((dw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q == 3 - s) {            // wave-uniform
+      float A = (s == 0) ? 0.0f : carry[lane];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int k = Q - 1 - i;
+        A = delta[k] + coef[k] * A;
+        r[k] = A + v[k];                                // returns, a2c_common.py:1060
+      }
+      carry[lane] = A;
+      float* rrow = tr + lane * RS + q * Q;             // only this wave ever touches this quarter
+#pragma unroll
+      for (int j = 0; j < Q / 4; ++j) {
+        const f32x4 o = {r[4 * j + 0], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]};
+        *reinterpret_cast<f32x4*>(rrow + 4 * j) = o;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- 3. coalesced stores + moments ----
+  f32x4* o_ret = reinterpret_cast<f32x4*>(out_ret) + base4;
+  f32x4* o_adv = reinterpret_cast<f32x4*>(out_adv) + base4;
+  double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = tid + 256 * k;
+    const int row = c / C;
+    const int col = (c - row * C) * 4;
+    const f32x4 ret = *reinterpret_cast<const f32x4*>(tr + row * RS + col);
+    const f32x4 val = *reinterpret_cast<const f32x4*>(tv + row * RS + col);
+    const f32x4 adv = ret - val;                        // a2c_common.py:1598
+    if (c < live_chunks) {
+      o_ret[c] = ret;
+      o_adv[c] = adv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double da = adv[e], dv = val[e], dr = ret[e];
+        m[0] += da;
+        m[1] = fma(da, da, m[1]);
+        m[2] += dv;
+        m[3] = fma(dv, dv, m[3]);
+        m[4] += dr;
+        m[5] = fma(dr, dr, m[5]);
+      }
+    }
+  }
+  if (partials) {
+    block_sum<6, 256>(m, red);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) partials[static_cast<long long>(blockIdx.x) * 6 + k] = m[k];
+    }
+  }
+}
+
+}  // namespace rlg
 
 // same bytes as the fused kernel: read r,v (f32) + d (u8), write ret, adv.
 __global__ __launch_bounds__(256) void copy_like_kernel(const f32x4* __restrict__ r, const f32x4* __restrict__ v,
@@ -179,6 +369,24 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(copy_like_kernel, dim3(8192), dim3(256), 0, 0, (f32x4*)s.r, (f32x4*)s.v, (u32x4*)s.d, (f32x4*)s.o0, (f32x4*)s.o1, (int)(nf / 4)); }, iters));
     report("product fused (f64 mom, 64thr)", time_it([&](int i) { auto& s = sets[i % nsets];
       rlg_gae_envmajor_fused(s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, H, 0.99f, 0.9405f, nullptr); }, iters));
+    report("coop 4 waves x H/4 (256thr/tile)", time_it([&](int i) { auto& s = sets[i % nsets];
+      hipLaunchKernelGGL((gae_envmajor_coop_kernel<32>), dim3(N / 64), dim3(256), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
+    if (nsets == 1 && !pmc) {   // bit-equality of the two kernels' outputs
+      auto& s = sets[0];
+      std::vector<float> a0(nf), a1(nf), b0(nf), b1(nf); std::vector<double> pa(N / 64 * 6), pb(N / 64 * 6);
+      rlg_gae_envmajor_fused(s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, H, 0.99f, 0.9405f, nullptr);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(a0.data(), s.o0, nf * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(a1.data(), s.o1, nf * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(pa.data(), s.part, pa.size() * 8, hipMemcpyDeviceToHost));
+      CK(hipMemset(s.o0, 0, nf * 4)); CK(hipMemset(s.o1, 0, nf * 4));
+      hipLaunchKernelGGL((gae_envmajor_coop_kernel<32>), dim3(N / 64), dim3(256), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(b0.data(), s.o0, nf * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b1.data(), s.o1, nf * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(pb.data(), s.part, pb.size() * 8, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < nf; ++i) bad += (memcmp(&a0[i], &b0[i], 4) != 0) + (memcmp(&a1[i], &b1[i], 4) != 0);
+      double pd = 0; for (size_t i = 0; i < pa.size(); ++i) pd = fmax(pd, fabs(pa[i] - pb[i]) / (fabs(pa[i]) + 1e-30));
+      printf("coop vs wave-private: %zu differing output words, max rel partial diff %.3e\n", bad, pd);
+    }
 #define RUNVARP(MOM, WAVES, PW, label) report(label, time_it([&](int i) { auto& s = sets[i % nsets]; \
       hipLaunchKernelGGL((gae_var_kernel<32, MOM, WAVES, PW>), dim3((N / 64 + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
 #define RUNVAR(MOM, WAVES, label) report(label, time_it([&](int i) { auto& s = sets[i % nsets]; \
