@@ -21,9 +21,15 @@ from . import ops
 
 
 class ManualMLP:
-    def __init__(self, net, arena, max_rows):
-        """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`."""
+    def __init__(self, net, arena, max_rows, concurrent_dw=True):
+        """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`.
+        concurrent_dw: run the weight-gradient GEMMs (which nothing downstream in the backward
+        chain waits for) on a second HIP stream, forked/joined with events - inside a captured HIP
+        graph these become parallel branches, which shortens the critical path of small
+        (multi-GPU, per-rank) minibatches from 3 kernels per layer to 2."""
         self.net = net
+        self.concurrent_dw = concurrent_dw
+        self._side = None
         self.arena = arena
         self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
         acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
@@ -107,7 +113,24 @@ class ManualMLP:
         rows = self._rows
         L = len(self.linears)
         a_last = self._last
-        torch.mm(d_heads.t(), a_last, out=self.head_w_grad)
+        main = torch.cuda.current_stream()
+        side = None
+        if self.concurrent_dw:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=d_heads.device)
+            side = self._side
+
+        def off_path(fn):
+            """Run fn (gradients nobody in this backward waits for) on the side stream, after
+            everything issued on the main stream so far."""
+            if side is None:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+
+        off_path(lambda: torch.mm(d_heads.t(), a_last, out=self.head_w_grad))
         d = self.dA[L - 1][:rows]
         torch.mm(d_heads, self.head_w, out=d)
         for l in range(L - 1, -1, -1):
@@ -116,10 +139,15 @@ class ManualMLP:
             nb = ops.act_bwd_blocks(rows, w)
             part = self.partials[l][:nb * w]
             ops.act_bwd_colsum(d, self.Z[l][:rows], d, self.act_kind, part, nb)
-            ops.colsum_finalize(part, nb, w, lin.bias.grad)
             a_prev = self.Hs[l - 1][:rows] if l > 0 else self._x
-            torch.mm(d.t(), a_prev, out=lin.weight.grad)
+
+            def grads(d=d, part=part, nb=nb, w=w, lin=lin, a_prev=a_prev):
+                ops.colsum_finalize(part, nb, w, lin.bias.grad)
+                torch.mm(d.t(), a_prev, out=lin.weight.grad)
+            off_path(grads)
             if l > 0:
                 d_prev = self.dA[l - 1][:rows]
                 torch.mm(d, lin.weight, out=d_prev)
                 d = d_prev
+        if side is not None:
+            main.wait_stream(side)
