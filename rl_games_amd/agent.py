@@ -305,6 +305,7 @@ class A2CAgent:
         self.is_rnn = self.model.is_rnn()
         self.bound_loss_type = config.get('bound_loss_type', 'bound')
         layout = None
+        self._grads_overwritten = False
         self._use_engine = ((not self.is_rnn) and (not self.is_discrete) and config.get('manual_mlp', True)
                             and not self.model.a2c_network.is_separate_critic())
         if self._use_engine:
@@ -312,6 +313,9 @@ class A2CAgent:
             net = self.model.a2c_network
             rest = [p for p in self.model.parameters() if all(p is not q for q in net.parameters())]
             layout = ManualMLP.layout(net) + rest
+            # with the engine every gradient slot is overwritten (GEMM out=, column-sum and loss
+            # finalise kernels), so the per-step zero fill of the arena is skipped
+            self._grads_overwritten = len(rest) == 0
         self.optimizer = FlatAdam(self.model.parameters(), self.last_lr, eps=1e-08,
                                   weight_decay=self.weight_decay, layout=layout)
         self._engine = None
@@ -319,7 +323,7 @@ class A2CAgent:
             try:
                 self._engine = ManualMLP(self.model.a2c_network, self.optimizer,
                                          max(self.minibatch_size, self.num_actors * self.num_agents),
-                                         concurrent_dw=bool(config.get('concurrent_dw', True)))
+                                         concurrent_dw=bool(config.get('concurrent_dw', False)))
             except NotImplementedError as e:
                 print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
                 self._engine = None
@@ -870,8 +874,9 @@ class A2CAgent:
             if self.zero_rnn_on_done:
                 batch['dones'] = input_dict['dones']
 
-        opt.zero_grad()
         eng = self._engine
+        if eng is None or not self._grads_overwritten:
+            opt.zero_grad()
         if eng is not None:
             with torch.no_grad():
                 if self.normalize_input:                                # updates the obs statistics

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const double* __r
 extern "C" {
 
 int rlg_act_bwd_num_blocks(long long rows, int cols) {
-  long long need = (rows * cols + 256LL * 64 - 1) / (256LL * 64);
+  // >= 16 elements per thread; small (per-rank, multi-GPU) minibatches still spread over the
+  // whole chip instead of a few dozen CUs (4,096 x 400: 100 -> 256 blocks).
+  long long need = (rows * cols + 256LL * 16 - 1) / (256LL * 16);
   if (need < 1) need = 1;
   if (need > 256) need = 256;      // one block per CU; fewer partial rows for the finalise pass
   return static_cast<int>(need);

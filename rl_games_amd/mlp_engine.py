@@ -21,12 +21,13 @@ from . import ops
 
 
 class ManualMLP:
-    def __init__(self, net, arena, max_rows, concurrent_dw=True):
+    def __init__(self, net, arena, max_rows, concurrent_dw=False):
         """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`.
         concurrent_dw: run the weight-gradient GEMMs (which nothing downstream in the backward
         chain waits for) on a second HIP stream, forked/joined with events - inside a captured HIP
-        graph these become parallel branches, which shortens the critical path of small
-        (multi-GPU, per-rank) minibatches from 3 kernels per layer to 2."""
+        graph these become parallel branches.  OFF by default: measured on MI355X / ROCm 7.2 the
+        cross-branch dependencies of a multi-branch hipGraph cost more than the overlap gains
+        (rank epoch 227 -> 243 ms at 32,768-row minibatches, 84 -> 98 ms at 4,096 rows)."""
         self.net = net
         self.concurrent_dw = concurrent_dw
         self._side = None
