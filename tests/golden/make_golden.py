@@ -258,7 +258,43 @@ def make_discrete():
     print('discrete.pt written', os.path.getsize(os.path.join(HERE, 'discrete.pt')) // 1024, 'KiB')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete}
+def make_checkpoint():
+    """A checkpoint written by the REAL reference agent (`A2CBase.save` -> torch_ext.save_checkpoint,
+    a2c_common.py:921-925, torch_ext.py:89-91) after one epoch, for the interop test."""
+    import copy
+    import shutil
+    import ref_import
+    ref_import.enable()
+    from rl_games.torch_runner import Runner
+    from rl_games_amd import configs
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    N, H, O_, A = 32, 8, 6, 2
+    params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
+                          train_dir='/tmp/rlg_golden_runs')
+    params['seed'] = 3
+    env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=77)
+    stored = copy.deepcopy(params)
+    runner = Runner()
+    runner.load({'params': copy.deepcopy(params)})
+    runner.params['config']['vec_env'] = env
+    runner.params['config']['env_info'] = env.get_env_info()
+    agent = runner.algo_factory.create(runner.algo_name, base_name='golden', params=runner.params)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.epoch_num = 4
+    agent.frame = 4 * N * H
+    agent.train_epoch()
+    agent.last_mean_rewards = 1.25
+    agent.save('/tmp/rlg_golden_ref_ckpt')
+    shutil.copy('/tmp/rlg_golden_ref_ckpt.pth', os.path.join(HERE, 'ref_checkpoint.pth'))
+    torch.save({'params': stored, 'env': {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 77}},
+               os.path.join(HERE, 'ref_checkpoint_meta.pt'))
+    ck = torch.load(os.path.join(HERE, 'ref_checkpoint.pth'), weights_only=False)
+    print('ref_checkpoint.pth keys', sorted(ck), 'lr', ck['optimizer']['param_groups'][0]['lr'],
+          os.path.getsize(os.path.join(HERE, 'ref_checkpoint.pth')) // 1024, 'KiB')
+
+
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'checkpoint': make_checkpoint}
 
 if __name__ == '__main__':
     only = sys.argv[1:] or list(SECTIONS)

@@ -332,3 +332,41 @@ def test_masked_rows_path_matches_oracle():
 def oracle_ds(oracle, key):
     # the oracle keeps the first-epoch dataset tensors; mu/sigma are updated in place, the rest is static
     return oracle.dataset[key]
+
+
+def test_restores_checkpoint_written_by_the_reference(golden):
+    """tests/golden/ref_checkpoint.pth was written by the real reference A2CAgent.save()
+    (make_golden.py, section `checkpoint`): our agent restores weights, normaliser statistics,
+    Adam moments/step, epoch/frame counters and keeps training from it."""
+    import os
+    from rl_games_amd.agent import A2CAgent
+    meta = golden('ref_checkpoint_meta.pt')
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'ref_checkpoint.pth')
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    params = copy.deepcopy(meta['params'])
+    params['config']['device'] = DEV
+    env = SyntheticTensorEnv(meta['env']['num_envs'], meta['env']['obs_dim'], meta['env']['act_dim'],
+                             device=DEV, seed=meta['env']['seed'])
+    params['config']['vec_env'] = env
+    params['config']['env_info'] = env.get_env_info()
+    agent = A2CAgent('interop', params)
+    agent.restore(path)
+    sd = agent.model.state_dict()
+    assert list(sd.keys()) == list(ck['model'].keys())
+    for k, v in ck['model'].items():
+        assert sd[k].dtype == v.dtype and torch.equal(sd[k].cpu(), v), k
+    assert agent.epoch_num == ck['epoch'] and agent.frame == ck['frame']
+    assert agent.last_mean_rewards == ck['last_mean_rewards']
+    opt = agent.optimizer.state_dict()
+    assert opt['param_groups'][0]['lr'] == ck['optimizer']['param_groups'][0]['lr']
+    for i, st in ck['optimizer']['state'].items():
+        assert torch.equal(opt['state'][i]['exp_avg'].cpu(), st['exp_avg']), i
+        assert torch.equal(opt['state'][i]['exp_avg_sq'].cpu(), st['exp_avg_sq']), i
+        assert int(float(opt['state'][i]['step'])) == int(float(st['step']))
+    # and the restored agent trains on
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.update_epoch()
+    res = agent.train_epoch()
+    assert all(torch.isfinite(x) for x in res[4] + res[5])
+    assert agent.optimizer.step_count == int(float(ck['optimizer']['state'][0]['step'])) + len(res[4])

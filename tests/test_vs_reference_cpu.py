@@ -199,3 +199,45 @@ def test_experience_buffer_equals_reference_layout_and_flatten():
     for k in a:
         assert torch.equal(a[k], b[k]), k
         assert b[k].data_ptr() == m.storage[k].data_ptr()       # zero-copy in the env-major layout
+
+
+def test_reference_restores_amd_checkpoint(tmp_path):
+    """Interop, reverse direction: tests/golden/amd_checkpoint.pth was written by
+    rl_games_amd.A2CAgent.save() on an MI355X (tests/golden/make_amd_checkpoint.py).  The REAL
+    reference agent restores it (`A2CBase.restore`, a2c_common.py:927-930) - weights, normaliser
+    statistics, Adam state, counters - and trains on."""
+    import copy
+    from rl_games.torch_runner import Runner
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    src = os.path.join(HERE, 'golden', 'amd_checkpoint.pth')
+    ck = torch.load(src, map_location='cpu', weights_only=False)
+    meta = ck.pop('_meta')
+    path = str(tmp_path / 'amd_ckpt.pth')
+    torch.save(ck, path)
+    params = copy.deepcopy(meta['params'])
+    params['config'].update(device='cpu', train_dir=str(tmp_path / 'runs'))
+    env = SyntheticTensorEnv(meta['env']['num_envs'], meta['env']['obs_dim'], meta['env']['act_dim'],
+                             device='cpu', seed=meta['env']['seed'])
+    runner = Runner()
+    runner.load({'params': copy.deepcopy(params)})
+    runner.params['config']['vec_env'] = env
+    runner.params['config']['env_info'] = env.get_env_info()
+    agent = runner.algo_factory.create(runner.algo_name, base_name='interop', params=runner.params)
+    agent.restore(path)
+    sd = agent.model.state_dict()
+    assert list(sd.keys()) == list(ck['model'].keys())
+    for k, v in ck['model'].items():
+        assert sd[k].dtype == v.dtype and torch.equal(sd[k], v), k
+    assert agent.epoch_num == ck['epoch'] == 2 and agent.frame == ck['frame']
+    assert agent.last_mean_rewards == ck['last_mean_rewards'] == -3.5
+    # (the reference restores the optimiser's lr but keeps `last_lr` at the config value)
+    assert agent.optimizer.param_groups[0]['lr'] == ck['optimizer']['param_groups'][0]['lr']
+    ref_opt = agent.optimizer.state_dict()
+    for i, st in ck['optimizer']['state'].items():
+        assert torch.equal(ref_opt['state'][i]['exp_avg'], st['exp_avg']), i
+        assert float(ref_opt['state'][i]['step']) == float(st['step'])
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.epoch_num += 1
+    res = agent.train_epoch()
+    assert all(torch.isfinite(x).all() for x in res[4] + res[5])
