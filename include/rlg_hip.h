@@ -304,6 +304,23 @@ int rlg_mlp_forward_layer(const float* x, long long ldx, const float* weight, lo
                           long long ldh, int rows, int out_features, int in_features, int act_kind,
                           void* stream);
 
+/* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
+ * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state
+ * resets of rl_games/common/layers/recurrent.py:26-58 (LSTMWithDones) as used by A2CBuilder
+ * (rl_games/algos_torch/network_builder.py:447-512, rnn after the MLP) and autograd's BPTT.
+ * gates [S*T, 4H] (row = seq*T + t) holds x_t W_ih^T + b_ih + b_hh on entry and the activated
+ * gates (i, f, g, o) on exit; the state entering step t is zeroed where dones[seq*T+t] != 0.
+ * hidden must satisfy rlg_lstm_supported (W_hh stays in LDS for the whole sequence). */
+int rlg_lstm_supported(int hidden);
+int rlg_lstm_seq_forward(float* gates, const float* w_hh, const float* h0, const float* c0,
+                         const unsigned char* dones_or_null, float* out, float* c_all_or_null,
+                         float* hprev_or_null, float* h_final_or_null, float* c_final_or_null,
+                         int num_seqs, int seq_len, int hidden, void* stream);
+/* d_gates [S*T, 4H] = d loss / d gate pre-activations given d_out = d loss / d h_t. */
+int rlg_lstm_seq_backward(const float* gates, const float* c_all, const float* c0,
+                          const unsigned char* dones_or_null, const float* w_hh, const float* d_out,
+                          float* d_gates, int num_seqs, int seq_len, int hidden, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -397,3 +397,35 @@ def mlp_forward_layer(x, weight, bias, out, pre_act=None, act_kind=0):
         None if pre_act is None else pre_act.data_ptr(), 0 if pre_act is None else pre_act.stride(0),
         out.data_ptr(), out.stride(0), rows, N, K, act_kind, _stream(x)), 'rlg_mlp_forward_layer')
     return out
+
+
+# ------------------------------------------------------------------ recurrent policy (LSTM)
+
+def lstm_supported(hidden):
+    return bool(_lib.load().rlg_lstm_supported(int(hidden)))
+
+
+def lstm_seq_forward(gates, w_hh, h0, c0, dones, out, c_all=None, hprev=None, h_final=None, c_final=None,
+                     seq_len=1):
+    """gates [S*T, 4H]: input projection (+ both biases) in, activated gates out.  See csrc/lstm.hip."""
+    lib = _lib.load()
+    B, G = gates.shape
+    H = G // 4
+    S = B // seq_len
+    if S * seq_len != B:
+        raise ValueError(f'rows ({B}) must be a multiple of seq_len ({seq_len})')
+    _lib.check(lib.rlg_lstm_seq_forward(
+        _need(gates, F32, 'gates'), _need(w_hh, F32, 'w_hh'), _need(h0, F32, 'h0'), _need(c0, F32, 'c0'),
+        _opt(dones, torch.uint8, 'dones'), _need(out, F32, 'out'), _opt(c_all, F32, 'c_all'),
+        _opt(hprev, F32, 'hprev'), _opt(h_final, F32, 'h_final'), _opt(c_final, F32, 'c_final'),
+        S, seq_len, H, _stream(gates)), 'rlg_lstm_seq_forward')
+
+
+def lstm_seq_backward(gates, c_all, c0, dones, w_hh, d_out, d_gates, seq_len):
+    lib = _lib.load()
+    B, G = gates.shape
+    _lib.check(lib.rlg_lstm_seq_backward(
+        _need(gates, F32, 'gates'), _need(c_all, F32, 'c_all'), _need(c0, F32, 'c0'),
+        _opt(dones, torch.uint8, 'dones'), _need(w_hh, F32, 'w_hh'), _need(d_out, F32, 'd_out'),
+        _need(d_gates, F32, 'd_gates'), B // seq_len, seq_len, G // 4, _stream(gates)),
+        'rlg_lstm_seq_backward')
