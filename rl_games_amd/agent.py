@@ -306,8 +306,9 @@ class A2CAgent:
         self.bound_loss_type = config.get('bound_loss_type', 'bound')
         layout = None
         self._grads_overwritten = False
-        self._use_engine = ((not self.is_rnn) and (not self.is_discrete) and config.get('manual_mlp', True)
-                            and not self.model.a2c_network.is_separate_critic())
+        self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True)
+                            and not self.model.a2c_network.is_separate_critic()
+                            and (not self.is_rnn or config.get('manual_lstm', True)))
         if self._use_engine:
             from .mlp_engine import ManualMLP
             net = self.model.a2c_network
@@ -327,6 +328,7 @@ class A2CAgent:
             except NotImplementedError as e:
                 print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
                 self._engine = None
+                self._grads_overwritten = False
         self.dataset = PPODataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn,
                                   dev, self.seq_length)
         if self.normalize_value:
@@ -361,6 +363,7 @@ class A2CAgent:
         self._hip_graphs = bool(config.get('hip_graphs', True))
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_failed = False
+        self._rnn_state_store = None
         self._eager_epochs = 0
         self._graph_rows = torch.zeros(max(1, self.num_minibatches), 8, dtype=torch.float32, device=dev)
         self._obs_norm_mb = (torch.empty((mb,) + tuple(self.obs_shape), dtype=torch.float32, device=dev)
@@ -661,7 +664,10 @@ class A2CAgent:
             obs_n = ops.rms_apply(obs, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
         else:
             obs_n = obs
-        heads = eng.forward(obs_n)
+        if self.is_rnn:
+            heads = eng.forward(obs_n, keep=False, rnn_states=self.rnn_states, seq_length=1)
+        else:
+            heads = eng.forward(obs_n)
         torch.randn(self._roll_noise.shape, device=self._roll_noise.device, out=self._roll_noise)
         vs = None
         eps = 1e-5
@@ -671,7 +677,10 @@ class A2CAgent:
         ops.rollout_policy_head(heads, self.model.a2c_network.sigma.data, self._roll_noise, vs, eps,
                                 self._roll_actions, self._roll_values, buf.storage, self.horizon_length, n)
         buf.store_step(n, {'obses': obs, 'dones': self.dones})
-        return {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
+        res = {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
+        if self.is_rnn:
+            res['rnn_states'] = eng.last_states
+        return res
 
     def _fast_values(self, obs):
         """get_values on the engine: de-normalised critic values [N] of `obs`."""
@@ -682,7 +691,10 @@ class A2CAgent:
         if self.normalize_input:
             m = self.model.running_mean_std
             x = ops.rms_apply(x, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
-        heads = eng.forward(x)
+        if self.is_rnn:
+            heads = eng.forward(x, keep=False, rnn_states=self.rnn_states, seq_length=1)
+        else:
+            heads = eng.forward(x)
         v = heads[:, 0].contiguous()
         if self.normalize_value:
             vm = self.model.value_mean_std
@@ -690,7 +702,7 @@ class A2CAgent:
         return v
 
     def _fast_rollout_ok(self):
-        return (self._engine is not None and self.value_size == 1 and not self.is_rnn
+        return (self._engine is not None and self.value_size == 1
                 and self.config.get('fused_rollout', True))
 
     def play_steps(self):
@@ -736,13 +748,17 @@ class A2CAgent:
         step_time = 0.0
         mb_valid = None
         rows = self.num_actors * self.num_agents
+        fast = self._fast_rollout_ok()
         if self.mask_autoreset_rows:
             mb_valid = torch.ones((self.horizon_length, rows), dtype=torch.float32, device=self.ppo_device)
         for n in range(self.horizon_length):
             if n % self.seq_length == 0:
                 for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
                     mb_s[n // self.seq_length, :, :, :] = s
-            res_dict = self.get_action_values(self.obs)
+            if fast:
+                res_dict = self._fast_policy_step(n)
+            else:
+                res_dict = self.get_action_values(self.obs)
             self.rnn_states = [s.contiguous() for s in res_dict['rnn_states']]
             fields = {'obses': self.obs['obs'], 'dones': self.dones}
             if mb_valid is not None:
@@ -753,9 +769,10 @@ class A2CAgent:
                 if self.zero_rnn_on_done:
                     for s in self.rnn_states:
                         ops.rnn_zero_done_states(s, prev)
-            for k in self.update_list:
-                fields[k] = res_dict[k]
-            buf.store_step(n, fields)
+            if not fast:
+                for k in self.update_list:
+                    fields[k] = res_dict[k]
+                buf.store_step(n, fields)
             t0 = time.perf_counter()
             self.obs, rewards, dones, infos = self.env_step(res_dict['actions'])
             self.dones = self._as_u8(dones)
@@ -774,10 +791,14 @@ class A2CAgent:
             rnn_dones[1:] = torch.maximum(rnn_dones[1:], garbage[:-1].to(rnn_dones.dtype))
             batch_dict['dones'] = swap_and_flatten01(rnn_dones)
         states = []
-        for mb_s in self.mb_rnn_states:
+        for k, mb_s in enumerate(self.mb_rnn_states):
             t_size = mb_s.size()[0] * mb_s.size()[2]
             h_size = mb_s.size()[3]
-            states.append(mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, h_size))
+            flat = mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, h_size)
+            if self._rnn_state_store is None or len(self._rnn_state_store) <= k:
+                self._rnn_state_store = (self._rnn_state_store or []) + [torch.empty_like(flat)]
+            self._rnn_state_store[k].copy_(flat)      # same storage every epoch (HIP-graph replays)
+            states.append(self._rnn_state_store[k])
         batch_dict['rnn_states'] = states
         return batch_dict
 
@@ -884,7 +905,11 @@ class A2CAgent:
                     obs_n = self.model.running_mean_std(obs_batch, out=out)
                 else:
                     obs_n = obs_batch
-                heads = eng.forward(obs_n)
+                if self.is_rnn:
+                    heads = eng.forward(obs_n, rnn_states=batch['rnn_states'], dones=batch.get('dones'),
+                                        seq_length=self.seq_length)
+                else:
+                    heads = eng.forward(obs_n)
             mu, values = eng.mu_view(heads), eng.values_view(heads)
             logstd = net.sigma
         else:
@@ -944,7 +969,9 @@ class A2CAgent:
         scalar hyper-parameters passed by value to the kernels."""
         vd = self.dataset.values_dict
         ptrs = tuple(vd[k].data_ptr() for k in ('obs', 'actions', 'old_logp_actions', 'advantages',
-                                               'old_values', 'returns', 'mu', 'sigma'))
+                                               'old_values', 'returns', 'mu', 'sigma', 'dones'))
+        if self.is_rnn:
+            ptrs += tuple(s.data_ptr() for s in vd['rnn_states'])
         s = self.scheduler
         sched = (getattr(s, 'kl_threshold', None), getattr(s, 'min_lr', None), getattr(s, 'max_lr', None),
                  getattr(s, 'lr_multiplier', None))

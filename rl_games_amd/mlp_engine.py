@@ -11,6 +11,11 @@ so the backward pass is written out explicitly instead of being recorded by auto
   * the value and mu heads (`a2c_network.value`, `a2c_network.mu`,
     rl_games/algos_torch/network_builder.py:295-311) are adjacent in the parameter arena and
     run as one [1+A, K] GEMM operand; their bias gradients come out of the loss kernel.
+  * an optional single-layer LSTM between the trunk and the heads (BASELINE config #5,
+    `rnn: {name: lstm, layers: 1}`, network_builder.py:447-512) runs as ONE sequence-persistent
+    kernel per direction (csrc/lstm.hip) instead of a Python loop of per-timestep MIOpen calls
+    with done resets (rl_games/common/layers/recurrent.py:26-58) and autograd BPTT through it;
+    its input projection and all four weight/bias gradients are whole-sequence GEMMs.
 Numerics: identical formulas (elu'(z) = exp(z) from the pre-activation, like aten); GEMM
 results are the library's, as before.  Parameters keep their reference names and shapes.
 """
@@ -51,6 +56,12 @@ class ManualMLP:
         self.A = net.mu.out_features
         self.V = net.value.out_features
         K = net.mu.in_features
+        self.lstm = None
+        if getattr(net, 'has_rnn', False):
+            if net.rnn_name != 'lstm' or net.rnn_layers != 1 or not ops.lstm_supported(net.rnn_units):
+                raise NotImplementedError('manual engine: only a single-layer LSTM with 16/32/64 units')
+            self.lstm = net.rnn.rnn
+            self.Hr = net.rnn_units
         wp, wg = arena.span(net.value.weight, net.mu.weight)
         bp, bg = arena.span(net.value.bias, net.mu.bias)
         self.head_w, self.head_w_grad = wp.view(self.V + self.A, K), wg.view(self.V + self.A, K)
@@ -65,6 +76,21 @@ class ManualMLP:
         self.d_heads = torch.empty(max_rows, self.V + self.A, device=dev)
         self.nb = [ops.act_bwd_blocks(max_rows, w) for w in widths]
         self.partials = [torch.empty(nb * w, dtype=torch.float64, device=dev) for nb, w in zip(self.nb, widths)]
+        if self.lstm is not None:
+            Hr = self.Hr
+            self.gates = torch.empty(max_rows, 4 * Hr, device=dev)
+            self.d_gates = torch.empty(max_rows, 4 * Hr, device=dev)
+            self.rnn_out = torch.empty(max_rows, Hr, device=dev)
+            self.d_rnn_out = torch.empty(max_rows, Hr, device=dev)
+            self.c_all = torch.empty(max_rows, Hr, device=dev)
+            self.hprev = torch.empty(max_rows, Hr, device=dev)
+            self.bias_sum = torch.empty(4 * Hr, device=dev)
+            self.gate_partials = torch.empty(ops.act_bwd_blocks(max_rows, 4 * Hr) * 4 * Hr,
+                                             dtype=torch.float64, device=dev)
+            # final states of the last forward, ping-pong so that a caller may feed them back in
+            self._state_buf = [[torch.empty(1, max_rows, Hr, device=dev) for _ in range(2)] for _ in range(2)]
+            self._state_flip = 0
+            self.last_states = None
 
     @staticmethod
     def layout(net):
@@ -77,9 +103,12 @@ class ManualMLP:
 
     # ------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, keep=True):
+    def forward(self, x, keep=True, rnn_states=None, dones=None, seq_length=1):
         """x: [rows, in] normalised observations.  Returns heads [rows, V+A] (col 0..V-1 value,
-        then mu).  `keep` retains the pre-activations for backward()."""
+        then mu).  `keep` retains the pre-activations for backward().  LSTM policies: rows are
+        ordered (sequence, t) with `seq_length` steps each, rnn_states = (h0, c0) of shape
+        [1, rows/seq_length, H], dones [rows] u8 resets the state entering a step (or None);
+        the final states are left in `self.last_states`."""
         rows = x.shape[0]
         a = x
         for l, lin in enumerate(self.linears):
@@ -95,6 +124,28 @@ class ManualMLP:
             else:
                 h = z
             a = h
+        if self.lstm is not None:
+            rnn = self.lstm
+            S = rows // seq_length
+            if S * seq_length != rows:
+                raise ValueError(f'rows ({rows}) must be a multiple of seq_length ({seq_length})')
+            h0, c0 = rnn_states[0][0], rnn_states[1][0]
+            if h0.shape[0] != S or not h0.is_contiguous() or not c0.is_contiguous():
+                raise ValueError(f'rnn_states must be contiguous [1, {S}, {self.Hr}] tensors')
+            torch.add(rnn.bias_ih_l0, rnn.bias_hh_l0, out=self.bias_sum)
+            gates = self.gates[:rows]
+            torch.addmm(self.bias_sum, a, rnn.weight_ih_l0.t(), out=gates)
+            out = self.rnn_out[:rows]
+            # write the final states into whichever buffer pair the inputs do NOT live in
+            self._state_flip = 1 if h0.data_ptr() == self._state_buf[0][0].data_ptr() else 0
+            hT = self._state_buf[self._state_flip][0][:, :S]
+            cT = self._state_buf[self._state_flip][1][:, :S]
+            ops.lstm_seq_forward(gates, rnn.weight_hh_l0, h0, c0, dones, out,
+                                 self.c_all[:rows] if keep else None, self.hprev[:rows] if keep else None,
+                                 hT[0], cT[0], seq_len=seq_length)
+            self.last_states = (hT, cT)
+            self._rnn_in, self._c0, self._dones, self._T = a, c0, dones, seq_length
+            a = out
         heads = self.heads[:rows]
         torch.addmm(self.head_b, a, self.head_w.t(), out=heads)
         self._x, self._rows, self._last = x, rows, a
@@ -132,8 +183,26 @@ class ManualMLP:
                 fn()
 
         off_path(lambda: torch.mm(d_heads.t(), a_last, out=self.head_w_grad))
-        d = self.dA[L - 1][:rows]
-        torch.mm(d_heads, self.head_w, out=d)
+        if self.lstm is not None:
+            rnn = self.lstm
+            d_out = self.d_rnn_out[:rows]
+            torch.mm(d_heads, self.head_w, out=d_out)
+            gates, dg = self.gates[:rows], self.d_gates[:rows]
+            ops.lstm_seq_backward(gates, self.c_all[:rows], self._c0, self._dones, rnn.weight_hh_l0, d_out, dg,
+                                  self._T)
+            G = 4 * self.Hr
+            nbg = ops.act_bwd_blocks(rows, G)
+            gpart = self.gate_partials[:nbg * G]
+            ops.act_bwd_colsum(dg, None, dg, 0, gpart, nbg)          # identity: column sums only
+            ops.colsum_finalize(gpart, nbg, G, rnn.bias_ih_l0.grad)
+            rnn.bias_hh_l0.grad.copy_(rnn.bias_ih_l0.grad)
+            torch.mm(dg.t(), self.hprev[:rows], out=rnn.weight_hh_l0.grad)
+            torch.mm(dg.t(), self._rnn_in, out=rnn.weight_ih_l0.grad)
+            d = self.dA[L - 1][:rows]
+            torch.mm(dg, rnn.weight_ih_l0, out=d)
+        else:
+            d = self.dA[L - 1][:rows]
+            torch.mm(d_heads, self.head_w, out=d)
         for l in range(L - 1, -1, -1):
             lin = self.linears[l]
             w = lin.out_features

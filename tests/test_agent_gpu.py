@@ -246,12 +246,16 @@ def test_fused_rollout_step_matches_model_forward():
     assert torch.allclose(agent._fast_values(agent.obs).view(-1, 1), agent.get_values(agent.obs), rtol=1e-5, atol=1e-5)
 
 
-def test_lstm_update_matches_reference_epoch(golden):
-    """BASELINE.json config #5 path (play_steps_rnn / seq_length chunks / RnnWithDones) against the
-    real reference's LSTM agent on identical rollout tensors and initial rnn states."""
+@pytest.mark.parametrize('manual_lstm', [True, False])
+def test_lstm_update_matches_reference_epoch(golden, manual_lstm):
+    """BASELINE.json config #5 path (play_steps_rnn / seq_length chunks / done resets) against the
+    real reference's LSTM agent on identical rollout tensors and initial rnn states - through the
+    sequence-persistent LSTM kernels (manual engine) and through torch autograd (RnnWithDones)."""
     cap = golden('epoch.pt')['lstm']
-    agent = _make_agent(cap)
-    assert agent.is_rnn and agent._engine is None
+    agent = _make_agent(cap, manual_lstm=manual_lstm)
+    assert agent.is_rnn and (agent._engine is not None) == manual_lstm
+    if manual_lstm:
+        assert agent._engine.lstm is not None
     agent.model.load_state_dict(cap['state_after_rollout'])
     batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else [s.to(DEV) for s in v])
              for k, v in cap['batch'].items()}
@@ -275,15 +279,72 @@ def test_lstm_update_matches_reference_epoch(golden):
         assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
 
 
-def test_lstm_config_train_epoch_runs():
+def test_lstm_engine_matches_autograd_gradients_and_rollout():
+    """LSTM policy: (i) the engine's rollout step (fused head + persistent LSTM kernel, T = 1) leaves
+    the same buffer contents as the torch model path given the same noise-free quantities, and
+    (ii) for one minibatch the hand-written BPTT produces autograd's gradients."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
-    params = configs.pendulum_lstm_4096(num_actors=256)
+    base = configs.pendulum_lstm_4096(num_actors=128, minibatch_size=1024, grad_norm=1e9, lr_schedule=None,
+                                      learning_rate=0.0)
+    base['config']['env_config']['p_done'] = 0.2          # plenty of mid-sequence resets
+    torch.manual_seed(0)
+    a1 = A2CAgent('eng', copy.deepcopy(base))
+    p2 = copy.deepcopy(base)
+    p2['config']['manual_lstm'] = False
+    a2 = A2CAgent('auto', p2)
+    assert a1._engine is not None and a1._engine.lstm is not None and a2._engine is None
+    a2.model.load_state_dict(a1.model.state_dict())
+    a1.init_tensors()
+    a1.obs = a1.env_reset()
+    a1.set_eval()
+    with torch.no_grad():
+        batch = a1.play_steps_rnn()
+    # (i) values / mus stored by the fused rollout == the torch model evaluated on the stored
+    # observations with the stored initial states, sequence by sequence
+    a2.init_tensors()
+    a2.set_eval()
+    H, N = a1.horizon_length, a1.num_actors
+    obs = batch['obses'].reshape(N, H, -1)
+    with torch.no_grad():
+        st = [s[:, :N].contiguous() for s in batch['rnn_states']]     # states at t = 0 (one seq per env)
+        for t in range(H):
+            keep = (1.0 - a1.experience_buffer.tensor_dict['dones'][t].float()).reshape(1, -1, 1)
+            st = [s * keep for s in st] if t > 0 else st
+            res = a2.model({'is_train': False, 'obs': obs[:, t], 'rnn_states': st})
+            st = res['rnn_states']
+            assert torch.allclose(res['mus'], batch['mus'].reshape(N, H, -1)[:, t], rtol=1e-4, atol=2e-6), t
+            assert torch.allclose(res['values'], batch['values'].reshape(N, H, 1)[:, t], rtol=1e-4, atol=2e-5), t
+    # (ii) gradients
+    snapshot = {k: v.detach().clone() for k, v in a1.model.state_dict().items()}
+    grads = []
+    for ag in (a1, a2):
+        b = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items() if k != '_fused'}
+        ag.model.load_state_dict(snapshot)
+        ag.set_train()
+        ag.prepare_dataset(b)
+        ag.train_actor_critic(ag.dataset[1])
+        grads.append({n: p.grad.detach().clone() for n, p in ag.model.named_parameters()})
+        res = ag.train_result
+        grads[-1]['_scalars'] = torch.stack([res[0], res[1], res[2], res[3], res[8]])
+    g1, g2 = grads
+    assert torch.allclose(g1.pop('_scalars'), g2.pop('_scalars'), rtol=1e-5, atol=1e-7)
+    for n in g2:
+        scale = g2[n].abs().max().item() + 1e-12
+        assert torch.allclose(g1[n], g2[n], rtol=1e-4, atol=5e-6 * scale), (n, (g1[n] - g2[n]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('manual_lstm', [True, False])
+def test_lstm_config_train_epoch_runs(manual_lstm):
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.pendulum_lstm_4096(num_actors=256, manual_lstm=manual_lstm)
     agent = A2CAgent('lstm', params)
     agent.init_tensors()
     agent.obs = agent.env_reset()
-    agent.update_epoch()
-    out = agent.train_epoch()
+    for _ in range(3):                      # 1 eager epoch, then HIP-graph replays on the engine path
+        agent.update_epoch()
+        out = agent.train_epoch()
     assert len(out[4]) == agent.mini_epochs_num * agent.num_minibatches
     assert all(torch.isfinite(x).item() for x in out[4])
     st = agent.dataset.values_dict
