@@ -82,13 +82,15 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the hot path)')
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
+    from rl_games_amd import distributed as rdist
+    dev_index = rdist.local_device_index(local_rank)     # = local_rank outside the single-GPU test mode
+    torch.cuda.set_device(dev_index)
+    device = f'cuda:{dev_index}'
     multi = world > 1
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(rdist.backend_for(True), rank=rank, world_size=world)
 
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
@@ -129,6 +131,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    in_sync = None
+    if multi:   # outside the timed region: every rank must hold bit-identical parameters and lr
+        probe = torch.stack([agent.optimizer.flat_params.double().sum(),
+                             agent.optimizer.flat_params.double().abs().sum(),
+                             torch.tensor(agent.optimizer.last_and_next_lr()[1], dtype=torch.float64, device=device)])
+        lo, hi = probe.clone(), probe.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+
     pairs = agent.kernel_timers.get('gae_envmajor_fused', [])
     gae_us = sum(p.elapsed_us() for p in pairs) / max(len(pairs), 1)
     gae_bytes = envs * HORIZON * GAE_BYTES_PER_ENV_STEP
@@ -166,6 +178,8 @@ def main():
                 'timing': 'HIP events on the launch stream around each in-epoch launch (timed region)',
             },
         }
+        if in_sync is not None:
+            out['config']['ranks_in_sync'] = in_sync
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(4, os.cpu_count() or 1))
             out['cpu_baseline'] = cpu_baseline(args.cpu_sample_envs, threads)

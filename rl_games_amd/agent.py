@@ -155,8 +155,9 @@ class A2CAgent:
         self.world_size = 1
         if self.multi_gpu:
             self.local_rank, self.global_rank, self.world_size = rdist.env_ranks()
-            config['device'] = 'cuda:' + str(self.local_rank)
-            torch.cuda.set_device(self.local_rank)
+            dev_index = rdist.local_device_index(self.local_rank)
+            config['device'] = 'cuda:' + str(dev_index)
+            torch.cuda.set_device(dev_index)
             rdist.init_process_group(True)
             if self.global_rank != 0:
                 config['print_stats'] = False

@@ -24,13 +24,28 @@ def env_ranks():
             int(os.getenv('WORLD_SIZE', '1')))
 
 
+def single_gpu_test_mode():
+    """RLG_TEST_SINGLE_GPU=1 (tests only): every rank uses GPU 0 and the collectives go through
+    gloo, so the whole multi-rank agent path can be exercised on a one-GPU box.  RCCL refuses two
+    ranks on one device, which is why the production backend cannot be used for that."""
+    return os.environ.get('RLG_TEST_SINGLE_GPU', '0') not in ('0', '')
+
+
+def backend_for(device_is_gpu=True):
+    return 'nccl' if (device_is_gpu and not single_gpu_test_mode()) else 'gloo'
+
+
+def local_device_index(local_rank):
+    return 0 if single_gpu_test_mode() else int(local_rank)
+
+
 def init_process_group(device_is_gpu=True):
     if dist.is_initialized():
         return
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     _, rank, world = env_ranks()
-    dist.init_process_group('nccl' if device_is_gpu else 'gloo', rank=rank, world_size=world)
+    dist.init_process_group(backend_for(device_is_gpu), rank=rank, world_size=world)
 
 
 def all_reduce_sum(t):

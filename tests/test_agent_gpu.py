@@ -431,3 +431,31 @@ def test_restores_checkpoint_written_by_the_reference(golden):
     res = agent.train_epoch()
     assert all(torch.isfinite(x) for x in res[4] + res[5])
     assert agent.optimizer.step_count == int(float(ck['optimizer']['state'][0]['step'])) + len(res[4])
+
+
+def test_two_rank_bench_on_one_gpu():
+    """The multi-rank agent path end to end (device-side lr from the all-reduced KL, eager gradient
+    all-reduce between the two HIP-graph replays, pooled running-statistics merge, parameter
+    broadcast) with 2 ranks sharing this box's single GPU: RLG_TEST_SINGLE_GPU=1 switches the
+    collectives to gloo (RCCL refuses two ranks per device); everything else is the production path
+    of `bench.py --gpus 2`."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RLG_TEST_SINGLE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--steps', '1', '--warmup', '2']
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['envs_per_gpu'] == 32768
+    assert out['config']['ranks_in_sync'] is True
+    assert out['value'] > 0 and out['roofline']['launches'] == 1
