@@ -304,6 +304,17 @@ int rlg_mlp_forward_layer(const float* x, long long ldx, const float* weight, lo
                           long long ldh, int rows, int out_features, int in_features, int act_kind,
                           void* stream);
 
+/* ---- MLP weight gradients on f32 MFMA ------------------------------------------------------
+ * G_l [No, Mi] = dZ_l^T X_l for every nn.Linear of the policy MLP in ONE launch (+ one finalise
+ * launch): replaces autograd's `grad_output.t().mm(input)` of A2CBuilder's layers
+ * (rl_games/algos_torch/network_builder.py:118-147, heads :295-311; torch.nn.Linear backward).
+ * rlg_mlp_dw_plan fills plan4 = {bo, tiles_o, tiles_i, ksplit} for one layer and returns the
+ * workspace size in floats (-1: shape unsupported, use the library GEMM). */
+long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4);
+int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
+                      float* const* grad, const int* out_features, const int* in_features,
+                      const int* plans4, int rows, void* stream);
+
 /* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
  * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state
  * resets of rl_games/common/layers/recurrent.py:26-58 (LSTMWithDones) as used by A2CBuilder

@@ -61,6 +61,8 @@ _PROTOTYPES = {
     'rlg_ppo_loss_partials_per_block': [_c_int],
     'rlg_ppo_loss_fused': [_P] * 15 + [_c_int] * 6 + [_c_float, _c_float, _c_float, _c_int, _c_int,
                                                       _c_int, _c_int, _P],
+    'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
+    'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
     'rlg_lstm_supported': [_c_int],
     'rlg_lstm_seq_forward': [_P] * 10 + [_c_int, _c_int, _c_int, _P],
     'rlg_lstm_seq_backward': [_P] * 7 + [_c_int, _c_int, _c_int, _P],
@@ -95,6 +97,9 @@ def exported_prototypes():
     return dict(_PROTOTYPES)
 
 
+_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan'}
+
+
 def load():
     """dlopen librlg_hip.so once and attach argtypes.  Raises if it is not built."""
     global _lib
@@ -114,7 +119,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f'{LIB_PATH} does not export {name}; rebuild it') from e
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = _c_ll if name in _RETURNS_LONG_LONG else _c_int
     _lib = lib
     return lib
 

@@ -399,6 +399,54 @@ def mlp_forward_layer(x, weight, bias, out, pre_act=None, act_kind=0):
     return out
 
 
+# ------------------------------------------------------------------ MLP weight gradients (MFMA)
+
+class MlpDwPlan:
+    """All weight-gradient GEMMs of one MLP backward as one launch (csrc/mlp_dw.hip).
+
+    layers: list of (dz [rows, No], x [rows, Mi], grad [No, Mi]) with static addresses.  Raises
+    NotImplementedError when a shape is not supported (callers use the library GEMMs then)."""
+
+    def __init__(self, layers, rows, target_blocks=512):
+        import ctypes
+        lib = _lib.load()
+        n = len(layers)
+        self.rows = int(rows)
+        self.n = n
+        plans = (ctypes.c_int * (4 * n))()
+        self.workspaces = []
+        for k, (dz, x, grad) in enumerate(layers):
+            No, Mi = grad.shape
+            if dz.shape != (rows, No) or x.shape != (rows, Mi):
+                raise ValueError(f'layer {k}: dz {tuple(dz.shape)} / x {tuple(x.shape)} / grad {tuple(grad.shape)}')
+            for t, nm in ((dz, 'dz'), (x, 'x'), (grad, 'grad')):
+                _need(t, F32, f'layer {k} {nm}')
+            p4 = (ctypes.c_int * 4)()
+            need = lib.rlg_mlp_dw_plan(self.rows, No, Mi, target_blocks, p4)
+            if need < 0 or any(t.data_ptr() % 16 for t in (dz, x, grad)):
+                raise NotImplementedError(f'dW shape [{No} x {Mi}] is not supported by the MFMA path')
+            plans[4 * k:4 * k + 4] = list(p4)
+            self.workspaces.append(torch.empty(need, dtype=F32, device=grad.device))
+        P = ctypes.c_void_p * n
+        self._dz = P(*[l[0].data_ptr() for l in layers])
+        self._x = P(*[l[1].data_ptr() for l in layers])
+        self._ws = P(*[w.data_ptr() for w in self.workspaces])
+        self._grad = P(*[l[2].data_ptr() for l in layers])
+        self._no = (ctypes.c_int * n)(*[l[2].shape[0] for l in layers])
+        self._mi = (ctypes.c_int * n)(*[l[2].shape[1] for l in layers])
+        self._plans = plans
+        self._keep = layers
+        self._device = layers[0][2].device
+
+    def plan(self, k):
+        return tuple(self._plans[4 * k:4 * k + 4])
+
+    def launch(self):
+        _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
+                                                 self._mi, self._plans, self.rows,
+                                                 _lib.stream_handle(self._device)), 'rlg_mlp_dw_launch')
+
+
 # ------------------------------------------------------------------ recurrent policy (LSTM)
 
 def lstm_supported(hidden):
