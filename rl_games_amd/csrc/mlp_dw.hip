@@ -219,25 +219,50 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
   else dw_tile<1>(L, args.rows, local, lds);
 }
 
-// grad[e] = sum_z partial[z][e], z in a fixed order; float4 per thread.
+// grad[e] = sum_z partial[z][e].  64 float4 elements x 4 z-groups per block: group g sums the
+// slices z = g, g+4, ... (4 independent loads in flight), the groups are combined through LDS in a
+// fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args) {
+  __shared__ f32x4 part[4][64];
   int l = 0;
   int base = 0;
 #pragma unroll 1
   for (int k = 0; k < args.num_layers; ++k) {
     const int n4 = (args.layer[k].No * args.layer[k].Mi) >> 2;
-    const int blocks = (n4 + 255) / 256;
-    if (static_cast<int>(blockIdx.x) >= base && static_cast<int>(blockIdx.x) < base + blocks) l = k;
-    if (static_cast<int>(blockIdx.x) >= base + blocks) base += blocks; else break;
+    const int blocks = (n4 + 63) / 64;
+    if (static_cast<int>(blockIdx.x) < base + blocks) { l = k; break; }
+    base += blocks;
   }
   const DwLayer& L = args.layer[l];
   const int n4 = (L.No * L.Mi) >> 2;
-  const int e = (blockIdx.x - base) * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const f32x4* src = reinterpret_cast<const f32x4*>(L.partial) + e;
-  f32x4 s = src[0];
-  for (int z = 1; z < L.ksplit; ++z) s += src[static_cast<long long>(z) * n4];
-  reinterpret_cast<f32x4*>(L.grad)[e] = s;
+  const int el = threadIdx.x & 63;
+  const int g = threadIdx.x >> 6;
+  const int e = (blockIdx.x - base) * 64 + el;
+  f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (e < n4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(L.partial) + e;
+    int z = g;
+    for (; z + 12 < L.ksplit; z += 16) {
+      const f32x4 v0 = src[static_cast<long long>(z) * n4];
+      const f32x4 v1 = src[static_cast<long long>(z + 4) * n4];
+      const f32x4 v2 = src[static_cast<long long>(z + 8) * n4];
+      const f32x4 v3 = src[static_cast<long long>(z + 12) * n4];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; z < L.ksplit; z += 4) s += src[static_cast<long long>(z) * n4];
+  }
+  part[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < n4) {
+    f32x4 t = part[0][el];
+    t += part[1][el];
+    t += part[2][el];
+    t += part[3][el];
+    reinterpret_cast<f32x4*>(L.grad)[e] = t;
+  }
 }
 
 }  // namespace rlg
@@ -293,7 +318,7 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
         L.Mi % 4 != 0 || L.No % L.bo != 0 || (L.bo != 1 && L.bo != 2))
       return static_cast<int>(hipErrorInvalidValue);
     blocks += L.tiles_o * L.tiles_i * L.ksplit;
-    fin_blocks += ((L.No * L.Mi) / 4 + 255) / 256;
+    fin_blocks += ((L.No * L.Mi) / 4 + 63) / 64;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);

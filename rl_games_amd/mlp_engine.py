@@ -26,16 +26,14 @@ from . import ops
 
 
 class ManualMLP:
-    def __init__(self, net, arena, max_rows, concurrent_dw=False):
+    def __init__(self, net, arena, max_rows, mfma_dw=True):
         """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`.
-        concurrent_dw: run the weight-gradient GEMMs (which nothing downstream in the backward
-        chain waits for) on a second HIP stream, forked/joined with events - inside a captured HIP
-        graph these become parallel branches.  OFF by default: measured on MI355X / ROCm 7.2 the
-        cross-branch dependencies of a multi-branch hipGraph cost more than the overlap gains
-        (rank epoch 227 -> 243 ms at 32,768-row minibatches, 84 -> 98 ms at 4,096 rows)."""
+        mfma_dw: weight gradients through the one-launch f32-MFMA kernel (csrc/mlp_dw.hip).
+        (Measured and rejected: forking the library dW GEMMs onto a second stream - multi-branch
+        hipGraphs cost more in cross-branch dependencies than the overlap gains.)"""
         self.net = net
-        self.concurrent_dw = concurrent_dw
-        self._side = None
+        self.mfma_dw = mfma_dw
+        self._dw_plans = {}
         self.arena = arena
         self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
         acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
@@ -161,28 +159,12 @@ class ManualMLP:
     def backward(self, d_heads):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
-        finalise kernel)."""
+        finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
+        chain waits for - are then ONE f32-MFMA launch for all layers (csrc/mlp_dw.hip), or the
+        library GEMMs when a shape is outside that kernel's envelope / `mfma_dw` is off."""
         rows = self._rows
         L = len(self.linears)
-        a_last = self._last
-        main = torch.cuda.current_stream()
-        side = None
-        if self.concurrent_dw:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=d_heads.device)
-            side = self._side
-
-        def off_path(fn):
-            """Run fn (gradients nobody in this backward waits for) on the side stream, after
-            everything issued on the main stream so far."""
-            if side is None:
-                fn()
-                return
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                fn()
-
-        off_path(lambda: torch.mm(d_heads.t(), a_last, out=self.head_w_grad))
+        jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         if self.lstm is not None:
             rnn = self.lstm
             d_out = self.d_rnn_out[:rows]
@@ -196,8 +178,8 @@ class ManualMLP:
             ops.act_bwd_colsum(dg, None, dg, 0, gpart, nbg)          # identity: column sums only
             ops.colsum_finalize(gpart, nbg, G, rnn.bias_ih_l0.grad)
             rnn.bias_hh_l0.grad.copy_(rnn.bias_ih_l0.grad)
-            torch.mm(dg.t(), self.hprev[:rows], out=rnn.weight_hh_l0.grad)
-            torch.mm(dg.t(), self._rnn_in, out=rnn.weight_ih_l0.grad)
+            jobs.append((dg, self.hprev[:rows], rnn.weight_hh_l0.grad))
+            jobs.append((dg, self._rnn_in, rnn.weight_ih_l0.grad))
             d = self.dA[L - 1][:rows]
             torch.mm(dg, rnn.weight_ih_l0, out=d)
         else:
@@ -209,15 +191,27 @@ class ManualMLP:
             nb = ops.act_bwd_blocks(rows, w)
             part = self.partials[l][:nb * w]
             ops.act_bwd_colsum(d, self.Z[l][:rows], d, self.act_kind, part, nb)
+            ops.colsum_finalize(part, nb, w, lin.bias.grad)
             a_prev = self.Hs[l - 1][:rows] if l > 0 else self._x
-
-            def grads(d=d, part=part, nb=nb, w=w, lin=lin, a_prev=a_prev):
-                ops.colsum_finalize(part, nb, w, lin.bias.grad)
-                torch.mm(d.t(), a_prev, out=lin.weight.grad)
-            off_path(grads)
+            jobs.append((d, a_prev, lin.weight.grad))
             if l > 0:
                 d_prev = self.dA[l - 1][:rows]
                 torch.mm(d, lin.weight, out=d_prev)
                 d = d_prev
-        if side is not None:
-            main.wait_stream(side)
+        self._weight_grads(jobs, rows)
+
+    def _weight_grads(self, jobs, rows):
+        if self.mfma_dw:
+            key = (rows,) + tuple(tuple(g.shape) for _, _, g in jobs)
+            plan = self._dw_plans.get(key)
+            if plan is None:
+                try:
+                    plan = ops.MlpDwPlan([tuple(g.shape) for _, _, g in jobs], rows, jobs[0][2].device)
+                except NotImplementedError:
+                    plan = False
+                self._dw_plans[key] = plan
+            if plan and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for job in jobs for t in job):
+                plan.launch(jobs)
+                return
+        for dz, x, g in jobs:
+            torch.mm(dz.t(), x, out=g)

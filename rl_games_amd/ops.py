@@ -404,44 +404,47 @@ def mlp_forward_layer(x, weight, bias, out, pre_act=None, act_kind=0):
 class MlpDwPlan:
     """All weight-gradient GEMMs of one MLP backward as one launch (csrc/mlp_dw.hip).
 
-    layers: list of (dz [rows, No], x [rows, Mi], grad [No, Mi]) with static addresses.  Raises
-    NotImplementedError when a shape is not supported (callers use the library GEMMs then)."""
+    shapes: [(No, Mi)] per weight matrix, for minibatches of `rows` rows.  The plan owns the split-K
+    workspaces; `launch(jobs)` takes the (dz [rows, No], x [rows, Mi], grad [No, Mi]) tensors of the
+    step.  Raises NotImplementedError when a shape is outside the kernel's envelope (callers use
+    the library GEMMs then)."""
 
-    def __init__(self, layers, rows, target_blocks=512):
+    def __init__(self, shapes, rows, device, target_blocks=256):
         import ctypes
         lib = _lib.load()
-        n = len(layers)
-        self.rows = int(rows)
-        self.n = n
-        plans = (ctypes.c_int * (4 * n))()
+        n = len(shapes)
+        self.rows, self.n, self.shapes = int(rows), n, [tuple(s) for s in shapes]
+        self._plans = (ctypes.c_int * (4 * n))()
         self.workspaces = []
-        for k, (dz, x, grad) in enumerate(layers):
-            No, Mi = grad.shape
-            if dz.shape != (rows, No) or x.shape != (rows, Mi):
-                raise ValueError(f'layer {k}: dz {tuple(dz.shape)} / x {tuple(x.shape)} / grad {tuple(grad.shape)}')
-            for t, nm in ((dz, 'dz'), (x, 'x'), (grad, 'grad')):
-                _need(t, F32, f'layer {k} {nm}')
+        for k, (No, Mi) in enumerate(self.shapes):
             p4 = (ctypes.c_int * 4)()
             need = lib.rlg_mlp_dw_plan(self.rows, No, Mi, target_blocks, p4)
-            if need < 0 or any(t.data_ptr() % 16 for t in (dz, x, grad)):
+            if need < 0:
                 raise NotImplementedError(f'dW shape [{No} x {Mi}] is not supported by the MFMA path')
-            plans[4 * k:4 * k + 4] = list(p4)
-            self.workspaces.append(torch.empty(need, dtype=F32, device=grad.device))
+            self._plans[4 * k:4 * k + 4] = list(p4)
+            self.workspaces.append(torch.empty(need, dtype=F32, device=device))
         P = ctypes.c_void_p * n
-        self._dz = P(*[l[0].data_ptr() for l in layers])
-        self._x = P(*[l[1].data_ptr() for l in layers])
+        self._dz, self._x, self._grad = P(), P(), P()
         self._ws = P(*[w.data_ptr() for w in self.workspaces])
-        self._grad = P(*[l[2].data_ptr() for l in layers])
-        self._no = (ctypes.c_int * n)(*[l[2].shape[0] for l in layers])
-        self._mi = (ctypes.c_int * n)(*[l[2].shape[1] for l in layers])
-        self._plans = plans
-        self._keep = layers
-        self._device = layers[0][2].device
+        self._no = (ctypes.c_int * n)(*[s[0] for s in self.shapes])
+        self._mi = (ctypes.c_int * n)(*[s[1] for s in self.shapes])
+        self._device = device
 
     def plan(self, k):
         return tuple(self._plans[4 * k:4 * k + 4])
 
-    def launch(self):
+    def launch(self, jobs):
+        if len(jobs) != self.n:
+            raise ValueError('job count does not match the plan')
+        for k, (dz, x, grad) in enumerate(jobs):
+            No, Mi = self.shapes[k]
+            if tuple(dz.shape) != (self.rows, No) or tuple(x.shape) != (self.rows, Mi) or \
+                    tuple(grad.shape) != (No, Mi):
+                raise ValueError(f'layer {k}: dz {tuple(dz.shape)} / x {tuple(x.shape)} / grad {tuple(grad.shape)} '
+                                 f'do not match the planned [{self.rows}] x [{No} x {Mi}]')
+            self._dz[k] = _need(dz, F32, 'dz')
+            self._x[k] = _need(x, F32, 'x')
+            self._grad[k] = _need(grad, F32, 'grad')
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows,
                                                  _lib.stream_handle(self._device)), 'rlg_mlp_dw_launch')

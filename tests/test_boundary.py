@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, 'include', 'rlg_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(rlg_\w+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(?:int|long long)\s+(rlg_\w+)\s*\(', text)))
 
 
 def test_header_declares_symbols():

@@ -494,23 +494,24 @@ def test_mlp_dw_mfma_matches_library_gemm(rows):
         grad = torch.full((No, Mi), float('nan'), device=DEV)
         layers.append((dz, x, grad))
         refs.append((dz.t() @ x, dz.double().t() @ x.double()))
-    plan = ops.MlpDwPlan(layers, rows)
-    plan.launch()
+    plan = ops.MlpDwPlan(shapes, rows, DEV)
+    plan.launch(layers)
     for (dz, x, grad), (lib32, t64) in zip(layers, refs):
         assert torch.isfinite(grad).all()
         err = (grad.double() - t64).abs().max().item()
         err_lib = (lib32.double() - t64).abs().max().item()
         scale = t64.abs().max().item()
         assert err <= max(4 * err_lib, 1e-6 * scale), (tuple(grad.shape), err, err_lib, scale)
-    plan.launch()          # deterministic: same bits on a second launch
+    plan.launch(layers)    # deterministic: same bits on a second launch
     again = [l[2].clone() for l in layers]
-    plan.launch()
+    plan.launch(layers)
     assert all(torch.equal(a, l[2]) for a, l in zip(again, layers))
 
 
 def test_mlp_dw_plan_rejects_unsupported_shapes():
     from rl_games_amd import ops
-    dz = torch.zeros(64, 10, device=DEV)
-    x = torch.zeros(64, 7, device=DEV)
     with pytest.raises(NotImplementedError):
-        ops.MlpDwPlan([(dz, x, torch.zeros(10, 7, device=DEV))], 64)
+        ops.MlpDwPlan([(10, 7)], 64, DEV)
+    plan = ops.MlpDwPlan([(8, 12)], 64, DEV)
+    with pytest.raises(ValueError):
+        plan.launch([(torch.zeros(64, 8, device=DEV), torch.zeros(64, 16, device=DEV), torch.zeros(8, 12, device=DEV))])

@@ -23,10 +23,10 @@ fl = sum(2.0 * rows * No * Mi for No, Mi in shapes)
 t_lib = timeit(lambda: [torch.mm(dz.t(), x, out=g) for dz, x, g in layers])
 print(f'library (tuned) 4 GEMMs: {t_lib:7.1f} us ({fl/t_lib/1e6:5.1f} TF)')
 for tb in targets:
-    plan = ops.MlpDwPlan(layers, rows, target_blocks=tb)
-    t = timeit(plan.launch)
+    plan = ops.MlpDwPlan(shapes, rows, dev, target_blocks=tb)
+    t = timeit(lambda: plan.launch(layers))
     print(f'MFMA one launch, target_blocks {tb:5d}: {t:7.1f} us ({fl/t/1e6:5.1f} TF)  plans {[plan.plan(k) for k in range(4)]}')
     for k, (No, Mi) in enumerate(shapes):
-        p1 = ops.MlpDwPlan([layers[k]], rows, target_blocks=tb)
-        t1 = timeit(p1.launch)
+        p1 = ops.MlpDwPlan([shapes[k]], rows, dev, target_blocks=tb)
+        t1 = timeit(lambda: p1.launch([layers[k]]))
         print(f'    [{No}x{Mi}] alone {t1:6.1f} us ({2.0*rows*No*Mi/t1/1e6:5.1f} TF) plan {p1.plan(0)}')
