@@ -34,6 +34,7 @@ class ManualMLP:
         self.net = net
         self.mfma_dw = mfma_dw
         self._dw_plans = {}
+        self.last_dw_path = None
         self.arena = arena
         self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
         acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
@@ -92,12 +93,18 @@ class ManualMLP:
 
     @staticmethod
     def layout(net):
-        """Physical arena order: everything in parameters() order except that the head weights
-        (value, mu) and head biases (value, mu) are made adjacent."""
-        heads = [net.value.weight, net.mu.weight, net.value.bias, net.mu.bias]
-        skip = {id(p) for p in heads}
+        """Physical arena order: every weight MATRIX first (parameters() order, the value and mu
+        head weights last and adjacent), then the vectors (biases, sigma; value and mu head biases
+        last and adjacent).  Matrix sizes are multiples of 4 floats for every supported shape, so
+        all weight / weight-gradient views stay 16-byte aligned (vector loads/stores of the MFMA
+        kernels); the logical (optimizer-state) order is untouched."""
+        head_w = [net.value.weight, net.mu.weight]
+        head_b = [net.value.bias, net.mu.bias]
+        skip = {id(p) for p in head_w + head_b}
         rest = [p for p in net.parameters() if id(p) not in skip]
-        return rest + heads
+        mats = [p for p in rest if p.dim() >= 2]
+        vecs = [p for p in rest if p.dim() < 2]
+        return mats + head_w + vecs + head_b
 
     # ------------------------------------------------------------------
     @torch.no_grad()
@@ -212,6 +219,8 @@ class ManualMLP:
                 self._dw_plans[key] = plan
             if plan and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for job in jobs for t in job):
                 plan.launch(jobs)
+                self.last_dw_path = 'mfma'
                 return
+        self.last_dw_path = 'library'
         for dz, x, g in jobs:
             torch.mm(dz.t(), x, out=g)

@@ -207,6 +207,7 @@ def test_manual_mlp_engine_matches_autograd_gradients():
         res = ag.train_result
         grads[-1]['_scalars'] = torch.stack([res[0], res[1], res[2], res[3], res[8]])
     g1, g2 = grads
+    assert a1._engine.last_dw_path == 'mfma'      # the f32-MFMA weight-gradient launch, not a fallback
     assert torch.allclose(g1.pop('_scalars'), g2.pop('_scalars'), rtol=1e-6, atol=1e-8)
     for n in g2:
         scale = g2[n].abs().max().item() + 1e-12
@@ -328,6 +329,7 @@ def test_lstm_engine_matches_autograd_gradients_and_rollout():
         res = ag.train_result
         grads[-1]['_scalars'] = torch.stack([res[0], res[1], res[2], res[3], res[8]])
     g1, g2 = grads
+    assert a1._engine.last_dw_path == 'mfma'
     assert torch.allclose(g1.pop('_scalars'), g2.pop('_scalars'), rtol=1e-5, atol=1e-7)
     for n in g2:
         scale = g2[n].abs().max().item() + 1e-12
