@@ -208,19 +208,33 @@ class ManualMLP:
         self._weight_grads(jobs, rows)
 
     def _weight_grads(self, jobs, rows):
+        """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
+        envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
+        (e.g. a first layer over 3 observations) uses the library GEMM."""
+        fast, slow = [], []
         if self.mfma_dw:
-            key = (rows,) + tuple(tuple(g.shape) for _, _, g in jobs)
+            for job in jobs:
+                g = job[2]
+                ok = (g.shape[1] % 4 == 0 and g.shape[1] >= 4
+                      and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in job))
+                (fast if ok else slow).append(job)
+        else:
+            slow = list(jobs)
+        if fast:
+            key = (rows,) + tuple(tuple(g.shape) for _, _, g in fast)
             plan = self._dw_plans.get(key)
             if plan is None:
                 try:
-                    plan = ops.MlpDwPlan([tuple(g.shape) for _, _, g in jobs], rows, jobs[0][2].device)
+                    plan = ops.MlpDwPlan([tuple(g.shape) for _, _, g in fast], rows, fast[0][2].device)
                 except NotImplementedError:
                     plan = False
                 self._dw_plans[key] = plan
-            if plan and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for job in jobs for t in job):
-                plan.launch(jobs)
-                self.last_dw_path = 'mfma'
-                return
-        self.last_dw_path = 'library'
-        for dz, x, g in jobs:
+            if plan:
+                plan.launch(fast)
+            else:
+                slow = slow + fast
+                fast = []
+        self.last_dw_path = 'mfma' if fast else 'library'
+        self.last_dw_library_jobs = len(slow)
+        for dz, x, g in slow:
             torch.mm(dz.t(), x, out=g)
