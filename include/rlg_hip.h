@@ -304,6 +304,19 @@ int rlg_mlp_forward_layer(const float* x, long long ldx, const float* weight, lo
                           long long ldh, int rows, int out_features, int in_features, int act_kind,
                           void* stream);
 
+/* ---- MLP forward / input-gradient GEMMs on f32 MFMA with fused epilogues -------------------
+ * H = act(X W^T + b) (+ Z) replaces nn.Linear + activation of A2CBuilder._build_sequential_mlp and
+ * the heads (rl_games/algos_torch/network_builder.py:118-147, :295-311, forward :498-512);
+ * dZ_prev = (dZ W) * act'(Z_prev) replaces their autograd (grad_output.mm(weight) + elu_backward).
+ * in_features (forward) / out_features (backward) must be a multiple of 4 (rlg_mlp_rowgemm_supported). */
+int rlg_mlp_rowgemm_supported(int reduction_dim, long long leading_dim);
+int rlg_mlp_linear_act_forward(const float* x, long long ldx, const float* w, const float* bias_or_null,
+                               float* pre_act_or_null, float* out, long long ldo, int rows, int out_features,
+                               int in_features, int act_kind, void* stream);
+int rlg_mlp_linear_act_backward(const float* dz, long long lddz, const float* w, const float* z_prev_or_null,
+                                float* dz_prev, long long ldo, int rows, int out_features, int in_features,
+                                int act_kind, void* stream);
+
 /* ---- MLP weight gradients on f32 MFMA ------------------------------------------------------
  * G_l [No, Mi] = dZ_l^T X_l for every nn.Linear of the policy MLP in ONE launch (+ one finalise
  * launch): replaces autograd's `grad_output.t().mm(input)` of A2CBuilder's layers

@@ -61,6 +61,9 @@ _PROTOTYPES = {
     'rlg_ppo_loss_partials_per_block': [_c_int],
     'rlg_ppo_loss_fused': [_P] * 15 + [_c_int] * 6 + [_c_float, _c_float, _c_float, _c_int, _c_int,
                                                       _c_int, _c_int, _P],
+    'rlg_mlp_rowgemm_supported': [_c_int, _c_ll],
+    'rlg_mlp_linear_act_forward': [_P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
+    'rlg_mlp_linear_act_backward': [_P, _c_ll, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
     'rlg_lstm_supported': [_c_int],

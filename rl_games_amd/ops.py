@@ -399,6 +399,44 @@ def mlp_forward_layer(x, weight, bias, out, pre_act=None, act_kind=0):
     return out
 
 
+# ------------------------------------------------------------------ MLP forward / dX (MFMA, fused epilogues)
+
+def mlp_rowgemm_supported(reduction_dim, leading_dim):
+    return bool(_lib.load().rlg_mlp_rowgemm_supported(int(reduction_dim), int(leading_dim)))
+
+
+def mlp_linear_act_forward(x, w, bias, out, pre_act=None, act_kind=0):
+    """out = act(x @ w.T + bias); pre_act (optional) receives x @ w.T + bias.  csrc/mlp_rowgemm.hip."""
+    lib = _lib.load()
+    rows, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or out.shape != (rows, N) or x.stride(1) != 1 or out.stride(1) != 1:
+        raise ValueError('mlp_linear_act_forward: shape mismatch')
+    if pre_act is not None and (pre_act.shape != out.shape or pre_act.stride() != out.stride()):
+        raise ValueError('pre_act must have the layout of out')
+    _lib.require_gpu(x, 'x')
+    _lib.check(lib.rlg_mlp_linear_act_forward(
+        x.data_ptr(), x.stride(0), _need(w, F32, 'w'), _opt(bias, F32, 'bias'),
+        None if pre_act is None else pre_act.data_ptr(), out.data_ptr(), out.stride(0), rows, N, K,
+        act_kind, _stream(x)), 'rlg_mlp_linear_act_forward')
+
+
+def mlp_linear_act_backward(dz, w, z_prev, dz_prev, act_kind=0):
+    """dz_prev = (dz @ w) * act'(z_prev)  (z_prev None: plain dz @ w).  csrc/mlp_rowgemm.hip."""
+    lib = _lib.load()
+    rows, No = dz.shape
+    Mi = w.shape[1]
+    if w.shape[0] != No or dz_prev.shape != (rows, Mi) or dz.stride(1) != 1 or dz_prev.stride(1) != 1:
+        raise ValueError('mlp_linear_act_backward: shape mismatch')
+    if z_prev is not None and (z_prev.shape != dz_prev.shape or z_prev.stride() != dz_prev.stride()):
+        raise ValueError('z_prev must have the layout of dz_prev')
+    _lib.require_gpu(dz, 'dz')
+    _lib.check(lib.rlg_mlp_linear_act_backward(
+        dz.data_ptr(), dz.stride(0), _need(w, F32, 'w'), None if z_prev is None else z_prev.data_ptr(),
+        dz_prev.data_ptr(), dz_prev.stride(0), rows, No, Mi, act_kind, _stream(dz)),
+        'rlg_mlp_linear_act_backward')
+
+
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)
 
 class MlpDwPlan:

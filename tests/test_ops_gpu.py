@@ -515,3 +515,43 @@ def test_mlp_dw_plan_rejects_unsupported_shapes():
     plan = ops.MlpDwPlan([(8, 12)], 64, DEV)
     with pytest.raises(ValueError):
         plan.launch([(torch.zeros(64, 8, device=DEV), torch.zeros(64, 16, device=DEV), torch.zeros(8, 12, device=DEV))])
+
+
+@pytest.mark.parametrize('rows,N,K,act', [(32768, 400, 108, 'elu'), (4096, 200, 400, 'elu'), (1000, 100, 200, 'tanh'),
+                                          (333, 22, 100, 'None'), (65, 64, 4, 'relu'), (130, 400, 108, 'elu')])
+def test_mlp_rowgemm_forward_and_backward_match_torch(rows, N, K, act):
+    """LDS-free f32-MFMA Linear+activation forward and (dZ W)*act'(Z) backward vs torch and fp64."""
+    from rl_games_amd import ops
+    g = torch.Generator().manual_seed(rows + N + K)
+    x = torch.randn(rows, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    kind = ops.ACT_KINDS[act]
+    fn = {'elu': torch.nn.functional.elu, 'tanh': torch.tanh, 'relu': torch.relu, 'None': lambda t: t}[act]
+    z = torch.full((rows, N), float('nan'), device=DEV)
+    hh = torch.full((rows, N), float('nan'), device=DEV)
+    ops.mlp_linear_act_forward(x, w, b, hh, pre_act=z, act_kind=kind)
+    z64 = torch.addmm(b.double(), x.double(), w.double().t())
+    z32 = torch.addmm(b, x, w.t())
+    err, err_lib = (z.double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
+    assert err <= max(4 * err_lib, 1e-6 * z64.abs().max().item()), (err, err_lib)
+    assert torch.allclose(hh, fn(z), rtol=1e-6, atol=1e-7)          # activation of the kernel's own Z
+    h2 = torch.full((rows, N), float('nan'), device=DEV)
+    ops.mlp_linear_act_forward(x, w, b, h2, act_kind=kind)           # inference form (no Z)
+    assert torch.equal(h2, hh)
+    # backward: d_prev = (dz @ w) * act'(z_prev) with dz [rows, N], w [N, K], z_prev [rows, K]
+    if N % 4 == 0:
+        dz = torch.randn(rows, N, generator=g).to(DEV)
+        zp = torch.randn(rows, K, generator=g).to(DEV)
+        out = torch.full((rows, K), float('nan'), device=DEV)
+        ops.mlp_linear_act_backward(dz, w, zp, out, act_kind=kind)
+        zp_ = zp.double().requires_grad_(True)
+        fn(zp_).backward(dz.double() @ w.double())
+        t64 = zp_.grad
+        lib = (dz @ w) * torch.autograd.grad(fn(zp.requires_grad_(True)).sum(), zp)[0] if act != 'None' else dz @ w
+        e, e_lib = (out.double() - t64).abs().max().item(), (lib.double() - t64).abs().max().item()
+        assert e <= max(4 * e_lib, 1e-6 * t64.abs().max().item()), (e, e_lib)
+        out2 = torch.empty(rows, K, device=DEV)
+        ops.mlp_linear_act_backward(dz, w, None, out2)
+        e2 = (out2.double() - dz.double() @ w.double()).abs().max().item()
+        assert e2 <= max(4 * ((dz @ w).double() - dz.double() @ w.double()).abs().max().item(), 1e-6)
