@@ -32,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kDwMaxLayers = 8;
-constexpr int kDwMaxTiles = 16;    // tiles per dimension (<= 32 blocks of 32 along No, 64 along Mi)
 constexpr int kDwUnroll = 4;       // k-pairs per prefetch batch
 
 struct DwLayer {
@@ -41,12 +40,9 @@ struct DwLayer {
   float* partial;      // [ksplit][No][Mi] workspace
   float* grad;         // [No, Mi]
   int No, Mi;
+  int bo;              // 1 or 2 interleaved output blocks per wave (No % bo == 0); 4 would need 512 registers
   int tiles_o, tiles_i, ksplit;
   int block_begin;     // first blockIdx.x of this layer
-  // tile t of a dimension covers `cnt` 32-wide blocks starting at block `start`; cnt is the
-  // interleave factor of that tile (1 or 2 along No, 1 / 2 / 4 along Mi), so a dimension of e.g.
-  // 13 blocks is cut 4+4+4+1 and only padded to the next multiple of 32
-  unsigned char o_start[kDwMaxTiles], o_cnt[kDwMaxTiles], i_start[kDwMaxTiles], i_cnt[kDwMaxTiles];
 };
 
 struct DwArgs {
@@ -63,14 +59,20 @@ template <> struct VecOf<4> { using type = f32x4; };
 template <int BO> __device__ __forceinline__ float vec_get(const typename VecOf<BO>::type& v, int b) { return v[b]; }
 template <> __device__ __forceinline__ float vec_get<1>(const float& v, int) { return v; }
 
-template <int BO, int BI>
-__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int z, int o0, int i0, float* lds) {
+template <int BO>
+__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int local_block, float* lds) {
   using VA = typename VecOf<BO>::type;
-  using VB = typename VecOf<BI>::type;
+  constexpr int BI = 4;
   const int lane = lane_id();
   const int wave = wave_id();
   const int half = lane >> 5;
   const int j = lane & 31;
+  const int tiles = L.tiles_o * L.tiles_i;
+  const int z = local_block / tiles;
+  const int t = local_block - z * tiles;
+  const int to = t / L.tiles_i;
+  const int ti = t - to * L.tiles_i;
+  const int o0 = to * 32 * BO, i0 = ti * 32 * BI;
   const int o_col = min(o0 + BO * j, L.No - BO);      // clamp: out-of-range lanes feed rows never stored
   const int i_col = min(i0 + BI * j, L.Mi - BI);
 
@@ -98,23 +100,23 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int z, int o
   // full batches: rows 2p+half .. are all < rows when 2*(p + U) <= rows
   const int p_full_end = min(p_end, rows >> 1);
   VA a_cur[kDwUnroll];
-  VB b_cur[kDwUnroll];
-  auto load_batch = [&](VA (&av)[kDwUnroll], VB (&bv)[kDwUnroll], int p0) {
+  f32x4 b_cur[kDwUnroll];
+  auto load_batch = [&](VA (&av)[kDwUnroll], f32x4 (&bv)[kDwUnroll], int p0) {
 #pragma unroll
     for (int u = 0; u < kDwUnroll; ++u) {
       const long long r = 2LL * (p0 + u) + half;
       av[u] = *reinterpret_cast<const VA*>(pa + r * lda);
-      bv[u] = *reinterpret_cast<const VB*>(pb + r * ldb);
+      bv[u] = *reinterpret_cast<const f32x4*>(pb + r * ldb);
     }
   };
-  auto mfma_batch = [&](const VA (&av)[kDwUnroll], const VB (&bv)[kDwUnroll]) {
+  auto mfma_batch = [&](const VA (&av)[kDwUnroll], const f32x4 (&bv)[kDwUnroll]) {
 #pragma unroll
     for (int u = 0; u < kDwUnroll; ++u) {
 #pragma unroll
       for (int a = 0; a < BO; ++a) {
 #pragma unroll
         for (int b = 0; b < BI; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av[u], a), vec_get<BI>(bv[u], b), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av[u], a), bv[u][b], acc[a][b], 0, 0, 0);
         }
       }
     }
@@ -124,7 +126,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int z, int o
     p += kDwUnroll;
     while (p + kDwUnroll <= p_full_end) {
       VA a_nxt[kDwUnroll];
-      VB b_nxt[kDwUnroll];
+      f32x4 b_nxt[kDwUnroll];
       load_batch(a_nxt, b_nxt, p);          // in flight while the MFMAs of the current batch run
       mfma_batch(a_cur, b_cur);
 #pragma unroll
@@ -137,19 +139,19 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int z, int o
   for (; p < p_end; ++p) {
     const long long r = 2LL * p + half;
     VA av;
-    VB bv;
+    f32x4 bv;
     if (r < rows) {
       av = *reinterpret_cast<const VA*>(pa + r * lda);
-      bv = *reinterpret_cast<const VB*>(pb + r * ldb);
+      bv = *reinterpret_cast<const f32x4*>(pb + r * ldb);
     } else {
       av = VA(0.0f);
-      bv = VB(0.0f);
+      bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 #pragma unroll
     for (int a = 0; a < BO; ++a) {
 #pragma unroll
       for (int b = 0; b < BI; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av, a), vec_get<BI>(bv, b), acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av, a), bv[b], acc[a][b], 0, 0, 0);
     }
   }
 
@@ -195,14 +197,8 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int z, int o
           const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
           const int o = o0 + BO * row + a;
           if (o < L.No) {
-            VB v;
-            if constexpr (BI == 1) {
-              v = acc[a][0][q];
-            } else {
-#pragma unroll
-              for (int b = 0; b < BI; ++b) v[b] = acc[a][b][q];
-            }
-            *reinterpret_cast<VB*>(out + static_cast<long long>(o) * L.Mi + i) = v;
+            const f32x4 v = {acc[a][0][q], acc[a][1][q], acc[a][2][q], acc[a][3][q]};
+            *reinterpret_cast<f32x4*>(out + static_cast<long long>(o) * L.Mi + i) = v;
           }
         }
       }
@@ -219,21 +215,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
   }
   const DwLayer& L = args.layer[l];
   const int local = blockIdx.x - L.block_begin;
-  const int tiles = L.tiles_o * L.tiles_i;
-  const int z = local / tiles;
-  const int t = local - z * tiles;
-  const int to = t / L.tiles_i;
-  const int ti = t - to * L.tiles_i;
-  const int o0 = 32 * L.o_start[to], i0 = 32 * L.i_start[ti];
-  const int cfg = L.o_cnt[to] * 8 + L.i_cnt[ti];        // block-uniform
-  switch (cfg) {
-    case 2 * 8 + 4: dw_tile<2, 4>(L, args.rows, z, o0, i0, lds); break;
-    case 2 * 8 + 2: dw_tile<2, 2>(L, args.rows, z, o0, i0, lds); break;
-    case 2 * 8 + 1: dw_tile<2, 1>(L, args.rows, z, o0, i0, lds); break;
-    case 1 * 8 + 4: dw_tile<1, 4>(L, args.rows, z, o0, i0, lds); break;
-    case 1 * 8 + 2: dw_tile<1, 2>(L, args.rows, z, o0, i0, lds); break;
-    default: dw_tile<1, 1>(L, args.rows, z, o0, i0, lds); break;
-  }
+  if (L.bo == 2) dw_tile<2>(L, args.rows, local, lds);
+  else dw_tile<1>(L, args.rows, local, lds);
 }
 
 // grad[e] = sum_z partial[z][e].  64 float4 elements x 4 z-groups per block: group g sums the
@@ -286,37 +269,21 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args) {
 
 extern "C" {
 
-// Cuts `nblk` 32-wide blocks into tiles of max_cnt, max_cnt/2, ... blocks (greedy, largest first).
-static int rlg_dw_cut(int nblk, int max_cnt, int vec_limit, unsigned char* start, unsigned char* cnt) {
-  int n = 0, at = 0;
-  while (at < nblk) {
-    int c = max_cnt;
-    while (c > 1 && (at + c > nblk || c > vec_limit)) c >>= 1;
-    if (n >= rlg::kDwMaxTiles) return -1;
-    start[n] = static_cast<unsigned char>(at);
-    cnt[n] = static_cast<unsigned char>(c);
-    ++n;
-    at += c;
-  }
-  return n;
-}
-
-static int rlg_dw_vec_limit(int features) { return features % 4 == 0 ? 4 : (features % 2 == 0 ? 2 : 1); }
-
-// Plans one layer: plan4 = {reserved, tiles_o, tiles_i, ksplit}; returns the workspace size in
-// floats, or -1 when the shape is outside the kernel's envelope (caller uses the library GEMM).
+// Plans one layer: writes {bo, tiles_o, tiles_i, ksplit} and returns the workspace floats needed,
+// or -1 when the shape is not supported by the MFMA path (caller falls back to the library GEMM).
 long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4) {
   if (rows <= 0 || out_features <= 0 || in_features < 4 || in_features % 4 != 0) return -1;
-  unsigned char s[rlg::kDwMaxTiles], c[rlg::kDwMaxTiles];
-  const int tiles_o = rlg_dw_cut((out_features + 31) / 32, 2, rlg_dw_vec_limit(out_features), s, c);
-  const int tiles_i = rlg_dw_cut((in_features + 31) / 32, 4, rlg_dw_vec_limit(in_features), s, c);
-  if (tiles_o < 0 || tiles_i < 0) return -1;
+  if ((static_cast<long long>(out_features) * in_features) % 4 != 0) return -1;
+  int bo = 1;
+  if (out_features % 2 == 0 && out_features > 32) bo = 2;
+  const int tiles_o = (out_features + 32 * bo - 1) / (32 * bo);
+  const int tiles_i = (in_features + 127) / 128;
   int ksplit = target_blocks / (tiles_o * tiles_i);
   const int max_split = (rows / 2 + 4 * rlg::kDwUnroll * 2 - 1) / (4 * rlg::kDwUnroll * 2);   // >= 2 batches per wave
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit > 128) ksplit = 128;
   if (ksplit < 1) ksplit = 1;
-  plan4[0] = 0;
+  plan4[0] = bo;
   plan4[1] = tiles_o;
   plan4[2] = tiles_i;
   plan4[3] = ksplit;
@@ -341,13 +308,14 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     L.grad = grad[l];
     L.No = out_features[l];
     L.Mi = in_features[l];
-    L.tiles_o = rlg_dw_cut((L.No + 31) / 32, 2, rlg_dw_vec_limit(L.No), L.o_start, L.o_cnt);
-    L.tiles_i = rlg_dw_cut((L.Mi + 31) / 32, 4, rlg_dw_vec_limit(L.Mi), L.i_start, L.i_cnt);
+    L.bo = plans4[4 * l + 0];
+    L.tiles_o = plans4[4 * l + 1];
+    L.tiles_i = plans4[4 * l + 2];
     L.ksplit = plans4[4 * l + 3];
     L.block_begin = blocks;
     if ((reinterpret_cast<uintptr_t>(L.dz) | reinterpret_cast<uintptr_t>(L.x) |
          reinterpret_cast<uintptr_t>(L.partial) | reinterpret_cast<uintptr_t>(L.grad)) % 16 != 0 ||
-        L.Mi % 4 != 0 || L.tiles_o != plans4[4 * l + 1] || L.tiles_i != plans4[4 * l + 2] || L.ksplit < 1)
+        L.Mi % 4 != 0 || L.No % L.bo != 0 || (L.bo != 1 && L.bo != 2))
       return static_cast<int>(hipErrorInvalidValue);
     blocks += L.tiles_o * L.tiles_i * L.ksplit;
     fin_blocks += ((L.No * L.Mi) / 4 + 63) / 64;

@@ -228,6 +228,7 @@ class ManualMLP:
         else:
             slow = list(jobs)
         if fast:
+            fast.sort(key=lambda job: -job[2].numel())          # heaviest layer's blocks first in the launch
             key = (rows,) + tuple(tuple(g.shape) for _, _, g in fast)
             plan = self._dw_plans.get(key)
             if plan is None:
