@@ -317,23 +317,6 @@ int rlg_mlp_linear_act_backward(const float* dz, long long lddz, const float* w,
                                 float* dz_prev, long long ldo, int rows, int out_features, int in_features,
                                 int act_kind, void* stream);
 
-/* ---- feature-major MLP chain (activations stored [features, samples]) ---------------------
- * Same reference functions as the block above (nn.Linear + activation forward / autograd of
- * A2CBuilder._build_sequential_mlp and the heads, network_builder.py:118-147, :295-311, :498-512),
- * in the outer-product form that needs no operand staging: Z^T = W X^T + b, H^T = act(Z^T) and
- * dZ_prev^T = (W^T dZ^T) * act'(Z_prev^T); both can also emit the sample-major copy that the
- * weight-gradient kernel consumes.  rlg_fm_transpose / rlg_fm_row_sum: layout change of the MLP's
- * boundary tensors (obs, d_heads, W -> W^T) and bias gradients (`grad_output.sum(0)`). */
-int rlg_mlp_fm_forward(const float* wt, const float* xt, const float* bias_or_null, float* zt_or_null,
-                       float* ht_or_null, float* h_sm_or_null, long long ld_sm, int in_features,
-                       int out_features, int samples, long long ldm, int act_kind, void* stream);
-int rlg_mlp_fm_backward(const float* w, const float* dzt, const float* zt_prev_or_null, float* dzt_prev_or_null,
-                        float* dz_prev_sm_or_null, long long ld_sm, int out_features, int in_features,
-                        int samples, long long ldm, int act_kind, void* stream);
-int rlg_fm_transpose(const float* src, long long lds, float* dst, long long ldd, int rows, int cols,
-                     void* stream);
-int rlg_fm_row_sum(const float* dzt, long long ldm, int num_rows, int samples, float* out, void* stream);
-
 /* ---- MLP weight gradients on f32 MFMA ------------------------------------------------------
  * G_l [No, Mi] = dZ_l^T X_l for every nn.Linear of the policy MLP in ONE launch (+ one finalise
  * launch): replaces autograd's `grad_output.t().mm(input)` of A2CBuilder's layers

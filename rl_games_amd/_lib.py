@@ -64,10 +64,6 @@ _PROTOTYPES = {
     'rlg_mlp_rowgemm_supported': [_c_int, _c_ll],
     'rlg_mlp_linear_act_forward': [_P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_linear_act_backward': [_P, _c_ll, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
-    'rlg_mlp_fm_forward': [_P, _P, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_int, _P],
-    'rlg_mlp_fm_backward': [_P, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_ll, _c_int, _P],
-    'rlg_fm_transpose': [_P, _c_ll, _P, _c_ll, _c_int, _c_int, _P],
-    'rlg_fm_row_sum': [_P, _c_ll, _c_int, _c_int, _P, _P],
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
     'rlg_lstm_supported': [_c_int],

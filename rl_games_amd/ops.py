@@ -437,65 +437,6 @@ def mlp_linear_act_backward(dz, w, z_prev, dz_prev, act_kind=0):
         'rlg_mlp_linear_act_backward')
 
 
-# ------------------------------------------------------------------ feature-major MLP chain (MFMA)
-
-def _p(t):
-    return None if t is None else t.data_ptr()
-
-
-def mlp_fm_forward(wt, xt, bias, zt, ht, h_sm=None, act_kind=0):
-    """wt [K, N] = W^T, xt [K, M] feature-major input; zt / ht [N, M] feature-major outputs (either may
-    be None), h_sm [M, N] optional sample-major copy of ht's values.  csrc/mlp_fm.hip."""
-    lib = _lib.load()
-    K, N = wt.shape
-    M = xt.shape[1]
-    _lib.require_gpu(xt, 'xt')
-    ref = ht if ht is not None else zt
-    ldm = xt.stride(0)
-    if xt.shape[0] != K or xt.stride(1) != 1 or (ref is not None and (ref.shape != (N, M) or ref.stride(0) != ldm)):
-        raise ValueError('mlp_fm_forward: shape / leading-dimension mismatch')
-    if zt is not None and ht is not None and zt.stride() != ht.stride():
-        raise ValueError('zt and ht must share a layout')
-    _lib.check(lib.rlg_mlp_fm_forward(
-        _need(wt, F32, 'wt'), xt.data_ptr(), _opt(bias, F32, 'bias'), _p(zt), _p(ht), _p(h_sm),
-        0 if h_sm is None else h_sm.stride(0), K, N, M, ldm, act_kind, _stream(xt)), 'rlg_mlp_fm_forward')
-
-
-def mlp_fm_backward(w, dzt, zt_prev, dzt_prev, dz_prev_sm=None, act_kind=0):
-    """w [No, Mi]; dzt [No, M]; zt_prev (or None) / dzt_prev (or None) [Mi, M]; dz_prev_sm [M, Mi]."""
-    lib = _lib.load()
-    No, Mi = w.shape
-    M = dzt.shape[1]
-    _lib.require_gpu(dzt, 'dzt')
-    ldm = dzt.stride(0)
-    for t in (zt_prev, dzt_prev):
-        if t is not None and (t.shape != (Mi, M) or t.stride(0) != ldm):
-            raise ValueError('mlp_fm_backward: shape / leading-dimension mismatch')
-    _lib.check(lib.rlg_mlp_fm_backward(
-        _need(w, F32, 'w'), dzt.data_ptr(), _p(zt_prev), _p(dzt_prev), _p(dz_prev_sm),
-        0 if dz_prev_sm is None else dz_prev_sm.stride(0), No, Mi, M, ldm, act_kind, _stream(dzt)),
-        'rlg_mlp_fm_backward')
-
-
-def fm_transpose(src, dst):
-    """dst [C, R] = src [R, C]^T (unit inner strides, arbitrary leading dimensions)."""
-    lib = _lib.load()
-    R, C = src.shape
-    if dst.shape != (C, R) or src.stride(1) != 1 or dst.stride(1) != 1:
-        raise ValueError('fm_transpose: shape mismatch')
-    _lib.require_gpu(src, 'src')
-    _lib.check(lib.rlg_fm_transpose(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), R, C,
-                                    _stream(src)), 'rlg_fm_transpose')
-
-
-def fm_row_sum(dzt, out):
-    lib = _lib.load()
-    N, M = dzt.shape
-    _lib.require_gpu(dzt, 'dzt')
-    _lib.check(lib.rlg_fm_row_sum(dzt.data_ptr(), dzt.stride(0), N, M, _need(out, F32, 'out'), _stream(dzt)),
-               'rlg_fm_row_sum')
-
-
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)
 
 class MlpDwPlan:

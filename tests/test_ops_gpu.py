@@ -555,53 +555,3 @@ def test_mlp_rowgemm_forward_and_backward_match_torch(rows, N, K, act):
         ops.mlp_linear_act_backward(dz, w, None, out2)
         e2 = (out2.double() - dz.double() @ w.double()).abs().max().item()
         assert e2 <= max(4 * ((dz @ w).double() - dz.double() @ w.double()).abs().max().item(), 1e-6)
-
-
-@pytest.mark.parametrize('M,N,K,act', [(32768, 400, 108, 'elu'), (4096, 200, 400, 'elu'), (1000, 100, 200, 'tanh'),
-                                       (512, 22, 100, 'None'), (68, 64, 3, 'relu'), (132, 400, 108, 'elu')])
-def test_mlp_feature_major_forward_backward_match_torch(M, N, K, act):
-    """Feature-major f32-MFMA layer: Z^T/H^T (+ sample-major H) and (W^T dZ^T)*act'(Z^T) (+ sample-major
-    copy) against torch in fp32 and an fp64 evaluation; transposes and row sums too."""
-    from rl_games_amd import ops
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g).to(DEV)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
-    b = torch.randn(N, generator=g).to(DEV)
-    kind = ops.ACT_KINDS[act]
-    fn = {'elu': torch.nn.functional.elu, 'tanh': torch.tanh, 'relu': torch.relu, 'None': lambda t: t}[act]
-    xt = torch.empty(K, M, device=DEV)
-    ops.fm_transpose(x, xt)
-    assert torch.equal(xt, x.t())
-    wt = torch.empty(K, N, device=DEV)
-    ops.fm_transpose(w, wt)
-    zt = torch.full((N, M), float('nan'), device=DEV)
-    ht = torch.full((N, M), float('nan'), device=DEV)
-    h_sm = torch.full((M, N), float('nan'), device=DEV)
-    ops.mlp_fm_forward(wt, xt, b, zt, ht, h_sm, act_kind=kind)
-    z64 = torch.addmm(b.double(), x.double(), w.double().t())
-    z32 = torch.addmm(b, x, w.t())
-    err, err_lib = (zt.t().double() - z64).abs().max().item(), (z32.double() - z64).abs().max().item()
-    assert err <= max(4 * err_lib, 1e-6 * z64.abs().max().item()), (err, err_lib)
-    assert torch.allclose(ht, fn(zt), rtol=1e-6, atol=1e-7)
-    assert torch.equal(h_sm, ht.t())
-    # backward through this layer: dZ_prev^T [K, M] = (W^T dZ^T) * act'(Zprev^T)
-    dz = torch.randn(M, N, generator=g).to(DEV)
-    dzt = dz.t().contiguous()
-    zp = torch.randn(M, K, generator=g).to(DEV)
-    zpt = zp.t().contiguous()
-    if K % 2 == 0:
-        out_t = torch.full((K, M), float('nan'), device=DEV)
-        out_sm = torch.full((M, K), float('nan'), device=DEV)
-        ops.mlp_fm_backward(w, dzt, zpt, out_t, out_sm, act_kind=kind)
-        zp_ = zp.double().requires_grad_(True)
-        fn(zp_).backward(dz.double() @ w.double())
-        t64 = zp_.grad
-        lib = (dz @ w) * torch.autograd.grad(fn(zp.clone().requires_grad_(True)).sum(), zp)[0] if False else None
-        zq = zp.clone().requires_grad_(True)
-        fn(zq).backward(dz @ w)
-        e, e_lib = (out_t.t().double() - t64).abs().max().item(), (zq.grad.double() - t64).abs().max().item()
-        assert e <= max(4 * e_lib, 1e-6 * t64.abs().max().item()), (e, e_lib)
-        assert torch.equal(out_sm, out_t.t())
-    rs = torch.empty(N, device=DEV)
-    ops.fm_row_sum(dzt, rs)
-    assert torch.allclose(rs.double(), dz.double().sum(0), rtol=1e-6, atol=1e-6 * dz.abs().sum(0).max().item())
