@@ -221,6 +221,14 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
                        float critic_coef, float bounds_coef, int clip_value, int use_smooth_clamp,
                        int bound_kind, int write_back, void* stream);
 
+/* Value-only loss of the central value network - replaces CentralValueTrain.calc_loss
+ * (rl_games/algos_torch/central_value.py:262-276: common_losses.critic_loss + apply_masks).
+ * partials [ceil(mb/256)][7] feed rlg_ppo_loss_finalize (actions_num 0, critic_coef 2 -> total =
+ * mean c_loss); d_values [mb] = d mean(c) / d value. */
+int rlg_value_loss(const float* values, const float* old_values, const float* returns,
+                   const float* mask_or_null, const float* mask_sum_or_null, float* d_values, double* partials,
+                   int minibatch, float e_clip, int clip_value, void* stream);
+
 /* Discrete (Categorical) variant - replaces rl_games/algos_torch/a2c_discrete.py:
  * DiscreteA2CAgent.calc_gradients :121-209 with the ModelA2C epilogue (models.py:95-111): logits
  * [mb, n] (row stride ld), actions int64 [mb]; emits d_logits [mb, n] (actor + entropy terms,

@@ -141,8 +141,7 @@ class A2CAgent:
         self.algo_observer = features.get('observer') or NullObserver()
         self.algo_observer.before_init(base_name, config, self.experiment_name)
         self.network = config['network'] = PolicyBuilder(params)          # load_networks :516-525
-        if config.get('central_value_config') is not None:
-            raise NotImplementedError('central_value_config is outside the MI355X hot path (SURVEY 2, row 16)')
+        self.central_value_config = config.get('central_value_config', None)
         if config.get('use_action_masks', False):
             raise NotImplementedError('action masks are not implemented for continuous actions')
 
@@ -184,7 +183,15 @@ class A2CAgent:
         self.observation_space = self.env_info['observation_space']
         self.num_agents = self.env_info.get('agents', 1)
         self.weight_decay = config.get('weight_decay', 0.0)
-        self.has_central_value = False
+        self.has_central_value = self.central_value_config is not None
+        if self.has_central_value:                                   # a2c_common.py:254-266
+            self.state_space = self.env_info.get('state_space', None)
+            if self.state_space is None:
+                self.state_space = self.observation_space
+                self.env_info['state_space'] = self.state_space
+            if type(self.state_space).__name__ == 'Dict':
+                raise NotImplementedError('dict state spaces are not implemented on the MI355X hot path')
+            self.state_shape = self.state_space.shape
         self.use_action_masks = False
         self.is_train = config.get('is_train', True)
 
@@ -332,12 +339,26 @@ class A2CAgent:
                 self._grads_overwritten = False
         self.dataset = PPODataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn,
                                   dev, self.seq_length)
+        self.central_value_net = None
+        if self.has_central_value:                                   # a2c_continuous.py:44-66
+            from .central_value import CentralValueTrain
+            cv_cfg = self.central_value_config
+            cv_builder = PolicyBuilder({'model': cv_cfg.get('model', {'name': 'central_value'}),
+                                        'network': cv_cfg['network']})
+            self.central_value_net = CentralValueTrain(
+                state_shape=self.state_shape, value_size=self.value_size, ppo_device=dev,
+                num_agents=self.num_agents, horizon_length=self.horizon_length, num_actors=self.num_actors,
+                num_actions=self.actions_num, seq_length=self.seq_length, normalize_value=self.normalize_value,
+                network=cv_builder, config=cv_cfg, writter=self.writer, max_epochs=self.max_epochs,
+                multi_gpu=self.multi_gpu, zero_rnn_on_done=self.zero_rnn_on_done)
+        self.use_experimental_cv = config.get('use_experimental_cv', True)
         if self.normalize_value:
-            self.value_mean_std = self.model.value_mean_std
+            self.value_mean_std = (self.central_value_net.model.value_mean_std if self.has_central_value
+                                   else self.model.value_mean_std)
         if self.normalize_advantage and self.normalize_rms_advantage:
             momentum = config.get('adv_rms_momentum', 0.5)
             self.advantage_mean_std = GeneralizedMovingStats((1,), decay=momentum).to(dev)
-        self.has_value_loss = True
+        self.has_value_loss = self.use_experimental_cv or not self.has_central_value
 
         # device-side episode meters (game_rewards / game_shaped_rewards / game_lengths)
         self._meter_sizes = torch.zeros(3, dtype=torch.int32, device=dev)
@@ -463,10 +484,23 @@ class A2CAgent:
         input_dict = {'is_train': False, 'prev_actions': None, 'obs': processed_obs,
                       'rnn_states': self.rnn_states}
         with torch.no_grad():
-            return self.model(input_dict)
+            res_dict = self.model(input_dict)
+            if self.has_central_value:                               # a2c_common.py:593-600
+                res_dict['values'] = self.get_central_value({'is_train': False, 'states': obs['states']})
+        return res_dict
+
+    def get_central_value(self, obs_dict):
+        return self.central_value_net.get_value(obs_dict)
+
+    def train_central_value(self):
+        return self.central_value_net.train_net()
 
     def get_values(self, obs):
         with torch.no_grad():
+            if self.has_central_value:                               # a2c_common.py:605-614
+                self.central_value_net.eval()
+                return self.get_central_value({'is_train': False, 'states': obs['states'], 'actions': None,
+                                               'is_done': self.dones})
             self.model.eval()
             processed_obs = self._preproc_obs(obs['obs'])
             input_dict = {'is_train': False, 'prev_actions': None, 'obs': processed_obs,
@@ -703,7 +737,7 @@ class A2CAgent:
         return v
 
     def _fast_rollout_ok(self):
-        return (self._engine is not None and self.value_size == 1
+        return (self._engine is not None and self.value_size == 1 and not self.has_central_value
                 and self.config.get('fused_rollout', True))
 
     def play_steps(self):
@@ -725,6 +759,8 @@ class A2CAgent:
                 fields = {'obses': self.obs['obs'], 'dones': self.dones}
                 for k in self.update_list:
                     fields[k] = res_dict[k]
+                if self.has_central_value:
+                    fields['states'] = self.obs['states']
                 buf.store_step(n, fields)
             if mb_valid is not None:
                 prev = self._autoreset_prev_dones
@@ -864,6 +900,11 @@ class A2CAgent:
         if not self.is_discrete:
             dataset_dict['mu'], dataset_dict['sigma'] = batch_dict['mus'], batch_dict['sigmas']
         self.dataset.update_values_dict(dataset_dict)
+        if self.has_central_value:                                   # a2c_common.py:1651-1660
+            self.central_value_net.update_dataset({
+                'old_values': nv, 'advantages': na, 'returns': nr, 'actions': batch_dict['actions'],
+                'obs': batch_dict['states'], 'dones': batch_dict['dones'], 'rnn_masks': rnn_masks,
+            })
 
     # ================================================================== update
     def train_actor_critic(self, input_dict):
@@ -878,7 +919,8 @@ class A2CAgent:
         self._forward_loss_backward(input_dict, row)
         self.trancate_gradients_and_step()
         # dataset.update_mu_sigma happened inside the loss kernel (write_back)
-        self.train_result = (row[0], row[1], row[2], row[4], self._host_lr, 1.0,
+        c_loss = row[1] if self.has_value_loss else torch.zeros((), device=row.device)
+        self.train_result = (row[0], c_loss, row[2], row[4], self._host_lr, 1.0,
                              input_dict['mu'], input_dict['sigma'], row[3])
 
     def _forward_loss_backward(self, input_dict, row):
@@ -929,6 +971,9 @@ class A2CAgent:
         else:
             d_mu, d_val = self._d_mu[:mb], self._d_val[:mb]
             mu_bias_grad = value_bias_grad = None
+        # central value without `use_experimental_cv`: the actor's own value head is not trained
+        # (c_loss = zeros, a2c_continuous.py:112-115) - a zero coefficient removes it from loss and grads
+        coef_c = self.critic_coef if self.has_value_loss else 0.0
         with torch.no_grad():
             ops.ppo_loss_fused(
                 mu.detach(), logstd.detach(), values.detach().reshape(mb, -1)[:, 0] if eng is not None
@@ -936,10 +981,10 @@ class A2CAgent:
                 input_dict['old_logp_actions'], input_dict['advantages'],
                 input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
                 input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
-                self._loss_partials, self.e_clip, self.critic_coef, coef_b, self.clip_value,
+                self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
                 self.use_smooth_clamp, kind, True, mask, mask_sum)
             ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
-                                  self.critic_coef, self.entropy_coef, coef_b, row, net.sigma.grad,
+                                  coef_c, self.entropy_coef, coef_b, row, net.sigma.grad,
                                   opt.kl_slot, mu_bias_grad, value_bias_grad)
             if eng is not None:
                 eng.backward(d_heads)
@@ -1034,6 +1079,9 @@ class A2CAgent:
         self.algo_observer.after_steps()
 
         a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
+        if self.has_central_value:                                   # a2c_common.py:1536-1537
+            self.train_central_value()
+            self.set_train()
         self._mb_index = 0
         device_schedule = self.is_adaptive_lr and self.schedule_type == 'per_minibatch'
         last_lr, lr_mul = self.last_lr, 1.0
@@ -1110,6 +1158,12 @@ class A2CAgent:
             mods.append(self.model.running_mean_std)
         if self.normalize_value and getattr(self.model, 'value_mean_std', None) is not None:
             mods.append(self.model.value_mean_std)
+        if self.has_central_value:                                   # a2c_common.py:759-765
+            cv_model = self.central_value_net.model
+            if getattr(cv_model, 'running_mean_std', None) is not None:
+                mods.append(cv_model.running_mean_std)
+            if getattr(cv_model, 'value_mean_std', None) is not None:
+                mods.append(cv_model.value_mean_std)
         return mods
 
     def _seed_stats_sync_snapshots(self):
@@ -1135,6 +1189,8 @@ class A2CAgent:
         state = {}
         if self.normalize_rms_advantage:
             state['advantage_mean_std'] = self.advantage_mean_std.state_dict()
+        if self.has_central_value:
+            state['central_val_stats'] = self.central_value_net.get_stats_weights(model_stats)
         if model_stats:
             if self.normalize_input:
                 state['running_mean_std'] = self.model.running_mean_std.state_dict()
@@ -1166,6 +1222,9 @@ class A2CAgent:
         state['epoch'] = self.epoch_num
         state['frame'] = self.frame
         state['optimizer'] = self.optimizer.state_dict()
+        if self.has_central_value:
+            state['assymetric_vf_nets'] = self.central_value_net.state_dict()
+            state['assymetric_vf_optimizer'] = self.central_value_net.optimizer.state_dict()
         state['last_mean_rewards'] = self.last_mean_rewards
         if self.vec_env is not None:
             state['env_state'] = self.vec_env.get_env_state()
@@ -1179,6 +1238,10 @@ class A2CAgent:
         if set_epoch:
             self.epoch_num = weights['epoch']
             self.frame = weights['frame']
+        if self.has_central_value:
+            self.set_central_value_function_weights(weights)
+            if 'assymetric_vf_optimizer' in weights:
+                self.central_value_net.optimizer.load_state_dict(weights['assymetric_vf_optimizer'])
         self.optimizer.load_state_dict(weights['optimizer'])
         self._host_lr = self.last_lr = self.optimizer.param_groups[0]['lr']
         self.last_mean_rewards = weights.get('last_mean_rewards', -float('inf'))
@@ -1198,8 +1261,14 @@ class A2CAgent:
         checkpoint = torch.load(fn, map_location=self.ppo_device, weights_only=False)
         self.set_full_state_weights(checkpoint, set_epoch=set_epoch)
 
+    def set_central_value_function_weights(self, weights):
+        state = {k.replace('_orig_mod.', ''): v for k, v in weights['assymetric_vf_nets'].items()}
+        self.central_value_net.load_state_dict(state)
+        self._seed_stats_sync_snapshots()
+
     def restore_central_value_function(self, fn):
-        raise NotImplementedError('central value function is outside the MI355X hot path')
+        checkpoint = torch.load(fn, map_location=self.ppo_device, weights_only=False)
+        self.set_central_value_function_weights(checkpoint)
 
     def get_param(self, param_name):
         if param_name in ('grad_norm', 'critic_coef', 'bounds_loss_coef', 'entropy_coef', 'kl_threshold',
@@ -1232,6 +1301,8 @@ class A2CAgent:
             return
         import torch.distributed as dist
         dist.broadcast(self.optimizer.flat_params, 0)
+        if self.has_central_value:
+            dist.broadcast(self.central_value_net.optimizer.flat_params, 0)
         for m in self._stats_sync_modules():
             rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
         self._seed_stats_sync_snapshots()

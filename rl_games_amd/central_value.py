@@ -1,0 +1,182 @@
+"""Central (asymmetric) value function on MI355X - host mirror of `CentralValueTrain`
+(rl_games/algos_torch/central_value.py:14-383): a value-only network over the privileged `states`,
+trained on its own minibatches before the actor's, whose predictions replace the actor's values in
+the rollout (a2c_common.py:593-615) and therefore in GAE.
+
+Same kernels as the actor path: the state normaliser and value de-normaliser are `RunningMeanStd`
+(csrc/running_stats.hip), the clipped value loss + its gradient + masked mean is one fused kernel
+(`rlg_value_loss`) reduced by `rlg_ppo_loss_finalize`, clipping + Adam run on a flat parameter arena
+(`FlatAdam`, csrc/optim.hip) with one in-place all-reduce per step in multi-GPU runs.  The MLP's
+backward goes through autograd (GEMMs on rocBLAS/hipBLASLt).
+
+Scope: MLP central value networks, `num_agents == 1`; recurrent critics and multi-agent state
+broadcasting raise NotImplementedError.
+"""
+import torch
+from torch import nn
+
+from . import distributed as rdist
+from . import ops
+from .flat_optim import FlatAdam
+from .lr_control import IdentityScheduler, LinearScheduler
+from .minibatch import PPODataset
+
+
+class CentralValueTrain(nn.Module):
+    def __init__(self, state_shape, value_size, ppo_device, num_agents, horizon_length, num_actors,
+                 num_actions, seq_length, normalize_value, network, config, writter, max_epochs, multi_gpu,
+                 zero_rnn_on_done):
+        super().__init__()
+        if num_agents != 1:
+            raise NotImplementedError('central value with num_agents > 1 is not implemented on this path')
+        self.ppo_device = ppo_device
+        self.num_agents, self.horizon_length, self.num_actors = num_agents, horizon_length, num_actors
+        self.seq_length, self.normalize_value, self.num_actions = seq_length, normalize_value, num_actions
+        self.state_shape, self.value_size, self.max_epochs = state_shape, value_size, max_epochs
+        self.multi_gpu, self.config = multi_gpu, config
+        self.normalize_input = config['normalize_input']
+        self.zero_rnn_on_done = zero_rnn_on_done
+        self.model = network.build({
+            'value_size': value_size, 'input_shape': state_shape, 'actions_num': num_actions,
+            'num_agents': num_agents, 'num_seqs': num_actors, 'normalize_input': self.normalize_input,
+            'normalize_value': self.normalize_value,
+        }).to(ppo_device)
+        if self.model.is_rnn():
+            raise NotImplementedError('recurrent central value networks are not implemented on this path')
+        self.is_rnn = False
+        self.rnn_states = None
+        self.lr = float(config['learning_rate'])
+        self.linear_lr = config.get('lr_schedule') == 'linear'
+        if self.linear_lr:
+            self.scheduler = LinearScheduler(self.lr, max_steps=self.max_epochs, apply_to_entropy=False,
+                                             start_entropy_coef=0)
+        else:
+            self.scheduler = IdentityScheduler()
+        self.mini_epoch = config['mini_epochs']
+        if 'minibatch_size' not in config and 'minibatch_size_per_env' not in config:
+            raise ValueError("Configuration must include either 'minibatch_size' or 'minibatch_size_per_env'. "
+                             'Neither was found in the provided config.')
+        self.minibatch_size_per_env = config.get('minibatch_size_per_env', 0)
+        self.minibatch_size = config.get('minibatch_size', self.num_actors * self.minibatch_size_per_env)
+        self.num_minibatches = self.horizon_length * self.num_actors // self.minibatch_size
+        self.clip_value = config['clip_value']
+        self.writter = writter
+        self.weight_decay = config.get('weight_decay', 0.0)
+        self.optimizer = FlatAdam(self.model.parameters(), self.lr, eps=1e-08, weight_decay=self.weight_decay)
+        self.frame = 0
+        self.epoch_num = 0
+        self.grad_norm = config.get('grad_norm', 1)
+        self.truncate_grads = config.get('truncate_grads', False)
+        self.e_clip = config.get('e_clip', 0.2)
+        self.batch_size = self.horizon_length * self.num_actors
+        self.local_rank = self.global_rank = 0
+        self.world_size = 1
+        if self.multi_gpu:
+            self.local_rank, self.global_rank, self.world_size = rdist.env_ranks()
+        self.dataset = PPODataset(self.batch_size, self.minibatch_size, True, False, ppo_device, self.seq_length)
+        mb = self.minibatch_size
+        self._d_val = torch.empty(mb, dtype=torch.float32, device=ppo_device)
+        self._partials = torch.empty((mb + 255) // 256, 7, dtype=torch.float64, device=ppo_device)
+        self._rows = torch.zeros(max(1, self.mini_epoch * self.num_minibatches), 8, dtype=torch.float32,
+                                 device=ppo_device)
+        self._no_logstd = torch.zeros(1, dtype=torch.float32, device=ppo_device)
+        self._row_index = 0
+
+    # ------------------------------------------------------------------ reference API
+    def update_lr(self, lr):
+        self.optimizer.set_lr(float(lr))           # identical on every rank by construction
+
+    def get_stats_weights(self, model_stats=False):
+        state = {}
+        if model_stats:
+            if self.normalize_input:
+                state['running_mean_std'] = self.model.running_mean_std.state_dict()
+            if self.normalize_value:
+                state['reward_mean_std'] = self.model.value_mean_std.state_dict()
+        return state
+
+    def set_stats_weights(self, weights):
+        pass
+
+    def update_dataset(self, batch_dict):
+        self.dataset.update_values_dict(batch_dict)
+
+    def _preproc_obs(self, obs_batch):
+        if obs_batch.dtype == torch.uint8:
+            obs_batch = obs_batch.float() / 255.0
+        return obs_batch
+
+    def pre_step_rnn(self, n):
+        return
+
+    def post_step_rnn(self, all_done_indices, zero_rnn_on_done=True):
+        return
+
+    def forward(self, input_dict):
+        return self.model(input_dict)
+
+    def get_value(self, input_dict):
+        self.eval()
+        obs_batch = self._preproc_obs(input_dict['states'])
+        with torch.no_grad():
+            res = self.forward({'obs': obs_batch, 'actions': input_dict.get('actions', None),
+                                'rnn_states': self.rnn_states, 'is_train': False})
+        return res['values']
+
+    def train_critic(self, input_dict):
+        self.train()
+        return self.calc_gradients(input_dict)
+
+    def train_net(self):
+        """central_value.py:236-260.  Returns the mean loss as a 0-dim device tensor (one host read
+        per epoch instead of the reference's `.item()` per minibatch)."""
+        self.train()
+        self._row_index = 0
+        count = 0
+        for _ in range(self.mini_epoch):
+            if self.config.get('freeze_critic', False):
+                break
+            for i in range(len(self.dataset)):
+                self.train_critic(self.dataset[i])
+                count += 1
+            if self.normalize_input:
+                self.model.running_mean_std.eval()
+        total = self._rows[:count, 5].sum() if count else torch.zeros((), device=self.ppo_device)
+        avg_loss = total / (self.mini_epoch * self.num_minibatches)
+        self.epoch_num += 1
+        self.lr, _ = self.scheduler.update(self.lr, 0, self.epoch_num, self.frame, 0)
+        self.update_lr(self.lr)
+        self.frame += self.batch_size
+        if self.writter is not None:
+            self.writter.add_scalar('losses/cval_loss', avg_loss.item(), self.frame)
+            self.writter.add_scalar('info/cval_lr', self.lr, self.frame)
+        return avg_loss
+
+    def calc_gradients(self, batch):
+        """central_value.py:278-335: forward, fused value loss + gradient, backward, (all-reduce,)
+        clip, Adam.  Returns the minibatch loss (0-dim device tensor)."""
+        opt = self.optimizer
+        obs_batch = self._preproc_obs(batch['obs'])
+        rnn_masks = batch.get('rnn_masks')
+        opt.zero_grad()
+        values = self.model.forward_values(obs_batch)                   # [mb, 1], autograd graph
+        mb = values.shape[0]
+        mask = mask_sum = None
+        if rnn_masks is not None:
+            mask = rnn_masks.reshape(-1).float().contiguous()
+            mask_sum = mask.sum().reshape(1)
+        row = self._rows[self._row_index % self._rows.shape[0]]
+        self._row_index += 1
+        d_val = self._d_val[:mb]
+        with torch.no_grad():
+            ops.value_loss(values.detach().reshape(-1), batch['old_values'].reshape(-1).contiguous(),
+                           batch['returns'].reshape(-1).contiguous(), d_val, self._partials, self.e_clip,
+                           self.clip_value, mask, mask_sum)
+            ops.ppo_loss_finalize(self._partials, (mb + 255) // 256, 0, mb, mask is not None, 2.0, 0.0, 0.0,
+                                  row, self._no_logstd)
+        torch.autograd.backward([values], [d_val.view(mb, 1)])
+        if self.multi_gpu:
+            rdist.all_reduce_sum(opt.flat_grads)
+        scale = 1.0 / self.world_size if self.multi_gpu else 1.0
+        opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None)
+        return row[5]

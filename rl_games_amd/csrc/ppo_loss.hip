@@ -468,6 +468,51 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Value-only loss of the central value network - CentralValueTrain.calc_loss
+// (rl_games/algos_torch/central_value.py:262-276): common_losses.critic_loss (clipped or plain,
+// common_losses.py:16-29) + torch_ext.apply_masks mean.  Emits d loss / d value per row and the
+// block partials {0, sum c, 0, 0, 0, sum mask, 0} that rlg_ppo_loss_finalize (actions_num 0)
+// reduces; with critic_coef = 2 there its total "loss" slot is exactly mean(c).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void value_loss_kernel(
+    const float* __restrict__ values, const float* __restrict__ old_values, const float* __restrict__ returns,
+    const float* __restrict__ mask, const float* __restrict__ mask_sum, float* __restrict__ d_values,
+    double* __restrict__ partials, int mb, float e_clip, int clip_value) {
+  __shared__ double red[kLossScalars * 4];
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (i < mb) {
+    const float v = values[i], vo = old_values[i], R = returns[i];
+    float c_loss, g_v;
+    if (clip_value) {
+      const float delta = v - vo;
+      const float vclip = vo + fminf(fmaxf(delta, -e_clip), e_clip);
+      const float d1 = v - R, d2 = vclip - R;
+      const float c1 = d1 * d1, c2 = d2 * d2;
+      c_loss = fmaxf(c1, c2);
+      const float in = (delta >= -e_clip && delta <= e_clip) ? 1.0f : 0.0f;
+      if (c1 > c2) g_v = 2.0f * d1; else if (c2 > c1) g_v = 2.0f * d2 * in;
+      else g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
+    } else {
+      const float d = R - v;
+      c_loss = d * d;
+      g_v = -2.0f * d;
+    }
+    const float m = mask ? mask[i] : 1.0f;
+    const float denom = mask ? fmaxf(*mask_sum, 1.0f) : static_cast<float>(mb);
+    d_values[i] = g_v * (m / denom);
+    acc[1] = static_cast<double>(c_loss) * m;
+    acc[5] = m;
+  }
+  block_sum<kLossScalars, 256>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kLossScalars; ++k) partials[static_cast<long long>(blockIdx.x) * kLossScalars + k] = acc[k];
+  }
+}
+
 }  // namespace rlg
 
 extern "C" {
@@ -527,6 +572,17 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   const int grid = rlg_ppo_loss_num_blocks(minibatch);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossThreads), shm,
                      static_cast<hipStream_t>(stream), p);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_value_loss(const float* values, const float* old_values, const float* returns,
+                   const float* mask_or_null, const float* mask_sum_or_null, float* d_values, double* partials,
+                   int minibatch, float e_clip, int clip_value, void* stream) {
+  if (minibatch <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::value_loss_kernel, dim3((minibatch + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), values, old_values, returns, mask_or_null,
+                     mask_sum_or_null, d_values, partials, minibatch, e_clip, clip_value);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

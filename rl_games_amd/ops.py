@@ -289,6 +289,17 @@ def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_val
         'rlg_ppo_loss_fused')
 
 
+def value_loss(values, old_values, returns, d_values, partials, e_clip, clip_value=True, mask=None, mask_sum=None):
+    """Central-value critic loss + its gradient; partials [ceil(mb/256), 7] for ppo_loss_finalize."""
+    lib = _lib.load()
+    mb = values.shape[0]
+    _lib.check(lib.rlg_value_loss(_need(values, F32, 'values'), _need(old_values, F32, 'old_values'),
+                                  _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'),
+                                  _opt(mask_sum, F32, 'mask_sum'), _need(d_values, F32, 'd_values'),
+                                  _need(partials, F64, 'partials'), mb, float(np.float32(e_clip)),
+                                  1 if clip_value else 0, _stream(values)), 'rlg_value_loss')
+
+
 def ppo_loss_discrete_blocks(minibatch):
     return _lib.load().rlg_ppo_loss_discrete_num_blocks(int(minibatch))
 

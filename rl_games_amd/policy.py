@@ -98,6 +98,10 @@ class ActorCriticNetwork(nn.Module):
         self.separate = bool(net_params.get('separate', False))
         if self.separate and 'rnn' in net_params:
             raise NotImplementedError('separate actor/critic trunks with an RNN are not implemented')
+        self.central_value = bool(net_params.get('central_value', False))
+        if self.central_value:
+            self._init_central_value(net_params, input_shape, value_size, num_seqs)
+            return
         space = net_params.get('space', {})
         self.is_discrete = 'discrete' in space
         if 'multi_discrete' in space:
@@ -161,6 +165,26 @@ class ActorCriticNetwork(nn.Module):
                     nn.init.zeros_(m.bias)
         _initializer(self.space_config['mu_init'])(self.mu.weight)
         _initializer(self.space_config['sigma_init'])(self.sigma)
+
+    def _init_central_value(self, net_params, input_shape, value_size, num_seqs):
+        """`central_value: True` networks (network_builder.py:497,556): MLP trunk + value head only."""
+        mlp = net_params['mlp']
+        if mlp.get('d2rl', False) or net_params.get('normalization') or 'rnn' in net_params or 'cnn' in net_params:
+            raise NotImplementedError('central value network: plain MLP only on this path')
+        self.is_discrete = False
+        self.separate = False
+        self.units = list(mlp['units'])
+        self.value_size, self.num_seqs, self.actions_num = value_size, num_seqs, 0
+        self.has_rnn = False
+        assert len(input_shape) == 1, 'flat states only'
+        self.actor_mlp = self._mlp_like(input_shape[0], mlp['activation'])
+        self.value = nn.Linear(self.units[-1], value_size)
+        self.value_act = _activation(net_params.get('value_activation', 'None'))
+        mlp_init = _initializer(mlp['initializer'])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                mlp_init(m.weight)
+                nn.init.zeros_(m.bias)
 
     def _init_discrete(self, net_params, actions_num, input_shape, value_size, num_seqs):
         """Categorical head (network_builder.py:298-299): `logits` Linear in place of mu/sigma."""
@@ -241,6 +265,8 @@ class ActorCriticNetwork(nn.Module):
         out, states = self.trunk(obs_dict['obs'], obs_dict.get('rnn_states'), obs_dict.get('dones'),
                                  obs_dict.get('seq_length', 1))
         value = self.value_act(self.value(self.critic_features(obs_dict['obs'], out)))
+        if self.central_value:                                  # (value, states) :497-498
+            return value, states
         if self.is_discrete:                                   # (logits, value, states) :431-433,:500-502
             return self.logits(out), value, states
         mu = self.mu_act(self.mu(out))
@@ -350,6 +376,24 @@ class DiscreteA2CModel(ContinuousA2CLogStdModel):
                 'actions': selected_action, 'logits': categorical.logits, 'rnn_states': states}
 
 
+class CentralValueModel(ContinuousA2CLogStdModel):
+    """The reference's `ModelCentralValue.Network` contract (models.py:425-464): normalised states in,
+    {'values', 'rnn_states'} out; values de-normalised outside training."""
+
+    def forward(self, input_dict):
+        is_train = input_dict.get('is_train', True)
+        obs = self.norm_obs(input_dict['obs'])
+        value, states = self.a2c_network({'obs': obs})
+        if not is_train:
+            value = self.denorm_value(value)
+        return {'values': value, 'rnn_states': states}
+
+    def forward_values(self, obs):
+        """Training fast path: normalise (and update) the states, return raw values [B, V]."""
+        value, _ = self.a2c_network({'obs': self.norm_obs(obs)})
+        return value
+
+
 class PolicyBuilder:
     """Stands in for `model_builder.ModelBuilder().load(params)` (rl_games/algos_torch/
     model_builder.py:56-60): `.build(config)` returns the model for one agent."""
@@ -357,7 +401,7 @@ class PolicyBuilder:
     def __init__(self, params):
         model_name = params.get('model', {}).get('name', 'continuous_a2c_logstd')
         net_name = params.get('network', {}).get('name', 'actor_critic')
-        if model_name not in ('continuous_a2c_logstd', 'discrete_a2c'):
+        if model_name not in ('continuous_a2c_logstd', 'discrete_a2c', 'central_value'):
             raise NotImplementedError(f"model '{model_name}' is not implemented on the MI355X PPO path")
         self.model_name = model_name
         if net_name != 'actor_critic':
@@ -369,6 +413,13 @@ class PolicyBuilder:
                                  input_shape=config['input_shape'],
                                  value_size=config.get('value_size', 1),
                                  num_seqs=config.get('num_seqs', 1))
+        if self.model_name == 'central_value' or net.central_value:
+            if not net.central_value:
+                raise ValueError("model 'central_value' needs a network with `central_value: True`")
+            return CentralValueModel(net, obs_shape=config['input_shape'],
+                                     normalize_value=config.get('normalize_value', False),
+                                     normalize_input=config.get('normalize_input', False),
+                                     value_size=config.get('value_size', 1))
         cls = DiscreteA2CModel if self.model_name == 'discrete_a2c' else ContinuousA2CLogStdModel
         if (self.model_name == 'discrete_a2c') != net.is_discrete:
             raise ValueError(f"model '{self.model_name}' does not match the network's action space")

@@ -13,9 +13,10 @@ from .spaces import Box, Discrete
 
 class SyntheticTensorEnv:
     def __init__(self, num_envs, obs_dim, act_dim=0, device='cuda:0', seed=1234, p_done=0.05,
-                 value_size=1, discrete_actions=None, autoreset_mode='same_step'):
+                 value_size=1, discrete_actions=None, autoreset_mode='same_step', state_dim=0):
         self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
         self.autoreset_mode = autoreset_mode
+        self.state_dim = state_dim      # > 0: privileged `states` for a central value function
         self.device = torch.device(device)
         self.p_done = p_done
         self.value_size = value_size
@@ -28,7 +29,11 @@ class SyntheticTensorEnv:
             self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
 
     def _obs(self):
-        return torch.randn(self.num_envs, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
+        obs = torch.randn(self.num_envs, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
+        if self.state_dim > 0:
+            states = torch.randn(self.num_envs, self.state_dim, device=self.device, generator=self.gen) * 2.0 - 0.5
+            return {'obs': obs, 'states': states}
+        return obs
 
     def reset(self):
         return self._obs()
@@ -46,8 +51,11 @@ class SyntheticTensorEnv:
         return obs, rewards, dones.to(torch.uint8), {'time_outs': time_outs}
 
     def get_env_info(self):
-        return {'observation_space': self.observation_space, 'action_space': self.action_space,
+        info = {'observation_space': self.observation_space, 'action_space': self.action_space,
                 'agents': 1, 'value_size': self.value_size, 'autoreset_mode': self.autoreset_mode}
+        if self.state_dim > 0:
+            info['state_space'] = Box(-np.inf, np.inf, (self.state_dim,), np.float32)
+        return info
 
     def has_action_masks(self):
         return False

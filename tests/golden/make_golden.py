@@ -294,7 +294,86 @@ def make_checkpoint():
           os.path.getsize(os.path.join(HERE, 'ref_checkpoint.pth')) // 1024, 'KiB')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'checkpoint': make_checkpoint}
+def make_central_value():
+    """One train_epoch of the REAL reference A2CAgent with a central (asymmetric) value function
+    (central_value.py CentralValueTrain): privileged states, own optimiser/minibatches."""
+    import copy
+    import ref_import
+    ref_import.enable()
+    from rl_games.torch_runner import Runner
+    from rl_games_amd import configs
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    out = {}
+    for name, over in {'experimental_cv': dict(), 'no_actor_value_loss': dict(use_experimental_cv=False)}.items():
+        N, H, O_, A, S_ = 64, 8, 12, 3, 20
+        params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
+                              train_dir='/tmp/rlg_golden_runs', **over)
+        params['config']['central_value_config'] = {
+            'minibatch_size': N * H // 4, 'mini_epochs': 2, 'learning_rate': 5e-4, 'clip_value': True,
+            'normalize_input': True, 'truncate_grads': True, 'grad_norm': 1.0,
+            'network': {'name': 'actor_critic', 'central_value': True,
+                        'mlp': {'units': [24, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}},
+        }
+        params['config']['env_config']['state_dim'] = S_
+        params['seed'] = 9
+        env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=4321, state_dim=S_)
+        stored = copy.deepcopy(params)
+        runner = Runner()
+        runner.load({'params': copy.deepcopy(params)})
+        runner.params['config']['vec_env'] = env
+        runner.params['config']['env_info'] = env.get_env_info()
+        agent = runner.algo_factory.create(runner.algo_name, base_name='golden', params=runner.params)
+        assert agent.has_central_value
+        torch.manual_seed(17)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        cap = {'lrs': []}
+        orig_play = agent.play_steps
+
+        def play():
+            b = orig_play()
+            cap['batch'] = _clone({k: v for k, v in b.items() if isinstance(v, torch.Tensor)})
+            cap['state_after_rollout'] = _clone(agent.model.state_dict())
+            cap['cv_state_after_rollout'] = _clone(agent.central_value_net.state_dict())
+            return b
+        agent.play_steps = play
+        orig_update_lr = agent.update_lr
+
+        def update_lr(lr):
+            cap['lrs'].append(float(lr))
+            return orig_update_lr(lr)
+        agent.update_lr = update_lr
+        cv_losses = []
+        orig_cv = agent.central_value_net.calc_gradients
+
+        def cv_calc(batch):
+            loss = orig_cv(batch)
+            cv_losses.append(loss.detach().clone())
+            return loss
+        agent.central_value_net.calc_gradients = cv_calc
+        agent.epoch_num = 1
+        res = agent.train_epoch()
+        (_, _, _, _, a_losses, c_losses, b_losses, entropies, kls, last_lr, lr_mul) = res
+        cap['a_losses'] = torch.stack([x.detach() for x in a_losses])
+        cap['c_losses'] = torch.stack([x.detach().reshape(()) for x in c_losses])
+        cap['entropies'] = torch.stack([x.detach() for x in entropies])
+        cap['mini_epoch_kls'] = torch.stack([x.detach() for x in kls])
+        cap['cv_losses'] = torch.stack(cv_losses)
+        vd = agent.dataset.values_dict
+        cap['dataset'] = _clone({k: vd[k] for k in ('old_values', 'returns', 'advantages')})
+        cap['final_state'] = _clone(agent.model.state_dict())
+        cap['cv_final_state'] = _clone(agent.central_value_net.state_dict())
+        cap['params'] = stored
+        cap['env'] = {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 4321, 'state_dim': S_}
+        out[name] = cap
+        print('central_value', name, 'cv losses', cap['cv_losses'].tolist()[:3], 'c_losses', cap['c_losses'].tolist()[:2],
+              'keys', sorted(cap['batch'])[:12])
+    torch.save(out, os.path.join(HERE, 'central_value.pt'))
+    print('central_value.pt written', os.path.getsize(os.path.join(HERE, 'central_value.pt')) // 1024, 'KiB')
+
+
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'checkpoint': make_checkpoint,
+            'central_value': make_central_value}
 
 if __name__ == '__main__':
     only = sys.argv[1:] or list(SECTIONS)

@@ -468,3 +468,85 @@ def test_two_rank_bench_on_one_gpu():
     assert out['n_gpus'] == 2 and out['config']['envs_per_gpu'] == 32768
     assert out['config']['ranks_in_sync'] is True
     assert out['value'] > 0 and out['roofline']['launches'] == 1
+
+
+@pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss'])
+def test_central_value_update_matches_reference_epoch(golden, variant):
+    """Central (asymmetric) value function: the update phase against golden vectors
+    of the REAL reference agent with `central_value_config` - critic minibatches first
+    (CentralValueTrain.train_net), then the actor's, on identical rollout tensors."""
+    from rl_games_amd.agent import A2CAgent
+    cap = golden('central_value.pt')[variant]
+    params = copy.deepcopy(cap['params'])
+    params['config']['device'] = DEV
+    env = SyntheticTensorEnv(cap['env']['num_envs'], cap['env']['obs_dim'], cap['env']['act_dim'], device=DEV,
+                             seed=cap['env']['seed'], state_dim=cap['env']['state_dim'])
+    params['config']['vec_env'] = env
+    params['config']['env_info'] = env.get_env_info()
+    agent = A2CAgent('cv', params)
+    assert agent.has_central_value and agent.has_value_loss == (variant == 'experimental_cv')
+    agent.init_tensors()
+    agent.model.load_state_dict(cap['state_after_rollout'])
+    agent.central_value_net.load_state_dict(cap['cv_state_after_rollout'])
+    assert list(agent.central_value_net.state_dict().keys()) == list(cap['cv_state_after_rollout'].keys())
+    batch = {k: v.to(DEV) for k, v in cap['batch'].items()}
+    agent.set_train()
+    agent.epoch_num = 1
+    agent.prepare_dataset(batch)
+    ds, vd = cap['dataset'], agent.dataset.values_dict
+    for k in ('old_values', 'returns', 'advantages'):
+        assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
+    cv = agent.central_value_net
+    cv.train_net()
+    n_cv = cv.mini_epoch * cv.num_minibatches
+    assert torch.allclose(cv._rows[:n_cv, 5].cpu(), cap['cv_losses'], rtol=1e-5, atol=1e-6)
+    agent.set_train()
+    rows = []
+    for mini_ep in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            rows.append(torch.stack([a, c.reshape(()), e, kl]).clone())
+    rows = torch.stack(rows).cpu()
+    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
+    kls = rows[:, 3].reshape(agent.mini_epochs_num, -1).mean(1)
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-4, atol=1e-7)
+    assert agent.optimizer.last_and_next_lr()[1] == cap['lrs'][-1]
+    for final, want in ((agent.model.state_dict(), cap['final_state']),
+                        (cv.state_dict(), cap['cv_final_state'])):
+        for k, v in want.items():
+            tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
+            assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+
+
+def test_central_value_train_epoch_and_checkpoint(tmp_path):
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=64, horizon=8)
+    params['config']['central_value_config'] = {
+        'minibatch_size': 128, 'mini_epochs': 2, 'learning_rate': 5e-4, 'clip_value': True,
+        'normalize_input': True, 'truncate_grads': True, 'grad_norm': 1.0,
+        'network': {'name': 'actor_critic', 'central_value': True,
+                    'mlp': {'units': [32, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}}
+    params['config']['env_config']['state_dim'] = 9
+    a1 = A2CAgent('cv', copy.deepcopy(params))
+    a1.init_tensors()
+    a1.obs = a1.env_reset()
+    for _ in range(2):
+        a1.update_epoch()
+        out = a1.train_epoch()
+    assert all(torch.isfinite(x) for x in out[4] + out[5])
+    assert a1.experience_buffer.tensor_dict['states'].shape == (8, 64, 9)
+    cvm = a1.central_value_net.model
+    assert cvm.running_mean_std.count.item() == 1 + 2 * 2 * 64 * 8        # states: per CV minibatch pass
+    assert cvm.value_mean_std.count.item() == 1 + 2 * 2 * 64 * 8          # values + returns per epoch
+    path = a1.save(str(tmp_path / 'cv_ckpt'))
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert 'assymetric_vf_nets' in ck and 'assymetric_vf_optimizer' in ck
+    a2 = A2CAgent('cv', copy.deepcopy(params))
+    a2.restore(path)
+    for (k1, v1), (k2, v2) in zip(a1.central_value_net.state_dict().items(),
+                                  a2.central_value_net.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert torch.equal(a1.central_value_net.optimizer.exp_avg, a2.central_value_net.optimizer.exp_avg)
