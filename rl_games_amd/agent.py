@@ -568,7 +568,7 @@ class A2CAgent:
     def init_tensors(self):
         rows = self.num_agents * self.num_actors
         algo_info = {'num_actors': self.num_actors, 'horizon_length': self.horizon_length,
-                     'has_central_value': False, 'use_action_masks': False}
+                     'has_central_value': self.has_central_value, 'use_action_masks': False}
         self.experience_buffer = ExperienceBuffer(self.env_info, algo_info, self.ppo_device)
         self.init_current_rewards(rows, (rows, self.value_size))
         dev = self.ppo_device
