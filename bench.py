@@ -175,7 +175,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'traffic_note': 'HBM bytes/launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r1_gae_pmc.txt',
                 'algorithmic_bytes_per_launch': gae_bytes, 'avg_launch_us': gae_us, 'launches': len(pairs),
-                'timing': 'HIP events on the launch stream around each in-epoch launch (timed region)',
+                'timing': 'HIP start/stop events attached to each in-epoch GAE dispatch on its launch stream (hipExtLaunchKernelGGL), timed region',
             },
         }
         if in_sync is not None:

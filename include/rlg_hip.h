@@ -66,7 +66,8 @@ int rlg_gae_envmajor_fused(const float* rewards, const float* values, const uint
                            float gamma, float gamma_tau, void* stream);
 
 /* Profiling hooks used by bench.py (not part of the reference surface): hipEvent handles as
- * void*, and the fused GAE launch bracketed by event records on the same stream inside one call. */
+ * void*, and the fused GAE launch with start/stop events attached to that dispatch on the same
+ * stream (hipExtLaunchKernelGGL) - elapsed time = the kernel's own duration, as rocprofv3 reports it. */
 int rlg_event_create(void** event_out);
 int rlg_event_destroy(void* event);
 int rlg_event_elapsed_us(void* start, void* stop, float* us_out);   /* synchronises on `stop` */

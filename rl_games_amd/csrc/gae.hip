@@ -33,6 +33,7 @@
 //                           env-step = 17 B.
 
 #include "rlg_device.hpp"
+#include <hip/hip_ext.h>
 
 namespace rlg {
 
@@ -343,13 +344,21 @@ template <int H, bool kRaw>
 static int launch_envmajor(const float* rewards, const float* values, const uint8_t* dones,
                            const float* last_values, const uint8_t* last_dones, float* out0,
                            float* out1, double* partials, int N, float gamma, float gamma_tau,
-                           hipStream_t stream) {
+                           hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const int tiles = (N + kWave - 1) / kWave;
   const int grid = (tiles + kGaeWavesPerBlock - 1) / kGaeWavesPerBlock;
-  hipLaunchKernelGGL((gae_envmajor_kernel<H, kRaw>), dim3(grid), dim3(kWave * kGaeWavesPerBlock), 0,
-                     stream, rewards,
-                     values, dones, last_values, last_dones, out0, out1, partials, N, gamma,
-                     gamma_tau);
+  if (ev_start && ev_stop) {
+    // events bound to THIS dispatch's begin/end timestamps (what rocprofv3 reports), not to
+    // separate marker packets before/after it
+    hipExtLaunchKernelGGL((gae_envmajor_kernel<H, kRaw>), dim3(grid), dim3(kWave * kGaeWavesPerBlock), 0,
+                          stream, ev_start, ev_stop, 0, rewards, values, dones, last_values, last_dones,
+                          out0, out1, partials, N, gamma, gamma_tau);
+  } else {
+    hipLaunchKernelGGL((gae_envmajor_kernel<H, kRaw>), dim3(grid), dim3(kWave * kGaeWavesPerBlock), 0,
+                       stream, rewards,
+                       values, dones, last_values, last_dones, out0, out1, partials, N, gamma,
+                       gamma_tau);
+  }
   RLG_RETURN_LAUNCH_STATUS();
 }
 
@@ -358,11 +367,11 @@ static int dispatch_envmajor(int H, const float* rewards, const float* values,
                              const uint8_t* dones, const float* last_values,
                              const uint8_t* last_dones, float* out0, float* out1,
                              double* partials, int N, float gamma, float gamma_tau,
-                             hipStream_t stream) {
+                             hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
 #define RLG_CASE(HH)                                                                          \
   case HH:                                                                                    \
     return launch_envmajor<HH, kRaw>(rewards, values, dones, last_values, last_dones, out0,   \
-                                     out1, partials, N, gamma, gamma_tau, stream)
+                                     out1, partials, N, gamma, gamma_tau, stream, ev_start, ev_stop)
   switch (H) {
     RLG_CASE(4);
     RLG_CASE(8);
@@ -410,8 +419,9 @@ int rlg_gae_envmajor_fused(const float* rewards, const float* values, const uint
                                        gamma_tau, static_cast<hipStream_t>(stream));
 }
 
-// Profiling hooks (bench.py): HIP events recorded on the launch stream immediately around the
-// kernel, inside one C call, so that no host-side Python latency sits between the markers.
+// Profiling hooks (bench.py): HIP events on the launch stream, attached to the GAE dispatch itself
+// (hipExtLaunchKernelGGL start/stop events = the dispatch's begin/end timestamps, the quantity
+// rocprofv3 --kernel-trace reports), so neither host latency nor marker packets are included.
 int rlg_event_create(void** event_out) {
   hipEvent_t ev;
   const hipError_t e = hipEventCreate(&ev);
@@ -435,14 +445,11 @@ int rlg_gae_envmajor_fused_timed(const float* rewards, const float* values, cons
                                  float* advantages, double* moment_partials, int num_envs,
                                  int horizon, float gamma, float gamma_tau, void* stream,
                                  void* ev_start, void* ev_stop) {
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipEventRecord(static_cast<hipEvent_t>(ev_start), st);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const int rc = rlg_gae_envmajor_fused(rewards, values, dones, last_values, last_dones, returns,
-                                        advantages, moment_partials, num_envs, horizon, gamma,
-                                        gamma_tau, stream);
-  if (rc != 0) return rc;
-  return static_cast<int>(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
+  if (num_envs <= 0) return 0;
+  return rlg::dispatch_envmajor<false>(horizon, rewards, values, dones, last_values, last_dones, returns,
+                                       advantages, moment_partials, num_envs, gamma, gamma_tau,
+                                       static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start),
+                                       static_cast<hipEvent_t>(ev_stop));
 }
 
 int rlg_gae_envmajor_raw(const float* rewards, const float* values, const uint8_t* dones,
