@@ -304,15 +304,6 @@ int rlg_colsum_finalize(const double* partials, int num_blocks, int cols, float*
  *   :498) and the mu/value heads (:295-311).
  * ---------------------------------------------------------------------------------- */
 
-/* out = act(x @ weight^T + bias) [rows, out_features]; pre_act_or_null additionally receives
- * x @ weight^T + bias (kept for the backward pass).  x [rows, in_features] row stride ldx,
- * weight [out_features, in_features] row stride ldw (nn.Linear layout).  act_kind 0 identity,
- * 1 elu(alpha 1), 2 relu, 3 tanh. */
-int rlg_mlp_forward_layer(const float* x, long long ldx, const float* weight, long long ldw,
-                          const float* bias_or_null, float* pre_act_or_null, long long ldz, float* out,
-                          long long ldh, int rows, int out_features, int in_features, int act_kind,
-                          void* stream);
-
 /* ---- MLP forward / input-gradient GEMMs on f32 MFMA with fused epilogues -------------------
  * H = act(X W^T + b) (+ Z) replaces nn.Linear + activation of A2CBuilder._build_sequential_mlp and
  * the heads (rl_games/algos_torch/network_builder.py:118-147, :295-311, forward :498-512);

@@ -79,9 +79,6 @@ _PROTOTYPES = {
     'rlg_act_bwd_num_blocks': [_c_ll, _c_int],
     'rlg_act_bwd_colsum': [_P, _P, _P, _c_ll, _c_int, _c_ll, _c_int, _P, _c_int, _P],
     'rlg_colsum_finalize': [_P, _c_int, _c_int, _P, _c_int, _P],
-    # mlp_gemm.hip
-    'rlg_mlp_forward_layer': [_P, _c_ll, _P, _c_ll, _P, _P, _c_ll, _P, _c_ll, _c_int, _c_int, _c_int,
-                              _c_int, _P],
     # optim.hip
     'rlg_grad_norm_num_blocks': [_c_ll],
     'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P, _P],

@@ -394,19 +394,6 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
 
 # ------------------------------------------------------------------ fp32-MFMA MLP layers
 
-def mlp_forward_layer(x, weight, bias, out, pre_act=None, act_kind=0):
-    """out = act(x @ weight.T + bias); pre_act (optional) receives the pre-activation."""
-    lib = _lib.load()
-    rows, K = x.shape
-    N = weight.shape[0]
-    for t, name in ((x, 'x'), (weight, 'weight'), (out, 'out')):
-        _lib.require_gpu(t, name)
-        if t.dtype != F32 or t.stride(1) != 1:
-            raise ValueError(f'{name}: fp32 with unit inner stride expected')
-    _lib.check(lib.rlg_mlp_forward_layer(
-        x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _opt(bias, F32, 'bias'),
-        None if pre_act is None else pre_act.data_ptr(), 0 if pre_act is None else pre_act.stride(0),
-        out.data_ptr(), out.stride(0), rows, N, K, act_kind, _stream(x)), 'rlg_mlp_forward_layer')
     return out
 
 

@@ -450,35 +450,7 @@ def test_ppo_loss_on_strided_head_views_and_bias_grads():
     assert torch.allclose(bval.cpu(), d_val.cpu().double().sum().float().reshape(1), rtol=1e-5, atol=1e-9)
 
 
-# ----------------------------------------------------------------------------- fp32-MFMA layer kernel
-
-@pytest.mark.parametrize('M,N,K', [(4096, 400, 108), (1000, 200, 400), (777, 100, 200), (513, 22, 100),
-                                   (300, 64, 3), (1000, 100, 37), (129, 33, 16)])
-@pytest.mark.parametrize('act', ['elu', 'None'])
-def test_mfma_forward_layer_matches_addmm(M, N, K, act):
-    """out = act(x W^T + b) on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) against
-    an fp64 evaluation: as accurate as the library GEMM it can replace (csrc/mlp_gemm.hip; not on
-    the default path in round 1)."""
-    from rl_games_amd import ops
-    gen = g(M + N + K)
-    x = torch.randn(M, K, generator=gen)
-    w = torch.randn(N, K, generator=gen) / K ** 0.5
-    b = torch.randn(N, generator=gen)
-    z64 = torch.addmm(b.double(), x.double(), w.double().t())
-    h64 = torch.nn.functional.elu(z64) if act == 'elu' else z64
-    z = torch.empty(M, N, device=DEV)
-    h = torch.empty(M, N, device=DEV)
-    ops.mlp_forward_layer(x.to(DEV), w.to(DEV), b.to(DEV), h, pre_act=z, act_kind=ops.ACT_KINDS[act])
-    lib = torch.addmm(b, x, w.t())
-    err_lib = (lib.double() - z64).abs().max().item()
-    assert (z.cpu().double() - z64).abs().max().item() <= 4 * err_lib + 1e-6
-    assert torch.allclose(h.cpu().double(), h64, rtol=1e-5, atol=2e-5)
-    # strided output (column view of a wider buffer) and no pre-activation output
-    wide = torch.zeros(M, N + 5, device=DEV)
-    ops.mlp_forward_layer(x.to(DEV), w.to(DEV), None, wide[:, 2:2 + N], act_kind=0)
-    assert torch.allclose(wide[:, 2:2 + N].cpu().double(), z64 - b.double(), rtol=1e-5, atol=2e-5)
-    assert torch.count_nonzero(wide[:, :2]) == 0 and torch.count_nonzero(wide[:, 2 + N:]) == 0
-
+# ----------------------------------------------------------------------------- fp32-MFMA MLP kernels
 
 @pytest.mark.parametrize('rows', [32768, 4096, 1000, 37, 2])
 def test_mlp_dw_mfma_matches_library_gemm(rows):
