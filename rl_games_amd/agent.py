@@ -1003,9 +1003,7 @@ class A2CAgent:
         scale = 1.0 / self.world_size if self.multi_gpu else 1.0
         schedule = None
         if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
-            s = self.scheduler
-            schedule = dict(kl_threshold=s.kl_threshold, min_lr=s.min_lr, max_lr=s.max_lr,
-                            lr_multiplier=s.lr_multiplier)
+            schedule = self.scheduler.device_rule()
         opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
                  schedule=schedule, kl_scale=scale)
 
