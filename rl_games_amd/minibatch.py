@@ -51,33 +51,36 @@ class PPODataset:
                 else:
                     self.values_dict[key] = value[perm]
 
-    @staticmethod
-    def _rows(data, start, end):
-        if isinstance(data, dict):
-            return {k: v[start:end] for k, v in data.items()}
-        return None if data is None else data[start:end]
-
-    def _get_item_rnn(self, idx):
-        gstart, gend = idx * self.num_games_batch, (idx + 1) * self.num_games_batch
-        start, end = gstart * self.seq_length, gend * self.seq_length
-        self.last_range = (start, end)
-        item = {k: self._rows(v, start, end) for k, v in self.values_dict.items()
-                if k not in self.special_names}
-        item['rnn_states'] = [s[:, gstart:gend, :].contiguous() for s in self.values_dict['rnn_states']]
-        return item
-
-    def _get_item(self, idx):
-        start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
-        self.last_range = (start, end)
-        return {k: self._rows(v, start, end) for k, v in self.values_dict.items()
-                if k not in self.special_names and v is not None}
+    def _span(self, idx):
+        """Row range [start, end) of minibatch idx and, for RNN data, its sequence range."""
+        if self.is_rnn:
+            g0 = idx * self.num_games_batch
+            g1 = g0 + self.num_games_batch
+            return g0 * self.seq_length, g1 * self.seq_length, (g0, g1)
+        start = idx * self.minibatch_size
+        return start, start + self.minibatch_size, None
 
     def __getitem__(self, idx):
-        return self._get_item_rnn(idx) if self.is_rnn else self._get_item(idx)
+        start, end, games = self._span(idx)
+        self.last_range = (start, end)
+
+        def cut(v):
+            return {k: t[start:end] for k, t in v.items()} if isinstance(v, dict) else v[start:end]
+        item = {}
+        for name, v in self.values_dict.items():
+            if name in self.special_names:
+                continue
+            if v is None:
+                if self.is_rnn:
+                    item[name] = None          # RNN batches keep the key (rnn_masks: None)
+                continue
+            item[name] = cut(v)
+        if games is not None:
+            item['rnn_states'] = [s[:, games[0]:games[1], :].contiguous() for s in self.values_dict['rnn_states']]
+        return item
 
     def __len__(self):
         return self.length
 
     def __iter__(self):
-        for idx in range(self.length):
-            yield self[idx]
+        return (self[i] for i in range(self.length))
