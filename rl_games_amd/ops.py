@@ -392,11 +392,6 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
         'rlg_adam_step')
 
 
-# ------------------------------------------------------------------ fp32-MFMA MLP layers
-
-    return out
-
-
 # ------------------------------------------------------------------ MLP forward / dX (MFMA, fused epilogues)
 
 def mlp_rowgemm_supported(reduction_dim, leading_dim):
