@@ -592,3 +592,58 @@ def test_player_restores_checkpoint_and_plays(tmp_path, golden):
     rplayer.has_batch_dimension = True
     a = rplayer.get_action(torch.randn(7, meta['env']['obs_dim'], device=DEV), True)
     assert a.shape == (7, meta['env']['act_dim']) and torch.isfinite(a).all() and a.abs().max() <= 1.0
+
+
+def test_train_loop_runs_to_max_epochs_with_checkpoints_and_observer(tmp_path):
+    """The Runner's entry point: agent.train() -> (last_mean_rewards, epoch_num), with periodic and
+    best checkpoints, observer callbacks and a stop after max_epochs (a2c_common.py:1662-1782)."""
+    import os
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+
+    class Observer:
+        def __init__(self):
+            self.calls = []
+
+        def before_init(self, base_name, config, experiment_name):
+            self.calls.append('before_init')
+
+        def after_init(self, algo):
+            self.calls.append('after_init')
+
+        def process_infos(self, infos, done_indices):
+            self.calls.append('process_infos')
+
+        def after_steps(self):
+            self.calls.append('after_steps')
+
+        def after_clear_stats(self):
+            self.calls.append('after_clear_stats')
+
+        def after_print_stats(self, frame, epoch_num, total_time):
+            self.calls.append(('after_print_stats', frame, epoch_num))
+
+    obs = Observer()
+    params = configs.tiny(num_actors=64, horizon=8, max_epochs=6, save_frequency=2, save_best_after=0,
+                          train_dir=str(tmp_path), full_experiment_name='loop')
+    params['config']['features'] = {'observer': obs}
+    params['config']['env_config']['p_done'] = 0.2
+    agent = A2CAgent('loop', params)
+    last_mean_rewards, epoch_num = agent.train()
+    assert epoch_num == 6 and agent.frame == 6 * 64 * 8
+    assert np.isfinite(last_mean_rewards)
+    nn_dir = os.path.join(str(tmp_path), 'loop', 'nn')
+    files = sorted(os.listdir(nn_dir))
+    assert any(f.startswith('last_tiny_ep_6') for f in files), files
+    assert 'tiny.pth' in files                                              # best-so-far checkpoint
+    assert sum(f.startswith('last_tiny_ep_') and '_rew_' in f for f in files) == 3   # epochs 2, 4, 6
+    assert obs.calls[:2] == ['before_init', 'after_init']
+    assert obs.calls.count('after_steps') == 6
+    stats = [c for c in obs.calls if isinstance(c, tuple)]
+    assert [c[2] for c in stats] == [1, 2, 3, 4, 5, 6] and stats[-1][1] == 6 * 64 * 8
+    # restart from the last checkpoint continues the epoch counter
+    p2 = configs.tiny(num_actors=64, horizon=8, max_epochs=8, train_dir=str(tmp_path), full_experiment_name='loop2')
+    a2 = A2CAgent('loop2', p2)
+    a2.restore(os.path.join(nn_dir, [f for f in files if f.startswith('last_tiny_ep_6') and '_rew_' not in f][0]))
+    _, e2 = a2.train()
+    assert e2 == 8 and a2.frame == 8 * 64 * 8
