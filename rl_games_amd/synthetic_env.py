@@ -13,9 +13,10 @@ from .spaces import Box, Discrete
 
 class SyntheticTensorEnv:
     def __init__(self, num_envs, obs_dim, act_dim=0, device='cuda:0', seed=1234, p_done=0.05,
-                 value_size=1, discrete_actions=None, autoreset_mode='same_step', state_dim=0):
+                 value_size=1, discrete_actions=None, autoreset_mode='same_step', state_dim=0, agents=1):
         self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
         self.autoreset_mode = autoreset_mode
+        self.agents = agents            # agents per env: every per-step tensor has num_envs * agents rows
         self.state_dim = state_dim      # > 0: privileged `states` for a central value function
         self.device = torch.device(device)
         self.p_done = p_done
@@ -29,7 +30,7 @@ class SyntheticTensorEnv:
             self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
 
     def _obs(self):
-        obs = torch.randn(self.num_envs, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
+        obs = torch.randn(self.num_envs * self.agents, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
         if self.state_dim > 0:
             states = torch.randn(self.num_envs, self.state_dim, device=self.device, generator=self.gen) * 2.0 - 0.5
             return {'obs': obs, 'states': states}
@@ -39,7 +40,7 @@ class SyntheticTensorEnv:
         return self._obs()
 
     def step(self, actions):
-        n = self.num_envs
+        n = self.num_envs * self.agents
         obs = self._obs()
         if self.value_size == 1:
             rewards = torch.randn(n, device=self.device, generator=self.gen)
@@ -52,7 +53,7 @@ class SyntheticTensorEnv:
 
     def get_env_info(self):
         info = {'observation_space': self.observation_space, 'action_space': self.action_space,
-                'agents': 1, 'value_size': self.value_size, 'autoreset_mode': self.autoreset_mode}
+                'agents': self.agents, 'value_size': self.value_size, 'autoreset_mode': self.autoreset_mode}
         if self.state_dim > 0:
             info['state_space'] = Box(-np.inf, np.inf, (self.state_dim,), np.float32)
         return info
@@ -61,7 +62,7 @@ class SyntheticTensorEnv:
         return False
 
     def get_number_of_agents(self):
-        return 1
+        return self.agents
 
     def set_train_info(self, env_frames, *args, **kwargs):
         pass

@@ -647,3 +647,24 @@ def test_train_loop_runs_to_max_epochs_with_checkpoints_and_observer(tmp_path):
     a2.restore(os.path.join(nn_dir, [f for f in files if f.startswith('last_tiny_ep_6') and '_rew_' not in f][0]))
     _, e2 = a2.train()
     assert e2 == 8 and a2.frame == 8 * 64 * 8
+
+
+def test_multi_agent_env_rows():
+    """num_agents > 1 (a2c_common.py:184,1039-1040): every per-step tensor has num_actors * num_agents
+    rows, batch_size counts them, the epoch runs and the buffer keeps the env-major row order."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=32, horizon=8, minibatch_size=128)
+    params['config']['env_config']['agents'] = 2
+    agent = A2CAgent('ma', params)
+    assert agent.num_agents == 2 and agent.batch_size == 32 * 2 * 8
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    assert agent.obs['obs'].shape[0] == 64
+    for _ in range(2):
+        agent.update_epoch()
+        out = agent.train_epoch()
+    assert len(out[4]) == agent.mini_epochs_num * (512 // 128)
+    assert all(torch.isfinite(x) for x in out[4] + out[5])
+    assert agent.experience_buffer.tensor_dict['obses'].shape == (8, 64, 12)
+    assert agent.dataset.values_dict['obs'].shape == (512, 12)
