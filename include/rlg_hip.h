@@ -231,18 +231,20 @@ int rlg_value_loss(const float* values, const float* old_values, const float* re
                    int minibatch, float e_clip, int clip_value, void* stream);
 
 /* Discrete (Categorical) variant - replaces rl_games/algos_torch/a2c_discrete.py:
- * DiscreteA2CAgent.calc_gradients :121-209 with the ModelA2C epilogue (models.py:95-111): logits
- * [mb, n] (row stride ld), actions int64 [mb]; emits d_logits [mb, n] (actor + entropy terms,
- * scaled) and d_values [mb]; partials [blocks][7] feed rlg_ppo_loss_finalize with actions_num = 0
+ * DiscreteA2CAgent.calc_gradients :121-209 with the model epilogues ModelA2C (models.py:95-111) and
+ * ModelA2CMultiDiscrete (:153-179) incl. CategoricalMasked (common/extensions/distributions.py:24-47):
+ * logits [mb, n] (row stride ld), n = sum(branch_sizes); actions int64 [mb, num_branches];
+ * action_masks bool [mb, n] or NULL.  Emits d_logits [mb, n] (actor + entropy terms, scaled) and
+ * d_values [mb]; partials [blocks][7] feed rlg_ppo_loss_finalize with actions_num = 0
  * (kl = 0.5 (old_nlp - nlp)^2, :192-198). */
 int rlg_ppo_loss_discrete_num_blocks(int minibatch);
 int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
-                          const long long* actions, const float* old_neglogp, const float* advantages,
-                          const float* old_values, const float* returns, const float* mask_or_null,
-                          const float* mask_sum_or_null, float* d_logits, float* d_values,
-                          double* partials, int minibatch, int num_actions, float e_clip,
-                          float critic_coef, float entropy_coef, int clip_value, int use_smooth_clamp,
-                          void* stream);
+                          const long long* actions, const unsigned char* action_masks_or_null,
+                          const int* branch_sizes, int num_branches, const float* old_neglogp,
+                          const float* advantages, const float* old_values, const float* returns,
+                          const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
+                          float* d_values, double* partials, int minibatch, float e_clip, float critic_coef,
+                          float entropy_coef, int clip_value, int use_smooth_clamp, void* stream);
 
 /* scalars8 = {a_loss, c_loss, entropy, b_loss, kl, loss, sum(mask), 0}; d_logstd [A];
  * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena);

@@ -349,15 +349,34 @@ def distribution_loss_and_grads(mu, logstd, values, batch, hp, mask=None):
             'd_values': values.grad}
 
 
-def categorical_loss_and_grads(logits, values, batch, hp, mask=None):
-    """Discrete agent: ModelA2C epilogue (rl_games/algos_torch/models.py:95-111, Categorical(logits):
-    neglogp, entropy) + DiscreteA2CAgent.calc_gradients losses and KL
-    (rl_games/algos_torch/a2c_discrete.py:166-198), backward by autograd."""
+def masked_categorical(logits, masks=None):
+    """CategoricalMasked (rl_games/common/extensions/distributions.py:24-47): returns
+    (distribution, entropy) with disallowed logits replaced by -1e8 and dropped from the entropy."""
+    if masks is None:
+        cat = torch.distributions.Categorical(logits=logits)
+        return cat, cat.entropy()
+    cat = torch.distributions.Categorical(logits=torch.where(masks, logits, torch.tensor(-1e+8, dtype=logits.dtype)))
+    p_log_p = torch.where(masks, cat.logits * cat.probs, torch.tensor(0.0, dtype=logits.dtype))
+    return cat, -p_log_p.sum(-1)
+
+
+def categorical_loss_and_grads(logits, values, batch, hp, mask=None, branch_sizes=None, action_masks=None):
+    """Discrete agent: ModelA2C / ModelA2CMultiDiscrete epilogues (rl_games/algos_torch/models.py:95-111,
+    :153-179: per-head Categorical(Masked), neglogp and entropy summed over heads) +
+    DiscreteA2CAgent.calc_gradients losses and KL (rl_games/algos_torch/a2c_discrete.py:166-198),
+    backward by autograd.  logits [mb, sum(branch_sizes)] (heads concatenated)."""
     logits = logits.detach().clone().requires_grad_(True)
     values = values.detach().clone().requires_grad_(True)
-    cat = torch.distributions.Categorical(logits=logits)
-    nlp = torch.squeeze(-cat.log_prob(batch['actions']))
-    ent = cat.entropy()
+    sizes = [logits.shape[1]] if branch_sizes is None else list(branch_sizes)
+    heads = torch.split(logits, sizes, dim=1)
+    head_masks = [None] * len(sizes) if action_masks is None else torch.split(action_masks.bool(), sizes, dim=1)
+    acts = batch['actions'].reshape(logits.shape[0], len(sizes))
+    nlp = 0
+    ent = 0
+    for b, (lg, am) in enumerate(zip(heads, head_masks)):
+        cat, h = masked_categorical(lg, am)
+        nlp = nlp + (-cat.log_prob(acts[:, b]))
+        ent = ent + h
     a = actor_loss(batch['old_logp_actions'], nlp, batch['advantages'], hp['e_clip'], True,
                    hp.get('use_smooth_clamp', False))
     c = critic_loss(batch['old_values'], values, hp['e_clip'], batch['returns'], hp.get('clip_value', True))

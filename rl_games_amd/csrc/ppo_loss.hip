@@ -373,11 +373,14 @@ __global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(
 // backward: d nlp/d z_j = p_j - [j == a] ;  d H/d z_j = -p_j (log p_j + H).
 // One thread per row (the number of actions is small: 2 for config #1's CartPole).
 // ---------------------------------------------------------------------------------
+constexpr int kMaxBranches = 16;
+
 struct DiscreteLossArgs {
-  const float* logits;       // [mb, n] row stride ld
+  const float* logits;       // [mb, n] row stride ld; n = sum of branch widths
   long long ld;
   const float* values;       // [mb]
-  const long long* actions;  // [mb] int64
+  const long long* actions;  // [mb, nb] int64 (nb = 1: [mb])
+  const unsigned char* action_masks;   // [mb, n] bool (1 = allowed) or nullptr
   const float* old_neglogp;
   const float* advantages;
   const float* old_values;
@@ -387,10 +390,17 @@ struct DiscreteLossArgs {
   float* d_logits;           // [mb, n] contiguous
   float* d_values;           // [mb]
   double* partials;          // [gridDim.x][kLossScalars]
-  int mb, n;
+  int mb, n, nb;
+  int off[kMaxBranches + 1]; // branch b covers logits [off[b], off[b+1])
   float e_clip, critic_coef, entropy_coef;
   int clip_value, smooth;
 };
+
+// CategoricalMasked (rl_games/common/extensions/distributions.py:24-47): disallowed logits are
+// replaced by -1e8 before the softmax, contribute 0 to the entropy and receive no gradient.
+__device__ __forceinline__ float masked_logit(const DiscreteLossArgs& p, const float* z, const unsigned char* am, int j) {
+  return (am == nullptr || am[j]) ? z[j] : -1e8f;
+}
 
 __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs p) {
   __shared__ double red[kLossScalars * 4];
@@ -398,17 +408,29 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
   double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < p.mb) {
     const float* z = p.logits + i * p.ld;
-    float zmax = z[0];
-    for (int j = 1; j < p.n; ++j) zmax = fmaxf(zmax, z[j]);
-    float se = 0.0f;
-    for (int j = 0; j < p.n; ++j) se += expf(z[j] - zmax);
-    const float lse = zmax + logf(se);                       // logits - logsumexp (Categorical.__init__)
-    const int a = static_cast<int>(p.actions[i]);
-    const float nlp = -(z[a] - lse);
-    float H = 0.0f;
-    for (int j = 0; j < p.n; ++j) {
-      const float lp = z[j] - lse;
-      H -= expf(lp) * lp;
+    const unsigned char* am = p.action_masks ? p.action_masks + i * p.n : nullptr;
+    // ---- pass 1: per-branch log-sum-exp, neglogp and entropy (ModelA2CMultiDiscrete sums them,
+    //      models.py:168-173; a single branch is ModelA2C, :95-111)
+    float nlp = 0.0f, H = 0.0f;
+    float lse_b[kMaxBranches], H_b[kMaxBranches];
+    for (int b = 0; b < p.nb; ++b) {
+      const int j0 = p.off[b], j1 = p.off[b + 1];
+      float zmax = masked_logit(p, z, am, j0);
+      for (int j = j0 + 1; j < j1; ++j) zmax = fmaxf(zmax, masked_logit(p, z, am, j));
+      float se = 0.0f;
+      for (int j = j0; j < j1; ++j) se += expf(masked_logit(p, z, am, j) - zmax);
+      const float lse = zmax + logf(se);
+      const int a = j0 + static_cast<int>(p.actions[i * p.nb + b]);
+      nlp += -(masked_logit(p, z, am, a) - lse);
+      float Hb = 0.0f;
+      for (int j = j0; j < j1; ++j) {
+        if (am && !am[j]) continue;
+        const float lp = z[j] - lse;
+        Hb -= expf(lp) * lp;
+      }
+      lse_b[b] = lse;
+      H_b[b] = Hb;
+      H += Hb;
     }
     const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
     const float adv = p.advantages[i];
@@ -446,12 +468,21 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
     const float m = p.mask ? p.mask[i] : 1.0f;
     const float denom = p.mask ? fmaxf(*p.mask_sum, 1.0f) : static_cast<float>(p.mb);
     const float w = m / denom;
-    for (int j = 0; j < p.n; ++j) {
-      const float lp = z[j] - lse;
-      const float pj = expf(lp);
-      const float dnlp = pj - (j == a ? 1.0f : 0.0f);
-      const float dH = -pj * (lp + H);
-      p.d_logits[i * p.n + j] = w * (g_nlp * dnlp - p.entropy_coef * dH);
+    // ---- pass 2: d loss / d logits.  d nlp/d z_j = p_j - [j == a];  d H_b/d z_j = -p_j (log p_j + H_b)
+    for (int b = 0; b < p.nb; ++b) {
+      const int j0 = p.off[b], j1 = p.off[b + 1];
+      const int a = j0 + static_cast<int>(p.actions[i * p.nb + b]);
+      for (int j = j0; j < j1; ++j) {
+        float g = 0.0f;
+        if (!am || am[j]) {
+          const float lp = z[j] - lse_b[b];
+          const float pj = expf(lp);
+          const float dnlp = pj - (j == a ? 1.0f : 0.0f);
+          const float dH = -pj * (lp + H_b[b]);
+          g = w * (g_nlp * dnlp - p.entropy_coef * dH);
+        }
+        p.d_logits[i * p.n + j] = g;
+      }
     }
     p.d_values[i] = (0.5f * p.critic_coef) * g_v * w;
     const float dk = old_nlp - nlp;
@@ -467,7 +498,6 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
     for (int k = 0; k < kLossScalars; ++k) p.partials[static_cast<long long>(blockIdx.x) * kLossScalars + k] = acc[k];
   }
 }
-
 
 // ---------------------------------------------------------------------------------
 // Value-only loss of the central value network - CentralValueTrain.calc_loss
@@ -589,20 +619,27 @@ int rlg_value_loss(const float* values, const float* old_values, const float* re
 int rlg_ppo_loss_discrete_num_blocks(int minibatch) { return (minibatch + 255) / 256; }
 
 int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
-                          const long long* actions, const float* old_neglogp, const float* advantages,
-                          const float* old_values, const float* returns, const float* mask_or_null,
-                          const float* mask_sum_or_null, float* d_logits, float* d_values,
-                          double* partials, int minibatch, int num_actions, float e_clip,
-                          float critic_coef, float entropy_coef, int clip_value, int use_smooth_clamp,
-                          void* stream) {
+                          const long long* actions, const unsigned char* action_masks_or_null,
+                          const int* branch_sizes, int num_branches, const float* old_neglogp,
+                          const float* advantages, const float* old_values, const float* returns,
+                          const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
+                          float* d_values, double* partials, int minibatch, float e_clip, float critic_coef,
+                          float entropy_coef, int clip_value, int use_smooth_clamp, void* stream) {
   using namespace rlg;
-  if (minibatch <= 0 || num_actions <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (minibatch <= 0 || num_branches <= 0 || num_branches > kMaxBranches)
+    return static_cast<int>(hipErrorInvalidValue);
   if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
   DiscreteLossArgs p;
+  p.off[0] = 0;
+  for (int b = 0; b < num_branches; ++b) {
+    if (branch_sizes[b] <= 0) return static_cast<int>(hipErrorInvalidValue);
+    p.off[b + 1] = p.off[b] + branch_sizes[b];
+  }
   p.logits = logits;
   p.ld = ld_logits;
   p.values = values;
   p.actions = actions;
+  p.action_masks = action_masks_or_null;
   p.old_neglogp = old_neglogp;
   p.advantages = advantages;
   p.old_values = old_values;
@@ -613,7 +650,8 @@ int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float*
   p.d_values = d_values;
   p.partials = partials;
   p.mb = minibatch;
-  p.n = num_actions;
+  p.nb = num_branches;
+  p.n = p.off[num_branches];
   p.e_clip = e_clip;
   p.critic_coef = critic_coef;
   p.entropy_coef = entropy_coef;

@@ -306,19 +306,36 @@ def ppo_loss_discrete_blocks(minibatch):
 
 def ppo_loss_discrete(logits, values, actions, old_neglogp, advantages, old_values, returns, d_logits,
                       d_values, partials, e_clip, critic_coef, entropy_coef, clip_value=True,
-                      smooth=False, mask=None, mask_sum=None):
+                      smooth=False, mask=None, mask_sum=None, branch_sizes=None, action_masks=None):
+    """Categorical PPO loss + gradients.  branch_sizes: widths of the multi-discrete heads
+    (default: one head of logits.shape[1]); actions [mb] or [mb, branches] int64; action_masks
+    [mb, n] bool/uint8 or None."""
+    import ctypes
     lib = _lib.load()
     mb, n = logits.shape
     _lib.require_gpu(logits, 'logits')
     if logits.dtype != F32 or logits.stride(1) != 1:
         raise ValueError('logits: fp32 with unit inner stride expected')
+    sizes = [n] if branch_sizes is None else [int(s) for s in branch_sizes]
+    if sum(sizes) != n:
+        raise ValueError(f'branch sizes {sizes} do not add up to {n} logits')
+    if actions.numel() != mb * len(sizes):
+        raise ValueError(f'actions must hold {len(sizes)} indices per row')
+    am = None
+    if action_masks is not None:
+        if action_masks.dtype == torch.bool:
+            action_masks = action_masks.view(torch.uint8)
+        if tuple(action_masks.shape) != (mb, n):
+            raise ValueError('action_masks must be [minibatch, sum(branch sizes)]')
+        am = _need(action_masks, torch.uint8, 'action_masks')
+    arr = (ctypes.c_int * len(sizes))(*sizes)
     _lib.check(lib.rlg_ppo_loss_discrete(
         logits.data_ptr(), logits.stride(0), _need(values, F32, 'values'),
-        _need(actions, torch.int64, 'actions'), _need(old_neglogp, F32, 'old_neglogp'),
+        _need(actions, torch.int64, 'actions'), am, arr, len(sizes), _need(old_neglogp, F32, 'old_neglogp'),
         _need(advantages, F32, 'advantages'), _need(old_values, F32, 'old_values'),
         _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'),
         _need(d_logits, F32, 'd_logits'), _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'),
-        mb, n, float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(entropy_coef)),
+        mb, float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(entropy_coef)),
         1 if clip_value else 0, 1 if smooth else 0, _stream(logits)), 'rlg_ppo_loss_discrete')
 
 

@@ -65,6 +65,62 @@ def test_discrete_loss_kernel_matches_oracle(mb, n, masked, smooth):
     assert err_kv <= max(8 * (ref['d_values'].double() - t_v).abs().max(), 2e-6 * t_v.abs().max())
 
 
+@pytest.mark.parametrize('sizes,with_masks', [([3, 5, 7], True), ([4, 4], False), ([6], True), ([2, 9, 3, 5], True)])
+def test_multi_discrete_masked_loss_kernel_matches_oracle(sizes, with_masks):
+    """Multi-discrete heads (ModelA2CMultiDiscrete) and action masks (CategoricalMasked): scalars,
+    d_logits (zero on masked logits) and d_values vs the oracle; bit-exact zero gradient where masked."""
+    from rl_games_amd import ops
+    mb, n = 777, sum(sizes)
+    g = torch.Generator().manual_seed(n * 13 + len(sizes))
+    logits = torch.randn(mb, n, generator=g) * 1.5
+    values = torch.randn(mb, 1, generator=g)
+    am = None
+    if with_masks:
+        am = torch.rand(mb, n, generator=g) > 0.4
+        o = 0
+        for s in sizes:                      # at least one allowed action per head
+            am[torch.arange(mb), o + torch.randint(0, s, (mb,), generator=g)] = True
+            o += s
+    acts = []
+    o = 0
+    for s in sizes:                          # sample allowed actions
+        w = torch.ones(mb, s) if am is None else am[:, o:o + s].float()
+        acts.append(torch.multinomial(w, 1, generator=g))
+        o += s
+    actions = torch.cat(acts, 1)
+    batch = {'actions': actions, 'advantages': torch.randn(mb, generator=g),
+             'old_values': torch.randn(mb, 1, generator=g), 'returns': torch.randn(mb, 1, generator=g)}
+    hp = dict(e_clip=0.2, clip_value=True, critic_coef=1.0, entropy_coef=0.02)
+    probe = O.categorical_loss_and_grads(logits, values, dict(batch, old_logp_actions=torch.zeros(mb)), hp,
+                                         None, sizes, am)
+    batch['old_logp_actions'] = probe['neglogp'] + 0.3 * torch.randn(mb, generator=g)
+    rowmask = (torch.rand(mb, generator=g) > 0.2).float()
+    ref = O.categorical_loss_and_grads(logits, values, batch, hp, rowmask, sizes, am)
+    ref64 = O.categorical_loss_and_grads(logits.double(), values.double(),
+                                         {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()},
+                                         hp, rowmask.double(), sizes, am)
+    d_logits = torch.full((mb, n), float('nan'), device=DEV)
+    d_val = torch.empty(mb, device=DEV)
+    partials = torch.empty(ops.ppo_loss_discrete_blocks(mb), 7, dtype=torch.float64, device=DEV)
+    row = torch.zeros(8, device=DEV)
+    dm = rowmask.to(DEV)
+    ops.ppo_loss_discrete(logits.to(DEV), values.to(DEV).reshape(-1), actions.to(DEV).contiguous(),
+                          batch['old_logp_actions'].to(DEV), batch['advantages'].to(DEV),
+                          batch['old_values'].to(DEV).reshape(-1), batch['returns'].to(DEV).reshape(-1),
+                          d_logits, d_val, partials, 0.2, 1.0, 0.02, True, False, dm, dm.sum().reshape(1),
+                          branch_sizes=sizes, action_masks=None if am is None else am.to(DEV))
+    ops.ppo_loss_finalize(partials, partials.shape[0], 0, mb, True, 1.0, 0.02, 0.0, row, torch.zeros(1, device=DEV))
+    row = row.cpu()
+    for i, k in ((0, 'a_loss'), (1, 'c_loss'), (2, 'entropy'), (4, 'kl'), (5, 'loss')):
+        assert torch.allclose(row[i], ref[k].float(), rtol=2e-5, atol=2e-6), (k, row[i], ref[k])
+    t_l = ref64['d_logits']
+    err_k = (d_logits.cpu().double() - t_l).abs().max()
+    err_o = (ref['d_logits'].double() - t_l).abs().max()
+    assert err_k <= max(8 * err_o, 2e-6 * t_l.abs().max()), (err_k, err_o)
+    if am is not None:
+        assert torch.count_nonzero(d_logits.cpu()[~am]) == 0
+
+
 def _make_agent(cap, **over):
     from rl_games_amd.discrete_agent import DiscreteA2CAgent
     params = copy.deepcopy(cap['params'])
