@@ -142,8 +142,6 @@ class A2CAgent:
         self.algo_observer.before_init(base_name, config, self.experiment_name)
         self.network = config['network'] = PolicyBuilder(params)          # load_networks :516-525
         self.central_value_config = config.get('central_value_config', None)
-        if config.get('use_action_masks', False):
-            raise NotImplementedError('action masks are not implemented for continuous actions')
 
         # ---- ranks / device (a2c_common.py:193-220) ----
         self.multi_gpu = config.get('multi_gpu', False)
@@ -192,7 +190,9 @@ class A2CAgent:
             if type(self.state_space).__name__ == 'Dict':
                 raise NotImplementedError('dict state spaces are not implemented on the MI355X hot path')
             self.state_shape = self.state_space.shape
-        self.use_action_masks = False
+        self.use_action_masks = bool(config.get('use_action_masks', False))
+        if self.use_action_masks and not self._supports_action_masks():
+            raise NotImplementedError('action masks are not implemented for continuous actions')
         self.is_train = config.get('is_train', True)
 
         self.save_freq = config.get('save_frequency', 0)
@@ -417,6 +417,9 @@ class A2CAgent:
     def _rollout_fields(self):
         return ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
 
+    def _supports_action_masks(self):
+        return False
+
     # ================================================================== small helpers
     @property
     def device(self):
@@ -568,7 +571,7 @@ class A2CAgent:
     def init_tensors(self):
         rows = self.num_agents * self.num_actors
         algo_info = {'num_actors': self.num_actors, 'horizon_length': self.horizon_length,
-                     'has_central_value': self.has_central_value, 'use_action_masks': False}
+                     'has_central_value': self.has_central_value, 'use_action_masks': self.use_action_masks}
         self.experience_buffer = ExperienceBuffer(self.env_info, algo_info, self.ppo_device)
         self.init_current_rewards(rows, (rows, self.value_size))
         dev = self.ppo_device
@@ -755,7 +758,10 @@ class A2CAgent:
             if fast:
                 res_dict = self._fast_policy_step(n)
             else:
-                res_dict = self.get_action_values(self.obs)
+                if self.use_action_masks:                        # a2c_common.py:995-997
+                    res_dict = self.get_masked_action_values(self.obs, self.vec_env.get_action_masks())
+                else:
+                    res_dict = self.get_action_values(self.obs)
                 fields = {'obses': self.obs['obs'], 'dones': self.dones}
                 for k in self.update_list:
                     fields[k] = res_dict[k]
@@ -899,6 +905,8 @@ class A2CAgent:
         }
         if not self.is_discrete:
             dataset_dict['mu'], dataset_dict['sigma'] = batch_dict['mus'], batch_dict['sigmas']
+        if self.use_action_masks:                                    # a2c_common.py:1346-1347
+            dataset_dict['action_masks'] = batch_dict['action_masks']
         self.dataset.update_values_dict(dataset_dict)
         if self.has_central_value:                                   # a2c_common.py:1651-1660
             self.central_value_net.update_dataset({

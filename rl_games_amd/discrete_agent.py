@@ -3,8 +3,9 @@
 rl_games/common/a2c_common.py:1204-1359), BASELINE.json config #1 (CartPole-shaped).
 
 Shares the rollout / GAE / dataset-preparation / optimiser path with `A2CAgent`; what differs:
-  * single `Discrete` action space, int64 actions, update_list without mus/sigmas
-    (a2c_common.py:1224-1229);
+  * `Discrete` or `Tuple`-of-`Discrete` (multi-discrete) action spaces, int64 actions, update_list
+    without mus/sigmas, optional action masks from `vec_env.get_action_masks()` with
+    CategoricalMasked semantics (a2c_common.py:995-997,1224-1229; a2c_discrete.py:92-114);
   * the minibatch loss is the categorical one, a single fused HIP kernel
     (csrc/ppo_loss.hip `ppo_loss_discrete_kernel`) that emits d loss/d logits and d loss/d value;
     the MLP backward runs through autograd (`torch.autograd.backward` on the two heads);
@@ -22,22 +23,31 @@ class DiscreteA2CAgent(A2CAgent):
         """DiscreteA2CBase.__init__ (a2c_common.py:1206-1222)."""
         action_space = self.env_info['action_space']
         kind = type(action_space).__name__
-        if kind == 'Tuple':
-            raise NotImplementedError('multi-discrete action spaces are not implemented on the MI355X path')
-        if kind != 'Discrete':
+        rows = self.num_agents * self.num_actors
+        if kind == 'Discrete':
+            self.actions_shape = (self.horizon_length, rows)
+            self.actions_num = int(action_space.n)
+            self.branch_sizes = [self.actions_num]
+            self.is_multi_discrete = False
+        elif kind == 'Tuple':
+            self.actions_shape = (self.horizon_length, rows, len(action_space))
+            self.actions_num = [int(a.n) for a in action_space]
+            self.branch_sizes = list(self.actions_num)
+            self.is_multi_discrete = True
+        else:
             raise ValueError(f'Unsupported action space type for DiscreteA2CBase: {type(action_space)}')
         self.is_discrete = True
-        self.is_multi_discrete = False
-        self.actions_num = int(action_space.n)
-        self.actions_shape = (self.horizon_length, self.num_agents * self.num_actors)
         self.bounds_loss_coef = None
         self.clip_actions = False
         # the reference's discrete train_epoch has no per-minibatch scheduling: it always updates
         # the lr once per mini-epoch with the mean KL - the base class's 'standard' schedule
         self.schedule_type = 'standard'
 
+    def _supports_action_masks(self):
+        return True
+
     def _alloc_loss_scratch(self, mb, dev):
-        self._d_logits = torch.empty(mb, self.actions_num, dtype=torch.float32, device=dev)
+        self._d_logits = torch.empty(mb, sum(self.branch_sizes), dtype=torch.float32, device=dev)
         self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
         self._loss_blocks = ops.ppo_loss_discrete_blocks(mb)
         self._loss_partials = torch.empty(self._loss_blocks, ops.ppo_loss_partials_per_block(0),
@@ -45,7 +55,21 @@ class DiscreteA2CAgent(A2CAgent):
         self._no_logstd = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def _rollout_fields(self):
-        return ['actions', 'neglogpacs', 'values']
+        fields = ['actions', 'neglogpacs', 'values']               # a2c_common.py:1224-1229
+        return fields + ['action_masks'] if self.use_action_masks else fields
+
+    def get_masked_action_values(self, obs, action_masks):
+        """a2c_discrete.py:92-114.  action_masks: bool [rows, sum(head sizes)] (numpy or tensor)."""
+        processed_obs = self._preproc_obs(obs['obs'])
+        action_masks = torch.as_tensor(action_masks, dtype=torch.bool, device=self.ppo_device)
+        self.model.eval()
+        with torch.no_grad():
+            res_dict = self.model({'is_train': False, 'prev_actions': None, 'obs': processed_obs,
+                                   'action_masks': action_masks, 'rnn_states': self.rnn_states})
+            if self.has_central_value:
+                res_dict['values'] = self.get_central_value({'is_train': False, 'states': obs['states']})
+        res_dict['action_masks'] = action_masks
+        return res_dict
 
     def preprocess_actions(self, actions):
         """a2c_common.py:736-739 - discrete actions go to the env as they are."""
@@ -79,10 +103,12 @@ class DiscreteA2CAgent(A2CAgent):
                                   input_dict['actions'], input_dict['old_logp_actions'],
                                   input_dict['advantages'], input_dict['old_values'].reshape(-1),
                                   input_dict['returns'].reshape(-1), d_logits, d_val, self._loss_partials,
-                                  self.e_clip, self.critic_coef, self.entropy_coef, self.clip_value,
-                                  self.use_smooth_clamp, mask, mask_sum)
+                                  self.e_clip, self.critic_coef if self.has_value_loss else 0.0,
+                                  self.entropy_coef, self.clip_value, self.use_smooth_clamp, mask, mask_sum,
+                                  branch_sizes=self.branch_sizes, action_masks=input_dict.get('action_masks'))
             ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_discrete_blocks(mb), 0, mb,
-                                  mask is not None, self.critic_coef, self.entropy_coef, 0.0, row,
+                                  mask is not None, self.critic_coef if self.has_value_loss else 0.0,
+                                  self.entropy_coef, 0.0, row,
                                   self._no_logstd, opt.kl_slot)
         torch.autograd.backward([logits, values], [d_logits, d_val.view(mb, 1)])
 

@@ -103,9 +103,8 @@ class ActorCriticNetwork(nn.Module):
             self._init_central_value(net_params, input_shape, value_size, num_seqs)
             return
         space = net_params.get('space', {})
-        self.is_discrete = 'discrete' in space
-        if 'multi_discrete' in space:
-            raise NotImplementedError('multi-discrete action spaces are not implemented on this path')
+        self.is_multi_discrete = 'multi_discrete' in space
+        self.is_discrete = 'discrete' in space or self.is_multi_discrete
         if self.is_discrete:
             self._init_discrete(net_params, actions_num, input_shape, value_size, num_seqs)
             return
@@ -206,12 +205,21 @@ class ActorCriticNetwork(nn.Module):
             self.critic_mlp = self._mlp_like(input_shape[0], mlp['activation'])
         self.value = nn.Linear(last, value_size)
         self.value_act = _activation(net_params.get('value_activation', 'None'))
-        self.logits = nn.Linear(last, actions_num)
+        if self.is_multi_discrete:                              # network_builder.py:303-304
+            self.logits = nn.ModuleList([nn.Linear(last, int(n)) for n in actions_num])
+        else:
+            self.logits = nn.Linear(last, actions_num)
         mlp_init = _initializer(mlp['initializer'])
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 mlp_init(m.weight)
                 nn.init.zeros_(m.bias)
+
+    def head_logits(self, out):
+        """Single head: tensor [B, n]; multi-discrete: list of [B, n_b] (network_builder.py:431-436)."""
+        if self.is_multi_discrete:
+            return [head(out) for head in self.logits]
+        return self.logits(out)
 
     def _mlp_like(self, in_size, activation):
         layers, last = [], in_size
@@ -267,8 +275,8 @@ class ActorCriticNetwork(nn.Module):
         value = self.value_act(self.value(self.critic_features(obs_dict['obs'], out)))
         if self.central_value:                                  # (value, states) :497-498
             return value, states
-        if self.is_discrete:                                   # (logits, value, states) :431-433,:500-502
-            return self.logits(out), value, states
+        if self.is_discrete:                                   # (logits, value, states) :431-436,:500-504
+            return self.head_logits(out), value, states
         mu = self.mu_act(self.mu(out))
         sigma = self.sigma_act(self.sigma)
         return mu, mu * 0 + sigma, value, states
@@ -347,33 +355,63 @@ class ContinuousA2CLogStdModel(nn.Module):
 
 
 class DiscreteA2CModel(ContinuousA2CLogStdModel):
-    """The reference's `ModelA2C.Network` contract (models.py:66-125) without action masks:
-    Categorical(logits) sampling in rollout, neglogp/entropy in training."""
+    """The reference's `ModelA2C.Network` / `ModelA2CMultiDiscrete.Network` contracts
+    (models.py:66-125, :128-206): Categorical heads (one, or one per sub-action), optional action
+    masks with CategoricalMasked semantics (common/extensions/distributions.py:24-47)."""
+
+    @staticmethod
+    def _dist(logits, masks):
+        if masks is None:
+            cat = torch.distributions.Categorical(logits=logits)
+            return cat, cat.entropy()
+        floor = torch.tensor(-1e+8, dtype=logits.dtype, device=logits.device)
+        cat = torch.distributions.Categorical(logits=torch.where(masks, logits, floor))
+        p_log_p = torch.where(masks, cat.logits * cat.probs, torch.zeros((), dtype=logits.dtype, device=logits.device))
+        return cat, -p_log_p.sum(-1)
+
+    def branch_sizes(self):
+        net = self.a2c_network
+        if net.is_multi_discrete:
+            return [head.out_features for head in net.logits]
+        return [net.logits.out_features]
 
     def forward_heads(self, input_dict):
-        """Training fast path: (logits [B,n], value [B,V]) for the fused categorical loss kernel."""
+        """Training fast path: (logits [B, sum(branch sizes)] with the heads concatenated, value
+        [B, V]) for the fused categorical loss kernel."""
         obs = self.norm_obs(input_dict['obs'])
         net = self.a2c_network
         out, _ = net.trunk(obs)
-        return net.logits(out), net.value_act(net.value(net.critic_features(obs, out)))
+        logits = net.head_logits(out)
+        if net.is_multi_discrete:
+            logits = torch.cat(logits, dim=1)
+        return logits, net.value_act(net.value(net.critic_features(obs, out)))
 
     def forward(self, input_dict):
         is_train = input_dict.get('is_train', True)
-        if input_dict.get('action_masks', None) is not None:
-            raise NotImplementedError('action masks are not implemented on this path')
+        action_masks = input_dict.get('action_masks', None)
         prev_actions = input_dict.get('prev_actions', None)
         input_dict = dict(input_dict)
         input_dict['obs'] = self.norm_obs(input_dict['obs'])
         logits, value, states = self.a2c_network(input_dict)
-        categorical = torch.distributions.Categorical(logits=logits)
+        multi = self.a2c_network.is_multi_discrete
+        heads = logits if multi else [logits]
+        if action_masks is None:
+            masks = [None] * len(heads)
+        else:
+            masks = torch.split(action_masks.bool(), [h.shape[-1] for h in heads], dim=1)
+        dists = [self._dist(h, m) for h, m in zip(heads, masks)]
+        norm_logits = [d.logits for d, _ in dists]
         if is_train:
-            prev_neglogp = -categorical.log_prob(prev_actions)
-            return {'prev_neglogp': torch.squeeze(prev_neglogp), 'logits': categorical.logits,
-                    'values': value, 'entropy': categorical.entropy(), 'rnn_states': states}
-        selected_action = categorical.sample().long()
-        neglogp = -categorical.log_prob(selected_action)
-        return {'neglogpacs': torch.squeeze(neglogp), 'values': self.denorm_value(value),
-                'actions': selected_action, 'logits': categorical.logits, 'rnn_states': states}
+            acts = prev_actions.reshape(prev_actions.shape[0], len(heads))
+            neglogp = sum(-d.log_prob(acts[:, b]) for b, (d, _) in enumerate(dists))
+            entropy = sum(h for _, h in dists)
+            return {'prev_neglogp': torch.squeeze(neglogp), 'logits': norm_logits if multi else norm_logits[0],
+                    'values': value, 'entropy': torch.squeeze(entropy), 'rnn_states': states}
+        selected = [d.sample().long() for d, _ in dists]
+        neglogp = sum(-d.log_prob(a) for (d, _), a in zip(dists, selected))
+        actions = torch.stack(selected, dim=-1) if multi else selected[0]
+        return {'neglogpacs': torch.squeeze(neglogp), 'values': self.denorm_value(value), 'actions': actions,
+                'logits': norm_logits if multi else norm_logits[0], 'rnn_states': states}
 
 
 class CentralValueModel(ContinuousA2CLogStdModel):
@@ -401,7 +439,7 @@ class PolicyBuilder:
     def __init__(self, params):
         model_name = params.get('model', {}).get('name', 'continuous_a2c_logstd')
         net_name = params.get('network', {}).get('name', 'actor_critic')
-        if model_name not in ('continuous_a2c_logstd', 'discrete_a2c', 'central_value'):
+        if model_name not in ('continuous_a2c_logstd', 'discrete_a2c', 'multi_discrete_a2c', 'central_value'):
             raise NotImplementedError(f"model '{model_name}' is not implemented on the MI355X PPO path")
         self.model_name = model_name
         if net_name != 'actor_critic':
@@ -420,8 +458,9 @@ class PolicyBuilder:
                                      normalize_value=config.get('normalize_value', False),
                                      normalize_input=config.get('normalize_input', False),
                                      value_size=config.get('value_size', 1))
-        cls = DiscreteA2CModel if self.model_name == 'discrete_a2c' else ContinuousA2CLogStdModel
-        if (self.model_name == 'discrete_a2c') != net.is_discrete:
+        discrete_model = self.model_name in ('discrete_a2c', 'multi_discrete_a2c')
+        cls = DiscreteA2CModel if discrete_model else ContinuousA2CLogStdModel
+        if discrete_model != net.is_discrete or (self.model_name == 'multi_discrete_a2c') != net.is_multi_discrete:
             raise ValueError(f"model '{self.model_name}' does not match the network's action space")
         return cls(net, obs_shape=config['input_shape'],
                                         normalize_value=config.get('normalize_value', False),

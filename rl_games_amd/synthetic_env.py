@@ -8,12 +8,13 @@ torch device so that the CPU baseline drives the very same environment."""
 import numpy as np
 import torch
 
-from .spaces import Box, Discrete
+from .spaces import Box, Discrete, Tuple
 
 
 class SyntheticTensorEnv:
     def __init__(self, num_envs, obs_dim, act_dim=0, device='cuda:0', seed=1234, p_done=0.05,
-                 value_size=1, discrete_actions=None, autoreset_mode='same_step', state_dim=0, agents=1):
+                 value_size=1, discrete_actions=None, autoreset_mode='same_step', state_dim=0, agents=1,
+                 action_masks=False):
         self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
         self.autoreset_mode = autoreset_mode
         self.agents = agents            # agents per env: every per-step tensor has num_envs * agents rows
@@ -24,8 +25,13 @@ class SyntheticTensorEnv:
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
-        if discrete_actions is not None:          # CartPole-like (BASELINE config #1)
+        self.action_masks = bool(action_masks)    # discrete only: random masks, >= 1 allowed action per head
+        if isinstance(discrete_actions, (list, tuple)):
+            self.action_space = Tuple([Discrete(n) for n in discrete_actions])      # multi-discrete
+            self.head_sizes = [int(n) for n in discrete_actions]
+        elif discrete_actions is not None:        # CartPole-like (BASELINE config #1)
             self.action_space = Discrete(discrete_actions)
+            self.head_sizes = [int(discrete_actions)]
         else:
             self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
 
@@ -59,7 +65,21 @@ class SyntheticTensorEnv:
         return info
 
     def has_action_masks(self):
-        return False
+        return self.action_masks
+
+    def get_action_masks(self):
+        """bool [rows, sum(head sizes)] - numpy on the CPU (the reference wraps it in torch.BoolTensor,
+        a2c_discrete.py:94), a device tensor otherwise."""
+        rows = self.num_envs * self.agents
+        total = sum(self.head_sizes)
+        masks = torch.rand(rows, total, device=self.device, generator=self.gen) > 0.4
+        pick = torch.rand(rows, len(self.head_sizes), device=self.device, generator=self.gen)
+        at = 0
+        for b, n in enumerate(self.head_sizes):
+            forced = at + (pick[:, b] * n).long().clamp(max=n - 1)
+            masks[torch.arange(rows, device=self.device), forced] = True
+            at += n
+        return masks.cpu().numpy() if self.device.type == 'cpu' else masks
 
     def get_number_of_agents(self):
         return self.agents

@@ -188,6 +188,9 @@ def make_discrete():
         'masked_adaptive': dict(normalize_input=True, normalize_value=True, lr_schedule='adaptive',
                                 learning_rate=3e-4, kl_threshold=0.002, p_done=0.15),
         'plain': dict(_autoreset='same_step', entropy_coef=0.02, p_done=0.05),
+        # ModelA2CMultiDiscrete + CategoricalMasked: two heads (3 and 4 actions), random action masks
+        'multi_discrete_masked': dict(_autoreset='same_step', _heads=[3, 4], _masks=True, entropy_coef=0.02,
+                                      p_done=0.05, normalize_input=True),
     }
     out = {}
     for name, over in variants.items():
@@ -195,9 +198,17 @@ def make_discrete():
         N, H, O_, n_act = 16, 8, 4, 3
         p_done = over.pop('p_done')
         mode = over.pop('_autoreset', 'next_step')
+        heads = over.pop('_heads', None)
+        masks = over.pop('_masks', False)
         params = configs.cartpole_discrete(num_actors=N, horizon_length=H, minibatch_size=32, mini_epochs=2,
                                            device='cpu', train_dir='/tmp/rlg_golden_runs', **over)
-        env_kw = dict(obs_dim=O_, discrete_actions=n_act, autoreset_mode=mode, p_done=p_done, seed=99)
+        env_kw = dict(obs_dim=O_, discrete_actions=heads or n_act, autoreset_mode=mode, p_done=p_done, seed=99,
+                      action_masks=masks)
+        if heads:
+            params['network']['space'] = {'multi_discrete': None}
+            params['model']['name'] = 'multi_discrete_a2c'
+        if masks:
+            params['config']['use_action_masks'] = True
         params['config']['env_config'] = dict(env_kw)
         params['seed'] = 5
         env = SyntheticTensorEnv(N, device='cpu', **env_kw)
@@ -247,6 +258,8 @@ def make_discrete():
         vd = agent.dataset.values_dict
         cap['dataset'] = _clone({k: vd[k] for k in ('old_values', 'returns', 'advantages', 'actions',
                                                       'old_logp_actions')})
+        if masks:
+            cap['dataset']['action_masks'] = _clone(vd['action_masks'])
         cap['final_state'] = _clone(agent.model.state_dict())
         cap['params'] = stored_params
         cap['num_envs'] = N

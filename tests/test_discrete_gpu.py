@@ -133,7 +133,7 @@ def _make_agent(cap, **over):
     return agent
 
 
-@pytest.mark.parametrize('variant', ['masked_adaptive', 'plain'])
+@pytest.mark.parametrize('variant', ['masked_adaptive', 'plain', 'multi_discrete_masked'])
 def test_discrete_update_matches_reference_epoch(golden, variant):
     cap = golden('discrete.pt')[variant]
     agent = _make_agent(cap)
@@ -146,6 +146,8 @@ def test_discrete_update_matches_reference_epoch(golden, variant):
     for k in ('old_values', 'returns', 'advantages'):
         assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
     assert torch.equal(vd['actions'].cpu(), ds['actions'])
+    if 'action_masks' in ds:
+        assert agent.use_action_masks and torch.equal(vd['action_masks'].cpu(), ds['action_masks'])
     rows, lrs = [], []
     nmb = len(agent.dataset)
     for mini_ep in range(agent.mini_epochs_num):
@@ -195,3 +197,28 @@ def test_discrete_train_epoch_runs_on_cartpole_shaped_config():
     assert vd['rnn_masks'] is not None
     moved = [k for k, v in agent.model.state_dict().items() if not torch.equal(v, before[k])]
     assert any('logits' in k for k in moved) and any('critic_mlp' in k for k in moved)
+
+
+def test_multi_discrete_masked_train_epoch_runs():
+    """Multi-discrete policy with action masks end to end: sampled actions respect the masks, the
+    masks travel through buffer and dataset, losses stay finite."""
+    from rl_games_amd import configs
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    params = configs.cartpole_discrete(num_actors=32, use_action_masks=True)
+    params['network']['space'] = {'multi_discrete': None}
+    params['model']['name'] = 'multi_discrete_a2c'
+    params['config']['env_config'].update(discrete_actions=[3, 5, 2], action_masks=True, autoreset_mode='same_step')
+    agent = DiscreteA2CAgent('md', params)
+    assert agent.is_multi_discrete and agent.branch_sizes == [3, 5, 2]
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    for _ in range(2):
+        agent.epoch_num += 1
+        res = agent.train_epoch()
+    assert all(torch.isfinite(x).all() for x in res[4] + res[5] + res[6])
+    vd = agent.dataset.values_dict
+    acts, am = vd['actions'], vd['action_masks']
+    assert acts.shape == (32 * 32, 3) and am.shape == (32 * 32, 10) and am.dtype == torch.bool
+    offs = [0, 3, 8]
+    for b in range(3):                       # every sampled sub-action was allowed by its mask
+        assert am.gather(1, (acts[:, b] + offs[b]).view(-1, 1)).all()
