@@ -34,6 +34,7 @@ GLOBAL_ENVS = 65536
 HORIZON = 32
 GLOBAL_MINIBATCH = 32768
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 GAE_BYTES_PER_ENV_STEP = 17   # r 4 + v 4 + done 1 read, returns 4 + advantages 4 written
 
 
@@ -146,6 +147,32 @@ def main():
     gae_bytes = envs * HORIZON * GAE_BYTES_PER_ENV_STEP
     achieved = gae_bytes / (gae_us * 1e-6) / 1e9 if gae_us > 0 else 0.0
 
+    # second roofline: the f32-MFMA weight-gradient launch (the largest single kernel of the epoch).
+    # Timed with HIP events around back-to-back launches on the last minibatch's own operands,
+    # AFTER the timed region (inside it the launch is a node of a replayed HIP graph).
+    mfma = None
+    eng = getattr(agent, '_engine', None)
+    if eng is not None and getattr(eng, 'last_dw_jobs', None):
+        jobs, plan = eng.last_dw_jobs
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            plan.launch(jobs)
+        reps = 20
+        ev0.record()
+        for _ in range(reps):
+            plan.launch(jobs)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / reps
+        rows = jobs[0][0].shape[0]
+        flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
+        mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch)',
+                'bound': 'mfma', 'achieved': flops / us / 1e6, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'algorithmic_flops_per_launch': flops, 'avg_launch_us': us, 'launches': reps,
+                'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
+                        '(v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); timed after the timed region'}
+
     traffic = None
     try:   # PMC counters cannot be read inside a normal run: measured offline, see profiles/r1_gae_pmc.txt
         with open(os.path.join(ROOT, 'profiles', 'gae_pmc_traffic.json')) as f:
@@ -178,6 +205,8 @@ def main():
                 'timing': 'HIP start/stop events attached to each in-epoch GAE dispatch on its launch stream (hipExtLaunchKernelGGL), timed region',
             },
         }
+        if mfma is not None:
+            out['roofline_mfma'] = mfma
         if in_sync is not None:
             out['config']['ranks_in_sync'] = in_sync
         if world == 1 and not args.no_cpu_baseline:

@@ -35,6 +35,7 @@ class ManualMLP:
         self.mfma_dw = mfma_dw
         self._dw_plans = {}
         self.last_dw_path = None
+        self.last_dw_jobs = None
         self.arena = arena
         self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
         acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
@@ -239,6 +240,7 @@ class ManualMLP:
                 self._dw_plans[key] = plan
             if plan:
                 plan.launch(fast)
+                self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run
             else:
                 slow = slow + fast
                 fast = []
