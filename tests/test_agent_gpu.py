@@ -668,3 +668,53 @@ def test_multi_agent_env_rows():
     assert all(torch.isfinite(x) for x in out[4] + out[5])
     assert agent.experience_buffer.tensor_dict['obses'].shape == (8, 64, 12)
     assert agent.dataset.values_dict['obs'].shape == (512, 12)
+
+
+@pytest.mark.parametrize('N,H,obs_dim,act_dim,units,mbs', [
+    (37, 5, 7, 3, [20, 12], 37),          # nothing a multiple of 4 or 64: strided GAE, library dW for layer 1
+    (96, 12, 16, 2, [64, 32], 288),       # H multiple of 4 but not 16
+    (130, 16, 33, 5, [48, 24, 16], 520),  # ragged last GAE tile, odd obs width
+    (64, 64, 8, 1, [32], 1024),           # maximum fused horizon, single hidden layer, one action
+    (256, 4, 12, 21, [100, 52], 512),     # minimum fused horizon, BASELINE action count
+])
+def test_odd_shapes_match_oracle_epoch(N, H, obs_dim, act_dim, units, mbs):
+    """Shape robustness of the whole path (fused/strided GAE, ragged tiles, MFMA vs library weight
+    gradients, head GEMM paths): per-minibatch losses of a full update against the CPU oracle on the
+    same rollout, for shapes with no convenient alignment."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=N, horizon=H, obs_dim=obs_dim, act_dim=act_dim, minibatch_size=mbs,
+                          mini_epochs=2)
+    params['network']['mlp']['units'] = list(units)
+    agent = A2CAgent('odd', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps()
+    oracle = OracleAgent(copy.deepcopy(params), SyntheticTensorEnv(N, obs_dim, act_dim, device='cpu', seed=1))
+    oracle.model.load_full_state_dict({k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()})
+    ref = oracle.update({k: v.detach().cpu().clone() for k, v in batch.items() if isinstance(v, torch.Tensor)})
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    vd = agent.dataset.values_dict
+    assert torch.allclose(vd['advantages'].cpu(), oracle.dataset['advantages'], rtol=1e-5, atol=1e-6)
+    k = 0
+    for _ in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            res = agent.train_actor_critic(agent.dataset[i])
+            for got, key in ((res[0], 'a_loss'), (res[1], 'c_loss'), (res[2], 'entropy'), (res[3], 'kl'),
+                             (res[8], 'b_loss')):
+                assert np.isclose(got.item(), ref[k][key].item(), rtol=2e-4, atol=1e-5), (k, key, got.item(), ref[k][key].item())
+            k += 1
+    assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
+    final = agent.model.state_dict()
+    want = oracle.model.full_state_dict()
+    for name, v in want.items():
+        if v.is_floating_point():
+            assert torch.allclose(final[name].cpu().to(v.dtype), v, rtol=2e-3, atol=1e-5), name
+    # and two more epochs through the public entry point (HIP graphs from the 2nd on)
+    for _ in range(2):
+        agent.update_epoch()
+        out = agent.train_epoch()
+    assert all(torch.isfinite(x) for x in out[4] + out[5])
