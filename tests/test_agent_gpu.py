@@ -683,7 +683,8 @@ def test_odd_shapes_match_oracle_epoch(N, H, obs_dim, act_dim, units, mbs):
     same rollout, for shapes with no convenient alignment."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
-    params = configs.tiny(num_actors=N, horizon=H, obs_dim=obs_dim, act_dim=act_dim, minibatch_size=mbs)
+    params = configs.tiny(num_actors=N, horizon=H, obs_dim=obs_dim, act_dim=act_dim, minibatch_size=mbs,
+                          seq_length=1)      # PPODataset wants batch % seq_length == 0, like the reference
     params['network']['mlp']['units'] = list(units)
     agent = A2CAgent('odd', copy.deepcopy(params))
     agent.init_tensors()
