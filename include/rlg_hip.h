@@ -326,9 +326,13 @@ int rlg_mlp_linear_act_backward(const float* dz, long long lddz, const float* w,
  * rlg_mlp_dw_plan fills plan4 = {bo, tiles_o, tiles_i, ksplit} for one layer and returns the
  * workspace size in floats (-1: shape unsupported, use the library GEMM). */
 long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4);
+/* colsum_* (num_colsums may be 0): bias gradients `grad_output.sum(0)` finished in the same finalise
+ * launch from the per-block fp64 column sums of rlg_act_bwd_colsum (partials [blocks][cols]). */
 int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
                       float* const* grad, const int* out_features, const int* in_features,
-                      const int* plans4, int rows, void* stream);
+                      const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
+                      const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
+                      void* stream);
 
 /* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
  * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state

@@ -65,7 +65,7 @@ _PROTOTYPES = {
     'rlg_mlp_linear_act_forward': [_P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_linear_act_backward': [_P, _c_ll, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
-    'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
+    'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P],
     'rlg_lstm_supported': [_c_int],
     'rlg_lstm_seq_forward': [_P] * 10 + [_c_int, _c_int, _c_int, _P],
     'rlg_lstm_seq_backward': [_P] * 7 + [_c_int, _c_int, _c_int, _P],

@@ -51,6 +51,17 @@ struct DwArgs {
   int rows;
 };
 
+// Bias gradients ride along in the finalise launch: out[c] = sum_b partials[b][c] over the
+// per-block fp64 column sums that rlg_act_bwd_colsum left behind (one item per hidden layer).
+struct ColsumItems {
+  const double* partials[kDwMaxLayers];
+  float* out[kDwMaxLayers];
+  int nblocks[kDwMaxLayers];
+  int cols[kDwMaxLayers];
+  int count;
+  int first_block;     // blockIdx.x of the first column-sum block (after the dW finalise blocks)
+};
+
 template <int BO> struct VecOf;
 template <> struct VecOf<1> { using type = float; };
 template <> struct VecOf<2> { using type = f32x2; };
@@ -222,8 +233,37 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
 // grad[e] = sum_z partial[z][e].  64 float4 elements x 4 z-groups per block: group g sums the
 // slices z = g, g+4, ... (4 independent loads in flight), the groups are combined through LDS in a
 // fixed order, so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args) {
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs) {
   __shared__ f32x4 part[4][64];
+  if (static_cast<int>(blockIdx.x) >= cs.first_block) {
+    // ---- bias-gradient blocks: 32 columns x 8 row-slices per block, slices combined in order
+    __shared__ double cpart[8][33];
+    int b = blockIdx.x - cs.first_block;
+    int item = 0;
+#pragma unroll 1
+    for (int k = 0; k < cs.count; ++k) {
+      const int nb = (cs.cols[k] + 31) / 32;
+      if (b < nb) { item = k; break; }
+      b -= nb;
+    }
+    const int C = cs.cols[item];
+    const int col = b * 32 + (threadIdx.x & 31);
+    const int slice = threadIdx.x >> 5;
+    double s = 0.0;
+    if (col < C) {
+      const double* src = cs.partials[item] + col;
+      for (int r = slice; r < cs.nblocks[item]; r += 8) s += src[static_cast<long long>(r) * C];
+    }
+    cpart[slice][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (slice == 0 && col < C) {
+      double t = cpart[0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += cpart[k][threadIdx.x];
+      cs.out[item][col] = static_cast<float>(t);
+    }
+    return;
+  }
   int l = 0;
   int base = 0;
 #pragma unroll 1
@@ -293,9 +333,13 @@ long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int targe
 // All layers in one launch.  Arrays are indexed by layer; plans from rlg_mlp_dw_plan.
 int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
                       float* const* grad, const int* out_features, const int* in_features,
-                      const int* plans4, int rows, void* stream) {
+                      const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
+                      const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
+                      void* stream) {
   using namespace rlg;
-  if (num_layers <= 0 || num_layers > kDwMaxLayers || rows <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (num_layers <= 0 || num_layers > kDwMaxLayers || rows <= 0 || num_colsums < 0 ||
+      num_colsums > kDwMaxLayers)
+    return static_cast<int>(hipErrorInvalidValue);
   DwArgs args;
   args.num_layers = num_layers;
   args.rows = rows;
@@ -320,9 +364,21 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     blocks += L.tiles_o * L.tiles_i * L.ksplit;
     fin_blocks += ((L.No * L.Mi) / 4 + 63) / 64;
   }
+  ColsumItems cs;
+  cs.count = num_colsums;
+  cs.first_block = fin_blocks;
+  int cs_blocks = 0;
+  for (int k = 0; k < num_colsums; ++k) {
+    if (colsum_cols[k] <= 0 || colsum_blocks[k] <= 0) return static_cast<int>(hipErrorInvalidValue);
+    cs.partials[k] = colsum_partials[k];
+    cs.out[k] = colsum_out[k];
+    cs.nblocks[k] = colsum_blocks[k];
+    cs.cols[k] = colsum_cols[k];
+    cs_blocks += (colsum_cols[k] + 31) / 32;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
-  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(fin_blocks), dim3(256), 0, st, args);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(fin_blocks + cs_blocks), dim3(256), 0, st, args, cs);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -180,6 +180,7 @@ class ManualMLP:
         rows = self._rows
         L = len(self.linears)
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
+        colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
             rnn = self.lstm
             d_out = self.d_rnn_out[:rows]
@@ -191,8 +192,8 @@ class ManualMLP:
             nbg = ops.act_bwd_blocks(rows, G)
             gpart = self.gate_partials[:nbg * G]
             ops.act_bwd_colsum(dg, None, dg, 0, gpart, nbg)          # identity: column sums only
-            ops.colsum_finalize(gpart, nbg, G, rnn.bias_ih_l0.grad)
-            rnn.bias_hh_l0.grad.copy_(rnn.bias_ih_l0.grad)
+            colsums.append((gpart, nbg, G, rnn.bias_ih_l0.grad))
+            colsums.append((gpart, nbg, G, rnn.bias_hh_l0.grad))     # d b_hh = d b_ih
             jobs.append((dg, self.hprev[:rows], rnn.weight_hh_l0.grad))
             jobs.append((dg, self._rnn_in, rnn.weight_ih_l0.grad))
             d = self.dA[L - 1][:rows]
@@ -206,16 +207,16 @@ class ManualMLP:
             nb = ops.act_bwd_blocks(rows, w)
             part = self.partials[l][:nb * w]
             ops.act_bwd_colsum(d, self.Z[l][:rows], d, self.act_kind, part, nb)
-            ops.colsum_finalize(part, nb, w, lin.bias.grad)
+            colsums.append((part, nb, w, lin.bias.grad))
             a_prev = self.Hs[l - 1][:rows] if l > 0 else self._x
             jobs.append((d, a_prev, lin.weight.grad))
             if l > 0:
                 d_prev = self.dA[l - 1][:rows]
                 torch.mm(d, lin.weight, out=d_prev)
                 d = d_prev
-        self._weight_grads(jobs, rows)
+        self._weight_grads(jobs, rows, colsums)
 
-    def _weight_grads(self, jobs, rows):
+    def _weight_grads(self, jobs, rows, colsums=()):
         """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
@@ -239,11 +240,14 @@ class ManualMLP:
                     plan = False
                 self._dw_plans[key] = plan
             if plan:
-                plan.launch(fast)
+                plan.launch(fast, colsums)              # bias gradients finished in the same finalise launch
+                colsums = ()
                 self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run
             else:
                 slow = slow + fast
                 fast = []
+        for part, nb, cols, out in colsums:
+            ops.colsum_finalize(part, nb, cols, out)
         self.last_dw_path = 'mfma' if fast else 'library'
         self.last_dw_library_jobs = len(slow)
         for dz, x, g in slow:

@@ -481,9 +481,21 @@ class MlpDwPlan:
     def plan(self, k):
         return tuple(self._plans[4 * k:4 * k + 4])
 
-    def launch(self, jobs):
+    def launch(self, jobs, colsums=()):
+        """jobs: (dz, x, grad) per planned layer.  colsums: optional (partials fp64 [blocks*cols],
+        blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch."""
+        import ctypes
         if len(jobs) != self.n:
             raise ValueError('job count does not match the plan')
+        nc = len(colsums)
+        if nc:
+            P = ctypes.c_void_p * nc
+            cs_part = P(*[_need(c[0], F64, 'colsum partials') for c in colsums])
+            cs_out = P(*[_need(c[3], F32, 'colsum out') for c in colsums])
+            cs_blocks = (ctypes.c_int * nc)(*[int(c[1]) for c in colsums])
+            cs_cols = (ctypes.c_int * nc)(*[int(c[2]) for c in colsums])
+        else:
+            cs_part = cs_out = cs_blocks = cs_cols = None
         for k, (dz, x, grad) in enumerate(jobs):
             No, Mi = self.shapes[k]
             if tuple(dz.shape) != (self.rows, No) or tuple(x.shape) != (self.rows, Mi) or \
@@ -494,8 +506,9 @@ class MlpDwPlan:
             self._x[k] = _need(x, F32, 'x')
             self._grad[k] = _need(grad, F32, 'grad')
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
-                                                 self._mi, self._plans, self.rows,
-                                                 _lib.stream_handle(self._device)), 'rlg_mlp_dw_launch')
+                                                 self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
+                                                 cs_cols, cs_out, _lib.stream_handle(self._device)),
+                   'rlg_mlp_dw_launch')
 
 
 # ------------------------------------------------------------------ recurrent policy (LSTM)

@@ -474,6 +474,16 @@ def test_mlp_dw_mfma_matches_library_gemm(rows):
         err_lib = (lib32.double() - t64).abs().max().item()
         scale = t64.abs().max().item()
         assert err <= max(4 * err_lib, 1e-6 * scale), (tuple(grad.shape), err, err_lib, scale)
+    # bias gradients ride along: column sums of per-block fp64 partials
+    cs_items, want = [], []
+    for cols, nb in ((400, 37), (100, 256), (33, 1)):
+        part = torch.randn(nb * cols, generator=g, dtype=torch.float64).to(DEV)
+        out = torch.full((cols,), float('nan'), device=DEV)
+        cs_items.append((part, nb, cols, out))
+        want.append(part.view(nb, cols).sum(0).float())
+    plan.launch(layers, cs_items)
+    for (part, nb, cols, out), w in zip(cs_items, want):
+        assert torch.allclose(out, w, rtol=1e-6, atol=1e-6), cols
     plan.launch(layers)    # deterministic: same bits on a second launch
     again = [l[2].clone() for l in layers]
     plan.launch(layers)
