@@ -165,10 +165,16 @@ def main():
         torch.cuda.synchronize()
         us = ev0.elapsed_time(ev1) * 1e3 / reps
         rows = jobs[0][0].shape[0]
+        dw_traffic = None
+        try:   # HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/r1_dw_pmc.txt)
+            with open(os.path.join(ROOT, 'profiles', 'dw_pmc_traffic.json')) as f:
+                dw_traffic = json.load(f).get(str(rows), {}).get('traffic_bytes')
+        except Exception:
+            dw_traffic = None
         flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
         mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch)',
                 'bound': 'mfma', 'achieved': flops / us / 1e6, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': dw_traffic,
                 'algorithmic_flops_per_launch': flops, 'avg_launch_us': us, 'launches': reps,
                 'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
                         '(v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); timed after the timed region'}
