@@ -385,6 +385,7 @@ class A2CAgent:
         self._hip_graphs = bool(config.get('hip_graphs', True))
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_failed = False
+        self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
         self._rnn_state_store = None
         self._eager_epochs = 0
         self._graph_rows = torch.zeros(max(1, self.num_minibatches), 8, dtype=torch.float32, device=dev)
@@ -543,8 +544,12 @@ class A2CAgent:
             rescaled = rescaled.cpu().numpy()
         return rescaled
 
-    def env_step(self, actions):
-        actions = self.preprocess_actions(actions)
+    def env_step(self, actions, preprocessed=None):
+        """`preprocessed`: device tensor already clamped/rescaled by the fused rollout step."""
+        if preprocessed is None:
+            actions = self.preprocess_actions(actions)
+        else:
+            actions = preprocessed if self.is_tensor_obses else preprocessed.cpu().numpy()
         obs, rewards, dones, infos = self.vec_env.step(actions)
         dev = self.ppo_device
         if not isinstance(rewards, torch.Tensor):
@@ -689,11 +694,47 @@ class A2CAgent:
         return batch_dict
 
     def _fast_policy_step(self, n):
-        """Rollout forward of step n without autograd or torch element-wise ops: obs normalise ->
-        engine GEMMs -> fused policy-head kernel that also writes actions/mus/sigmas/neglogpacs/
-        values of the step into the buffer.  Same maths as get_action_values + update_data."""
+        """Rollout forward of step n on the engine (see _policy_step_kernels).  From the second epoch
+        on the ~12 launches of a step are replayed as one HIP graph per step index: the env-owned
+        inputs (observations, done flags, recurrent state) are copied into static buffers first."""
+        if not self._rollout_graphs_usable():
+            return self._policy_step_kernels(n, self.obs['obs'], self.dones, self.rnn_states)
+        key = (id(self.experience_buffer), tuple(self.obs['obs'].shape), self.obs['obs'].dtype)
+        if self._rollout_graph_key != key:
+            self._rollout_graphs.clear()
+            self._rollout_graph_key = key
+            st = {'obs': torch.empty_like(self.obs['obs']).contiguous(), 'dones': torch.empty_like(self.dones)}
+            if self.is_rnn:
+                st['rnn'] = [torch.empty_like(s) for s in self.rnn_states]
+            self._rollout_static = st
+        st = self._rollout_static
+        st['obs'].copy_(self.obs['obs'])
+        st['dones'].copy_(self.dones)
+        if self.is_rnn:
+            for dst, src in zip(st['rnn'], self.rnn_states):
+                dst.copy_(src)
+        entry = self._rollout_graphs.get(n)
+        if entry is None:
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                out = self._policy_step_kernels(n, st['obs'], st['dones'], st.get('rnn'))
+            entry = self._rollout_graphs[n] = (g, out)
+        entry[0].replay()
+        return entry[1]
+
+    def _rollout_graphs_usable(self):
+        return (self._hip_graphs and self.config.get('rollout_graphs', True) and self._eager_epochs >= 1
+                and not self._graph_failed and isinstance(self.obs['obs'], torch.Tensor))
+
+    def _policy_step_kernels(self, n, obs_raw, dones, rnn_states):
+        """obs normalise -> engine GEMMs -> fused policy-head kernel that also writes actions / mus /
+        sigmas / neglogpacs / values of the step into the buffer -> obs + dones into the buffer ->
+        action clamp/rescale for the env.  Same maths as get_action_values + update_data +
+        preprocess_actions; no autograd, nothing that depends on the host."""
         eng, buf = self._engine, self.experience_buffer
-        obs = self._preproc_obs(self.obs['obs'])
+        obs = self._preproc_obs(obs_raw)
         if not obs.is_contiguous():
             obs = obs.contiguous()
         rows = obs.shape[0]
@@ -703,7 +744,7 @@ class A2CAgent:
         else:
             obs_n = obs
         if self.is_rnn:
-            heads = eng.forward(obs_n, keep=False, rnn_states=self.rnn_states, seq_length=1)
+            heads = eng.forward(obs_n, keep=False, rnn_states=rnn_states, seq_length=1)
         else:
             heads = eng.forward(obs_n)
         torch.randn(self._roll_noise.shape, device=self._roll_noise.device, out=self._roll_noise)
@@ -714,8 +755,15 @@ class A2CAgent:
             vs, eps = (vm.running_mean, vm.running_var), vm.epsilon
         ops.rollout_policy_head(heads, self.model.a2c_network.sigma.data, self._roll_noise, vs, eps,
                                 self._roll_actions, self._roll_values, buf.storage, self.horizon_length, n)
-        buf.store_step(n, {'obses': obs, 'dones': self.dones})
+        # the buffer keeps the observation as the env delivered it (a2c_common.py:1000), not the
+        # /255-preprocessed copy
+        buf.store_step(n, {'obses': obs_raw if obs_raw.is_contiguous() else obs_raw.contiguous(), 'dones': dones})
         res = {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
+        if self.clip_actions:
+            res['env_actions'] = rescale_actions(self.actions_low, self.actions_high,
+                                                 torch.clamp(self._roll_actions, -1.0, 1.0))
+        else:
+            res['env_actions'] = self._roll_actions
         if self.is_rnn:
             res['rnn_states'] = eng.last_states
         return res
@@ -774,7 +822,7 @@ class A2CAgent:
                     prev = torch.zeros_like(self.dones)
                 mb_valid[n] = 1.0 - prev.float()
             t0 = time.perf_counter()
-            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'])
+            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'], res_dict.get('env_actions'))
             self.dones = self._as_u8(dones)
             if self.mask_autoreset_rows:
                 self._autoreset_prev_dones = self.dones.clone()
@@ -817,7 +865,7 @@ class A2CAgent:
                     fields[k] = res_dict[k]
                 buf.store_step(n, fields)
             t0 = time.perf_counter()
-            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'])
+            self.obs, rewards, dones, infos = self.env_step(res_dict['actions'], res_dict.get('env_actions'))
             self.dones = self._as_u8(dones)
             if self.mask_autoreset_rows:
                 self._autoreset_prev_dones = self.dones.clone()

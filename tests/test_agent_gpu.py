@@ -718,3 +718,33 @@ def test_odd_shapes_match_oracle_epoch(N, H, obs_dim, act_dim, units, mbs):
         agent.update_epoch()
         out = agent.train_epoch()
     assert all(torch.isfinite(x) for x in out[4] + out[5])
+
+
+@pytest.mark.parametrize('cfg', ['mlp', 'lstm'])
+def test_rollout_step_graphs_match_eager_rollout(cfg):
+    """The per-step rollout HIP graphs (policy forward + fused head + buffer writes + action
+    rescale) leave the same buffer contents as the eager fast path: two identically seeded agents,
+    one with `rollout_graphs` off, run three epochs; every rollout tensor of the last epoch is
+    bit-identical (same kernels, same RNG stream)."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    outs = []
+    for graphs in (True, False):
+        if cfg == 'mlp':
+            params = configs.tiny(num_actors=96, horizon=8, rollout_graphs=graphs, hip_graphs=True)
+        else:
+            params = configs.pendulum_lstm_4096(num_actors=64, rollout_graphs=graphs, hip_graphs=True)
+        torch.manual_seed(123)
+        agent = A2CAgent('rg', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(3):
+            agent.update_epoch()
+            agent.train_epoch()
+        assert bool(agent._rollout_graphs) == graphs
+        st = agent.experience_buffer.storage
+        outs.append({k: st[k].clone() for k in ('obses', 'actions', 'mus', 'sigmas', 'values', 'neglogpacs',
+                                                 'rewards', 'dones')})
+        outs[-1]['params'] = agent.optimizer.flat_params.clone()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
