@@ -144,14 +144,19 @@ class ManualMLP:
             gates = self.gates[:rows]
             torch.addmm(self.bias_sum, a, rnn.weight_ih_l0.t(), out=gates)
             out = self.rnn_out[:rows]
-            # write the final states into whichever buffer pair the inputs do NOT live in
-            self._state_flip = 1 if h0.data_ptr() == self._state_buf[0][0].data_ptr() else 0
-            hT = self._state_buf[self._state_flip][0][:, :S]
-            cT = self._state_buf[self._state_flip][1][:, :S]
+            # Final states are produced for inference calls only (keep=False: rollout / get_values),
+            # into whichever buffer pair the inputs do NOT live in.  A training forward must not touch
+            # these buffers: they hold the live rollout state that is carried into the next epoch.
+            hT = cT = None
+            if not keep:
+                self._state_flip = 1 if h0.data_ptr() == self._state_buf[0][0].data_ptr() else 0
+                hT = self._state_buf[self._state_flip][0][:, :S]
+                cT = self._state_buf[self._state_flip][1][:, :S]
             ops.lstm_seq_forward(gates, rnn.weight_hh_l0, h0, c0, dones, out,
                                  self.c_all[:rows] if keep else None, self.hprev[:rows] if keep else None,
-                                 hT[0], cT[0], seq_len=seq_length)
-            self.last_states = (hT, cT)
+                                 None if hT is None else hT[0], None if cT is None else cT[0],
+                                 seq_len=seq_length)
+            self.last_states = None if hT is None else (hT, cT)
             self._rnn_in, self._c0, self._dones, self._T = a, c0, dones, seq_length
             a = out
         heads = self.heads[:rows]

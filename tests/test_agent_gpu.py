@@ -738,9 +738,20 @@ def test_rollout_step_graphs_match_eager_rollout(cfg):
         agent = A2CAgent('rg', params)
         agent.init_tensors()
         agent.obs = agent.env_reset()
+        snap = {}
+        orig_prepare = agent.prepare_dataset
+
+        def prepare(batch_dict, _orig=orig_prepare, _agent=agent, _snap=snap):
+            if _agent.is_rnn:            # recurrent state as the rollout left it
+                _snap['rnn'] = [s.clone() for s in _agent.rnn_states]
+            return _orig(batch_dict)
+        agent.prepare_dataset = prepare
         for _ in range(3):
             agent.update_epoch()
             agent.train_epoch()
+            if agent.is_rnn:             # ... must survive the update phase untouched (it is carried on)
+                for s, want in zip(agent.rnn_states, snap['rnn']):
+                    assert torch.equal(s, want)
         assert bool(agent._rollout_graphs) == graphs
         st = agent.experience_buffer.storage
         outs.append({k: st[k].clone() for k in ('obses', 'actions', 'mus', 'sigmas', 'values', 'neglogpacs',
