@@ -759,3 +759,31 @@ def test_rollout_step_graphs_match_eager_rollout(cfg):
         outs[-1]['params'] = agent.optimizer.flat_params.clone()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize('cfg', ['mlp', 'lstm'])
+def test_hip_graph_replays_are_bit_identical_to_eager_training(cfg):
+    """Same seeds, `hip_graphs` on vs off, six epochs: identical kernels in identical order, so the
+    parameters, Adam moments, normaliser statistics and learning rate must match bit for bit."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for graphs in (True, False):
+        if cfg == 'mlp':
+            params = configs.tiny(num_actors=128, horizon=8, hip_graphs=graphs)
+        else:
+            params = configs.pendulum_lstm_4096(num_actors=64, hip_graphs=graphs)
+        torch.manual_seed(7)
+        agent = A2CAgent('g', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(6):
+            agent.update_epoch()
+            agent.train_epoch()
+        assert bool(agent._graphs) == graphs
+        res.append((agent.optimizer.flat_params.clone(), agent.optimizer.exp_avg.clone(),
+                    agent.optimizer.exp_avg_sq.clone(), agent.model.running_mean_std.running_mean.clone(),
+                    agent.model.value_mean_std.running_var.clone(), agent.optimizer.last_and_next_lr()))
+    for a, b in zip(res[0][:5], res[1][:5]):
+        assert torch.equal(a, b)
+    assert res[0][5] == res[1][5]
