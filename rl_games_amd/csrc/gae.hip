@@ -282,7 +282,6 @@ __global__ __launch_bounds__(64 * kGaeWavesPerBlock) void gae_envmajor_kernel(
   tile_regs_to_lds<H>(vbuf, tile_v);
   wave_lds_fence();
   float r[H], v[H];
-  float a[kRaw ? 1 : H];
   row_from_lds<H>(tile_r, r);
   row_from_lds<H>(tile_v, v);
 
@@ -294,13 +293,7 @@ __global__ __launch_bounds__(64 * kGaeWavesPerBlock) void gae_envmajor_kernel(
     const float vt = v[t];
     const float delta = (r[t] + (gamma * nv) * nnt) - vt;
     A = delta + (gamma_tau * nnt) * A;
-    if constexpr (kRaw) {
-      r[t] = A;
-    } else {
-      const float ret = A + vt;
-      r[t] = ret;
-      a[t] = ret - vt;
-    }
+    r[t] = kRaw ? A : A + vt;          // raw GAE, or returns = A + v (a2c_common.py:1060)
     nv = vt;
     const uint32_t dbyte = (dw[t >> 2] >> (8 * (t & 3))) & 0xffu;
     nnt = 1.0f - static_cast<float>(dbyte);
@@ -309,29 +302,46 @@ __global__ __launch_bounds__(64 * kGaeWavesPerBlock) void gae_envmajor_kernel(
   // ---- transpose back and store coalesced ----
   wave_lds_fence();
   row_to_lds<H>(tile_r, r);
-  if constexpr (!kRaw) row_to_lds<H>(tile_v, a);
   wave_lds_fence();
-  tile_lds_to_global<H>(tile_r, out0 + base, rows);
-  if constexpr (!kRaw) {
-    tile_lds_to_global<H>(tile_v, out1 + base, rows);
-    if (partials) {
-      // Moments are taken from registers after the stores have been issued, so the VALU
-      // work overlaps the store drain.  fp64 accumulation: exact enough that the downstream
-      // mean/var are limited by the fp32 inputs, not by the reduction.
-      double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if constexpr (kRaw) {
+    tile_lds_to_global<H>(tile_r, out0 + base, rows);
+  } else {
+    // tile_v still holds the values in the coalesced chunk layout they were loaded in, so
+    // advantages = returns - values (a2c_common.py:1598, the same single fp32 subtraction) and
+    // the fp64 moments are formed here, chunk by chunk, on the way out: one LDS tile less to write
+    // and no per-env advantage registers.
+    constexpr int CPR = TileGeom<H>::kChunksPerRow;
+    constexpr int ROW = TileGeom<H>::kRow;
+    const int live_chunks = rows * CPR;
+    double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < H; ++t) {
-        const double da = a[t], dv = v[t], dr = r[t];
-        m[0] += da;
-        m[1] = fma(da, da, m[1]);
-        m[2] += dv;
-        m[3] = fma(dv, dv, m[3]);
-        m[4] += dr;
-        m[5] = fma(dr, dr, m[5]);
+    for (int k = 0; k < H / 4; ++k) {
+      const int c = k * kWave + lane;
+      const int row = c / CPR;
+      const int col = (c - row * CPR) * 4;
+      const f32x4 ret = *reinterpret_cast<const f32x4*>(tile_r + row * ROW + col);
+      const f32x4 val = *reinterpret_cast<const f32x4*>(tile_v + row * ROW + col);
+      const f32x4 adv = ret - val;
+      if (rows == kWave || c < live_chunks) {
+        *reinterpret_cast<f32x4*>(out0 + base + c * 4) = ret;
+        *reinterpret_cast<f32x4*>(out1 + base + c * 4) = adv;
+        if (partials) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double da = adv[e], dv = val[e], dr = ret[e];
+            m[0] += da;
+            m[1] = fma(da, da, m[1]);
+            m[2] += dv;
+            m[3] = fma(dv, dv, m[3]);
+            m[4] += dr;
+            m[5] = fma(dr, dr, m[5]);
+          }
+        }
       }
-      // lanes past the last env scanned a re-read of env0's row: drop their moments
+    }
+    if (partials) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) m[k] = wave_sum(live ? m[k] : 0.0);
+      for (int k = 0; k < 6; ++k) m[k] = wave_sum(m[k]);
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) partials[static_cast<long long>(tile) * 6 + k] = m[k];
