@@ -718,7 +718,7 @@ class A2CAgent:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool):
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
                 out = self._policy_step_kernels(n, st['obs'], st['dones'], st.get('rnn'))
             entry = self._rollout_graphs[n] = (g, out)
         entry[0].replay()
@@ -1097,12 +1097,12 @@ class A2CAgent:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             item = self.dataset[i]
-            with torch.cuda.graph(g, pool=self._graph_pool):
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
                 self._forward_loss_backward(item, self._graph_rows[i])
             self._graphs[i] = g
         if self._graph_opt is None:
             go = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(go, pool=self._graph_pool):
+            with torch.cuda.graph(go, pool=self._graph_pool, capture_error_mode='thread_local'):
                 self._optimizer_kernels()
             self.optimizer.step_count -= 1        # capture advanced the host mirror, not the device
             self._graph_opt = go
