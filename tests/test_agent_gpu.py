@@ -787,3 +787,25 @@ def test_hip_graph_replays_are_bit_identical_to_eager_training(cfg):
     for a, b in zip(res[0][:5], res[1][:5]):
         assert torch.equal(a, b)
     assert res[0][5] == res[1][5]
+
+
+@pytest.mark.parametrize('kind', ['mlp', 'lstm', 'discrete', 'central_value'])
+def test_two_rank_training_keeps_ranks_in_sync(kind):
+    """2 ranks on this box's single GPU (RLG_TEST_SINGLE_GPU=1: gloo collectives), different data per
+    rank, 4 epochs of multi_gpu training for each agent kind: parameters, normaliser statistics
+    (pooled merge) and learning rate end bit-identical on both ranks."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RLG_TEST_SINGLE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'tools', 'two_rank_check.py'), kind]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert f'TWO_RANK_CHECK {kind} in_sync' in res.stdout

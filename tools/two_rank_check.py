@@ -1,0 +1,54 @@
+"""Launched by torch.distributed.run with RLG_TEST_SINGLE_GPU=1 (2 ranks on one GPU, gloo): trains a
+small agent of the requested kind with multi_gpu=True for a few epochs and checks that every rank
+ends with bit-identical parameters, normaliser statistics and learning rate."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch.distributed as dist
+from rl_games_amd import configs, distributed as rdist
+
+kind = sys.argv[1]
+rank = int(os.environ['RANK'])
+torch.manual_seed(100 + rank)
+if kind == 'lstm':
+    from rl_games_amd.agent import A2CAgent as Agent
+    params = configs.pendulum_lstm_4096(num_actors=64, multi_gpu=True)
+elif kind == 'discrete':
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent as Agent
+    params = configs.cartpole_discrete(num_actors=16, multi_gpu=True, normalize_input=True, normalize_value=True,
+                                       lr_schedule='adaptive')
+elif kind == 'central_value':
+    from rl_games_amd.agent import A2CAgent as Agent
+    params = configs.tiny(num_actors=64, horizon=8, multi_gpu=True)
+    params['config']['central_value_config'] = {
+        'minibatch_size': 128, 'mini_epochs': 2, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
+        'truncate_grads': True, 'grad_norm': 1.0,
+        'network': {'name': 'actor_critic', 'central_value': True,
+                    'mlp': {'units': [32, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}}
+    params['config']['env_config']['state_dim'] = 9
+else:
+    from rl_games_amd.agent import A2CAgent as Agent
+    params = configs.tiny(num_actors=64, horizon=8, multi_gpu=True)
+params['config']['env_config']['seed'] = 10 + rank          # different data per rank
+agent = Agent('mr', params)
+agent.init_tensors()
+agent.obs = agent.env_reset()
+agent.broadcast_parameters()
+for _ in range(4):
+    agent.update_epoch()
+    agent.train_epoch()
+probes = [agent.optimizer.flat_params.double().sum(), agent.optimizer.flat_params.double().abs().sum(),
+          torch.tensor(float(agent.optimizer.last_and_next_lr()[1]), dtype=torch.float64, device=agent.ppo_device)]
+for m in agent._stats_sync_modules():
+    probes += [m.running_mean.double().sum(), m.running_var.double().sum(), m.count.double()]
+if agent.has_central_value:
+    probes.append(agent.central_value_net.optimizer.flat_params.double().sum())
+p = torch.stack([x.reshape(()) for x in probes])
+lo, hi = p.clone(), p.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+ok = bool(torch.equal(lo, hi)) and bool(torch.isfinite(p).all())
+if rank == 0:
+    print('TWO_RANK_CHECK', kind, 'in_sync' if ok else f'OUT_OF_SYNC {lo.tolist()} {hi.tolist()}', flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
