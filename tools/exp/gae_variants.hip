@@ -234,7 +234,13 @@ __global__ __launch_bounds__(64 * WAVES) void gae_var_kernel(
   const bool live = lane < rows;
   const long long base = (long long)env0 * H;
   f32x4 rbuf[H / 4], vbuf[H / 4];
-  tile_load_issue<H>(rewards + base, rows, rbuf);
+  float r[H], v[H];
+  if (PW == 5) {   // EXPERIMENT: rewards stored time-major [H][N]: lane = env, one coalesced dword load per t
+#pragma unroll
+    for (int t = 0; t < H; ++t) r[t] = rewards[(long long)t * N + (live ? env : env0)];
+  } else {
+    tile_load_issue<H>(rewards + base, rows, rbuf);
+  }
   tile_load_issue<H>(values + base, rows, vbuf);
   uint32_t dw[H / 4];
   {
@@ -247,13 +253,12 @@ __global__ __launch_bounds__(64 * WAVES) void gae_var_kernel(
   }
   float nv = last_values[live ? env : env0];
   float nnt = 1.0f - (float)last_dones[live ? env : env0];
-  tile_regs_to_lds<H>(rbuf, tile_r);
+  if (PW != 5) tile_regs_to_lds<H>(rbuf, tile_r);
   tile_regs_to_lds<H>(vbuf, tile_v);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float r[H], v[H];
-  row_from_lds<H>(tile_r, r);
+  if (PW != 5) row_from_lds<H>(tile_r, r);
   row_from_lds<H>(tile_v, v);
   double m[6] = {0, 0, 0, 0, 0, 0};
   float f[6] = {0, 0, 0, 0, 0, 0};
@@ -399,6 +404,8 @@ int main(int argc, char** argv) {
     RUNVARP(4, 4, 1, "f32mom-after 4w partial stride128B");
     RUNVARP(4, 4, 2, "f32mom-after 4w NO partial write");
     RUNVARP(0, 4, 3, "nomom 4w + const partial write");
+    RUNVARP(0, 4, 5, "nomom 4w, rewards TIME-major (no LDS for r)");
+    RUNVARP(3, 4, 5, "f64mom-after 4w, rewards TIME-major");
     RUNVAR(3, 1, "var f64mom-after-store 1w");
     RUNVAR(4, 1, "var f32mom-after-store 1w");
     RUNVAR(3, 4, "var f64mom-after-store 4w");
