@@ -241,3 +241,83 @@ def test_reference_restores_amd_checkpoint(tmp_path):
     agent.epoch_num += 1
     res = agent.train_epoch()
     assert all(torch.isfinite(x).all() for x in res[4] + res[5])
+
+
+def test_schedulers_equal_reference_trajectories():
+    """lr_control (pure-function form) vs rl_games/common/schedulers.py: identical python-float
+    trajectories for the KL-band rule and the linear ramp (incl. the entropy ramp)."""
+    import random
+    from rl_games.common import schedulers as R
+    from rl_games_amd import lr_control as M
+    rnd = random.Random(0)
+    a, b = R.AdaptiveScheduler(0.008, 1e-6, 1e-2, 1.5), M.AdaptiveScheduler(0.008, 1e-6, 1e-2, 1.5)
+    lr1 = lr2 = 3e-4
+    for _ in range(5000):
+        kl = rnd.choice([0.001, 0.003, 0.004, 0.005, 0.01, 0.016, 0.02, 0.05, rnd.random() * 0.03])
+        lr1, e1 = a.update(lr1, 0.01, 0, 0, kl)
+        lr2, e2 = b.update(lr2, 0.01, 0, 0, kl)
+        assert lr1 == lr2 and e1 == e2
+    assert b.device_rule() == dict(kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2, lr_multiplier=1.5)
+    for use_epochs in (True, False):
+        l1 = R.LinearScheduler(3e-4, 1e-6, 1000, use_epochs, True, start_entropy_coef=0.01)
+        l2 = M.LinearScheduler(3e-4, 1e-6, 1000, use_epochs, True, start_entropy_coef=0.01)
+        for e in range(0, 1300, 7):
+            assert l1.update(0, 0.01, e, e * 3, 0) == l2.update(0, 0.01, e, e * 3, 0)
+    assert M.IdentityScheduler().update(1e-3, 0.5, 3, 4, 0.1) == R.IdentityScheduler().update(1e-3, 0.5, 3, 4, 0.1)
+
+
+@pytest.mark.parametrize('heads,with_masks', [([5], False), ([5], True), ([3, 4, 2], False), ([3, 4, 2], True)])
+def test_discrete_models_equal_reference_models(heads, with_masks):
+    """policy.DiscreteA2CModel vs the reference's ModelA2C / ModelA2CMultiDiscrete (models.py:66-206)
+    built by the reference's own ModelBuilder from the same params, same weights: training-mode
+    outputs (neglogp, entropy, values, normalised logits) are bit-identical, with and without
+    CategoricalMasked action masks."""
+    import copy
+    from rl_games.algos_torch import model_builder
+    from rl_games_amd import configs
+    from rl_games_amd.policy import PolicyBuilder
+    multi = len(heads) > 1
+    params = configs.cartpole_discrete()
+    if multi:
+        params['network']['space'] = {'multi_discrete': None}
+        params['model']['name'] = 'multi_discrete_a2c'
+    build_cfg = {'actions_num': heads if multi else heads[0], 'input_shape': (6,), 'num_seqs': 4, 'value_size': 1,
+                 'normalize_value': False, 'normalize_input': False}
+    ref_net = model_builder.ModelBuilder().load(copy.deepcopy(params))
+    ref = ref_net.build(copy.deepcopy(build_cfg))
+    mine = PolicyBuilder(copy.deepcopy(params)).build(copy.deepcopy(build_cfg))
+    assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+    mine.load_state_dict(ref.state_dict())
+    g = gen(sum(heads))
+    B, n = 64, sum(heads)
+    obs = torch.randn(B, 6, generator=g)
+    masks = None
+    if with_masks:
+        masks = torch.rand(B, n, generator=g) > 0.4
+        o = 0
+        for s in heads:
+            masks[torch.arange(B), o + torch.randint(0, s, (B,), generator=g)] = True
+            o += s
+    acts = []
+    o = 0
+    for s in heads:
+        w = torch.ones(B, s) if masks is None else masks[:, o:o + s].float()
+        acts.append(torch.multinomial(w, 1, generator=g))
+        o += s
+    prev = torch.cat(acts, 1) if multi else acts[0].squeeze(1)
+    a = ref({'is_train': True, 'obs': obs.clone(), 'prev_actions': prev, 'action_masks': masks})
+    b = mine({'is_train': True, 'obs': obs.clone(), 'prev_actions': prev, 'action_masks': masks})
+    assert torch.equal(a['prev_neglogp'], b['prev_neglogp'])
+    assert torch.equal(a['entropy'], b['entropy'])
+    assert torch.equal(a['values'], b['values'])
+    la = a['logits'] if multi else [a['logits']]
+    lb = b['logits'] if multi else [b['logits']]
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    # and the oracle's categorical loss consumes the same quantities
+    lg, vals = mine.forward_heads({'obs': obs})
+    batch = {'actions': prev, 'old_logp_actions': a['prev_neglogp'].detach() + 0.1, 'advantages': torch.randn(B, generator=g),
+             'old_values': torch.randn(B, 1, generator=g), 'returns': torch.randn(B, 1, generator=g)}
+    out = O.categorical_loss_and_grads(lg, vals, batch, dict(e_clip=0.2, clip_value=True, critic_coef=1.0, entropy_coef=0.01),
+                                       None, heads, masks)
+    assert torch.equal(out['neglogp'], a['prev_neglogp'].detach())
+    assert torch.allclose(out['entropy'], a['entropy'].mean().detach(), rtol=1e-6)
