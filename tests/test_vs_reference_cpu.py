@@ -321,3 +321,50 @@ def test_discrete_models_equal_reference_models(heads, with_masks):
                                        None, heads, masks)
     assert torch.equal(out['neglogp'], a['prev_neglogp'].detach())
     assert torch.allclose(out['entropy'], a['entropy'].mean().detach(), rtol=1e-6)
+
+
+@pytest.mark.parametrize('kind', ['mlp', 'lstm', 'central_value'])
+def test_continuous_and_recurrent_and_central_models_equal_reference(kind):
+    """policy.ContinuousA2CLogStdModel (MLP and LSTM with done resets) and CentralValueModel vs the
+    reference's ModelBuilder-built networks from the same params and weights (training-mode forward;
+    normalisers off - they are HIP kernels on our side and are tested on the GPU)."""
+    import copy
+    from rl_games.algos_torch import model_builder
+    from rl_games_amd import configs
+    from rl_games_amd.policy import PolicyBuilder
+    g = gen(11)
+    if kind == 'central_value':
+        params = {'model': {'name': 'central_value'},
+                  'network': {'name': 'actor_critic', 'central_value': True,
+                              'mlp': {'units': [24, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}}
+        cfg = {'actions_num': 3, 'input_shape': (9,), 'num_seqs': 4, 'value_size': 1, 'normalize_value': False,
+               'normalize_input': False, 'num_agents': 1}
+    else:
+        params = configs.pendulum_lstm_4096() if kind == 'lstm' else configs.tiny()
+        params = {k: params[k] for k in ('model', 'network')}
+        if kind == 'lstm':
+            params['network']['rnn'] = {'name': 'lstm', 'units': 16, 'layers': 1}
+        cfg = {'actions_num': 3, 'input_shape': (9,), 'num_seqs': 8, 'value_size': 1, 'normalize_value': False,
+               'normalize_input': False}
+    ref = model_builder.ModelBuilder().load(copy.deepcopy(params)).build(copy.deepcopy(cfg))
+    mine = PolicyBuilder(copy.deepcopy(params)).build(copy.deepcopy(cfg))
+    assert sorted(mine.state_dict().keys()) == sorted(ref.state_dict().keys())
+    mine.load_state_dict(ref.state_dict())
+    T, S = 4, 8
+    B = T * S
+    obs = torch.randn(B, 9, generator=g)
+    if kind == 'central_value':
+        a = ref({'is_train': True, 'obs': obs.clone()})
+        b = mine({'is_train': True, 'obs': obs.clone()})
+        assert torch.equal(a['values'], b['values'])
+        return
+    batch = {'is_train': True, 'obs': obs, 'prev_actions': torch.randn(B, 3, generator=g)}
+    if kind == 'lstm':
+        batch['rnn_states'] = [0.3 * torch.randn(1, S, 16, generator=g) for _ in range(2)]
+        batch['seq_length'] = T
+        batch['dones'] = (torch.rand(B, generator=g) < 0.3).to(torch.uint8)
+    a = ref({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+    b = mine({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+    tol = dict(rtol=1e-5, atol=1e-6) if kind == 'lstm' else dict(rtol=0, atol=0)   # per-step vs segment LSTM calls
+    for k in ('prev_neglogp', 'values', 'entropy', 'mus', 'sigmas'):
+        assert torch.allclose(a[k], b[k], **tol), k
