@@ -384,6 +384,7 @@ class A2CAgent:
         # optimiser kernels; the first epoch always runs eagerly (allocations, GEMM selection).
         self._hip_graphs = bool(config.get('hip_graphs', True))
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
+        self._graph_epoch = None
         self._graph_failed = False
         self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
         self._rnn_state_store = None
@@ -1090,6 +1091,7 @@ class A2CAgent:
         if sig != self._graph_sig:
             self._graphs.clear()
             self._graph_opt = None
+            self._graph_epoch = None
             self._graph_sig = sig
         g = self._graphs.get(i)
         if g is None:
@@ -1111,6 +1113,29 @@ class A2CAgent:
             rdist.all_reduce_sum(self.optimizer.flat_grads)
         self._graph_opt.replay()
         self.optimizer.step_count += 1
+
+    def _graph_mini_epoch(self, nmb):
+        """Single-GPU runs with nothing to do on the host between minibatches (device-side or
+        per-epoch lr schedule): ALL minibatches of a mini-epoch - forward, loss, backward, clip, Adam,
+        lr update, nmb times - are one HIP graph, replayed once per mini-epoch."""
+        sig = self._graph_signature()
+        if sig != self._graph_sig:
+            self._graphs.clear()
+            self._graph_opt = None
+            self._graph_epoch = None
+            self._graph_sig = sig
+        if self._graph_epoch is None:
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
+                for i in range(nmb):
+                    self._forward_loss_backward(self.dataset[i], self._graph_rows[i])
+                    self._optimizer_kernels()
+            self.optimizer.step_count -= nmb      # capture advanced the host mirror, not the device
+            self._graph_epoch = g
+        self._graph_epoch.replay()
+        self.optimizer.step_count += nmb
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,
@@ -1147,10 +1172,14 @@ class A2CAgent:
             if use_graphs:
                 try:
                     self.set_train()
-                    for i in range(nmb):
-                        self._graph_minibatch(i)
-                        if self.schedule_type == 'per_minibatch' and not device_schedule:
-                            self._host_schedule(None)
+                    host_between = self.schedule_type == 'per_minibatch' and not device_schedule
+                    if not self.multi_gpu and not host_between and self.config.get('mini_epoch_graph', True):
+                        self._graph_mini_epoch(nmb)
+                    else:
+                        for i in range(nmb):
+                            self._graph_minibatch(i)
+                            if host_between:
+                                self._host_schedule(None)
                     self._mb_scalars[first:first + nmb].copy_(self._graph_rows[:nmb])
                     self._mb_index += nmb
                     for i in range(nmb):
