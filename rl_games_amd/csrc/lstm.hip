@@ -24,12 +24,12 @@
 
 namespace rlg {
 
-constexpr int kLstmSeqPerBlock = 16;
+constexpr int kLstmMaxSeqPerBlock = 16;
 constexpr int kLstmThreads = 256;
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int H>
+template <int H, int kLstmSeqPerBlock>
 __global__ __launch_bounds__(kLstmThreads) void lstm_seq_fwd_kernel(
     float* __restrict__ gates,           // [S*T, 4H]  in: x-part + biases, out: activated gates
     const float* __restrict__ w_hh,      // [4H, H]
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kLstmThreads) void lstm_seq_fwd_kernel(
   }
 }
 
-template <int H>
+template <int H, int kLstmSeqPerBlock>
 __global__ __launch_bounds__(kLstmThreads) void lstm_seq_bwd_kernel(
     const float* __restrict__ gates,     // [S*T, 4H] activated gates of the forward pass
     const float* __restrict__ c_all,     // [S*T, H]
@@ -210,40 +210,80 @@ __global__ __launch_bounds__(kLstmThreads) void lstm_seq_bwd_kernel(
   }
 }
 
+// Sequences per block: 16 (4 per thread: every W_hh value read from LDS feeds 4 FMAs) when that still
+// gives >= 256 blocks, otherwise fewer, so that a 1,024-sequence minibatch uses the whole chip instead
+// of 64 CUs.
+static int lstm_seq_per_block(int S, int H) {
+  const int min_sb = kLstmThreads / H;                 // one sequence per thread group at least
+  int sb = kLstmMaxSeqPerBlock;
+  while (sb > min_sb && (S + sb - 1) / sb < 256) sb >>= 1;
+  return sb;
+}
+
+template <int H, int SB>
+static int launch_lstm_fwd_sb(float* gates, const float* w_hh, const float* h0, const float* c0,
+                              const uint8_t* dones, float* out, float* c_all, float* hprev, float* hT,
+                              float* cT, int S, int T, hipStream_t st) {
+  if constexpr (SB < kLstmThreads / H) {
+    return static_cast<int>(hipErrorInvalidValue);
+  } else {
+    const size_t shm = (static_cast<size_t>(4) * H * H + 2 * SB * H) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<H, SB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
+      if (e != hipSuccess) return static_cast<int>(e);
+      attr_set = true;
+    }
+    const int grid = (S + SB - 1) / SB;
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, SB>), dim3(grid), dim3(kLstmThreads), shm, st, gates, w_hh, h0,
+                       c0, dones, out, c_all, hprev, hT, cT, S, T);
+    RLG_RETURN_LAUNCH_STATUS();
+  }
+}
+
 template <int H>
 static int launch_lstm_fwd(float* gates, const float* w_hh, const float* h0, const float* c0,
                            const uint8_t* dones, float* out, float* c_all, float* hprev, float* hT,
                            float* cT, int S, int T, hipStream_t st) {
-  const size_t shm = (static_cast<size_t>(4) * H * H + 2 * kLstmSeqPerBlock * H) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<H>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
-    if (e != hipSuccess) return static_cast<int>(e);
-    attr_set = true;
+  switch (lstm_seq_per_block(S, H)) {
+    case 16: return launch_lstm_fwd_sb<H, 16>(gates, w_hh, h0, c0, dones, out, c_all, hprev, hT, cT, S, T, st);
+    case 8: return launch_lstm_fwd_sb<H, 8>(gates, w_hh, h0, c0, dones, out, c_all, hprev, hT, cT, S, T, st);
+    default: return launch_lstm_fwd_sb<H, 4>(gates, w_hh, h0, c0, dones, out, c_all, hprev, hT, cT, S, T, st);
   }
-  const int grid = (S + kLstmSeqPerBlock - 1) / kLstmSeqPerBlock;
-  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H>), dim3(grid), dim3(kLstmThreads), shm, st, gates, w_hh, h0, c0,
-                     dones, out, c_all, hprev, hT, cT, S, T);
-  RLG_RETURN_LAUNCH_STATUS();
+}
+
+template <int H, int SB>
+static int launch_lstm_bwd_sb(const float* gates, const float* c_all, const float* c0, const uint8_t* dones,
+                              const float* w_hh, const float* d_out, float* d_gates, int S, int T,
+                              hipStream_t st) {
+  if constexpr (SB < kLstmThreads / H) {
+    return static_cast<int>(hipErrorInvalidValue);
+  } else {
+    const size_t shm = (static_cast<size_t>(4) * H * H + SB * 4 * H) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<H, SB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
+      if (e != hipSuccess) return static_cast<int>(e);
+      attr_set = true;
+    }
+    const int grid = (S + SB - 1) / SB;
+    hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, SB>), dim3(grid), dim3(kLstmThreads), shm, st, gates, c_all, c0,
+                       dones, w_hh, d_out, d_gates, S, T);
+    RLG_RETURN_LAUNCH_STATUS();
+  }
 }
 
 template <int H>
 static int launch_lstm_bwd(const float* gates, const float* c_all, const float* c0, const uint8_t* dones,
                            const float* w_hh, const float* d_out, float* d_gates, int S, int T,
                            hipStream_t st) {
-  const size_t shm = (static_cast<size_t>(4) * H * H + kLstmSeqPerBlock * 4 * H) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<H>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
-    if (e != hipSuccess) return static_cast<int>(e);
-    attr_set = true;
+  switch (lstm_seq_per_block(S, H)) {
+    case 16: return launch_lstm_bwd_sb<H, 16>(gates, c_all, c0, dones, w_hh, d_out, d_gates, S, T, st);
+    case 8: return launch_lstm_bwd_sb<H, 8>(gates, c_all, c0, dones, w_hh, d_out, d_gates, S, T, st);
+    default: return launch_lstm_bwd_sb<H, 4>(gates, c_all, c0, dones, w_hh, d_out, d_gates, S, T, st);
   }
-  const int grid = (S + kLstmSeqPerBlock - 1) / kLstmSeqPerBlock;
-  hipLaunchKernelGGL((lstm_seq_bwd_kernel<H>), dim3(grid), dim3(kLstmThreads), shm, st, gates, c_all, c0,
-                     dones, w_hh, d_out, d_gates, S, T);
-  RLG_RETURN_LAUNCH_STATUS();
 }
 
 }  // namespace rlg
