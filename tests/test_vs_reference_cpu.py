@@ -368,3 +368,29 @@ def test_continuous_and_recurrent_and_central_models_equal_reference(kind):
     tol = dict(rtol=1e-5, atol=1e-6) if kind == 'lstm' else dict(rtol=0, atol=0)   # per-step vs segment LSTM calls
     for k in ('prev_neglogp', 'values', 'entropy', 'mus', 'sigmas'):
         assert torch.allclose(a[k], b[k], **tol), k
+
+
+def test_reference_runner_plugin_seam_constructs_our_agents():
+    """the REAL reference Runner with our agents registered in its
+    algo_factory (torch_runner.py:117-120) loads an unmodified params dict and calls our
+    constructors with (base_name, params) (:258).  Without a GPU the constructors stop at the
+    device check - after parsing the reference-format params - which is what this container can
+    verify; the GPU tests cover everything behind it."""
+    import copy
+    from rl_games.torch_runner import Runner
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    for params, cls, env_kw in ((configs.tiny(device='cpu'), A2CAgent, dict(obs_dim=12, act_dim=3)),
+                                (configs.cartpole_discrete(device='cpu'), DiscreteA2CAgent,
+                                 dict(obs_dim=4, discrete_actions=2))):
+        runner = Runner()
+        runner.algo_factory.register_builder('a2c_continuous', lambda **kw: A2CAgent(**kw))
+        runner.algo_factory.register_builder('a2c_discrete', lambda **kw: DiscreteA2CAgent(**kw))
+        runner.load({'params': copy.deepcopy(params)})
+        env = SyntheticTensorEnv(params['config']['num_actors'], device='cpu', **env_kw)
+        runner.params['config']['vec_env'] = env
+        runner.params['config']['env_info'] = env.get_env_info()
+        with pytest.raises(RuntimeError, match='MI355X HIP device only'):
+            runner.algo_factory.create(runner.algo_name, base_name='run', params=runner.params)
