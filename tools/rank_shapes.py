@@ -1,6 +1,6 @@
 """Single-GPU emulation of ONE rank's work at world sizes 1/2/4/8 (no collective): upper bound
 on strong scaling = T(world=1) / T_rank(world).  Optional A/B over agent config flags:
-    python tools/rank_shapes.py concurrent_dw=0,1 worlds=1,8"""
+    python tools/rank_shapes.py mini_epoch_graph=0,1 worlds=1,8"""
 import sys, os, time, itertools, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rl_games_amd import configs
