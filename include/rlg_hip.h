@@ -290,7 +290,9 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 int rlg_act_bwd_num_blocks(long long rows, int cols);
 
 /* d_pre = d_out * act'(pre_act) (may alias d_out), partials[block][cols] = column sums of d_pre.
- * act_kind 0 identity, 1 elu(alpha 1), 2 relu, 3 tanh.  cols % 4 == 0, ld = row stride. */
+ * act_kind 0 identity, 1 elu(alpha 1), 2 relu, 3 tanh; 17 / 18 / 19: the same derivatives evaluated
+ * from the layer OUTPUT act(z) passed as `pre_act` (in-place activations; aten's elu_backward with
+ * is_result = true: h > 0 ? 1 : h + 1).  cols % 4 == 0, ld = row stride. */
 int rlg_act_bwd_colsum(const float* d_out, const float* pre_act, float* d_pre, long long rows,
                        int cols, long long ld, int act_kind, double* partials, int num_blocks,
                        void* stream);

@@ -332,7 +332,8 @@ class A2CAgent:
             try:
                 self._engine = ManualMLP(self.model.a2c_network, self.optimizer,
                                          max(self.minibatch_size, self.num_actors * self.num_agents),
-                                         mfma_dw=bool(config.get('mfma_dw', True)))
+                                         mfma_dw=bool(config.get('mfma_dw', True)),
+                                         inplace_act=bool(config.get('inplace_act', True)))
             except NotImplementedError as e:
                 print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
                 self._engine = None

@@ -20,7 +20,10 @@ constexpr int kActBlock = 256;
 constexpr int kActWaves = kActBlock / kWave;
 constexpr int kActUnroll = 4;
 
-enum ActKind { kActIdentity = 0, kActElu = 1, kActRelu = 2, kActTanh = 3 };
+enum ActKind { kActIdentity = 0, kActElu = 1, kActRelu = 2, kActTanh = 3,
+               // the same derivatives evaluated from the layer OUTPUT h = act(z) (in-place activations:
+               // only h is kept), like aten's elu_backward(is_result = true): elu' = h > 0 ? 1 : h + 1
+               kActEluOut = 17, kActReluOut = 18, kActTanhOut = 19 };
 
 template <int ACT>
 __device__ __forceinline__ float act_grad(float z) {
@@ -30,6 +33,9 @@ __device__ __forceinline__ float act_grad(float z) {
     const float t = tanhf(z);
     return 1.0f - t * t;
   }
+  if (ACT == kActEluOut) return z > 0.0f ? 1.0f : z + 1.0f;
+  if (ACT == kActReluOut) return z > 0.0f ? 1.0f : 0.0f;
+  if (ACT == kActTanhOut) return 1.0f - z * z;
   return 1.0f;
 }
 
@@ -166,6 +172,18 @@ int rlg_act_bwd_colsum(const float* d_out, const float* pre_act, float* d_pre, l
       break;
     case kActTanh:
       hipLaunchKernelGGL((act_bwd_colsum_kernel<kActTanh>), grid, block, shm, st, d_out, pre_act,
+                         d_pre, rows, cols, ld, partials);
+      break;
+    case kActEluOut:
+      hipLaunchKernelGGL((act_bwd_colsum_kernel<kActEluOut>), grid, block, shm, st, d_out, pre_act,
+                         d_pre, rows, cols, ld, partials);
+      break;
+    case kActReluOut:
+      hipLaunchKernelGGL((act_bwd_colsum_kernel<kActReluOut>), grid, block, shm, st, d_out, pre_act,
+                         d_pre, rows, cols, ld, partials);
+      break;
+    case kActTanhOut:
+      hipLaunchKernelGGL((act_bwd_colsum_kernel<kActTanhOut>), grid, block, shm, st, d_out, pre_act,
                          d_pre, rows, cols, ld, partials);
       break;
     default:
