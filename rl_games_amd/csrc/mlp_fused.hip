@@ -7,7 +7,8 @@
 // replacing torch's `elu_backward` + `sum(0)` of nn.Linear's backward for the layers built by
 // `A2CBuilder._build_sequential_mlp` (rl_games/algos_torch/network_builder.py:118-147,
 // forward :498).  act'(z) for ELU(alpha=1): 1 for z > 0, exp(z) otherwise - evaluated from the
-// pre-activation exactly like aten's elu_backward (is_result = false).
+// pre-activation exactly like aten's elu_backward (is_result = false); the *Out kinds take the
+// derivative from the layer output instead (is_result = true) for in-place activations.
 //
 // Memory-bound: reads dH and Z, writes dZ (12 B per element); the column sums ride along in
 // registers (fp64 per lane, combined through LDS, per-block partials, no atomics).

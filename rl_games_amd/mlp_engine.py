@@ -16,7 +16,9 @@ so the backward pass is written out explicitly instead of being recorded by auto
     kernel per direction (csrc/lstm.hip) instead of a Python loop of per-timestep MIOpen calls
     with done resets (rl_games/common/layers/recurrent.py:26-58) and autograd BPTT through it;
     its input projection and all four weight/bias gradients are whole-sequence GEMMs.
-Numerics: identical formulas (elu'(z) = exp(z) from the pre-activation, like aten); GEMM
+Numerics: aten's formulas - by default (in-place activations) act' from the layer output like
+elu_backward(is_result=True): h > 0 ? 1 : h + 1; with `inplace_act=False` from the pre-activation
+(exp(z)); GEMM
 results are the library's, as before.  Parameters keep their reference names and shapes.
 """
 import torch
@@ -120,7 +122,7 @@ class ManualMLP:
     @torch.no_grad()
     def forward(self, x, keep=True, rnn_states=None, dones=None, seq_length=1):
         """x: [rows, in] normalised observations.  Returns heads [rows, V+A] (col 0..V-1 value,
-        then mu).  `keep` retains the pre-activations for backward().  LSTM policies: rows are
+        then mu).  `keep` retains what backward() needs (activations, LSTM cell states).  LSTM policies: rows are
         ordered (sequence, t) with `seq_length` steps each, rnn_states = (h0, c0) of shape
         [1, rows/seq_length, H], dones [rows] u8 resets the state entering a step (or None);
         the final states are left in `self.last_states`."""
