@@ -104,13 +104,16 @@ int rlg_rollout_post_step_num_blocks(int num_envs);
  * current_rewards/current_shaped_rewards/current_lengths accumulate + zero-on-done
  * (:1027-1051).  Finished-episode sums go to ep_partials[step][block][2V+2] (fp64) and are
  * folded into the meters by rlg_episode_meters_update.  time_outs_kind: 0 none, 1 u8/bool,
- * 2 fp32.  live_rows (next_step autoreset mask, :1002-1006) may be NULL. value_size <= 8. */
+ * 2 fp32.  live_rows (next_step autoreset mask, :1002-1006) may be NULL. value_size <= 8.
+ * num_envs counts rows (envs x agents); with num_agents > 1 only the first agent row of an env
+ * feeds the meters (all_done_indices[::num_agents], :1040-1044). */
 int rlg_rollout_post_step(const float* rewards, const uint8_t* dones, const void* time_outs,
                           int time_outs_kind, const float* values, const float* live_rows,
                           float* rewards_buf, float* cur_rewards, float* cur_shaped,
                           float* cur_lengths, double* ep_partials, float shift, float scale,
                           float rmin, float rmax, int clamp_rewards, int bootstrap, float gamma,
-                          int num_envs, int horizon, int value_size, int step, void* stream);
+                          int num_envs, int horizon, int value_size, int step, int num_agents,
+                          void* stream);
 
 /* Replays AverageMeter.update (rl_games/algos_torch/torch_ext.py:333-342) for the three
  * episode meters (game_rewards, game_shaped_rewards, game_lengths; a2c_common.py:1042-1044)

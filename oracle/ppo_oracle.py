@@ -14,7 +14,8 @@ function cites the reference lines it follows (paths relative to the reference c
 Pinning.  tests/golden/make_golden.py imports the real reference from /root/reference (with
 test-only stubs for the absent `gymnasium`/`tensorboardX` packages), runs its leaf functions
 and a full `A2CAgent.train_epoch` on seeded inputs, and stores inputs+outputs as fixtures;
-tests/test_oracle_golden.py checks every function here against those fixtures and against
+tests/test_oracle_epoch.py, tests/test_oracle_gae.py and tests/test_vs_reference_cpu.py check every
+function here against those fixtures, against the imported reference functions and against
 the reference's own known-answer tests (tests/test_triton_gae.py:20-61 fp64 recursion,
 tests/test_multigpu_stats_sync.py pooled moments, tests/test_rms_advantage.py EMA stats,
 tests/test_ppo_masking.py masked means).  Rows with no known-answer test in the reference

@@ -40,7 +40,7 @@ _PROTOTYPES = {
     'rlg_rollout_post_step_num_blocks': [_c_int],
     'rlg_rollout_post_step': [_P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_float, _c_float,
                               _c_float, _c_float, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int,
-                              _c_int, _P],
+                              _c_int, _c_int, _P],
     'rlg_episode_meters_update': [_P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P],
     'rlg_rnn_zero_done_states': [_P, _P, _c_int, _c_int, _c_int, _P],
     'rlg_rollout_policy_head': [_P, _c_int, _P, _P, _P, _P, _c_float, _P, _P, _P, _P, _P, _P, _P,

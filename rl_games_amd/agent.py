@@ -56,6 +56,10 @@ def rescale_actions(low, high, action):
     return action * d + m
 
 
+class GraphCaptureError(RuntimeError):
+    """A HIP graph capture failed; nothing ran on the device and host mirrors were rolled back."""
+
+
 class NullObserver:
     """AlgoObserver interface (rl_games/common/algo_observer.py:6-26) with no-op hooks."""
 
@@ -655,7 +659,8 @@ class A2CAgent:
         ops.rollout_post_step(rewards.float() if rewards.dtype != torch.float32 else rewards, self.dones,
                               time_outs, values, live, buf.storage['rewards'], self.current_rewards,
                               self.current_shaped_rewards, self.current_lengths, self._ep_partials,
-                              self._shaper, time_outs is not None, self.gamma, self.horizon_length, n)
+                              self._shaper, time_outs is not None, self.gamma, self.horizon_length, n,
+                              num_agents=self.num_agents)
         if self._observer_needs_infos:
             done_indices = self.dones.nonzero(as_tuple=False)[::self.num_agents]
             self.algo_observer.process_infos(infos, done_indices)
@@ -1085,6 +1090,23 @@ class A2CAgent:
         return (self._hip_graphs and self._engine is not None and self._eager_epochs >= 1
                 and self.dataset.values_dict.get('rnn_masks') is None and not self._graph_failed)
 
+    def _capture(self, body):
+        """Capture `body` into a HIP graph.  Capturing executes nothing on the device; host mirrors
+        that the body advances (the optimiser's step count) are restored afterwards, also when the
+        capture fails (GraphCaptureError: the caller then continues on the eager path)."""
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        count0 = self.optimizer.step_count
+        try:
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
+                body()
+        except Exception as e:
+            raise GraphCaptureError('HIP graph capture failed') from e
+        finally:
+            self.optimizer.step_count = count0
+        return g
+
     def _graph_minibatch(self, i):
         """Replay (capturing on first use) the forward/loss/backward graph of minibatch i, run the
         gradient all-reduce eagerly, then replay the (norm, Adam, lr) graph."""
@@ -1096,19 +1118,10 @@ class A2CAgent:
             self._graph_sig = sig
         g = self._graphs.get(i)
         if g is None:
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            g = torch.cuda.CUDAGraph()
             item = self.dataset[i]
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
-                self._forward_loss_backward(item, self._graph_rows[i])
-            self._graphs[i] = g
+            g = self._graphs[i] = self._capture(lambda: self._forward_loss_backward(item, self._graph_rows[i]))
         if self._graph_opt is None:
-            go = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(go, pool=self._graph_pool, capture_error_mode='thread_local'):
-                self._optimizer_kernels()
-            self.optimizer.step_count -= 1        # capture advanced the host mirror, not the device
-            self._graph_opt = go
+            self._graph_opt = self._capture(self._optimizer_kernels)
         g.replay()
         if self.multi_gpu:
             rdist.all_reduce_sum(self.optimizer.flat_grads)
@@ -1126,15 +1139,11 @@ class A2CAgent:
             self._graph_epoch = None
             self._graph_sig = sig
         if self._graph_epoch is None:
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
+            def body():
                 for i in range(nmb):
                     self._forward_loss_backward(self.dataset[i], self._graph_rows[i])
                     self._optimizer_kernels()
-            self.optimizer.step_count -= nmb      # capture advanced the host mirror, not the device
-            self._graph_epoch = g
+            self._graph_epoch = self._capture(body)
         self._graph_epoch.replay()
         self.optimizer.step_count += nmb
 
@@ -1170,34 +1179,41 @@ class A2CAgent:
         nmb = len(self.dataset)
         for mini_ep in range(self.mini_epochs_num):
             first = self._mb_index
+            done = 0                     # minibatches of this mini-epoch already stepped
             if use_graphs:
                 try:
                     self.set_train()
                     host_between = self.schedule_type == 'per_minibatch' and not device_schedule
                     if not self.multi_gpu and not host_between and self.config.get('mini_epoch_graph', True):
                         self._graph_mini_epoch(nmb)
+                        done = nmb
                     else:
                         for i in range(nmb):
                             self._graph_minibatch(i)
+                            done = i + 1
                             if host_between:
                                 self._host_schedule(None)
-                    self._mb_scalars[first:first + nmb].copy_(self._graph_rows[:nmb])
-                    self._mb_index += nmb
-                    for i in range(nmb):
-                        row = self._mb_scalars[first + i]
-                        a_losses.append(row[0])
-                        c_losses.append(row[1])
-                        entropies.append(row[2])
-                        if self.bounds_loss_coef is not None:
-                            b_losses.append(row[3])
-                except Exception as e:        # pragma: no cover - capture problems fall back to eager
-                    print(f'rl_games_amd: HIP graph path disabled ({type(e).__name__}: {e})')
+                except GraphCaptureError as e:
+                    # A capture executes nothing and the host mirrors were rolled back, so the
+                    # remaining minibatches of this mini-epoch (and all later ones) run eagerly.
+                    print(f'rl_games_amd: HIP graph capture failed ({e.__cause__!r}); continuing eagerly')
                     self._graph_failed = True
-                    raise
-            else:
-                if self.is_discrete:                  # a2c_common.py:1263 (no-op unless `permute`)
+                    self._graphs.clear()
+                    self._graph_opt = self._graph_epoch = None
+                    use_graphs = False
+                self._mb_scalars[first:first + done].copy_(self._graph_rows[:done])
+                self._mb_index += done
+                for i in range(done):
+                    row = self._mb_scalars[first + i]
+                    a_losses.append(row[0])
+                    c_losses.append(row[1])
+                    entropies.append(row[2])
+                    if self.bounds_loss_coef is not None:
+                        b_losses.append(row[3])
+            if done < nmb:
+                if self.is_discrete and done == 0:    # a2c_common.py:1263 (no-op unless `permute`)
                     self.dataset.apply_permutation()
-                for i in range(nmb):
+                for i in range(done, nmb):
                     res = self.train_actor_critic(self.dataset[i])
                     a_loss, c_loss, entropy, kl, last_lr, lr_mul = res[:6]
                     b_loss = res[8] if len(res) > 8 else None

@@ -98,6 +98,7 @@ struct PostStepArgs {
   int bootstrap;               // value_bootstrap and 'time_outs' in infos
   float gamma;
   int N, H, V, step;
+  int num_agents;              // meters take one row per env: rows with row % num_agents == 0
 };
 
 constexpr int kPostBlock = 256;
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepA
     }
     const float live = a.live_rows ? a.live_rows[env] : 1.0f;
     const float alive = 1.0f - done;
+    // game_rewards / game_shaped_rewards / game_lengths are fed from all_done_indices[::num_agents]
+    // (a2c_common.py:1040-1044): the first agent row of every finished env (the agents of one env
+    // finish together, which is also what the reference's stride over the done list assumes).
+    const bool metered = is_done && (a.num_agents <= 1 || env % a.num_agents == 0);
 #pragma unroll
     for (int k = 0; k < kMaxV; ++k) {
       if (k < V) {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepA
           cr = a.cur_rewards[env * V + k] + rew;
           cs = a.cur_shaped[env * V + k] + shaped;
         }
-        if (is_done) {
+        if (metered) {
           acc[k] = cr;
           acc[kMaxV + k] = cs;
         }
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepA
       }
     }
     const float cl = a.cur_lengths[env] + (a.live_rows ? live : 1.0f);
-    if (is_done) {
+    if (metered) {
       acc[2 * kMaxV] = cl;
       acc[2 * kMaxV + 1] = 1.0;
     }
@@ -373,7 +378,8 @@ int rlg_rollout_post_step(const float* rewards, const uint8_t* dones, const void
                           float* rewards_buf, float* cur_rewards, float* cur_shaped,
                           float* cur_lengths, double* ep_partials, float shift, float scale,
                           float rmin, float rmax, int clamp_rewards, int bootstrap, float gamma,
-                          int num_envs, int horizon, int value_size, int step, void* stream) {
+                          int num_envs, int horizon, int value_size, int step, int num_agents,
+                          void* stream) {
   using namespace rlg;
   if (num_envs <= 0) return 0;
   if (value_size < 1 || value_size > kMaxV || step < 0 || step >= horizon)
@@ -401,6 +407,7 @@ int rlg_rollout_post_step(const float* rewards, const uint8_t* dones, const void
   a.H = horizon;
   a.V = value_size;
   a.step = step;
+  a.num_agents = num_agents < 1 ? 1 : num_agents;
   const int grid = rlg_rollout_post_step_num_blocks(num_envs);
   hipLaunchKernelGGL(rollout_post_step_kernel, dim3(grid), dim3(kPostBlock), 0,
                      static_cast<hipStream_t>(stream), a);

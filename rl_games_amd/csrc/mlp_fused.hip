@@ -45,7 +45,7 @@ __device__ __forceinline__ float act_grad(float z) {
 // rpp = 64 / units consecutive rows per pass so its lanes read one contiguous span.
 template <int ACT>
 __global__ __launch_bounds__(kActBlock) void act_bwd_colsum_kernel(
-    const float* __restrict__ dH, const float* __restrict__ Z, float* __restrict__ dZ,
+    const float* dH, const float* __restrict__ Z, float* dZ,   // dZ may alias dH (in-place call)
     long long rows, int C, long long ld, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];   // [kActWaves][64][4]
   const int upr = C / 4;

@@ -133,14 +133,17 @@ class FlatAdam(FlatArena):
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):
         state = {}
-        for i, (off, n) in enumerate(self.offsets):
+        # like torch.optim.Adam: no per-parameter state before the first step, and the reference's
+        # defaults (`fused: None`, `foreach: None`) so that a reference agent restoring this
+        # checkpoint keeps its own default (foreach) implementation
+        for i, (off, n) in enumerate(self.offsets if self.step_count > 0 else ()):
             shape = self.params[i].shape
             state[i] = {'step': torch.tensor(float(self.step_count)),
                         'exp_avg': self.exp_avg[off:off + n].view(shape).clone(),
                         'exp_avg_sq': self.exp_avg_sq[off:off + n].view(shape).clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         group.update(lr=self.current_lr(), amsgrad=False, maximize=False, foreach=None, capturable=False,
-                     differentiable=False, fused=True, decoupled_weight_decay=False,
+                     differentiable=False, fused=None, decoupled_weight_decay=False,
                      params=list(range(len(self.params))))
         return {'state': state, 'param_groups': [group]}
 

@@ -64,7 +64,8 @@ def post_step_num_blocks(num_envs):
 
 
 def rollout_post_step(rewards, dones, time_outs, values, live_rows, rewards_buf, cur_rewards,
-                      cur_shaped, cur_lengths, ep_partials, shaper, bootstrap, gamma, horizon, step):
+                      cur_shaped, cur_lengths, ep_partials, shaper, bootstrap, gamma, horizon, step,
+                      num_agents=1):
     """shaper = (shift, scale, min_val, max_val)."""
     lib = _lib.load()
     N, V = rewards.shape
@@ -86,7 +87,8 @@ def rollout_post_step(rewards, dones, time_outs, values, live_rows, rewards_buf,
         _need(cur_shaped, F32, 'cur_shaped'), _need(cur_lengths, F32, 'cur_lengths'),
         _need(ep_partials, F64, 'ep_partials'), float(np.float32(shift)), float(np.float32(scale)),
         float(np.float32(max(rmin, -3.0e38))), float(np.float32(min(rmax, 3.0e38))), clamp,
-        1 if bootstrap else 0, float(np.float32(gamma)), N, horizon, V, step, _stream(rewards)),
+        1 if bootstrap else 0, float(np.float32(gamma)), N, horizon, V, step, int(num_agents),
+        _stream(rewards)),
         'rlg_rollout_post_step')
 
 

@@ -46,11 +46,14 @@ def test_store_step_matches_indexed_assignment(N, H, O_, A):
         assert torch.equal(flat.cpu(), O.flatten_env_major(ref[k]))
 
 
-@pytest.mark.parametrize('V,masked,to_dtype', [(1, False, torch.bool), (2, False, torch.float32),
-                                                (1, True, torch.uint8), (1, False, None)])
-def test_post_step_matches_oracle(V, masked, to_dtype):
+@pytest.mark.parametrize('V,masked,to_dtype,agents', [(1, False, torch.bool, 1), (2, False, torch.float32, 1),
+                                                       (1, True, torch.uint8, 1), (1, False, None, 1),
+                                                       (1, False, torch.bool, 2), (2, False, None, 3)])
+def test_post_step_matches_oracle(V, masked, to_dtype, agents):
+    """agents > 1: rows are (env, agent); the agents of an env finish together and the meters
+    take all_done_indices[::num_agents] (a2c_common.py:1040-1044), i.e. one row per env."""
     from rl_games_amd import ops
-    N, H, gamma = 777, 6, 0.99
+    N, H, gamma = (777, 6, 0.99) if agents == 1 else (258 * agents, 6, 0.99)
     gen = g(1)
     shaper = (0.5, 2.0, -3.0, 3.0)
     nb = ops.post_step_num_blocks(N)
@@ -66,7 +69,7 @@ def test_post_step_matches_oracle(V, masked, to_dtype):
     for step in range(H):
         rewards = torch.randn(N, V, generator=gen)
         values = torch.randn(N, V, generator=gen)
-        dones = (torch.rand(N, generator=gen) < 0.2).to(torch.uint8)
+        dones = (torch.rand(N // agents, generator=gen) < 0.2).to(torch.uint8).repeat_interleave(agents)
         time_outs = (torch.rand(N, generator=gen) < 0.5) & dones.bool()
         live = (torch.rand(N, generator=gen) < 0.8).float() if masked else None
         shaped = O.shape_rewards(rewards, scale=shaper[1], shift=shaper[0], min_val=shaper[2],
@@ -75,7 +78,7 @@ def test_post_step_matches_oracle(V, masked, to_dtype):
             shaped = O.bootstrap_timeouts(shaped, values, time_outs, gamma)
         ref_buf[step, :] = shaped
         cur_r, cur_s, cur_l, fin = O.episode_bookkeeping(cur_r, cur_s, cur_l, rewards, shaped, dones,
-                                                         live_rows=live)
+                                                         live_rows=live, num_agents=agents)
         for j, vals in enumerate(fin[:3]):
             vals = vals.reshape(vals.shape[0], -1) if j < 2 else vals.reshape(-1, 1)
             meters['m'][j], meters['n'][j] = O.average_meter_update(meters['m'][j], meters['n'][j],
@@ -83,7 +86,8 @@ def test_post_step_matches_oracle(V, masked, to_dtype):
         to = None if to_dtype is None else time_outs.to(to_dtype).to(DEV)
         ops.rollout_post_step(rewards.to(DEV), dones.to(DEV), to, values.to(DEV),
                               None if live is None else live.to(DEV), rewards_buf, d_cur[0], d_cur[1],
-                              d_cur[2], ep_partials, shaper, to_dtype is not None, gamma, H, step)
+                              d_cur[2], ep_partials, shaper, to_dtype is not None, gamma, H, step,
+                              num_agents=agents)
         assert torch.equal(d_cur[0].cpu(), cur_r) and torch.equal(d_cur[1].cpu(), cur_s)
         assert torch.equal(d_cur[2].cpu(), cur_l)
     assert torch.equal(rewards_buf.transpose(0, 1).cpu(), ref_buf)
