@@ -339,6 +339,38 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
                       void* stream);
 
+/* ---- the MLP as one vertically fused chain on f32 MFMA (csrc/mlp_chain.hip) ------------------
+ * forward : heads = head(act(... act(norm(x) W_0^T + b_0) ...)) for a row tile, every layer in ONE
+ *           launch with the activations resident in LDS; replaces A2CBuilder.Network.forward
+ *           (rl_games/algos_torch/network_builder.py:447-512: actor_mlp + value/mu heads, arranged
+ *           as one [1+A, K] last layer) and norm_obs in front of it (rl_games/algos_torch/models.py:
+ *           54-56; RunningMeanStd eval formula rl_games/algos_torch/running_mean_std.py:112-113).
+ *           act_out[l] (row stride act_ld[l]) receives layer l's output: required for the last
+ *           layer (the heads), optional (training: what backward needs) for the hidden ones;
+ *           xn_out (optional) receives the normalised observations [rows, in_0].
+ * backward: dZ_{l-1} = (dZ_l W_l) * act'_{l-1}(H_{l-1}) down the chain from d_out = d loss / d heads
+ *           (autograd's grad_output.mm(weight) + activation backward + bias sum(0) per nn.Linear);
+ *           dz_out[l] (l < last) receives dZ_l, bias_partials[l] (optional) [num_blocks, out_l]
+ *           fp64 per-workgroup column sums of dZ_l (finished by rlg_mlp_dw_launch's colsum items).
+ * acts: 0 identity, 1 elu, 2 relu, 3 tanh (backward evaluates act' from the layer OUTPUT).
+ * groups: 16-row groups per workgroup, 1 / 2 / 4 (0 = chosen from rows: rlg_mlp_chain_groups).
+ * rlg_mlp_chain_lds_bytes: LDS of one workgroup (direction 0 forward, 1 backward), -1 if the
+ * network does not fit the 160 KiB LDS with that many groups. */
+int rlg_mlp_chain_groups(long long rows, int requested);
+int rlg_mlp_chain_num_blocks(long long rows, int groups);
+int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,
+                            int direction);
+int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,
+                          const int* in_features, const int* out_features, const int* acts,
+                          float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                          const double* rms_mean_or_null, const double* rms_var, float rms_eps,
+                          float* xn_out_or_null, long long rows, int groups, void* stream);
+int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const int* in_features,
+                           const int* out_features, const int* acts, const float* const* act_in,
+                           const long long* act_ld, const float* d_out, long long ld_dout,
+                           float* const* dz_out, const long long* dz_ld, double* const* bias_partials_or_null,
+                           long long rows, int groups, void* stream);
+
 /* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
  * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state
  * resets of rl_games/common/layers/recurrent.py:26-58 (LSTMWithDones) as used by A2CBuilder

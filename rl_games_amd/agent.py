@@ -337,7 +337,8 @@ class A2CAgent:
                 self._engine = ManualMLP(self.model.a2c_network, self.optimizer,
                                          max(self.minibatch_size, self.num_actors * self.num_agents),
                                          mfma_dw=bool(config.get('mfma_dw', True)),
-                                         inplace_act=bool(config.get('inplace_act', True)))
+                                         inplace_act=bool(config.get('inplace_act', True)),
+                                         fused_chain=bool(config.get('fused_mlp', True)))
             except NotImplementedError as e:
                 print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
                 self._engine = None
@@ -745,15 +746,19 @@ class A2CAgent:
         if not obs.is_contiguous():
             obs = obs.contiguous()
         rows = obs.shape[0]
-        if self.normalize_input:
-            m = self.model.running_mean_std
-            obs_n = ops.rms_apply(obs, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
+        if eng.chain is not None:
+            # normaliser + every layer + heads in one launch; nothing but the heads is written
+            heads = eng.forward_obs(obs, self._obs_rms(), self._obs_eps(), keep=False)
         else:
-            obs_n = obs
-        if self.is_rnn:
-            heads = eng.forward(obs_n, keep=False, rnn_states=rnn_states, seq_length=1)
-        else:
-            heads = eng.forward(obs_n)
+            if self.normalize_input:
+                m = self.model.running_mean_std
+                obs_n = ops.rms_apply(obs, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
+            else:
+                obs_n = obs
+            if self.is_rnn:
+                heads = eng.forward(obs_n, keep=False, rnn_states=rnn_states, seq_length=1)
+            else:
+                heads = eng.forward(obs_n, keep=False)
         torch.randn(self._roll_noise.shape, device=self._roll_noise.device, out=self._roll_noise)
         vs = None
         eps = 1e-5
@@ -781,18 +786,30 @@ class A2CAgent:
         x = self._preproc_obs(obs['obs'])
         if not x.is_contiguous():
             x = x.contiguous()
-        if self.normalize_input:
-            m = self.model.running_mean_std
-            x = ops.rms_apply(x, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
-        if self.is_rnn:
-            heads = eng.forward(x, keep=False, rnn_states=self.rnn_states, seq_length=1)
+        if eng.chain is not None:
+            heads = eng.forward_obs(x, self._obs_rms(), self._obs_eps(), keep=False)
         else:
-            heads = eng.forward(x)
+            if self.normalize_input:
+                m = self.model.running_mean_std
+                x = ops.rms_apply(x, m.running_mean, m.running_var, m.epsilon, 0, out=self._roll_obs_norm)
+            if self.is_rnn:
+                heads = eng.forward(x, keep=False, rnn_states=self.rnn_states, seq_length=1)
+            else:
+                heads = eng.forward(x, keep=False)
         v = heads[:, 0].contiguous()
         if self.normalize_value:
             vm = self.model.value_mean_std
             v = ops.rms_apply(v.view(-1, 1), vm.running_mean, vm.running_var, vm.epsilon, 1).view(-1)
         return v
+
+    def _obs_rms(self):
+        if not self.normalize_input:
+            return None
+        m = self.model.running_mean_std
+        return (m.running_mean, m.running_var)
+
+    def _obs_eps(self):
+        return self.model.running_mean_std.epsilon if self.normalize_input else 1e-5
 
     def _fast_rollout_ok(self):
         return (self._engine is not None and self.value_size == 1 and not self.has_central_value
@@ -1006,12 +1023,21 @@ class A2CAgent:
             opt.zero_grad()
         if eng is not None:
             with torch.no_grad():
-                if self.normalize_input:                                # updates the obs statistics
+                if eng.chain is not None:
+                    if not obs_batch.is_contiguous():
+                        obs_batch = obs_batch.contiguous()
+                    if self.normalize_input and self.model.running_mean_std.training:
+                        self.model.running_mean_std.update(obs_batch)   # statistics first (models.py:54-56)
+                    heads = eng.forward_obs(obs_batch, self._obs_rms(), self._obs_eps())
+                    obs_n = None
+                elif self.normalize_input:                              # updates the obs statistics
                     out = self._obs_norm_mb[:obs_batch.shape[0]] if self._obs_norm_mb is not None else None
                     obs_n = self.model.running_mean_std(obs_batch, out=out)
                 else:
                     obs_n = obs_batch
-                if self.is_rnn:
+                if eng.chain is not None:
+                    pass
+                elif self.is_rnn:
                     heads = eng.forward(obs_n, rnn_states=batch['rnn_states'], dones=batch.get('dones'),
                                         seq_length=self.seq_length)
                 else:

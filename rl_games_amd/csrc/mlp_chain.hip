@@ -1,0 +1,696 @@
+// The actor-critic MLP as a vertically fused chain on f32 MFMA (gfx950): every layer of a row tile
+// in ONE launch, activations resident in LDS, weights streamed from L2.
+//
+//   forward :  obs -> [RunningMeanStd normalise] -> (Linear + act) x L -> fused (value | mu) head
+//   backward:  d heads -> ((dZ W) * act'(H)) x L   (+ per-layer bias-gradient partial sums)
+//
+// replaces `A2CBuilder.Network.forward` (rl_games/algos_torch/network_builder.py:447-512: actor_mlp,
+// value / mu heads), `norm_obs` (rl_games/algos_torch/models.py:54-56) in front of it, and the
+// autograd dX / activation-backward / bias-sum nodes behind it.  The weight gradients are the
+// separate launch of mlp_dw16.hip, which reads the dZ / H arrays this file writes.
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32, D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies
+// A[l&15][l>>4], B[l>>4][l&15] and receives D[4*(l>>4)+reg][l&15], reg = 0..3):
+//   * every product is computed TRANSPOSED: i = output feature, j = batch row, k = input feature.
+//     The weights are the A operand, the activations the B operand, and the result comes out with
+//     "lane = (row, 4 consecutive features)" - exactly the shape the next layer needs as ITS B
+//     operand.  A layer's output therefore goes to LDS with one ds_write_b128 per lane and comes
+//     back with one ds_read_b128 per lane, no transposes, no bank conflicts (lane-consecutive 16 B).
+//   * k is assigned so that a lane's 4 MFMA steps take 4 CONSECUTIVE input features
+//     (step s, lane l: feature 16c + 4*(l>>4) + s).  Forward: the lane's A operands of a k-chunk are
+//     one 16-byte load from the row-major weight W[out][in]; backward (A = W^T): four 4-byte loads,
+//     each 4 x 64 contiguous bytes per wave.  Nothing is packed or transposed on the host.
+//   * a workgroup (4 waves, one per SIMD) owns 16*G rows.  Per layer the output blocks of 16
+//     features are dealt to the waves; a wave computes a block for all G row groups at once (the A
+//     operand is loaded once per block), the remainder blocks are split by row group so that all
+//     four waves do the same number of MFMAs.
+//   * out-of-range weight rows are fetched through a bounds-checked buffer descriptor (zero), the
+//     K padding of a tile is zero in LDS, so padded features stay exactly zero through the chain.
+// Numerics: exact fp32 products, fp32 accumulation in k order (bitwise a chain of fmaf), bias
+// added after the sum like the library epilogue; ELU = x > 0 ? x : exp(x) - 1.
+// LDS tile of a layer with `nb` 16-feature blocks: [nb][G][64 lanes][4] floats (nb*G KiB).
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+constexpr int kChainMaxLayers = 8;
+constexpr int kChainWaves = 4;
+constexpr int kChainThreads = 64 * kChainWaves;
+constexpr unsigned kOob = 0x40000000u;     // byte offset far outside every weight buffer
+
+enum : int { kChIdentity = 0, kChElu = 1, kChRelu = 2, kChTanh = 3 };
+
+struct ChainLayer {
+  const float* w;        // [out, in] row-major
+  const float* bias;     // [out] (forward)
+  float* h;              // forward: activation output [rows, ldh] or nullptr;  backward: H of this layer (input)
+  float* dz;             // backward: dZ of this layer [rows, lddz] (output; nullptr for the last layer)
+  double* bias_partials; // backward: [gridDim.x, out] column sums of dZ, or nullptr
+  long long ldh, lddz;
+  int in, out;
+  int act;
+};
+
+struct ChainArgs {
+  ChainLayer layer[kChainMaxLayers];
+  int num_layers;
+  const float* x;              // forward: raw observations [rows, ldx]; backward: d(last layer output) [rows, ldx]
+  long long ldx;
+  const double* rms_mean;      // forward: RunningMeanStd state (fp64) or nullptr
+  const double* rms_var;
+  float rms_eps;
+  float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
+  long long rows;
+  int lds_b_floats;            // start of the second LDS region, in floats
+};
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+__device__ __forceinline__ float chain_act(float v, int act) {
+  if (act == kChElu) return v > 0.0f ? v : __expf(v) - 1.0f;
+  if (act == kChRelu) return v > 0.0f ? v : 0.0f;
+  if (act == kChTanh) return tanhf(v);
+  return v;
+}
+// act' from the layer OUTPUT h (aten's *_backward with is_result = true)
+__device__ __forceinline__ float chain_act_grad(float h, int act) {
+  if (act == kChElu) return h > 0.0f ? 1.0f : h + 1.0f;
+  if (act == kChRelu) return h > 0.0f ? 1.0f : 0.0f;
+  if (act == kChTanh) return 1.0f - h * h;
+  return 1.0f;
+}
+
+// A wave's share of one layer: `nunits` output units, unit j = the 16-feature block ob_of(j) for the NG
+// row groups g_of(j) .. g_of(j)+NG-1:
+//   pre(j);  acc[g] = sum over the KC k-chunks of  A(ob, chunk) x B(chunk, group);  epi(j, acc)
+// (pre: loads the epilogue will need, issued before the unit's MFMAs)
+// kTransposedA = false: A[i][k] = W[ob*16 + i][k]        (forward, W row-major [out=i][in=k], ld = K)
+// kTransposedA = true : A[i][k] = W[k][ob*16 + i]        (backward, W row-major [out=k][in=i], ld = I)
+// Software pipeline: k-chunks are issued in batches of 4 (16*NG MFMAs); the A operands of the NEXT
+// batch - which may be the first batch of the next unit - are in flight while the current batch
+// issues, the B fragments (LDS) are double-buffered one chunk ahead, also across unit boundaries,
+// so neither the L2 latency at the start of a unit nor the epilogue of the previous one is exposed.
+// All register arrays are indexed statically (a rotation through moves would make every step wait
+// for the load it has just issued); the K remainder (KC % 4 chunks) is a switch over straight-line
+// tails, so there is no branch between a fragment load and the MFMAs in front of which it is issued.
+// hipcc's scheduler otherwise sinks the prefetch loads down to their first use (and the fragment
+// reads to two MFMAs before theirs): pin the order issue-loads / MFMA group / issue-loads / ...
+#define RLG_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int NG, bool kTransposedA, class ObOf, class GOf, class Pre, class Epi>
+__device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, const float* in_tile, int G,
+                                            int nunits, ObOf ob_of, GOf g_of, Pre pre, Epi epi) {
+  if (nunits <= 0) return;
+  const int lane = lane_id();
+  const int KC = (K + 15) >> 4;
+  const int nfull = KC >> 2;
+  const int rem = KC & 3;
+  const unsigned astep = kTransposedA ? static_cast<unsigned>(16 * ld * 4) : 64u;
+  const int bstride = G * 256;
+  auto a_base = [&](int j) -> unsigned {
+    if (j >= nunits) return kOob;
+    const int i = ob_of(j) * 16 + (lane & 15);
+    if (i >= I) return kOob;
+    return kTransposedA ? static_cast<unsigned>(((4 * (lane >> 4)) * ld + i) * 4)
+                        : static_cast<unsigned>((i * ld + 4 * (lane >> 4)) * 4);
+  };
+  auto b_base = [&](int j) -> const float* {
+    const int jj = (j < nunits) ? j : nunits - 1;
+    return in_tile + (g_of(jj) * 64 + lane) * 4;
+  };
+  auto load_a = [&](unsigned base, int c) -> f32x4 {
+    const unsigned off = (c < KC) ? base + static_cast<unsigned>(c) * astep : kOob;
+    if (!kTransposedA) return buf_load4(wr, off);
+    f32x4 v;
+    v[0] = buf_load1(wr, off);
+    v[1] = buf_load1(wr, off + static_cast<unsigned>(ld * 4));
+    v[2] = buf_load1(wr, off + static_cast<unsigned>(ld * 8));
+    v[3] = buf_load1(wr, off + static_cast<unsigned>(ld * 12));
+    return v;
+  };
+  auto load_b = [&](f32x4 (&bv)[NG], const float* p) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p + g * 256);
+  };
+
+  unsigned abase = a_base(0);
+  const float* bp = b_base(0);
+  f32x4 cur[4], nxt[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cur[u] = load_a(abase, u);
+  f32x4 b0[NG], b1[NG];
+  load_b(b0, bp);
+
+  for (int j = 0; j < nunits; ++j) {
+    const unsigned abase_n = a_base(j + 1);
+    const float* bp_n = b_base(j + 1);
+    pre(j);
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // one k-chunk = 4 MFMA steps x NG groups; the fragment reads of the following chunk are issued
+    // after step 0, so that a wait for THIS chunk's fragments never includes them
+    auto mfma_head = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[g][0], acc[g], 0, 0, 0);
+    };
+    auto mfma_rest = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
+#pragma unroll
+      for (int s = 1; s < 4; ++s) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+      }
+    };
+    for (int bi = 0; bi < nfull; ++bi) {
+      const int c = bi * 4;
+      const bool wraps = (c + 4 >= KC);                 // the following chunk belongs to the next unit
+      const unsigned nbase = wraps ? abase_n : abase;
+      const int nc = wraps ? 0 : c + 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nxt[u] = load_a(nbase, nc + u);
+      mfma_head(cur[0], b0);
+      RLG_PIN();
+      load_b(b1, bp + (c + 1) * bstride);
+      RLG_PIN();
+      mfma_rest(cur[0], b0);
+      RLG_PIN();
+      mfma_head(cur[1], b1);
+      RLG_PIN();
+      load_b(b0, bp + (c + 2) * bstride);
+      RLG_PIN();
+      mfma_rest(cur[1], b1);
+      RLG_PIN();
+      mfma_head(cur[2], b0);
+      RLG_PIN();
+      load_b(b1, bp + (c + 3) * bstride);
+      RLG_PIN();
+      mfma_rest(cur[2], b0);
+      RLG_PIN();
+      mfma_head(cur[3], b1);
+      RLG_PIN();
+      load_b(b0, wraps ? bp_n : bp + (c + 4) * bstride);
+      RLG_PIN();
+      mfma_rest(cur[3], b1);
+      RLG_PIN();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    }
+    if (rem != 0) {
+      // tail chunks nfull*4 .. KC-1 are in cur[0..rem-1]; next comes the first batch of the next unit
+      const float* bt = bp + (nfull * 4) * bstride;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nxt[u] = load_a(abase_n, u);
+      if (rem == 1) {
+        mfma_head(cur[0], b0);
+        RLG_PIN();
+        load_b(b1, bp_n);
+        RLG_PIN();
+        mfma_rest(cur[0], b0);
+        RLG_PIN();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b0[g] = b1[g];
+      } else if (rem == 2) {
+        mfma_head(cur[0], b0);
+        RLG_PIN();
+        load_b(b1, bt + bstride);
+        RLG_PIN();
+        mfma_rest(cur[0], b0);
+        RLG_PIN();
+        mfma_head(cur[1], b1);
+        RLG_PIN();
+        load_b(b0, bp_n);
+        RLG_PIN();
+        mfma_rest(cur[1], b1);
+        RLG_PIN();
+      } else {
+        mfma_head(cur[0], b0);
+        RLG_PIN();
+        load_b(b1, bt + bstride);
+        RLG_PIN();
+        mfma_rest(cur[0], b0);
+        RLG_PIN();
+        mfma_head(cur[1], b1);
+        RLG_PIN();
+        load_b(b0, bt + 2 * bstride);
+        RLG_PIN();
+        mfma_rest(cur[1], b1);
+        RLG_PIN();
+        mfma_head(cur[2], b0);
+        RLG_PIN();
+        load_b(b1, bp_n);
+        RLG_PIN();
+        mfma_rest(cur[2], b0);
+        RLG_PIN();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b0[g] = b1[g];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    }
+    epi(j, acc);
+    abase = abase_n;
+    bp = bp_n;
+  }
+}
+
+// 4 consecutive features [f, f+4) of row `row` of a row-major array, masked to `width`
+__device__ __forceinline__ void store_row4(float* base, long long ld, long long row, int f, int width,
+                                           const f32x4& v, bool vec_ok) {
+  float* p = base + row * ld + f;
+  if (vec_ok && f + 4 <= width) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (f + e < width) p[e] = v[e];
+    }
+  }
+}
+__device__ __forceinline__ f32x4 load_row4(const float* base, long long ld, long long row, int f, int width,
+                                           bool vec_ok) {
+  const float* p = base + row * ld + f;
+  if (vec_ok && f + 4 <= width) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (f + e < width) v[e] = p[e];
+  }
+  return v;
+}
+__device__ __forceinline__ bool vec4_ok(const void* p, long long ld) {
+  return aligned16(p) && (ld & 3) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
+  float* tile_a = lds;
+  float* tile_b = lds + a.lds_b_floats;
+
+  // ---- prologue: observation tile -> LDS (fragment layout), normalised on the way -----------------
+  {
+    const int in0 = a.layer[0].in;
+    const int in0p = (in0 + 3) & ~3;
+    const bool norm = a.rms_mean != nullptr;
+    if (norm) {
+      // mean32 / denom exactly like rms_apply_kernel mode 0 (running_mean_std.py:112-113)
+      for (int f = threadIdx.x; f < in0; f += kChainThreads) {
+        tile_b[f] = static_cast<float>(a.rms_mean[f]);
+        tile_b[in0p + f] = sqrt_rn(static_cast<float>(a.rms_var[f]) + a.rms_eps);
+      }
+      __syncthreads();
+    }
+    const int KC0 = (in0 + 15) >> 4;
+    const bool xv = vec4_ok(a.x, a.ldx);
+    const bool xnv = a.xn != nullptr && vec4_ok(a.xn, in0);
+    for (int u = wave; u < KC0 * G; u += kChainWaves) {
+      const int c = u / G;
+      const int g = u - c * G;
+      const long long row = row0 + g * 16 + (lane & 15);
+      const int f = c * 16 + 4 * (lane >> 4);
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < a.rows) {
+        v = load_row4(a.x, a.ldx, row, f, in0, xv);
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (f + e < in0) v[e] = fminf(fmaxf((v[e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f), 5.0f);
+          }
+        }
+        if (a.xn) store_row4(a.xn, in0, row, f, in0, v, xnv);
+      }
+      *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- the layers ---------------------------------------------------------------------------------
+  float* tin = tile_a;
+  float* tout = tile_b;
+  for (int L = 0; L < a.num_layers; ++L) {
+    const ChainLayer& ly = a.layer[L];
+    const bool last = (L == a.num_layers - 1);
+    const rsrc_t wr = make_rsrc(ly.w, static_cast<unsigned>(ly.in) * ly.out * 4u);
+    const int NOB = (ly.out + 15) >> 4;
+    const int full = NOB / kChainWaves;
+    const bool hv = ly.h != nullptr && vec4_ok(ly.h, ly.ldh);
+    auto epilogue = [&](int ob, int g, const f32x4& accv) {
+      const int f = ob * 16 + 4 * (lane >> 4);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float bias = (f + e < ly.out) ? ly.bias[f + e] : 0.0f;
+        v[e] = chain_act(accv[e] + bias, ly.act);
+      }
+      if (!last) *reinterpret_cast<f32x4*>(tout + ((ob * G + g) * 64 + lane) * 4) = v;
+      const long long row = row0 + g * 16 + (lane & 15);
+      if (ly.h != nullptr && row < a.rows) store_row4(ly.h, ly.ldh, row, f, ly.out, v, hv);
+    };
+    // whole blocks: all G row groups, one weight stream per block
+    chain_units<G, false>(
+        wr, ly.out, ly.in, ly.in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; }, [](int) {},
+        [&](int j, const f32x4 (&acc)[G]) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) epilogue(wave * full + j, g, acc[g]);
+        });
+    // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
+    const int rem_first = full * kChainWaves;
+    const int rem_units = (NOB - rem_first) * G;
+    const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
+    chain_units<1, false>(
+        wr, ly.out, ly.in, ly.in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
+        [&](int j) { return (wave + j * kChainWaves) % G; }, [](int) {},
+        [&](int j, const f32x4 (&acc)[1]) {
+          const int u = wave + j * kChainWaves;
+          epilogue(rem_first + u / G, u % G, acc[0]);
+        });
+    __syncthreads();
+    float* t = tin;
+    tin = tout;
+    tout = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (dX chain): layer[num_layers-1] is the head, its dZ is `x` (d heads) itself.
+// For L = num_layers-1 .. 1:  dZ_{L-1} = (dZ_L W_L) * act'_{L-1}(H_{L-1});  layer 0 needs no dX.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
+  float* tile_a = lds;
+  float* tile_b = lds + a.lds_b_floats;
+
+  // ---- prologue: d heads tile -> LDS -----------------------------------------------------------
+  {
+    const int w = a.layer[a.num_layers - 1].out;
+    const int KC0 = (w + 15) >> 4;
+    const bool xv = vec4_ok(a.x, a.ldx);
+    for (int u = wave; u < KC0 * G; u += kChainWaves) {
+      const int c = u / G;
+      const int g = u - c * G;
+      const long long row = row0 + g * 16 + (lane & 15);
+      const int f = c * 16 + 4 * (lane >> 4);
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < a.rows) v = load_row4(a.x, a.ldx, row, f, w, xv);
+      *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
+    }
+    __syncthreads();
+  }
+
+  float* tin = tile_a;
+  float* tout = tile_b;
+  for (int L = a.num_layers - 1; L >= 1; --L) {
+    const ChainLayer& ly = a.layer[L];          // its weights; K = ly.out, outputs = ly.in features
+    const ChainLayer& lp = a.layer[L - 1];      // the layer whose dZ is produced (H, act, dz, bias partials)
+    const rsrc_t wr = make_rsrc(ly.w, static_cast<unsigned>(ly.in) * ly.out * 4u);
+    const int width = ly.in;                    // == lp.out
+    const int NOB = (width + 15) >> 4;
+    const int full = NOB / kChainWaves;
+    const bool keep_tile = (L - 1 >= 1);        // dZ_0 feeds nothing further down
+    const bool hv = vec4_ok(lp.h, lp.ldh);
+    const bool dv = vec4_ok(lp.dz, lp.lddz);
+    double* bpart = lp.bias_partials ? lp.bias_partials + static_cast<long long>(blockIdx.x) * width : nullptr;
+
+    // dZ = acc * act'(h); stores; returns the lane's 4 feature values (zero for rows past the end).
+    // `slot`: position of the (block, group) fragment in the output tile.
+    auto epilogue = [&](int ob, int g, int slot, bool to_lds, const f32x4& accv, const f32x4& hval) -> f32x4 {
+      const int f = ob * 16 + 4 * (lane >> 4);
+      const long long row = row0 + g * 16 + (lane & 15);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = accv[e] * chain_act_grad(hval[e], lp.act);
+      if (row >= a.rows) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (to_lds) *reinterpret_cast<f32x4*>(tout + (slot * 64 + lane) * 4) = v;
+      if (row < a.rows) store_row4(lp.dz, lp.lddz, row, f, width, v, dv);
+      return v;
+    };
+    auto load_h = [&](int ob, int g) -> f32x4 {
+      const int f = ob * 16 + 4 * (lane >> 4);
+      const long long row = row0 + g * 16 + (lane & 15);
+      if (row < a.rows) return load_row4(lp.h, lp.ldh, row, f, width, hv);
+      return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    // column sums over the block's rows of one 16-feature block: the 16 lanes that share l>>4 hold
+    // the 16 rows of a group for the same 4 features (fixed butterfly order: deterministic)
+    auto colsum_store = [&](int ob, f32x4 s) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = s[e];
+        t += __shfl_xor(t, 8, kWave);
+        t += __shfl_xor(t, 4, kWave);
+        t += __shfl_xor(t, 2, kWave);
+        t += __shfl_xor(t, 1, kWave);
+        s[e] = t;
+      }
+      if (bpart != nullptr && (lane & 15) == 0) {
+        const int f = ob * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (f + e < width) bpart[f + e] = static_cast<double>(s[e]);
+        }
+      }
+    };
+
+    f32x4 hval[G];
+    chain_units<G, true>(
+        wr, width, ly.out, ly.in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
+        [&](int j) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) hval[g] = load_h(wave * full + j, g);
+        },
+        [&](int j, const f32x4 (&acc)[G]) {
+          const int ob = wave * full + j;
+          f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int g = 0; g < G; ++g) s += epilogue(ob, g, ob * G + g, keep_tile, acc[g], hval[g]);
+          colsum_store(ob, s);
+        });
+    // remainder blocks, one row group at a time.  The groups of such a block belong to different
+    // waves, so every unit leaves its fragment in the output tile (at its normal place when the tile
+    // feeds the next step, else in the first slots) and, after the barrier, one wave per block adds
+    // the G groups in order.
+    const int rem_first = full * kChainWaves;
+    const int rem_blocks = NOB - rem_first;
+    const int rem_units = rem_blocks * G;
+    const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
+    chain_units<1, true>(
+        wr, width, ly.out, ly.in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
+        [&](int j) { return (wave + j * kChainWaves) % G; },
+        [&](int j) {
+          const int u = wave + j * kChainWaves;
+          hval[0] = load_h(rem_first + u / G, u % G);
+        },
+        [&](int j, const f32x4 (&acc)[1]) {
+          const int u = wave + j * kChainWaves;
+          const int ob = rem_first + u / G, g = u % G;
+          epilogue(ob, g, keep_tile ? ob * G + g : u, true, acc[0], hval[0]);
+        });
+    __syncthreads();
+    if (bpart != nullptr) {
+      for (int rb = wave; rb < rem_blocks; rb += kChainWaves) {
+        const int slot0 = keep_tile ? (rem_first + rb) * G : rb * G;
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int g = 0; g < G; ++g) s += *reinterpret_cast<const f32x4*>(tout + ((slot0 + g) * 64 + lane) * 4);
+        colsum_store(rem_first + rb, s);
+      }
+    }
+    float* t = tin;
+    tin = tout;
+    tout = t;
+  }
+}
+
+static int pick_groups(long long rows, int requested) {
+  if (requested == 1 || requested == 2 || requested == 4) return requested;
+  if (rows >= 64 * 256) return 4;       // >= one 64-row block per CU
+  if (rows >= 32 * 256) return 2;
+  return 1;
+}
+
+// LDS bytes of one workgroup, forward (direction 0) or backward (direction 1); also writes the
+// offset (in floats) of the second region.  -1: the chain does not fit the 160 KiB LDS.
+static int chain_lds(int num_layers, const int* in_features, const int* out_features, int G, int direction,
+                     int* b_floats_out) {
+  long long a_kb = 0, b_kb = 0;      // region sizes in units of G KiB = 256*G floats
+  if (direction == 0) {
+    // tiles: T0 = input of layer 0 (region A), T_{L+1} = output of layer L (alternating), last layer -> global
+    a_kb = (in_features[0] + 15) / 16;
+    for (int L = 0; L + 1 < num_layers; ++L) {
+      const long long nb = (out_features[L] + 15) / 16;
+      if (L % 2 == 0) b_kb = nb > b_kb ? nb : b_kb;
+      else a_kb = nb > a_kb ? nb : a_kb;
+    }
+  } else {
+    // tiles: d heads (region A), then dZ_{L-1} for L = n-1 .. 2 alternating starting with B
+    a_kb = (out_features[num_layers - 1] + 15) / 16;
+    int flip = 0;
+    for (int L = num_layers - 1; L >= 1; --L, flip ^= 1) {
+      // dZ_{L-1} tile; the last step (dZ_0 feeds nothing) only stages its <= 3 remainder blocks
+      const long long nb = (L >= 2) ? (in_features[L] + 15) / 16 : 3;
+      if (flip == 0) b_kb = nb > b_kb ? nb : b_kb;
+      else a_kb = nb > a_kb ? nb : a_kb;
+    }
+  }
+  long long a_floats = a_kb * 256 * G, b_floats = b_kb * 256 * G;
+  if (direction == 0) {
+    const long long stats = 2LL * ((in_features[0] + 3) & ~3);   // mean32 / denom scratch in region B
+    if (b_floats < stats) b_floats = (stats + 3) & ~3LL;
+  }
+  if (b_floats == 0) b_floats = 4;
+  *b_floats_out = static_cast<int>(a_floats);
+  const long long bytes = (a_floats + b_floats) * 4;
+  return bytes <= 160 * 1024 ? static_cast<int>(bytes) : -1;
+}
+
+static int chain_fill(ChainArgs& args, int num_layers, const float* const* weights, const int* in_features,
+                      const int* out_features, const int* acts) {
+  if (num_layers < 1 || num_layers > kChainMaxLayers) return 1;
+  for (int L = 0; L < num_layers; ++L) {
+    ChainLayer& ly = args.layer[L];
+    ly.w = weights[L];
+    ly.in = in_features[L];
+    ly.out = out_features[L];
+    ly.act = acts[L];
+    ly.bias = nullptr;
+    ly.h = nullptr;
+    ly.dz = nullptr;
+    ly.bias_partials = nullptr;
+    ly.ldh = ly.lddz = 0;
+    if (ly.in <= 0 || ly.out <= 0 || (L > 0 && ly.in != out_features[L - 1])) return 1;
+    if (static_cast<long long>(ly.in) * ly.out * 4 >= static_cast<long long>(kOob)) return 1;
+    if (reinterpret_cast<uintptr_t>(ly.w) % 4 != 0) return 1;
+  }
+  args.num_layers = num_layers;
+  return 0;
+}
+
+template <int G, bool kBackward>
+static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+  const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+  auto kern = kBackward ? mlp_chain_bwd_kernel<G> : mlp_chain_fwd_kernel<G>;
+  if (lds_bytes > 64 * 1024) {
+    static bool raised[2] = {false, false};
+    if (!raised[kBackward ? 1 : 0]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return static_cast<int>(e);
+      raised[kBackward ? 1 : 0] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kChainThreads), static_cast<size_t>(lds_bytes), st, args);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace rlg
+
+// ---------------------------------------------------------------------------------
+// C ABI (declared in include/rlg_hip.h)
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+int rlg_mlp_chain_groups(long long rows, int requested) { return rlg::pick_groups(rows, requested); }
+
+int rlg_mlp_chain_num_blocks(long long rows, int groups) {
+  const int G = rlg::pick_groups(rows, groups);
+  return static_cast<int>((rows + 16 * G - 1) / (16 * G));
+}
+
+int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,
+                            int direction) {
+  int b = 0;
+  if (num_layers < 1 || num_layers > rlg::kChainMaxLayers) return -1;
+  return rlg::chain_lds(num_layers, in_features, out_features, groups, direction, &b);
+}
+
+int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,
+                          const int* in_features, const int* out_features, const int* acts,
+                          float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                          const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                          long long rows, int groups, void* stream) {
+  using namespace rlg;
+  if (rows <= 0) return 0;
+  ChainArgs args;
+  if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
+  for (int L = 0; L < num_layers; ++L) {
+    args.layer[L].bias = biases[L];
+    args.layer[L].h = act_out[L];
+    args.layer[L].ldh = act_ld[L];
+  }
+  if (act_out[num_layers - 1] == nullptr) return static_cast<int>(hipErrorInvalidValue);
+  args.x = x;
+  args.ldx = ldx;
+  args.rms_mean = rms_mean;
+  args.rms_var = rms_mean ? rms_var : nullptr;
+  args.rms_eps = rms_eps;
+  args.xn = xn_out;
+  args.rows = rows;
+  const int G = pick_groups(rows, groups);
+  int b_floats = 0;
+  const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 0, &b_floats);
+  if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);
+  args.lds_b_floats = b_floats;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (G == 4) return chain_launch<4, false>(args, lds_bytes, st);
+  if (G == 2) return chain_launch<2, false>(args, lds_bytes, st);
+  return chain_launch<1, false>(args, lds_bytes, st);
+}
+
+int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const int* in_features,
+                           const int* out_features, const int* acts, const float* const* act_in,
+                           const long long* act_ld, const float* d_out, long long ld_dout,
+                           float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
+                           long long rows, int groups, void* stream) {
+  using namespace rlg;
+  if (rows <= 0) return 0;
+  if (num_layers < 2) return static_cast<int>(hipErrorInvalidValue);
+  ChainArgs args;
+  if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
+  for (int L = 0; L + 1 < num_layers; ++L) {
+    args.layer[L].h = const_cast<float*>(act_in[L]);
+    args.layer[L].ldh = act_ld[L];
+    args.layer[L].dz = dz_out[L];
+    args.layer[L].lddz = dz_ld[L];
+    args.layer[L].bias_partials = bias_partials ? bias_partials[L] : nullptr;
+    if (act_in[L] == nullptr || dz_out[L] == nullptr) return static_cast<int>(hipErrorInvalidValue);
+  }
+  args.x = d_out;
+  args.ldx = ld_dout;
+  args.rms_mean = args.rms_var = nullptr;
+  args.rms_eps = 0.0f;
+  args.xn = nullptr;
+  args.rows = rows;
+  const int G = pick_groups(rows, groups);
+  int b_floats = 0;
+  const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 1, &b_floats);
+  if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);
+  args.lds_b_floats = b_floats;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (G == 4) return chain_launch<4, true>(args, lds_bytes, st);
+  if (G == 2) return chain_launch<2, true>(args, lds_bytes, st);
+  return chain_launch<1, true>(args, lds_bytes, st);
+}
+
+}  // extern "C"

@@ -4,23 +4,26 @@
 //
 // replaces autograd's `grad_weight = grad_output.t().mm(input)` of every nn.Linear built by
 // A2CBuilder (rl_games/algos_torch/network_builder.py:118-147, heads :295-311).  These are the
-// worst-shaped GEMMs of the path - a 32,768-long reduction into a 400x108 ... 22x100 output -
-// where the tuned rocBLAS/hipBLASLt solutions reach 6-54 TFLOP/s (250 us per optimiser step, a
-// third of it; tools/bench_dw.py).
+// worst-shaped GEMMs of the path - a 32,768-long reduction into a 400x108 ... 22x100 output.
 //
-// A sum of outer products needs NO operand staging for v_mfma_f32_32x32x2_f32: the A operand of
-// one MFMA is A[m][k] = dZ[r0+k][o0+m] (k = lane/32, m = lane%32) and the B operand is
-// B[k][n] = X[r0+k][i0+n] - both are 32 consecutive floats of one row per half-wave, i.e. plain
-// coalesced global loads straight into the MFMA source registers.  No LDS, no transposes.
-//   * a wave owns BO x 4 accumulator blocks (32x32 each).  The BO (4) blocks are INTERLEAVED:
-//     lane j loads BO (4) consecutive floats at column BO*j (4*j), element b of that vector
-//     belongs to block b.  One 8/16-byte load per lane feeds BO (4) MFMA operands, and the
-//     epilogue stores 4 consecutive floats per lane (16-byte, coalesced) for free;
-//   * split-K over blocks (gridDim) and over the 4 waves of a block (reduced through LDS, one
-//     32x32 block at a time), per-block partial tiles to a workspace, one finalise kernel sums the
-//     K-slices in a fixed order (deterministic, no atomics) and writes W.grad;
-//   * every layer of the MLP is a work item of the same launch (descriptor table), so the four
-//     GEMM launches + their split-K post-kernels of the library path become two launches.
+// A sum of outer products needs NO operand staging for v_mfma_f32_16x16x4_f32
+// (D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies A[l&15][l>>4], B[l>>4][l&15]): with i = output
+// feature, j = input feature and k = minibatch row, the A operand is dZ[r0 + (l>>4)][o0 + (l&15)] and
+// the B operand X[r0 + (l>>4)][i0 + (l&15)] - plain row-major global loads straight into the MFMA
+// source registers.  No LDS, no transposes.
+//   * a wave owns a (16*BO) x (16*BI) output tile, BO, BI in {1, 2, 4}.  The BO (BI) blocks are
+//     INTERLEAVED: lane l&15 loads BO consecutive floats at column o0 + BO*(l&15), element e of that
+//     vector belongs to block e.  One 4/8/16-byte load per lane feeds BO MFMA operands, a wave load
+//     reads 4 rows x 64*BO contiguous bytes, and the epilogue stores BI consecutive floats per lane;
+//   * 16-wide blocks and the {64, 32, 16} tile widths keep the tile padding at 5 % (32x32 blocks: 36 %);
+//   * split-K over workgroups (k-slice z of EVERY tile has blockIdx = ... + z, so with ksplit a multiple
+//     of 8 a slice of rows is only ever touched by one XCD and stays in its L2) and over the 4 waves
+//     of a workgroup (combined through LDS, each wave finishing a quarter of the tile); per-slice
+//     partial tiles go to a workspace, one finalise kernel sums them in a fixed order (deterministic,
+//     no atomics) and writes W.grad;
+//   * loads are software-pipelined in batches of 4 k-steps (16 rows): the next batch is in flight
+//     while the 4*BO*BI MFMAs of the current one issue;
+//   * every layer of the MLP is a work item of the same launch (descriptor table).
 // Numerics: exact fp32 products, fp32 accumulation - same class as the library kernels it
 // replaces; only the summation order differs.
 
@@ -28,21 +31,24 @@
 
 namespace rlg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kDwMaxLayers = 8;
-constexpr int kDwUnroll = 4;       // k-pairs per prefetch batch
+constexpr int kDwMaxTiles = 16;    // tiles per dimension of one layer (<= 1024 features in 64-wide tiles)
+constexpr int kDwBatch = 4;        // k-steps (of 4 rows) per prefetch batch
 
 struct DwLayer {
-  const float* dz;     // [rows, No]
-  const float* x;      // [rows, Mi]
+  const float* dz;     // [rows, lda]
+  const float* x;      // [rows, ldb]
   float* partial;      // [ksplit][No][Mi] workspace
   float* grad;         // [No, Mi]
+  long long lda, ldb;
   int No, Mi;
-  int bo;              // 1 or 2 interleaved output blocks per wave (No % bo == 0); 4 would need 512 registers
   int tiles_o, tiles_i, ksplit;
   int block_begin;     // first blockIdx.x of this layer
+  // tile t of a dimension covers columns [start[t], start[t] + 16 * b[t]), b in {1, 2, 4}
+  short o_start[kDwMaxTiles], i_start[kDwMaxTiles];
+  signed char o_b[kDwMaxTiles], i_b[kDwMaxTiles];
 };
 
 struct DwArgs {
@@ -52,7 +58,7 @@ struct DwArgs {
 };
 
 // Bias gradients ride along in the finalise launch: out[c] = sum_b partials[b][c] over the
-// per-block fp64 column sums that rlg_act_bwd_colsum left behind (one item per hidden layer).
+// per-block fp64 column sums that the backward kernels left behind (one item per hidden layer).
 struct ColsumItems {
   const double* partials[kDwMaxLayers];
   float* out[kDwMaxLayers];
@@ -62,154 +68,143 @@ struct ColsumItems {
   int first_block;     // blockIdx.x of the first column-sum block (after the dW finalise blocks)
 };
 
-template <int BO> struct VecOf;
-template <> struct VecOf<1> { using type = float; };
-template <> struct VecOf<2> { using type = f32x2; };
-template <> struct VecOf<4> { using type = f32x4; };
+template <int B> struct DwVec;
+template <> struct DwVec<1> { using type = float; };
+template <> struct DwVec<2> { using type = f32x2; };
+template <> struct DwVec<4> { using type = f32x4; };
+template <int B> __device__ __forceinline__ float dw_get(const typename DwVec<B>::type& v, int e) { return v[e]; }
+template <> __device__ __forceinline__ float dw_get<1>(const float& v, int) { return v; }
+template <int B> __device__ __forceinline__ typename DwVec<B>::type dw_zero() { return typename DwVec<B>::type(0.0f); }
 
-template <int BO> __device__ __forceinline__ float vec_get(const typename VecOf<BO>::type& v, int b) { return v[b]; }
-template <> __device__ __forceinline__ float vec_get<1>(const float& v, int) { return v; }
+#define RLG_DW_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int BO>
-__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int local_block, float* lds) {
-  using VA = typename VecOf<BO>::type;
-  constexpr int BI = 4;
+template <int BO, int BI>
+__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int i0, int z, float* lds) {
+  using VA = typename DwVec<BO>::type;
+  using VB = typename DwVec<BI>::type;
   const int lane = lane_id();
-  const int wave = wave_id();
-  const int half = lane >> 5;
-  const int j = lane & 31;
-  const int tiles = L.tiles_o * L.tiles_i;
-  const int z = local_block / tiles;
-  const int t = local_block - z * tiles;
-  const int to = t / L.tiles_i;
-  const int ti = t - to * L.tiles_i;
-  const int o0 = to * 32 * BO, i0 = ti * 32 * BI;
-  const int o_col = min(o0 + BO * j, L.No - BO);      // clamp: out-of-range lanes feed rows never stored
+  const int wave = wave_id_uniform();
+  const int kq = lane >> 4;           // row within a k-step
+  const int j = lane & 15;
+  // out-of-range columns are clamped: they only feed output elements that are never stored
+  const int o_col = min(o0 + BO * j, L.No - BO);
   const int i_col = min(i0 + BI * j, L.Mi - BI);
+  const float* pa = L.dz + o_col;
+  const float* pb = L.x + i_col;
 
-  // rows of this block / wave (pairs of rows per MFMA)
-  const int pairs_total = (rows + 1) >> 1;
-  const int pairs_per_block = (pairs_total + L.ksplit - 1) / L.ksplit;
-  const int pairs_per_wave = (pairs_per_block + 3) >> 2;
-  const int p_begin = z * pairs_per_block + wave * pairs_per_wave;
-  const int p_end = min(min(p_begin + pairs_per_wave, (z + 1) * pairs_per_block), pairs_total);
+  // k-steps (4 rows each) of this workgroup's slice, dealt to the 4 waves as contiguous runs
+  const int steps_total = (rows + 3) >> 2;
+  const int steps_per_block = (steps_total + L.ksplit - 1) / L.ksplit;
+  const int steps_per_wave = (steps_per_block + 3) >> 2;
+  const int s_begin = z * steps_per_block + wave * steps_per_wave;
+  const int s_end = min(min(s_begin + steps_per_wave, (z + 1) * steps_per_block), steps_total);
+  const int s_full_end = min(s_end, rows >> 2);      // steps whose 4 rows all exist
 
-  f32x16 acc[BO][BI];
+  f32x4 acc[BO][BI];
 #pragma unroll
   for (int a = 0; a < BO; ++a) {
 #pragma unroll
-    for (int b = 0; b < BI; ++b) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
-    }
+    for (int b = 0; b < BI; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  const float* pa = L.dz + o_col;
-  const float* pb = L.x + i_col;
-  const long long lda = L.No, ldb = L.Mi;
-
-  int p = p_begin;
-  // full batches: rows 2p+half .. are all < rows when 2*(p + U) <= rows
-  const int p_full_end = min(p_end, rows >> 1);
-  VA a_cur[kDwUnroll];
-  f32x4 b_cur[kDwUnroll];
-  auto load_batch = [&](VA (&av)[kDwUnroll], f32x4 (&bv)[kDwUnroll], int p0) {
+  // row pointers of this lane, advanced by one batch (16 rows) at a time
+  const long long step_a = 4 * L.lda, step_b = 4 * L.ldb;
+  const float* ra = pa + (4LL * s_begin + kq) * L.lda;
+  const float* rb = pb + (4LL * s_begin + kq) * L.ldb;
+  auto load_batch = [&](VA (&av)[kDwBatch], VB (&bv)[kDwBatch]) {
 #pragma unroll
-    for (int u = 0; u < kDwUnroll; ++u) {
-      const long long r = 2LL * (p0 + u) + half;
-      av[u] = *reinterpret_cast<const VA*>(pa + r * lda);
-      bv[u] = *reinterpret_cast<const f32x4*>(pb + r * ldb);
+    for (int u = 0; u < kDwBatch; ++u) {
+      av[u] = *reinterpret_cast<const VA*>(ra + u * step_a);
+      bv[u] = *reinterpret_cast<const VB*>(rb + u * step_b);
     }
+    ra += kDwBatch * step_a;
+    rb += kDwBatch * step_b;
   };
-  auto mfma_batch = [&](const VA (&av)[kDwUnroll], const f32x4 (&bv)[kDwUnroll]) {
-#pragma unroll
-    for (int u = 0; u < kDwUnroll; ++u) {
-#pragma unroll
-      for (int a = 0; a < BO; ++a) {
-#pragma unroll
-        for (int b = 0; b < BI; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av[u], a), bv[u][b], acc[a][b], 0, 0, 0);
-        }
-      }
-    }
-  };
-  if (p + kDwUnroll <= p_full_end) {
-    load_batch(a_cur, b_cur, p);
-    p += kDwUnroll;
-    while (p + kDwUnroll <= p_full_end) {
-      VA a_nxt[kDwUnroll];
-      f32x4 b_nxt[kDwUnroll];
-      load_batch(a_nxt, b_nxt, p);          // in flight while the MFMAs of the current batch run
-      mfma_batch(a_cur, b_cur);
-#pragma unroll
-      for (int u = 0; u < kDwUnroll; ++u) { a_cur[u] = a_nxt[u]; b_cur[u] = b_nxt[u]; }
-      p += kDwUnroll;
-    }
-    mfma_batch(a_cur, b_cur);
-  }
-  // tail pairs (and the odd last row): predicated, zero-filled
-  for (; p < p_end; ++p) {
-    const long long r = 2LL * p + half;
-    VA av;
-    f32x4 bv;
-    if (r < rows) {
-      av = *reinterpret_cast<const VA*>(pa + r * lda);
-      bv = *reinterpret_cast<const f32x4*>(pb + r * ldb);
-    } else {
-      av = VA(0.0f);
-      bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
+  auto mfma_step = [&](const VA& av, const VB& bv) {
 #pragma unroll
     for (int a = 0; a < BO; ++a) {
 #pragma unroll
       for (int b = 0; b < BI; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<BO>(av, a), bv[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(dw_get<BO>(av, a), dw_get<BI>(bv, b), acc[a][b], 0, 0, 0);
     }
+  };
+  int s = s_begin;
+  if (s + kDwBatch <= s_full_end) {
+    VA a_cur[kDwBatch], a_nxt[kDwBatch];
+    VB b_cur[kDwBatch], b_nxt[kDwBatch];
+    load_batch(a_cur, b_cur);
+    s += kDwBatch;
+    while (s + kDwBatch <= s_full_end) {
+      load_batch(a_nxt, b_nxt);             // in flight while the MFMAs of the current batch issue
+      RLG_DW_PIN();
+#pragma unroll
+      for (int u = 0; u < kDwBatch; ++u) mfma_step(a_cur[u], b_cur[u]);
+      RLG_DW_PIN();
+#pragma unroll
+      for (int u = 0; u < kDwBatch; ++u) { a_cur[u] = a_nxt[u]; b_cur[u] = b_nxt[u]; }
+      s += kDwBatch;
+    }
+#pragma unroll
+    for (int u = 0; u < kDwBatch; ++u) mfma_step(a_cur[u], b_cur[u]);
+  }
+  // tail steps (and the ragged last rows): predicated, zero-filled
+  for (; s < s_end; ++s) {
+    const long long r = 4LL * s + kq;
+    VA av = dw_zero<BO>();
+    VB bv = dw_zero<BI>();
+    if (r < rows) {
+      av = *reinterpret_cast<const VA*>(pa + r * L.lda);
+      bv = *reinterpret_cast<const VB*>(pb + r * L.ldb);
+    }
+    mfma_step(av, bv);
   }
 
-  // ---- reduce the 4 waves' K-slices through LDS (one 32x32 block = 4 KB per wave at a time) and
-  //      store: acc[a][b][q] is G[o0 + BO*row + a][i0 + 4*j + b], row = (q&3) + 8*(q>>2) + 4*half.
-  float* out = L.partial + static_cast<long long>(z) * L.No * L.Mi;
+  // ---- combine the 4 waves' K-slices through LDS.  Fragment q = a*BI + b; wave w finishes the PER
+  //      consecutive fragments [w*PER, (w+1)*PER) - consecutive b of one a, so it stores PER
+  //      consecutive floats per lane.  LDS: [4 src waves][BO*BI fragments][64 lanes] float4.
+  constexpr int NF = BO * BI;
+  constexpr int PER = (NF >= 4) ? NF / 4 : 1;
+  f32x4* slots = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
   for (int a = 0; a < BO; ++a) {
 #pragma unroll
     for (int b = 0; b < BI; ++b) {
-      if (wave != 0) {
-        float* dst = lds + ((wave - 1) * 64 + lane) * 16;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<f32x4*>(dst + 4 * q4) =
-              f32x4{acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-      }
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const float* src = lds + (w * 64 + lane) * 16;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q4);
-            acc[a][b][4 * q4] += v[0];
-            acc[a][b][4 * q4 + 1] += v[1];
-            acc[a][b][4 * q4 + 2] += v[2];
-            acc[a][b][4 * q4 + 3] += v[3];
-          }
-        }
-      }
-      __syncthreads();
+      const int q = a * BI + b;
+      if (q / PER != wave) slots[(wave * NF + q) * 64 + lane] = acc[a][b];
     }
   }
-  if (wave == 0) {
-    const int i = i0 + BI * j;
-    if (i + BI <= L.Mi) {
+  __syncthreads();
+  float* out = L.partial + static_cast<long long>(z) * L.No * L.Mi;
 #pragma unroll
-      for (int a = 0; a < BO; ++a) {
+  for (int a = 0; a < BO; ++a) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
-          const int o = o0 + BO * row + a;
-          if (o < L.No) {
-            const f32x4 v = {acc[a][0][q], acc[a][1][q], acc[a][2][q], acc[a][3][q]};
-            *reinterpret_cast<f32x4*>(out + static_cast<long long>(o) * L.Mi + i) = v;
+    for (int b0 = 0; b0 < BI; b0 += PER) {
+      const int q0 = a * BI + b0;
+      if (q0 / PER == wave) {
+        f32x4 v[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          v[p] = acc[a][b0 + p];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (w != wave) v[p] += slots[(w * NF + q0 + p) * 64 + lane];
+          }
+        }
+        // v[p][reg] = G[o0 + BO*(4*kq + reg) + a][i0 + BI*j + b0 + p]
+        const int i = i0 + BI * j + b0;
+        if (i + PER <= L.Mi) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int o = o0 + BO * (4 * kq + reg) + a;
+            if (o < L.No) {
+              float* dst = out + static_cast<long long>(o) * L.Mi + i;
+              if constexpr (PER == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0][reg], v[1][reg], v[2][reg], v[3][reg]};
+              } else if constexpr (PER == 2) {
+                *reinterpret_cast<f32x2*>(dst) = f32x2{v[0][reg], v[1][reg]};
+              } else {
+                dst[0] = v[0][reg];
+              }
+            }
           }
         }
       }
@@ -218,16 +213,34 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int local_bl
 }
 
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * 64 * 16];
+  __shared__ __attribute__((aligned(16))) float lds[4 * 16 * 64 * 4];     // 64 KiB
   int l = 0;
 #pragma unroll 1
   for (int k = 1; k < args.num_layers; ++k) {
     if (static_cast<int>(blockIdx.x) >= args.layer[k].block_begin) l = k;
   }
   const DwLayer& L = args.layer[l];
+  // blockIdx = begin + tile * ksplit + z: the k-slice index is the fastest, so slice z of every tile
+  // runs on XCD (begin + z) % 8 when ksplit % 8 == 0
   const int local = blockIdx.x - L.block_begin;
-  if (L.bo == 2) dw_tile<2>(L, args.rows, local, lds);
-  else dw_tile<1>(L, args.rows, local, lds);
+  const int t = local / L.ksplit;
+  const int z = local - t * L.ksplit;
+  const int to = t / L.tiles_i;
+  const int ti = t - to * L.tiles_i;
+  const int o0 = L.o_start[to], i0 = L.i_start[ti];
+  const int bo = L.o_b[to], bi = L.i_b[ti];
+#define RLG_DW_CASE(BO_, BI_) \
+  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_>(L, args.rows, o0, i0, z, lds); return; }
+  RLG_DW_CASE(4, 4)
+  RLG_DW_CASE(4, 2)
+  RLG_DW_CASE(4, 1)
+  RLG_DW_CASE(2, 4)
+  RLG_DW_CASE(2, 2)
+  RLG_DW_CASE(2, 1)
+  RLG_DW_CASE(1, 4)
+  RLG_DW_CASE(1, 2)
+  RLG_DW_CASE(1, 1)
+#undef RLG_DW_CASE
 }
 
 // grad[e] = sum_z partial[z][e].  64 float4 elements x 4 z-groups per block: group g sums the
@@ -305,32 +318,68 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
   }
 }
 
+
+// Splits `width` columns into tiles of 64 / 32 / 16 (16*b, b = 4 / 2 / 1); `max_b` limits b by the
+// alignment of the operand rows (a b-float vector load per lane).  Returns the tile count.
+static int dw_split(int width, int max_b, short* start, signed char* b) {
+  int n = 0, c = 0;
+  while (c < width && n < kDwMaxTiles) {
+    const int left = width - c;
+    int bb = 1;
+    if (left > 48) bb = 4;
+    else if (left > 32) bb = (max_b >= 2) ? 2 : 1;      // 32 now, 16 next
+    else if (left > 16) bb = 2;
+    if (bb > max_b) bb = max_b;
+    start[n] = static_cast<short>(c);
+    b[n] = static_cast<signed char>(bb);
+    c += 16 * bb;
+    ++n;
+  }
+  return (c >= width) ? n : -1;
+}
+
+static int dw_max_b(const void* p, long long ld, int width) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  int b = 1;
+  if (a % 8 == 0 && ld % 2 == 0 && width >= 2) b = 2;
+  if (a % 16 == 0 && ld % 4 == 0 && width >= 4) b = 4;
+  return b;
+}
+
 }  // namespace rlg
 
 extern "C" {
 
-// Plans one layer: writes {bo, tiles_o, tiles_i, ksplit} and returns the workspace floats needed,
-// or -1 when the shape is not supported by the MFMA path (caller falls back to the library GEMM).
+// Plans one layer: writes {0, tiles_o, tiles_i, ksplit} and returns the workspace floats needed,
+// or -1 when the shape is not supported (caller falls back to the library GEMM).  The tile split
+// itself is recomputed at launch from the operand alignment; the counts here assume 16-byte aligned
+// operands with ld % 4 == 0 unless in/out features say otherwise.
 long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4) {
-  if (rows <= 0 || out_features <= 0 || in_features < 4 || in_features % 4 != 0) return -1;
-  if ((static_cast<long long>(out_features) * in_features) % 4 != 0) return -1;
-  int bo = 1;
-  if (out_features % 2 == 0 && out_features > 32) bo = 2;
-  const int tiles_o = (out_features + 32 * bo - 1) / (32 * bo);
-  const int tiles_i = (in_features + 127) / 128;
-  int ksplit = target_blocks / (tiles_o * tiles_i);
-  const int max_split = (rows / 2 + 4 * rlg::kDwUnroll * 2 - 1) / (4 * rlg::kDwUnroll * 2);   // >= 2 batches per wave
-  if (ksplit > max_split) ksplit = max_split;
-  if (ksplit > 128) ksplit = 128;
-  if (ksplit < 1) ksplit = 1;
-  plan4[0] = bo;
+  using namespace rlg;
+  if (rows <= 0 || out_features <= 0 || in_features <= 0) return -1;
+  if ((static_cast<long long>(out_features) * in_features) % 4 != 0) return -1;   // finalise works on float4
+  short st[kDwMaxTiles];
+  signed char bb[kDwMaxTiles];
+  const int mo = (out_features % 4 == 0) ? 4 : (out_features % 2 == 0 ? 2 : 1);
+  const int mi = (in_features % 4 == 0) ? 4 : (in_features % 2 == 0 ? 2 : 1);
+  const int tiles_o = dw_split(out_features, mo, st, bb);
+  const int tiles_i = dw_split(in_features, mi, st, bb);
+  if (tiles_o < 0 || tiles_i < 0) return -1;
+  // k-slices: a multiple of 8 (one XCD per slice of rows) with >= 2 prefetch batches per wave
+  const int steps = (rows + 3) / 4;
+  int ksplit = 8;
+  while (ksplit * 2 <= 64 && steps / (ksplit * 2 * 4) >= 2 * kDwBatch && tiles_o * tiles_i * ksplit < target_blocks)
+    ksplit *= 2;
+  while (ksplit > 1 && steps / (ksplit * 4) < kDwBatch) ksplit /= 2;
+  plan4[0] = 0;
   plan4[1] = tiles_o;
   plan4[2] = tiles_i;
   plan4[3] = ksplit;
   return static_cast<long long>(ksplit) * out_features * in_features;
 }
 
-// All layers in one launch.  Arrays are indexed by layer; plans from rlg_mlp_dw_plan.
+// All layers in one launch.  Arrays are indexed by layer; plans from rlg_mlp_dw_plan.  dz [rows, No]
+// and x [rows, Mi] are contiguous (row stride = width).
 int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
                       float* const* grad, const int* out_features, const int* in_features,
                       const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
@@ -352,15 +401,16 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     L.grad = grad[l];
     L.No = out_features[l];
     L.Mi = in_features[l];
-    L.bo = plans4[4 * l + 0];
-    L.tiles_o = plans4[4 * l + 1];
-    L.tiles_i = plans4[4 * l + 2];
+    L.lda = L.No;
+    L.ldb = L.Mi;
     L.ksplit = plans4[4 * l + 3];
-    L.block_begin = blocks;
-    if ((reinterpret_cast<uintptr_t>(L.dz) | reinterpret_cast<uintptr_t>(L.x) |
-         reinterpret_cast<uintptr_t>(L.partial) | reinterpret_cast<uintptr_t>(L.grad)) % 16 != 0 ||
-        L.Mi % 4 != 0 || L.No % L.bo != 0 || (L.bo != 1 && L.bo != 2))
+    if (L.ksplit < 1 || (reinterpret_cast<uintptr_t>(L.partial) | reinterpret_cast<uintptr_t>(L.grad)) % 16 != 0 ||
+        (static_cast<long long>(L.No) * L.Mi) % 4 != 0)
       return static_cast<int>(hipErrorInvalidValue);
+    L.tiles_o = dw_split(L.No, dw_max_b(L.dz, L.lda, L.No), L.o_start, L.o_b);
+    L.tiles_i = dw_split(L.Mi, dw_max_b(L.x, L.ldb, L.Mi), L.i_start, L.i_b);
+    if (L.tiles_o < 0 || L.tiles_i < 0) return static_cast<int>(hipErrorInvalidValue);
+    L.block_begin = blocks;
     blocks += L.tiles_o * L.tiles_i * L.ksplit;
     fin_blocks += ((L.No * L.Mi) / 4 + 63) / 64;
   }

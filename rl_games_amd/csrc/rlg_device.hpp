@@ -16,6 +16,8 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// the same value as a scalar (SGPR): loops and branches on it stay on the scalar unit
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll

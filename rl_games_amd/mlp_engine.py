@@ -28,9 +28,12 @@ from . import ops
 
 
 class ManualMLP:
-    def __init__(self, net, arena, max_rows, mfma_dw=True, inplace_act=True):
+    def __init__(self, net, arena, max_rows, mfma_dw=True, inplace_act=True, fused_chain=True):
         """net: policy.ActorCriticNetwork (no RNN); arena: FlatArena laid out by `layout(net)`.
         mfma_dw: weight gradients through the one-launch f32-MFMA kernel (csrc/mlp_dw.hip).
+        fused_chain: the whole MLP (observation normaliser, hidden layers, fused value|mu head) as
+        ONE forward launch and ONE backward launch with the activations of a row tile resident in
+        LDS (csrc/mlp_chain.hip); plain MLP policies only (the LSTM path keeps the per-layer GEMMs).
         (Measured and rejected: forking the library dW GEMMs onto a second stream - multi-branch
         hipGraphs cost more in cross-branch dependencies than the overlap gains.)"""
         self.net = net
@@ -86,6 +89,18 @@ class ManualMLP:
         self.heads = torch.empty(max_rows, self.V + self.A, device=dev)
         self.d_heads = torch.empty(max_rows, self.V + self.A, device=dev)
         self.nb = [ops.act_bwd_blocks(max_rows, w) for w in widths]
+        self.chain = None
+        self._pending_backward = False
+        if fused_chain and self.lstm is None:
+            try:
+                layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
+                layers.append((self.head_w, self.head_b, 'None'))
+                self.chain = ops.MlpChain(layers, dev)
+            except NotImplementedError:
+                self.chain = None
+        if self.chain is not None:
+            self.nb = [(max_rows + 15) // 16 for _ in widths]      # one partial row per 16-row group at most
+            self.xn = torch.empty(max_rows, self.linears[0].in_features, device=dev)
         self.partials = [torch.empty(nb * w, dtype=torch.float64, device=dev) for nb, w in zip(self.nb, widths)]
         if self.lstm is not None:
             Hr = self.Hr
@@ -127,6 +142,11 @@ class ManualMLP:
         [1, rows/seq_length, H], dones [rows] u8 resets the state entering a step (or None);
         the final states are left in `self.last_states`."""
         rows = x.shape[0]
+        if self._pending_backward and not keep:
+            # in-place activations: an inference forward reuses the buffers backward() reads
+            raise RuntimeError('ManualMLP.forward(keep=False) would overwrite the activations a pending '
+                               'backward() still needs')
+        self._pending_backward = bool(keep)
         a = x
         for l, lin in enumerate(self.linears):
             z = self.Z[l][:rows]
@@ -178,6 +198,25 @@ class ManualMLP:
         self._x, self._rows, self._last = x, rows, a
         return heads
 
+    @torch.no_grad()
+    def forward_obs(self, obs, rms=None, eps=1e-5, keep=True):
+        """Fused chain: obs [rows, in] RAW observations; rms = (running_mean, running_var) fp64 or None
+        (normalize_input off).  One launch: normalise -> hidden layers -> heads.  keep=True retains
+        the activations and the normalised observations for backward(); keep=False (rollout,
+        get_values) writes nothing but the heads, so it cannot disturb a pending backward."""
+        rows = obs.shape[0]
+        heads = self.heads[:rows]
+        if keep:
+            acts = [h[:rows] for h in self.Hs]
+            xn = self.xn[:rows] if rms is not None else None
+            self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn)
+            self._x = xn if rms is not None else obs
+            self._rows, self._last = rows, acts[-1]
+            self._pending_backward = True
+        else:
+            self.chain.forward(obs, heads, rms=rms, eps=eps)
+        return heads
+
     def values_view(self, heads):
         return heads[:, :self.V]
 
@@ -193,6 +232,22 @@ class ManualMLP:
         library GEMMs when a shape is outside that kernel's envelope / `mfma_dw` is off."""
         rows = self._rows
         L = len(self.linears)
+        self._pending_backward = False
+        if self.chain is not None:
+            # one launch: dZ of every hidden layer + per-workgroup bias-gradient column sums
+            nblk = self.chain.num_blocks(rows, 1)
+            acts = [h[:rows] for h in self.Hs]
+            dzs = [d[:rows] for d in self.dA]
+            parts = [p[:nblk * w.out_features] for p, w in zip(self.partials, self.linears)]
+            self.chain.backward(d_heads, acts, dzs, parts)
+            jobs = [(d_heads, acts[-1], self.head_w_grad)]
+            colsums = []
+            for l in range(L - 1, -1, -1):
+                lin = self.linears[l]
+                jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
+                colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
+            self._weight_grads(jobs, rows, colsums)
+            return
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:

@@ -449,6 +449,84 @@ def mlp_linear_act_backward(dz, w, z_prev, dz_prev, act_kind=0):
         'rlg_mlp_linear_act_backward')
 
 
+# ------------------------------------------------------------------ fused MLP chain (MFMA, LDS-resident)
+
+class MlpChain:
+    """The whole MLP (hidden layers + the fused value|mu head as the last layer) as ONE forward and
+    ONE backward launch (csrc/mlp_chain.hip).  `layers`: list of (weight [out, in], bias [out], act
+    name) - tensors are referenced, not copied, so optimiser updates are seen.  Raises
+    NotImplementedError if the network does not fit the LDS even with one 16-row group."""
+
+    def __init__(self, layers, device):
+        import ctypes
+        self.n = n = len(layers)
+        self.layers = layers
+        self.device = device
+        self.ins = [int(w.shape[1]) for w, _, _ in layers]
+        self.outs = [int(w.shape[0]) for w, _, _ in layers]
+        P, I, L = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
+        self._P, self._I, self._L = P, I, L
+        self._w = P(*[_need(w, F32, 'weight') for w, _, _ in layers])
+        self._b = P(*[_need(b, F32, 'bias') for _, b, _ in layers])
+        self._in, self._out = I(*self.ins), I(*self.outs)
+        self._act = I(*[ACT_KINDS[a] for _, _, a in layers])
+        lib = _lib.load()
+        self.max_groups = {}
+        for direction in (0, 1):
+            best = 0
+            for g in (1, 2, 4):
+                if lib.rlg_mlp_chain_lds_bytes(n, self._in, self._out, g, direction) >= 0:
+                    best = g
+            if best == 0 and (direction == 0 or n > 1):
+                raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
+            self.max_groups[direction] = best
+
+    def groups(self, rows, direction, requested=0):
+        g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested))
+        return min(g, self.max_groups[direction])
+
+    def num_blocks(self, rows, direction, requested=0):
+        return _lib.load().rlg_mlp_chain_num_blocks(int(rows), self.groups(rows, direction, requested))
+
+    def forward(self, x, heads, act_out=None, rms=None, eps=1e-5, xn_out=None, groups=0):
+        """x [rows, in0] (row stride free), heads [rows, out_last] out.  act_out: per hidden layer a
+        [rows, out_l] tensor or None.  rms = (running_mean, running_var) fp64 -> the observations are
+        normalised on the way in (xn_out [rows, in0] optionally receives them)."""
+        rows = x.shape[0]
+        n = self.n
+        outs = list(act_out) if act_out is not None else [None] * (n - 1)
+        outs = outs + [heads]
+        ptrs = self._P(*[None if t is None else _need(t, F32, 'act_out', contiguous=False) for t in outs])
+        lds = self._L(*[0 if t is None else t.stride(0) for t in outs])
+        _lib.require_gpu(x, 'x')
+        if x.dtype != F32 or (x.dim() == 2 and x.shape[1] != 1 and x.stride(1) != 1):
+            raise ValueError('x: fp32 rows with unit inner stride expected')
+        mean = var = None
+        if rms is not None:
+            mean, var = _need(rms[0], F64, 'running_mean'), _need(rms[1], F64, 'running_var')
+        _lib.check(_lib.load().rlg_mlp_chain_forward(
+            n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
+            mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), rows,
+            self.groups(rows, 0, groups), _stream(x)), 'rlg_mlp_chain_forward')
+
+    def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0):
+        """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
+        dZ_l output; bias_partials: per hidden layer fp64 [num_blocks(rows, 1), out_l] or None."""
+        rows = d_heads.shape[0]
+        n = self.n
+        h = self._P(*([_need(t, F32, 'H', contiguous=False) for t in acts] + [None]))
+        hl = self._L(*([t.stride(0) for t in acts] + [0]))
+        dz = self._P(*([_need(t, F32, 'dz', contiguous=False) for t in dz_out] + [None]))
+        dl = self._L(*([t.stride(0) for t in dz_out] + [0]))
+        bp = None
+        if bias_partials is not None:
+            bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
+        _lib.require_gpu(d_heads, 'd_heads')
+        _lib.check(_lib.load().rlg_mlp_chain_backward(
+            n, self._w, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl,
+            bp, rows, self.groups(rows, 1, groups), _stream(d_heads)), 'rlg_mlp_chain_backward')
+
+
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)
 
 class MlpDwPlan:

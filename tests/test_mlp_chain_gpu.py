@@ -1,0 +1,202 @@
+"""GPU parity tests of the vertically fused MLP kernels (csrc/mlp_chain.hip) and the 16x16x4 MFMA
+weight-gradient launch (csrc/mlp_dw.hip), through the C ABI.
+
+Reference = the same op chain the reference network runs (rl_games/algos_torch/network_builder.py:
+447-512 actor_mlp + value/mu heads, norm_obs rl_games/algos_torch/models.py:54-56) evaluated in fp64
+with torch; the kernels compute exact fp32 products with fp32 accumulation, so they must be as
+accurate as the fp32 library path (tolerance: a small multiple of the fp32 library's own error
+against fp64, floor 1e-6 of the tensor scale) - well inside the 1e-5 the losses are held to.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+ACT = {'elu': torch.nn.functional.elu, 'relu': torch.relu, 'tanh': torch.tanh, 'None': lambda t: t}
+
+
+def _net(in_dim, units, out_dim, act, seed):
+    g = torch.Generator().manual_seed(seed)
+    layers, last = [], in_dim
+    for u in list(units) + [out_dim]:
+        w = (torch.randn(u, last, generator=g) / last ** 0.5).to(DEV)
+        b = (0.1 * torch.randn(u, generator=g)).to(DEV)
+        layers.append([w, b, act])
+        last = u
+    layers[-1][2] = 'None'
+    return [tuple(l) for l in layers], g
+
+
+def _ref_forward(layers, x, dtype):
+    hs, a = [], x.to(dtype)
+    for w, b, act in layers:
+        a = ACT[act](torch.addmm(b.to(dtype), a, w.to(dtype).t()))
+        hs.append(a)
+    return hs
+
+
+def _close(got, ref64, lib32=None, mult=4.0, floor=1e-6):
+    err = (got.double() - ref64).abs().max().item()
+    scale = max(ref64.abs().max().item(), 1e-30)
+    bound = floor * scale
+    if lib32 is not None:
+        bound = max(bound, mult * (lib32.double() - ref64).abs().max().item())
+    assert err <= bound, (err, bound, scale)
+
+
+SHAPES = [
+    (108, [400, 200, 100], 22, 'elu'),      # BASELINE config #3 / #4
+    (60, [256, 128, 64], 9, 'elu'),         # BASELINE config #2
+    (13, [20, 36], 5, 'tanh'),              # nothing a multiple of 16, input not a multiple of 4
+    (3, [64, 64], 2, 'relu'),               # Pendulum-sized observations
+    (48, [32], 7, 'None'),
+]
+
+
+@pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
+@pytest.mark.parametrize('rows,groups', [(1, 0), (63, 1), (64, 2), (1000, 4), (4113, 0), (16384, 4)])
+def test_chain_forward_matches_fp64(in_dim, units, out_dim, act, rows, groups):
+    from rl_games_amd import ops
+    layers, g = _net(in_dim, units, out_dim, act, seed=rows + in_dim)
+    chain = ops.MlpChain(layers, DEV)
+    x = (3 * torch.randn(rows, in_dim, generator=g) + 1).to(DEV)
+    mean = torch.randn(in_dim, generator=g, dtype=torch.float64).to(DEV)
+    var = (torch.rand(in_dim, generator=g, dtype=torch.float64) * 4 + 0.1).to(DEV)
+    for rms in (None, (mean, var)):
+        heads = torch.full((rows, out_dim), float('nan'), device=DEV)
+        acts = [torch.full((rows, u), float('nan'), device=DEV) for u in units]
+        xn = torch.full((rows, in_dim), float('nan'), device=DEV) if rms is not None else None
+        chain.forward(x, heads, act_out=acts, rms=rms, eps=1e-5, xn_out=xn, groups=groups)
+        if rms is not None:
+            xn_ref = ops.rms_apply(x, mean, var, 1e-5, 0)           # the stand-alone normaliser kernel
+            assert torch.equal(xn, xn_ref)
+            xin = xn_ref
+        else:
+            xin = x
+        ref64 = _ref_forward(layers, xin, torch.float64)
+        lib32 = _ref_forward(layers, xin, torch.float32)
+        for got, r64, r32 in zip(acts + [heads], ref64, lib32):
+            assert torch.isfinite(got).all()
+            _close(got, r64, r32)
+        # inference form: nothing but the heads is written, same bits
+        heads2 = torch.full((rows, out_dim), float('nan'), device=DEV)
+        chain.forward(x, heads2, rms=rms, eps=1e-5, groups=groups)
+        assert torch.equal(heads2, heads)
+
+
+@pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
+@pytest.mark.parametrize('rows,groups', [(1, 0), (63, 1), (64, 2), (1000, 4), (4113, 0), (16384, 4)])
+def test_chain_backward_matches_autograd_fp64(in_dim, units, out_dim, act, rows, groups):
+    from rl_games_amd import ops
+    layers, g = _net(in_dim, units, out_dim, act, seed=7 * rows + in_dim)
+    chain = ops.MlpChain(layers, DEV)
+    x = torch.randn(rows, in_dim, generator=g).to(DEV)
+    heads = torch.empty(rows, out_dim, device=DEV)
+    acts = [torch.empty(rows, u, device=DEV) for u in units]
+    chain.forward(x, heads, act_out=acts, groups=groups)
+    d_heads = torch.randn(rows, out_dim, generator=g).to(DEV)
+    dzs = [torch.full((rows, u), float('nan'), device=DEV) for u in units]
+    nblk = chain.num_blocks(rows, 1, groups)
+    parts = [torch.full((nblk * u,), float('nan'), dtype=torch.float64, device=DEV) for u in units]
+    chain.backward(d_heads, acts, dzs, parts, groups=groups)
+
+    def ref(dtype):
+        # backward from the kernel's own activations (act' is taken from the layer output, like
+        # aten's in-place activation backward): dZ_{l-1} = (dZ_l W_l) * act'(H_{l-1})
+        out, d = [None] * len(units), d_heads.to(dtype)
+        for l in range(len(units), 0, -1):
+            w = layers[l][0].to(dtype)
+            h = acts[l - 1].to(dtype)
+            dh = d @ w
+            if act == 'elu':
+                d = dh * torch.where(h > 0, torch.ones_like(h), h + 1)
+            elif act == 'relu':
+                d = dh * (h > 0).to(dtype)
+            elif act == 'tanh':
+                d = dh * (1 - h * h)
+            else:
+                d = dh
+            out[l - 1] = d
+        return out
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    for l, u in enumerate(units):
+        assert torch.isfinite(dzs[l]).all()
+        _close(dzs[l], r64[l], r32[l])
+        colsum = parts[l].view(nblk, u).sum(0)
+        want = dzs[l].double().sum(0)                        # sums of the kernel's own dZ
+        assert torch.allclose(colsum, want, rtol=1e-5, atol=1e-5 * max(1.0, want.abs().max().item()))
+    # autograd through the same network in fp64 agrees as well (end-to-end check of the chain)
+    ws = [w.double().requires_grad_(True) for w, _, _ in layers]
+    a = x.double()
+    pre = []
+    for (w, b, actn), w64 in zip(layers, ws):
+        z = torch.addmm(b.double(), a, w64.t())
+        z.retain_grad()
+        pre.append(z)
+        a = ACT[actn](z)
+    a.backward(d_heads.double())
+    for l, u in enumerate(units):
+        _close(dzs[l], pre[l].grad, None, floor=2e-5)
+    # deterministic
+    again = [d.clone() for d in dzs]
+    chain.backward(d_heads, acts, dzs, parts, groups=groups)
+    assert all(torch.equal(p, q) for p, q in zip(again, dzs))
+
+
+@pytest.mark.parametrize('rows', [32768, 4096, 1000, 37, 2])
+def test_dw_odd_shapes_match_fp64(rows):
+    """Weight gradients for widths that are no multiples of 16 / 4 and a 22-wide dZ (row stride 88 B)."""
+    from rl_games_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(22, 100), (36, 20), (20, 12), (8, 6), (64, 60), (130, 260)]
+    layers, refs = [], []
+    for No, Mi in shapes:
+        dz = torch.randn(rows, No, generator=g).to(DEV)
+        x = torch.randn(rows, Mi, generator=g).to(DEV)
+        grad = torch.full((No, Mi), float('nan'), device=DEV)
+        layers.append((dz, x, grad))
+        refs.append((dz.t() @ x, dz.double().t() @ x.double()))
+    plan = ops.MlpDwPlan(shapes, rows, DEV)
+    plan.launch(layers)
+    for (dz, x, grad), (lib32, t64) in zip(layers, refs):
+        assert torch.isfinite(grad).all(), tuple(grad.shape)
+        _close(grad, t64, lib32)
+
+
+def test_engine_fused_chain_equals_per_layer_engine():
+    """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
+    gradients in the arena, on a BASELINE config #2 shaped network."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    outs = {}
+    for fused in (True, False):
+        torch.manual_seed(3)
+        params = configs.ant_4096(num_actors=256, minibatch_size=2048, fused_mlp=fused, hip_graphs=False)
+        agent = A2CAgent('t', params)
+        eng = agent._engine
+        assert (eng.chain is not None) == fused
+        g = torch.Generator().manual_seed(5)
+        obs = (2 * torch.randn(2048, 60, generator=g) + 0.5).to(DEV)
+        m = agent.model.running_mean_std
+        m.running_mean.copy_(torch.randn(60, generator=g, dtype=torch.float64))
+        m.running_var.copy_(torch.rand(60, generator=g, dtype=torch.float64) + 0.5)
+        if fused:
+            heads = eng.forward_obs(obs, (m.running_mean, m.running_var), m.epsilon).clone()
+        else:
+            from rl_games_amd import ops
+            heads = eng.forward(ops.rms_apply(obs, m.running_mean, m.running_var, m.epsilon, 0)).clone()
+        d_heads = eng.d_heads[:2048]
+        d_heads.copy_(torch.randn(2048, 9, generator=g).to(DEV))
+        agent.optimizer.flat_grads.fill_(float('nan'))
+        eng.backward(d_heads)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in agent.model.a2c_network.named_parameters()
+                 if p.grad is not None and 'bias' not in n.split('.')[-1] or n.startswith('actor_mlp')}
+        outs[fused] = (heads, grads)
+    assert torch.allclose(outs[True][0], outs[False][0], rtol=2e-5, atol=2e-6)
+    for n, gref in outs[False][1].items():
+        got = outs[True][1][n]
+        if not torch.isfinite(gref).all():
+            continue                                     # head biases come from the loss kernel
+        assert torch.allclose(got, gref, rtol=1e-4, atol=1e-5 * max(1.0, gref.abs().max().item())), n
