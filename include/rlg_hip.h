@@ -353,13 +353,17 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
  *           dz_out[l] (l < last) receives dZ_l, bias_partials[l] (optional) [num_blocks, out_l]
  *           fp64 per-workgroup column sums of dZ_l (finished by rlg_mlp_dw_launch's colsum items).
  * acts: 0 identity, 1 elu, 2 relu, 3 tanh (backward evaluates act' from the layer OUTPUT).
- * groups: 16-row groups per workgroup, 1 / 2 / 4 (0 = chosen from rows: rlg_mlp_chain_groups).
+ * groups: 16-row groups per workgroup, 1 / 2 / 4 (0 = chosen from rows and direction:
+ * rlg_mlp_chain_groups; rlg_mlp_chain_num_blocks takes the resolved value).
  * rlg_mlp_chain_lds_bytes: LDS of one workgroup (direction 0 forward, 1 backward), -1 if the
  * network does not fit the 160 KiB LDS with that many groups. */
-int rlg_mlp_chain_groups(long long rows, int requested);
+int rlg_mlp_chain_groups(long long rows, int requested, int direction);
 int rlg_mlp_chain_num_blocks(long long rows, int groups);
 int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,
                             int direction);
+/* tools only: the following forward launches record shader-clock stamps per phase into
+ * buffer [blocks][4 waves][32] (int64); NULL switches it off. */
+int rlg_mlp_chain_debug_stamps(long long* buffer);
 int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,
                           const int* in_features, const int* out_features, const int* acts,
                           float* const* act_out, const long long* act_ld, const float* x, long long ldx,

@@ -67,9 +67,10 @@ _PROTOTYPES = {
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P],
     # mlp_chain.hip
-    'rlg_mlp_chain_groups': [_c_ll, _c_int],
+    'rlg_mlp_chain_groups': [_c_ll, _c_int, _c_int],
     'rlg_mlp_chain_num_blocks': [_c_ll, _c_int],
     'rlg_mlp_chain_lds_bytes': [_c_int, _P, _P, _c_int, _c_int],
+    'rlg_mlp_chain_debug_stamps': [_P],
     'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P, _c_ll,
                               _c_int, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _c_ll, _c_int, _P],

@@ -63,9 +63,19 @@ struct ChainArgs {
   float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
   long long rows;
   int lds_b_floats;            // start of the second LDS region, in floats
+  long long* dbg;              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
 };
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+// phase stamps for tools/bench_mlp_chain.py --phases (one lane per wave; no effect when dbg is null)
+__device__ __forceinline__ void chain_stamp(long long* dbg, int wave, int& slot) {
+  if (dbg != nullptr) {
+    const long long t = __builtin_amdgcn_s_memtime();
+    if (lane_id() == 0 && slot < 32) dbg[(static_cast<long long>(blockIdx.x) * kChainWaves + wave) * 32 + slot] = t;
+    ++slot;
+  }
+}
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -93,7 +103,7 @@ __device__ __forceinline__ float chain_act_grad(float h, int act) {
 
 // A wave's share of one layer: `nunits` output units, unit j = the 16-feature block ob_of(j) for the NG
 // row groups g_of(j) .. g_of(j)+NG-1:
-//   pre(j);  acc[g] = sum over the KC k-chunks of  A(ob, chunk) x B(chunk, group);  epi(j, acc)
+//   [request the first batch of unit j+1];  pre(j);  acc[g] = sum over the KC k-chunks of  A(ob, chunk) x B(chunk, group);  epi(j, acc)
 // (pre: loads the epilogue will need, issued before the unit's MFMAs)
 // kTransposedA = false: A[i][k] = W[ob*16 + i][k]        (forward, W row-major [out=i][in=k], ld = K)
 // kTransposedA = true : A[i][k] = W[k][ob*16 + i]        (backward, W row-major [out=k][in=i], ld = I)
@@ -110,7 +120,8 @@ __device__ __forceinline__ float chain_act_grad(float h, int act) {
 
 template <int NG, bool kTransposedA, class ObOf, class GOf, class Pre, class Epi>
 __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, const float* in_tile, int G,
-                                            int nunits, ObOf ob_of, GOf g_of, Pre pre, Epi epi) {
+                                            int nunits, ObOf ob_of, GOf g_of, Pre pre, Epi epi,
+                                            long long* dbg = nullptr, int dbg_wave = 0, int* dbg_slot = nullptr) {
   if (nunits <= 0) return;
   const int lane = lane_id();
   const int KC = (K + 15) >> 4;
@@ -155,10 +166,17 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
   for (int j = 0; j < nunits; ++j) {
     const unsigned abase_n = a_base(j + 1);
     const float* bp_n = b_base(j + 1);
+    // the first batch of the NEXT unit is requested now: it has this whole unit to arrive
+    f32x4 nn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nn[u] = load_a(abase_n, u);
     pre(j);
     f32x4 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // NG == 1: a second accumulator takes the odd steps (40-cycle dependent-issue latency vs 32-cycle
+    // issue), folded in before the epilogue - a fixed order, so still deterministic
+    f32x4 acc_odd = {0.0f, 0.0f, 0.0f, 0.0f};
     // one k-chunk = 4 MFMA steps x NG groups; the fragment reads of the following chunk are issued
     // after step 0, so that a wait for THIS chunk's fragments never includes them
     auto mfma_head = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
@@ -167,20 +185,24 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[g][0], acc[g], 0, 0, 0);
     };
     auto mfma_rest = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
+      if constexpr (NG == 1) {
+        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[0][1], acc_odd, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[0][2], acc[0], 0, 0, 0);
+        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[0][3], acc_odd, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int s = 1; s < 4; ++s) {
+        for (int s = 1; s < 4; ++s) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+        }
       }
     };
     for (int bi = 0; bi < nfull; ++bi) {
       const int c = bi * 4;
       const bool wraps = (c + 4 >= KC);                 // the following chunk belongs to the next unit
-      const unsigned nbase = wraps ? abase_n : abase;
-      const int nc = wraps ? 0 : c + 4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) nxt[u] = load_a(nbase, nc + u);
+      for (int u = 0; u < 4; ++u) nxt[u] = load_a(wraps ? kOob : abase, c + 4 + u);
       mfma_head(cur[0], b0);
       RLG_PIN();
       load_b(b1, bp + (c + 1) * bstride);
@@ -208,11 +230,10 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
 #pragma unroll
       for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
+    if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the full batches
     if (rem != 0) {
       // tail chunks nfull*4 .. KC-1 are in cur[0..rem-1]; next comes the first batch of the next unit
       const float* bt = bp + (nfull * 4) * bstride;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) nxt[u] = load_a(abase_n, u);
       if (rem == 1) {
         mfma_head(cur[0], b0);
         RLG_PIN();
@@ -257,13 +278,64 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
 #pragma unroll
         for (int g = 0; g < NG; ++g) b0[g] = b1[g];
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cur[u] = nn[u];
+    // The next unit's first fragments (requested at the start of this unit) are claimed HERE, in front of the
+    // epilogue: hipcc would otherwise place the copy - and its s_waitcnt vmcnt(0) - at the top of
+    // the next unit, behind the epilogue's global stores, and wait for those as well.
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(cur[u]));
+    if constexpr (NG == 1) acc[0] += acc_odd;
+    if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the tail + claim of the next fragments
     epi(j, acc);
+    if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the epilogue
     abase = abase_n;
     bp = bp_n;
   }
+}
+
+// Kernel arguments that the epilogues use are copied into scalar registers ONCE per layer and made
+// opaque, otherwise hipcc re-materialises them as s_load from the kernarg segment at every use (a
+// scalar-cache round trip plus an lgkmcnt(0) per use - thousands of cycles per output block).
+__device__ __forceinline__ int pin_s(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long pin_s(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned long long>(v) & 0xffffffffu));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned long long>(v) >> 32));
+  return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T* pin_s(T* ptr) {
+  return reinterpret_cast<T*>(pin_s(reinterpret_cast<long long>(ptr)));
+}
+
+// activation of a fragment: one wave-uniform switch per fragment, not per element
+__device__ __forceinline__ f32x4 chain_act4(f32x4 v, int act) {
+  if (act == kChElu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : __expf(v[e]) - 1.0f;
+  } else if (act == kChRelu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+  } else if (act == kChTanh) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+  }
+  return v;
+}
+// acc * act'(h), act' from the layer OUTPUT h (aten's *_backward with is_result = true)
+__device__ __forceinline__ f32x4 chain_act_grad4(f32x4 d, f32x4 h, int act) {
+  if (act == kChElu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = d[e] * (h[e] > 0.0f ? 1.0f : h[e] + 1.0f);
+  } else if (act == kChRelu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = d[e] * (h[e] > 0.0f ? 1.0f : 0.0f);
+  } else if (act == kChTanh) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = d[e] * (1.0f - h[e] * h[e]);
+  }
+  return d;
 }
 
 // 4 consecutive features [f, f+4) of row `row` of a row-major array, masked to `width`
@@ -305,12 +377,58 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
   const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
   float* tile_a = lds;
   float* tile_b = lds + a.lds_b_floats;
+  int stamp = 0;
+  chain_stamp(a.dbg, wave, stamp);
 
   // ---- prologue: observation tile -> LDS (fragment layout), normalised on the way -----------------
   {
     const int in0 = a.layer[0].in;
     const int in0p = (in0 + 3) & ~3;
     const bool norm = a.rms_mean != nullptr;
+    const int KC0 = (in0 + 15) >> 4;
+    const int nfrag = KC0 * G;
+    const bool xv = vec4_ok(a.x, a.ldx);
+    const bool xnv = a.xn != nullptr && vec4_ok(a.xn, in0);
+    // kProBatch fragments per wave at a time: every load is issued before the first one is used (a
+    // rolled loop would pay one HBM round trip per fragment), and the first batch is requested
+    // BEFORE the normaliser statistics are prepared, so both latencies overlap.
+    constexpr int kProBatch = 8;
+    f32x4 xin[kProBatch];
+    auto load_frags = [&](int u0) {
+#pragma unroll
+      for (int k = 0; k < kProBatch; ++k) {
+        const int u = u0 + k * kChainWaves;
+        const int c = u / G;
+        const int g = u - c * G;
+        const long long row = row0 + g * 16 + (lane & 15);
+        xin[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (u < nfrag && row < a.rows) xin[k] = load_row4(a.x, a.ldx, row, c * 16 + 4 * (lane >> 4), in0, xv);
+      }
+    };
+    auto put_frags = [&](int u0) {
+#pragma unroll
+      for (int k = 0; k < kProBatch; ++k) {
+        const int u = u0 + k * kChainWaves;
+        if (u < nfrag) {
+          const int c = u / G;
+          const int g = u - c * G;
+          const long long row = row0 + g * 16 + (lane & 15);
+          const int f = c * 16 + 4 * (lane >> 4);
+          f32x4 v = xin[k];
+          if (row < a.rows) {
+            if (norm) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (f + e < in0) v[e] = fminf(fmaxf((v[e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f), 5.0f);
+              }
+            }
+            if (a.xn) store_row4(a.xn, in0, row, f, in0, v, xnv);
+          }
+          *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
+        }
+      }
+    };
+    load_frags(wave);
     if (norm) {
       // mean32 / denom exactly like rms_apply_kernel mode 0 (running_mean_std.py:112-113)
       for (int f = threadIdx.x; f < in0; f += kChainThreads) {
@@ -319,71 +437,81 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
       }
       __syncthreads();
     }
-    const int KC0 = (in0 + 15) >> 4;
-    const bool xv = vec4_ok(a.x, a.ldx);
-    const bool xnv = a.xn != nullptr && vec4_ok(a.xn, in0);
-    for (int u = wave; u < KC0 * G; u += kChainWaves) {
-      const int c = u / G;
-      const int g = u - c * G;
-      const long long row = row0 + g * 16 + (lane & 15);
-      const int f = c * 16 + 4 * (lane >> 4);
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row < a.rows) {
-        v = load_row4(a.x, a.ldx, row, f, in0, xv);
-        if (norm) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (f + e < in0) v[e] = fminf(fmaxf((v[e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f), 5.0f);
-          }
-        }
-        if (a.xn) store_row4(a.xn, in0, row, f, in0, v, xnv);
-      }
-      *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
+    put_frags(wave);
+    for (int u0 = wave + kChainWaves * kProBatch; u0 < nfrag; u0 += kChainWaves * kProBatch) {
+      load_frags(u0);
+      put_frags(u0);
     }
+    chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
   }
+  chain_stamp(a.dbg, wave, stamp);
 
   // ---- the layers ---------------------------------------------------------------------------------
   float* tin = tile_a;
   float* tout = tile_b;
   for (int L = 0; L < a.num_layers; ++L) {
-    const ChainLayer& ly = a.layer[L];
     const bool last = (L == a.num_layers - 1);
-    const rsrc_t wr = make_rsrc(ly.w, static_cast<unsigned>(ly.in) * ly.out * 4u);
-    const int NOB = (ly.out + 15) >> 4;
+    const int l_in = pin_s(a.layer[L].in), l_out = pin_s(a.layer[L].out), l_act = pin_s(a.layer[L].act);
+    const float* l_bias = pin_s(a.layer[L].bias);
+    float* l_h = pin_s(a.layer[L].h);
+    const long long l_ldh = pin_s(a.layer[L].ldh);
+    const long long n_rows = pin_s(a.rows);
+    const rsrc_t wr = make_rsrc(a.layer[L].w, static_cast<unsigned>(l_in) * l_out * 4u);
+    const int NOB = (l_out + 15) >> 4;
     const int full = NOB / kChainWaves;
-    const bool hv = ly.h != nullptr && vec4_ok(ly.h, ly.ldh);
+    // fast path: every fragment inside the matrix is one aligned 16-byte store
+    const bool h_on = l_h != nullptr;
+    const bool h_fast = pin_s(static_cast<int>(h_on && vec4_ok(l_h, l_ldh) && (l_out & 3) == 0)) != 0;
+    // bias of the unit's 4 features: requested before the unit's MFMAs (pre), used in its epilogue
+    f32x4 biasv = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool bias_fast = pin_s(static_cast<int>(aligned16(l_bias) && (l_out & 3) == 0)) != 0;
+    auto load_bias = [&](int ob) {
+      const int f = ob * 16 + 4 * (lane >> 4);
+      if (bias_fast) {
+        biasv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (f < l_out) biasv = *reinterpret_cast<const f32x4*>(l_bias + f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) biasv[e] = (f + e < l_out) ? l_bias[f + e] : 0.0f;
+      }
+    };
     auto epilogue = [&](int ob, int g, const f32x4& accv) {
       const int f = ob * 16 + 4 * (lane >> 4);
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float bias = (f + e < ly.out) ? ly.bias[f + e] : 0.0f;
-        v[e] = chain_act(accv[e] + bias, ly.act);
-      }
+      const f32x4 v = chain_act4(accv + biasv, l_act);
       if (!last) *reinterpret_cast<f32x4*>(tout + ((ob * G + g) * 64 + lane) * 4) = v;
       const long long row = row0 + g * 16 + (lane & 15);
-      if (ly.h != nullptr && row < a.rows) store_row4(ly.h, ly.ldh, row, f, ly.out, v, hv);
+      if (h_fast) {
+        if (row < n_rows && f < l_out) *reinterpret_cast<f32x4*>(l_h + row * l_ldh + f) = v;
+      } else if (h_on && row < n_rows) {
+        store_row4(l_h, l_ldh, row, f, l_out, v, false);
+      }
     };
     // whole blocks: all G row groups, one weight stream per block
     chain_units<G, false>(
-        wr, ly.out, ly.in, ly.in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; }, [](int) {},
+        wr, l_out, l_in, l_in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
+        [&](int j) { load_bias(wave * full + j); },
         [&](int j, const f32x4 (&acc)[G]) {
 #pragma unroll
           for (int g = 0; g < G; ++g) epilogue(wave * full + j, g, acc[g]);
-        });
+        },
+        (L < 2) ? a.dbg : nullptr, wave, &stamp);
+    chain_stamp(a.dbg, wave, stamp);
     // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
     const int rem_first = full * kChainWaves;
     const int rem_units = (NOB - rem_first) * G;
     const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
     chain_units<1, false>(
-        wr, ly.out, ly.in, ly.in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
-        [&](int j) { return (wave + j * kChainWaves) % G; }, [](int) {},
+        wr, l_out, l_in, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
+        [&](int j) { return (wave + j * kChainWaves) % G; },
+        [&](int j) { load_bias(rem_first + (wave + j * kChainWaves) / G); },
         [&](int j, const f32x4 (&acc)[1]) {
           const int u = wave + j * kChainWaves;
           epilogue(rem_first + u / G, u % G, acc[0]);
         });
+    chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
+    chain_stamp(a.dbg, wave, stamp);
     float* t = tin;
     tin = tout;
     tout = t;
@@ -423,34 +551,45 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
   float* tin = tile_a;
   float* tout = tile_b;
   for (int L = a.num_layers - 1; L >= 1; --L) {
-    const ChainLayer& ly = a.layer[L];          // its weights; K = ly.out, outputs = ly.in features
-    const ChainLayer& lp = a.layer[L - 1];      // the layer whose dZ is produced (H, act, dz, bias partials)
-    const rsrc_t wr = make_rsrc(ly.w, static_cast<unsigned>(ly.in) * ly.out * 4u);
-    const int width = ly.in;                    // == lp.out
+    // weights of layer L (K = its outputs, the produced features = its inputs); H / act / dZ / bias
+    // partials of layer L-1, the layer whose dZ is produced
+    const int l_in = pin_s(a.layer[L].in), l_out = pin_s(a.layer[L].out), p_act = pin_s(a.layer[L - 1].act);
+    const float* p_h = pin_s(a.layer[L - 1].h);
+    float* p_dz = pin_s(a.layer[L - 1].dz);
+    const long long p_ldh = pin_s(a.layer[L - 1].ldh), p_lddz = pin_s(a.layer[L - 1].lddz);
+    const long long n_rows = pin_s(a.rows);
+    const rsrc_t wr = make_rsrc(a.layer[L].w, static_cast<unsigned>(l_in) * l_out * 4u);
+    const int width = l_in;                     // == layer[L-1].out
     const int NOB = (width + 15) >> 4;
     const int full = NOB / kChainWaves;
     const bool keep_tile = (L - 1 >= 1);        // dZ_0 feeds nothing further down
-    const bool hv = vec4_ok(lp.h, lp.ldh);
-    const bool dv = vec4_ok(lp.dz, lp.lddz);
-    double* bpart = lp.bias_partials ? lp.bias_partials + static_cast<long long>(blockIdx.x) * width : nullptr;
+    const bool fast = pin_s(static_cast<int>(vec4_ok(p_h, p_ldh) && vec4_ok(p_dz, p_lddz) && (width & 3) == 0)) != 0;
+    double* bpart = pin_s(a.layer[L - 1].bias_partials);
+    if (bpart != nullptr) bpart += static_cast<long long>(blockIdx.x) * width;
 
     // dZ = acc * act'(h); stores; returns the lane's 4 feature values (zero for rows past the end).
     // `slot`: position of the (block, group) fragment in the output tile.
     auto epilogue = [&](int ob, int g, int slot, bool to_lds, const f32x4& accv, const f32x4& hval) -> f32x4 {
       const int f = ob * 16 + 4 * (lane >> 4);
       const long long row = row0 + g * 16 + (lane & 15);
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = accv[e] * chain_act_grad(hval[e], lp.act);
-      if (row >= a.rows) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 v = chain_act_grad4(accv, hval, p_act);
+      if (row >= n_rows) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (to_lds) *reinterpret_cast<f32x4*>(tout + (slot * 64 + lane) * 4) = v;
-      if (row < a.rows) store_row4(lp.dz, lp.lddz, row, f, width, v, dv);
+      if (fast) {
+        if (row < n_rows && f < width) *reinterpret_cast<f32x4*>(p_dz + row * p_lddz + f) = v;
+      } else if (row < n_rows) {
+        store_row4(p_dz, p_lddz, row, f, width, v, false);
+      }
       return v;
     };
     auto load_h = [&](int ob, int g) -> f32x4 {
       const int f = ob * 16 + 4 * (lane >> 4);
       const long long row = row0 + g * 16 + (lane & 15);
-      if (row < a.rows) return load_row4(lp.h, lp.ldh, row, f, width, hv);
+      if (fast) {
+        if (row < n_rows && f < width) return *reinterpret_cast<const f32x4*>(p_h + row * p_ldh + f);
+        return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      if (row < n_rows) return load_row4(p_h, p_ldh, row, f, width, false);
       return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     // column sums over the block's rows of one 16-feature block: the 16 lanes that share l>>4 hold
@@ -476,7 +615,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
 
     f32x4 hval[G];
     chain_units<G, true>(
-        wr, width, ly.out, ly.in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
+        wr, width, l_out, l_in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
         [&](int j) {
 #pragma unroll
           for (int g = 0; g < G; ++g) hval[g] = load_h(wave * full + j, g);
@@ -497,7 +636,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
     const int rem_units = rem_blocks * G;
     const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
     chain_units<1, true>(
-        wr, width, ly.out, ly.in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
+        wr, width, l_out, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
         [&](int j) { return (wave + j * kChainWaves) % G; },
         [&](int j) {
           const int u = wave + j * kChainWaves;
@@ -523,10 +662,14 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
   }
 }
 
-static int pick_groups(long long rows, int requested) {
+// Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
+// profiles/r2_mlp_chain_microbench_*.txt): forward - two 32-row workgroups per CU (G = 2, two waves
+// per SIMD) beat one 64-row workgroup (G = 4, one wave per SIMD): the second wave covers the epilogue
+// and unit-boundary stalls of the first; below 16,384 rows G = 1 keeps every CU busy.
+static int pick_groups(long long rows, int requested, int direction = 0) {
   if (requested == 1 || requested == 2 || requested == 4) return requested;
-  if (rows >= 64 * 256) return 4;       // >= one 64-row block per CU
-  if (rows >= 32 * 256) return 2;
+  // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU
+  if (rows >= 16384) return direction == 1 ? 4 : 2;
   return 1;
 }
 
@@ -584,6 +727,7 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
     if (reinterpret_cast<uintptr_t>(ly.w) % 4 != 0) return 1;
   }
   args.num_layers = num_layers;
+  args.dbg = nullptr;
   return 0;
 }
 
@@ -611,10 +755,12 @@ static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
 // ---------------------------------------------------------------------------------
 extern "C" {
 
-int rlg_mlp_chain_groups(long long rows, int requested) { return rlg::pick_groups(rows, requested); }
+int rlg_mlp_chain_groups(long long rows, int requested, int direction) {
+  return rlg::pick_groups(rows, requested, direction);
+}
 
 int rlg_mlp_chain_num_blocks(long long rows, int groups) {
-  const int G = rlg::pick_groups(rows, groups);
+  const int G = (groups == 1 || groups == 2 || groups == 4) ? groups : rlg::pick_groups(rows, 0);
   return static_cast<int>((rows + 16 * G - 1) / (16 * G));
 }
 
@@ -623,6 +769,13 @@ int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* o
   int b = 0;
   if (num_layers < 1 || num_layers > rlg::kChainMaxLayers) return -1;
   return rlg::chain_lds(num_layers, in_features, out_features, groups, direction, &b);
+}
+
+static long long* g_chain_dbg = nullptr;
+// tools only: phase stamps of the next forward launches ([blocks][4][32] int64), nullptr to stop
+int rlg_mlp_chain_debug_stamps(long long* buffer) {
+  g_chain_dbg = buffer;
+  return 0;
 }
 
 int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,
@@ -647,6 +800,7 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   args.rms_eps = rms_eps;
   args.xn = xn_out;
   args.rows = rows;
+  args.dbg = g_chain_dbg;
   const int G = pick_groups(rows, groups);
   int b_floats = 0;
   const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 0, &b_floats);
@@ -682,7 +836,7 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
   args.rms_eps = 0.0f;
   args.xn = nullptr;
   args.rows = rows;
-  const int G = pick_groups(rows, groups);
+  const int G = pick_groups(rows, groups, 1);
   int b_floats = 0;
   const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 1, &b_floats);
   if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);

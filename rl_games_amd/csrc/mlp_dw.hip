@@ -243,11 +243,14 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
 #undef RLG_DW_CASE
 }
 
-// grad[e] = sum_z partial[z][e].  64 float4 elements x 4 z-groups per block: group g sums the
-// slices z = g, g+4, ... (4 independent loads in flight), the groups are combined through LDS in a
-// fixed order, so the result does not depend on scheduling.
+// grad[e] = sum_z partial[z][e].  A block covers kFinElems consecutive float4 elements (a 256-byte
+// span per slice) with kFinGroups z-groups: group g sums the slices z = g, g+16, ... (up to 4 loads
+// in flight per thread), the groups are combined through LDS in a fixed order, so the result does
+// not depend on scheduling.  Many small blocks: the launch is latency bound, not bandwidth bound.
+constexpr int kFinElems = 16;
+constexpr int kFinGroups = 16;
 __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs) {
-  __shared__ f32x4 part[4][64];
+  __shared__ f32x4 part[kFinGroups][kFinElems];
   if (static_cast<int>(blockIdx.x) >= cs.first_block) {
     // ---- bias-gradient blocks: 32 columns x 8 row-slices per block, slices combined in order
     __shared__ double cpart[8][33];
@@ -282,38 +285,37 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
 #pragma unroll 1
   for (int k = 0; k < args.num_layers; ++k) {
     const int n4 = (args.layer[k].No * args.layer[k].Mi) >> 2;
-    const int blocks = (n4 + 63) / 64;
+    const int blocks = (n4 + kFinElems - 1) / kFinElems;
     if (static_cast<int>(blockIdx.x) < base + blocks) { l = k; break; }
     base += blocks;
   }
   const DwLayer& L = args.layer[l];
   const int n4 = (L.No * L.Mi) >> 2;
-  const int el = threadIdx.x & 63;
-  const int g = threadIdx.x >> 6;
-  const int e = (blockIdx.x - base) * 64 + el;
+  const int el = threadIdx.x & (kFinElems - 1);
+  const int g = threadIdx.x / kFinElems;
+  const int e = (blockIdx.x - base) * kFinElems + el;
   f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
   if (e < n4) {
     const f32x4* src = reinterpret_cast<const f32x4*>(L.partial) + e;
     int z = g;
-    for (; z + 12 < L.ksplit; z += 16) {
+    for (; z + 3 * kFinGroups < L.ksplit; z += 4 * kFinGroups) {      // 4 independent loads in flight
       const f32x4 v0 = src[static_cast<long long>(z) * n4];
-      const f32x4 v1 = src[static_cast<long long>(z + 4) * n4];
-      const f32x4 v2 = src[static_cast<long long>(z + 8) * n4];
-      const f32x4 v3 = src[static_cast<long long>(z + 12) * n4];
+      const f32x4 v1 = src[static_cast<long long>(z + kFinGroups) * n4];
+      const f32x4 v2 = src[static_cast<long long>(z + 2 * kFinGroups) * n4];
+      const f32x4 v3 = src[static_cast<long long>(z + 3 * kFinGroups) * n4];
       s += v0;
       s += v1;
       s += v2;
       s += v3;
     }
-    for (; z < L.ksplit; z += 4) s += src[static_cast<long long>(z) * n4];
+    for (; z < L.ksplit; z += kFinGroups) s += src[static_cast<long long>(z) * n4];
   }
   part[g][el] = s;
   __syncthreads();
   if (g == 0 && e < n4) {
     f32x4 t = part[0][el];
-    t += part[1][el];
-    t += part[2][el];
-    t += part[3][el];
+#pragma unroll
+    for (int k = 1; k < kFinGroups; ++k) t += part[k][el];
     reinterpret_cast<f32x4*>(L.grad)[e] = t;
   }
 }
@@ -412,7 +414,7 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     if (L.tiles_o < 0 || L.tiles_i < 0) return static_cast<int>(hipErrorInvalidValue);
     L.block_begin = blocks;
     blocks += L.tiles_o * L.tiles_i * L.ksplit;
-    fin_blocks += ((L.No * L.Mi) / 4 + 63) / 64;
+    fin_blocks += ((L.No * L.Mi) / 4 + kFinElems - 1) / kFinElems;
   }
   ColsumItems cs;
   cs.count = num_colsums;

@@ -482,7 +482,7 @@ class MlpChain:
             self.max_groups[direction] = best
 
     def groups(self, rows, direction, requested=0):
-        g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested))
+        g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested), int(direction))
         return min(g, self.max_groups[direction])
 
     def num_blocks(self, rows, direction, requested=0):
@@ -537,7 +537,7 @@ class MlpDwPlan:
     step.  Raises NotImplementedError when a shape is outside the kernel's envelope (callers use
     the library GEMMs then)."""
 
-    def __init__(self, shapes, rows, device, target_blocks=256):
+    def __init__(self, shapes, rows, device, target_blocks=1024):
         import ctypes
         lib = _lib.load()
         n = len(shapes)

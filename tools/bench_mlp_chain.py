@@ -36,6 +36,10 @@ def main():
     ap.add_argument('--rows', type=int, nargs='+', default=[32768])
     ap.add_argument('--net', default='humanoid')
     ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--no-lib', action='store_true', help='skip the library comparison rows')
+    ap.add_argument('--phases', action='store_true', help='per-phase shader-clock breakdown of the forward')
+    ap.add_argument('--groups', type=int, nargs='+', default=[4, 2, 1])
+    ap.add_argument('--dw-blocks', type=int, nargs='+', default=[256, 512, 1024])
     args = ap.parse_args()
     from rl_games_amd import ops
     dev = 'cuda:0'
@@ -59,7 +63,7 @@ def main():
         dzs = [torch.empty(rows, u, device=dev) for u in units]
         d_heads = torch.randn(rows, out_dim, generator=g).to(dev)
         print(f'== {args.net} rows {rows}: forward {2e-9 * rows * macs_f:.2f} GFLOP, dX {2e-9 * rows * macs_b:.2f}, dW {2e-9 * rows * macs_f:.2f}')
-        for G in (4, 2, 1):
+        for G in args.groups:
             if G > chain.max_groups[0]:
                 continue
             nblk = chain.num_blocks(rows, 1, G)
@@ -68,6 +72,32 @@ def main():
             print(f'  G={G} forward train   {t:8.1f} us  {2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
             t = timeit(lambda: chain.forward(x, heads, rms=(mean, var), groups=G), args.reps)
             print(f'  G={G} forward infer   {t:8.1f} us  {2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
+            if args.phases:
+                from rl_games_amd import _lib
+                nb = chain.num_blocks(rows, 0, G)
+                for train in (False, True):
+                    dbg = torch.zeros(nb * 4 * 32, dtype=torch.int64, device=dev)
+                    _lib.load().rlg_mlp_chain_debug_stamps(dbg.data_ptr())
+                    if train:
+                        chain.forward(x, heads, act_out=acts, rms=(mean, var), xn_out=xn, groups=G)
+                    else:
+                        chain.forward(x, heads, rms=(mean, var), groups=G)
+                    torch.cuda.synchronize()
+                    _lib.load().rlg_mlp_chain_debug_stamps(None)
+                    d = dbg.view(nb, 4, 32).cpu().double()
+                    n = int((d[0, 0] != 0).sum())
+                    # first-round blocks only (they start together): blocks 0..255
+                    sel = d[:min(nb, 256), :, :n]
+                    rel = sel - sel[:, :, :1]
+                    names = ['start', 'prologue done', 'barrier']
+                    for l in range(len(layers)):
+                        if l < 2:
+                            names += [f'L{l} u0 batches', f'L{l} u0 tail', f'L{l} u0 epilogue', f'L{l} u1 batches', f'L{l} u1 tail', f'L{l} u1 epilogue']
+                        names += [f'L{l} whole blocks', f'L{l} remainder', f'L{l} barrier']
+                    print(f'    phases ({"train" if train else "infer"}), mean shader-clock ticks since block start over the first {sel.shape[0]} blocks (per wave min/mean/max of the phase length):')
+                    for k in range(1, n):
+                        seg = sel[:, :, k] - sel[:, :, k - 1]
+                        print(f'      {names[k] if k < len(names) else k:22s} +{seg.mean().item():9.0f}  (min {seg.min().item():8.0f} max {seg.max().item():8.0f})   t={rel[:, :, k].mean().item():9.0f}')
             if G <= chain.max_groups[1]:
                 t = timeit(lambda: chain.backward(d_heads, acts, dzs, parts, groups=G), args.reps)
                 print(f'  G={G} backward (dX)   {t:8.1f} us  {2e-6 * rows * macs_b / t:6.1f} TFLOP/s')
@@ -77,11 +107,14 @@ def main():
         ins = [xn] + acts
         outs = dzs + [d_heads]
         jobs = sorted([(outs[l], ins[l], grads[l]) for l in range(len(layers))], key=lambda j: -j[2].numel())
-        for tb in (128, 256, 512):
+        for tb in args.dw_blocks:
             plan = ops.MlpDwPlan([tuple(j[2].shape) for j in jobs], rows, dev, target_blocks=tb)
             t = timeit(lambda: plan.launch(jobs), args.reps)
             print(f'  dW (16x16x4 MFMA, target_blocks {tb}, ksplit {[plan.plan(k)[3] for k in range(plan.n)]})  {t:8.1f} us  '
                   f'{2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
+
+        if args.no_lib:
+            continue
 
         # per-layer library path
         def lib_fwd():

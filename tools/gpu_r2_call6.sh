@@ -1,0 +1,11 @@
+set -x
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2c6
+mkdir -p $OUT
+python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -8 | tee $OUT/all_tests.log
+timeout 300 python tools/bench_mlp_chain.py --rows 32768 65536 4096 --dw-blocks 1024 2>&1 | tee $OUT/bench_chain.log
+timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/prof_log.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT/prof/bench_kernel_trace.csv 45 > $OUT/prof_summary.txt
+cat $OUT/prof_summary.txt
+rm -f $OUT/prof/bench_kernel_trace.csv
