@@ -1,26 +1,40 @@
 """bench.py - PPO env-steps/s of the MI355X hot path on BASELINE.json's headline workload.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--workload humanoid|ant]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one full PPO epoch of rl_games' ContinuousA2CBase.train_epoch on the
-Isaac-Humanoid-shaped synthetic workload (obs 108, act 21, 65,536 envs x horizon 32, MLP
-[400,200,100], minibatch 32,768, 5 mini-epochs = 320 optimiser steps): rollout with policy
-inference and every buffer write, GAE, dataset preparation, every minibatch forward / fused
-loss / backward / clip / Adam / adaptive-lr step.  Inputs are generated on the device (no PCIe
-in the timed region).  With N GPUs the 65,536 envs (and the minibatch) are sharded N ways
-("strong" scaling) with one gradient all-reduce per optimiser step.
+One "step" = one full PPO epoch of rl_games' ContinuousA2CBase.train_epoch on a synthetic,
+device-resident workload: rollout with policy inference and every buffer write, GAE, dataset
+preparation, every minibatch forward / fused loss / backward / clip / Adam / adaptive-lr step.
+  humanoid (default; BASELINE.json configs[2]/[3], the config `metric` is quoted on):
+      obs 108, act 21, 65,536 envs x horizon 32, MLP [400,200,100], minibatch 32,768, 5 mini-epochs
+      = 320 optimiser steps per epoch
+  ant (BASELINE.json configs[1]): obs 60, act 8, 4,096 envs x horizon 16, MLP [256,128,64],
+      minibatch 32,768, 4 mini-epochs
+Inputs are generated on the device (no PCIe in the timed region).  With N GPUs the envs (and the
+minibatch) are sharded N ways ("strong" scaling) with one gradient all-reduce per
+optimiser step.
 
-Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (the fused GAE kernel:
-17 algorithmic bytes per env-step / its mean launch duration from HIP events recorded on the
-launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU port of the
-reference epoch - oracle/ppo_epoch_oracle.py - timed on this box's host cores on a bounded
-sample of the same workload).
+Prints ONE JSON line on rank 0 with the contract keys plus
+  * `ms_per_step_stats`: min / median / mean / max of the K timed epochs (HIP events between the
+    epochs; `ms_per_step` itself is the barrier-to-barrier wall time / K),
+  * `roofline`: the fused GAE kernel - 17 algorithmic bytes per env-step / its mean launch duration
+    from HIP events bound to the dispatch itself (hipExtLaunchKernelGGL start/stop events = the
+    begin/end timestamps rocprofv3 --kernel-trace reports), measured inside the timed region;
+    `traffic` = HBM bytes per launch measured by rocprofv3 --pmc on THIS command
+    (tools/gpu_pmc_bench_gae.sh writes profiles/gae_pmc_traffic.json; null if that file does not
+    cover the workload),
+  * `roofline_mfma`: the weight-gradient launch against the dense fp32 MFMA peak,
+  * at N=1 `cpu_baseline`: the CPU port of the reference epoch (oracle/ppo_epoch_oracle.py) timed on
+    this box's host cores on a bounded sample, at the reference's default threading AND on all
+    cores, with the port -> untouched-reference calibration measured in the build container
+    (profiles/cpu_baseline_calibration.json, tools/cpu_reference_baseline.py).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,38 +44,82 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-GLOBAL_ENVS = 65536
-HORIZON = 32
-GLOBAL_MINIBATCH = 32768
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 GAE_BYTES_PER_ENV_STEP = 17   # r 4 + v 4 + done 1 read, returns 4 + advantages 4 written
 
+WORKLOADS = {
+    'humanoid': dict(envs=65536, horizon=32, minibatch=32768, mini_epochs=5, obs=108, act=21, units=[400, 200, 100],
+                     desc='Isaac-Humanoid-shaped PPO epoch (BASELINE.json configs[2]/[3]): obs 108, act 21, 65536 envs '
+                          'x horizon 32 global, MLP [400,200,100] elu, fixed sigma'),
+    'ant': dict(envs=4096, horizon=16, minibatch=32768, mini_epochs=4, obs=60, act=8, units=[256, 128, 64],
+                desc='Ant-v5-shaped PPO epoch (BASELINE.json configs[1]): obs 60, act 8, 4096 envs x horizon 16 global, '
+                     'MLP [256,128,64] elu, fixed sigma'),
+}
 
-def cpu_baseline(sample_envs, threads):
-    """The oracle epoch (CPU port of the reference path) on `sample_envs` envs x 32."""
-    from oracle.ppo_epoch_oracle import OracleAgent
+
+def make_params(workload, num_actors, minibatch, device, multi_gpu=False):
     from rl_games_amd import configs
+    if workload == 'humanoid':
+        return configs.humanoid_65536(num_actors=num_actors, minibatch_size=minibatch, device=device,
+                                      multi_gpu=multi_gpu)
+    return configs.ant_4096(num_actors=num_actors, minibatch_size=minibatch, device=device, multi_gpu=multi_gpu)
+
+
+def cpu_baseline(workload, sample_envs):
+    """The oracle epoch (CPU port of the reference path) on `sample_envs` envs, at the reference's
+    default threading (torch_threads = min(4, cores), torch_runner.py:217-226) and on many cores
+    (min(cores, 16): with all 256 threads of a GPU-box host the same epoch is ~400x SLOWER than with 4 -
+    measured 187 vs 86,511 env-steps/s - so "all cores" is neither a sensible baseline nor bounded)."""
+    from oracle.ppo_epoch_oracle import OracleAgent
     from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    w = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
     prev = torch.get_num_threads()
-    torch.set_num_threads(threads)
+    rows = {}
     try:
-        params = configs.humanoid_65536(num_actors=sample_envs, minibatch_size=GLOBAL_MINIBATCH, device='cpu')
-        env = SyntheticTensorEnv(sample_envs, 108, 21, device='cpu', seed=1234)
-        agent = OracleAgent(params, env, seed=0)
-        agent.train_epoch()                               # warm-up epoch
-        times = [agent.train_epoch()['total_time'] for _ in range(2)]
-        per_epoch = sum(times) / len(times)
-        return {
-            'value': sample_envs * HORIZON / per_epoch, 'unit': 'env-steps/s', 'cores': threads,
-            'kind': 'port',
-            'sample': f'{sample_envs} envs x {HORIZON} (1/{GLOBAL_ENVS // sample_envs} of the workload), same '
-                      f'model/minibatch 32768 x 5 mini-epochs, 1 warm-up + 2 timed epochs, torch CPU threads '
-                      f'{threads} (reference default torch_threads=min(4,cores)), host cores {os.cpu_count()}',
-            'seconds_per_epoch': per_epoch,
-        }
+        for label, threads in (('default_threads', max(1, min(4, cores))), ('all_cores', min(cores, 16))):
+            if label == 'all_cores' and threads == rows['default_threads']['threads']:
+                rows[label] = dict(rows['default_threads'])
+                continue
+            torch.set_num_threads(threads)
+            params = make_params(workload, sample_envs, min(w['minibatch'], sample_envs * w['horizon']), 'cpu')
+            env = SyntheticTensorEnv(sample_envs, w['obs'], w['act'], device='cpu', seed=1234)
+            agent = OracleAgent(params, env, seed=0)
+            warm = agent.train_epoch()['total_time']          # warm-up epoch
+            # bounded: a row never takes more than ~3 epochs of <= 15 s
+            times = [agent.train_epoch()['total_time'] for _ in range(2)] if warm < 15.0 else [warm]
+            per_epoch = sum(times) / len(times)
+            rows[label] = {'threads': threads, 'value': sample_envs * w['horizon'] / per_epoch,
+                           'seconds_per_epoch': per_epoch}
     finally:
         torch.set_num_threads(prev)
+    calibration = None
+    try:   # untouched reference vs this port, measured where /root/reference exists
+        with open(os.path.join(ROOT, 'profiles', 'cpu_baseline_calibration.json')) as f:
+            cal = json.load(f)
+        calibration = {
+            'source': 'profiles/cpu_baseline_calibration.json (tools/cpu_reference_baseline.py, build container: '
+                      'untouched rl_games a2c_continuous.A2CAgent.train_epoch vs this port, same config/env/host)',
+            'host_cores': cal.get('host_cores'),
+            'ref_over_port': {k: r['ref_over_port'] for k, r in cal['rows'].items()},
+            'reference_env_steps_per_s_build_container': {k: r['reference_env_steps_per_s'] for k, r in cal['rows'].items()},
+            'reference_leaf_seconds_build_container': {k: r.get('leaf_s') for k, r in cal['rows'].items()},
+        }
+    except Exception:
+        calibration = None
+    d = rows['default_threads']
+    out = {
+        'value': d['value'], 'unit': 'env-steps/s', 'cores': d['threads'], 'kind': 'port',
+        'sample': f'{sample_envs} envs x {w["horizon"]} (1/{max(1, w["envs"] // sample_envs)} of the workload), same '
+                  f'model / minibatch / mini-epochs, 1 warm-up + 2 timed epochs per row, host cores {cores}',
+        'seconds_per_epoch': d['seconds_per_epoch'], 'rows': rows, 'calibration': calibration,
+        'rows_note': "'all_cores' uses min(host cores, 16) torch threads (more threads run this workload slower)",
+    }
+    if calibration is not None:
+        out['calibrated_to_reference'] = {k: rows[k]['value'] * calibration['ref_over_port'][k]
+                                          for k in rows if k in calibration['ref_over_port']}
+    return out
 
 
 def main():
@@ -69,9 +127,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='humanoid')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-envs', type=int, default=4096)
+    ap.add_argument('--cpu-sample-envs', type=int, default=0, help='0: 4096 (humanoid) / 1024 (ant)')
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -93,13 +153,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(rdist.backend_for(True), rank=rank, world_size=world)
 
-    from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
-    if GLOBAL_ENVS % world or GLOBAL_MINIBATCH % world:
-        raise SystemExit('world size must divide 65536')
-    envs = GLOBAL_ENVS // world
-    params = configs.humanoid_65536(num_actors=envs, minibatch_size=GLOBAL_MINIBATCH // world, device=device,
-                                    multi_gpu=multi)
+    global_envs, horizon = w['envs'], w['horizon']
+    global_mb = min(w['minibatch'], global_envs * horizon)
+    if global_envs % world or global_mb % world:
+        raise SystemExit(f'world size must divide {global_envs} envs and the {global_mb}-row minibatch')
+    envs = global_envs // world
+    params = make_params(args.workload, envs, global_mb // world, device, multi_gpu=multi)
     params['config']['env_config']['seed'] = 1234 + rank
     # GEMM solution selection: shipped TunableOp file; shapes missing from it (other library
     # versions) are tuned during the untimed warm-up epochs.
@@ -120,17 +180,21 @@ def main():
         agent.update_epoch()
         agent.train_epoch()
     agent.kernel_timers = {}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         agent.update_epoch()
         agent.train_epoch()
+        marks[k + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    per_epoch_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
 
     in_sync = None
     if multi:   # outside the timed region: every rank must hold bit-identical parameters and lr
@@ -143,13 +207,14 @@ def main():
         in_sync = bool(torch.equal(lo, hi))
 
     pairs = agent.kernel_timers.get('gae_envmajor_fused', [])
-    gae_us = sum(p.elapsed_us() for p in pairs) / max(len(pairs), 1)
-    gae_bytes = envs * HORIZON * GAE_BYTES_PER_ENV_STEP
+    gae_each = [p.elapsed_us() for p in pairs]
+    gae_us = sum(gae_each) / max(len(gae_each), 1)
+    gae_bytes = envs * horizon * GAE_BYTES_PER_ENV_STEP
     achieved = gae_bytes / (gae_us * 1e-6) / 1e9 if gae_us > 0 else 0.0
 
-    # second roofline: the f32-MFMA weight-gradient launch (the largest single kernel of the epoch).
-    # Timed with HIP events around back-to-back launches on the last minibatch's own operands,
-    # AFTER the timed region (inside it the launch is a node of a replayed HIP graph).
+    # second roofline: the f32-MFMA weight-gradient launch (one of the three large kernels of the
+    # epoch).  Timed with HIP events around back-to-back launches on the last minibatch's own
+    # operands, AFTER the timed region (inside it the launch is a node of a replayed HIP graph).
     mfma = None
     eng = getattr(agent, '_engine', None)
     if eng is not None and getattr(eng, 'last_dw_jobs', None):
@@ -165,50 +230,53 @@ def main():
         torch.cuda.synchronize()
         us = ev0.elapsed_time(ev1) * 1e3 / reps
         rows = jobs[0][0].shape[0]
-        dw_traffic = None
-        try:   # HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/r1_dw_pmc.txt)
-            with open(os.path.join(ROOT, 'profiles', 'dw_pmc_traffic.json')) as f:
-                dw_traffic = json.load(f).get(str(rows), {}).get('traffic_bytes')
-        except Exception:
-            dw_traffic = None
         flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
-        mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch)',
+        mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch pair)',
                 'bound': 'mfma', 'achieved': flops / us / 1e6, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': dw_traffic,
+                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
                 'algorithmic_flops_per_launch': flops, 'avg_launch_us': us, 'launches': reps,
                 'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
-                        '(v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); timed after the timed region'}
+                        '(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); timed after the timed region'}
 
-    traffic = None
-    try:   # PMC counters cannot be read inside a normal run: measured offline, see profiles/r1_gae_pmc.txt
+    traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
+    try:
         with open(os.path.join(ROOT, 'profiles', 'gae_pmc_traffic.json')) as f:
-            traffic = json.load(f).get(f'{envs}x{HORIZON}', {}).get('traffic_bytes')
+            rec = json.load(f).get(f'{envs}x{horizon}')
+        if rec:
+            traffic = rec.get('traffic_bytes')
+            traffic_note = rec.get('note', 'rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction) + WRITE_SIZE per launch')
     except Exception:
-        traffic = None
+        pass
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            'metric': 'ppo_env_steps_per_sec', 'value': GLOBAL_ENVS * HORIZON * args.steps / elapsed,
+            'metric': 'ppo_env_steps_per_sec', 'value': global_envs * horizon * args.steps / elapsed,
             'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'ms_per_step_stats': {'min': min(per_epoch_ms), 'median': statistics.median(per_epoch_ms),
+                                  'mean': sum(per_epoch_ms) / len(per_epoch_ms), 'max': max(per_epoch_ms),
+                                  'note': 'per-epoch HIP event intervals on rank 0'},
             'config': {
-                'workload': 'Isaac-Humanoid-shaped PPO epoch (BASELINE.json configs[2]/[3]): obs 108, act 21, '
-                            '65536 envs x horizon 32 global, MLP [400,200,100] elu, fixed sigma',
-                'global_envs': GLOBAL_ENVS, 'horizon': HORIZON, 'envs_per_gpu': envs,
-                'minibatch_per_gpu': GLOBAL_MINIBATCH // world, 'mini_epochs': 5,
-                'optimizer_steps_per_epoch': 5 * (envs * HORIZON) // (GLOBAL_MINIBATCH // world),
+                'workload': w['desc'],
+                'global_envs': global_envs, 'horizon': horizon, 'envs_per_gpu': envs,
+                'minibatch_per_gpu': global_mb // world, 'mini_epochs': w['mini_epochs'],
+                'optimizer_steps_per_epoch': w['mini_epochs'] * (envs * horizon) // (global_mb // world),
                 'parallelism': f'dp{world}', 'step': 'one train_epoch (rollout+GAE+dataset+update)',
                 'lr_schedule': 'adaptive (device side)', 'mixed_precision': False,
+                'mlp': 'fused chain kernels' if (eng is not None and getattr(eng, 'chain', None) is not None)
+                       else 'per-layer engine',
             },
             'roofline': {
-                'kernel': 'rlg::gae_envmajor_kernel<32,false> (GAE + returns + advantages + fp64 moments)',
+                'kernel': f'rlg::gae_envmajor_kernel<{horizon},false> (GAE + returns + advantages + fp64 moments)',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'traffic_note': 'HBM bytes/launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r1_gae_pmc.txt',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_note': traffic_note,
                 'algorithmic_bytes_per_launch': gae_bytes, 'avg_launch_us': gae_us, 'launches': len(pairs),
-                'timing': 'HIP start/stop events attached to each in-epoch GAE dispatch on its launch stream (hipExtLaunchKernelGGL), timed region',
+                'launch_us_min': min(gae_each) if gae_each else None, 'launch_us_max': max(gae_each) if gae_each else None,
+                'timing': 'HIP start/stop events bound to each in-epoch GAE dispatch on its launch stream '
+                          '(hipExtLaunchKernelGGL) = the dispatch begin/end timestamps rocprofv3 --kernel-trace '
+                          'reports; timed region',
             },
         }
         if mfma is not None:
@@ -216,8 +284,8 @@ def main():
         if in_sync is not None:
             out['config']['ranks_in_sync'] = in_sync
         if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, min(4, os.cpu_count() or 1))
-            out['cpu_baseline'] = cpu_baseline(args.cpu_sample_envs, threads)
+            sample = args.cpu_sample_envs or (4096 if args.workload == 'humanoid' else 1024)
+            out['cpu_baseline'] = cpu_baseline(args.workload, sample)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
     if multi:

@@ -97,6 +97,10 @@ int rlg_rollout_store_step(int count, const void* const* srcs, void* const* dsts
                            const int* row_bytes, int num_envs, int horizon, int step,
                            void* stream);
 
+/* Non-temporal stores for buffer rows of >= 128 bytes (observations); returns the previous setting,
+ * enable < 0 only queries.  Default on. */
+int rlg_rollout_store_streaming(int enable);
+
 int rlg_rollout_post_step_num_blocks(int num_envs);
 
 /* After vec_env.step: DefaultRewardsShaper (rl_games/common/tr_helpers.py:33-42, log_val
@@ -357,6 +361,7 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
  * rlg_mlp_chain_groups; rlg_mlp_chain_num_blocks takes the resolved value).
  * rlg_mlp_chain_lds_bytes: LDS of one workgroup (direction 0 forward, 1 backward), -1 if the
  * network does not fit the 160 KiB LDS with that many groups. */
+int rlg_mlp_chain_prepare(void);   /* once per process, outside stream capture: raises the kernels' LDS limit */
 int rlg_mlp_chain_groups(long long rows, int requested, int direction);
 int rlg_mlp_chain_num_blocks(long long rows, int groups);
 int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,

@@ -37,6 +37,7 @@ _PROTOTYPES = {
     # experience.hip
     'rlg_rollout_store_step': [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_P),
                                ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _P],
+    'rlg_rollout_store_streaming': [_c_int],
     'rlg_rollout_post_step_num_blocks': [_c_int],
     'rlg_rollout_post_step': [_P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_float, _c_float,
                               _c_float, _c_float, _c_int, _c_int, _c_float, _c_int, _c_int, _c_int,
@@ -67,6 +68,7 @@ _PROTOTYPES = {
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P],
     # mlp_chain.hip
+    'rlg_mlp_chain_prepare': [],
     'rlg_mlp_chain_groups': [_c_ll, _c_int, _c_int],
     'rlg_mlp_chain_num_blocks': [_c_ll, _c_int],
     'rlg_mlp_chain_lds_bytes': [_c_int, _P, _P, _c_int, _c_int],

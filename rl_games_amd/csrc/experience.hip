@@ -35,7 +35,10 @@ struct StoreSegments {
   int count;
 };
 
-template <typename T>
+// kStream: non-temporal stores - the observation rows (28 MB per step at 65,536 x 108) are not read
+// again before the update phase, so they should not displace the rewards / values / done flags of
+// the rollout (the GAE kernel's inputs) from the 256 MB Infinity Cache.
+template <typename T, bool kStream>
 __device__ __forceinline__ void copy_units(const void* __restrict__ src, void* __restrict__ dst,
                                            long long units_total, int units_per_row,
                                            long long dst_row_stride_units, long long dst_off_units,
@@ -45,7 +48,8 @@ __device__ __forceinline__ void copy_units(const void* __restrict__ src, void* _
   for (long long i = first; i < units_total; i += stride) {
     const long long env = i / units_per_row;
     const long long c = i - env * units_per_row;
-    d[env * dst_row_stride_units + dst_off_units + c] = s[i];
+    if (kStream) __builtin_nontemporal_store(s[i], d + env * dst_row_stride_units + dst_off_units + c);
+    else d[env * dst_row_stride_units + dst_off_units + c] = s[i];
   }
 }
 
@@ -53,7 +57,7 @@ constexpr int kStoreBlock = 256;
 constexpr int kStoreUnitsPerThread = 4;
 
 __global__ __launch_bounds__(kStoreBlock) void rollout_store_kernel(StoreSegments seg, int N, int H,
-                                                                    int step) {
+                                                                    int step, int stream_wide_rows) {
   int s = 0;
 #pragma unroll
   for (int k = 1; k < kMaxSegments; ++k) {
@@ -69,11 +73,14 @@ __global__ __launch_bounds__(kStoreBlock) void rollout_store_kernel(StoreSegment
   const long long row_stride = static_cast<long long>(H) * upr;
   const long long off = static_cast<long long>(step) * upr;
   if (unit == 16) {
-    copy_units<u32x4>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+    if (stream_wide_rows && seg.row_bytes[s] >= 128)
+      copy_units<u32x4, true>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+    else
+      copy_units<u32x4, false>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
   } else if (unit == 4) {
-    copy_units<uint32_t>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+    copy_units<uint32_t, false>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
   } else {
-    copy_units<uint8_t>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
+    copy_units<uint8_t, false>(seg.src[s], seg.dst[s], total, upr, row_stride, off, first, stride);
   }
 }
 
@@ -339,6 +346,14 @@ __global__ __launch_bounds__(256) void rnn_zero_done_kernel(float* __restrict__ 
 
 extern "C" {
 
+// 1 (default): rows of >= 128 bytes (the observations) are written with non-temporal stores.
+static int g_stream_wide_rows = 1;
+int rlg_rollout_store_streaming(int enable) {
+  const int prev = g_stream_wide_rows;
+  if (enable >= 0) g_stream_wide_rows = enable ? 1 : 0;
+  return prev;
+}
+
 int rlg_rollout_store_step(int count, const void* const* srcs, void* const* dsts,
                            const int* row_bytes, int num_envs, int horizon, int step,
                            void* stream) {
@@ -365,7 +380,7 @@ int rlg_rollout_store_step(int count, const void* const* srcs, void* const* dsts
   }
   for (int k = count; k <= kMaxSegments; ++k) seg.block_begin[k] = blocks;
   hipLaunchKernelGGL(rollout_store_kernel, dim3(blocks), dim3(kStoreBlock), 0,
-                     static_cast<hipStream_t>(stream), seg, num_envs, horizon, step);
+                     static_cast<hipStream_t>(stream), seg, num_envs, horizon, step, g_stream_wide_rows);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

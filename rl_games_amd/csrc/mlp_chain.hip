@@ -764,6 +764,20 @@ int rlg_mlp_chain_num_blocks(long long rows, int groups) {
   return static_cast<int>((rows + 16 * G - 1) / (16 * G));
 }
 
+// Raises the dynamic-LDS limit of every chain kernel once, outside any stream capture (the launchers
+// would otherwise do it lazily on the first launch that needs more than 64 KiB).
+int rlg_mlp_chain_prepare(void) {
+  const void* kernels[] = {
+      reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<1>), reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<2>),
+      reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<4>), reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<1>),
+      reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<2>), reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<4>)};
+  for (const void* k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  return 0;
+}
+
 int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,
                             int direction) {
   int b = 0;

@@ -471,6 +471,7 @@ class MlpChain:
         self._in, self._out = I(*self.ins), I(*self.outs)
         self._act = I(*[ACT_KINDS[a] for _, _, a in layers])
         lib = _lib.load()
+        _lib.check(lib.rlg_mlp_chain_prepare(), 'rlg_mlp_chain_prepare')
         self.max_groups = {}
         for direction in (0, 1):
             best = 0

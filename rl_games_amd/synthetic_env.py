@@ -36,7 +36,14 @@ class SyntheticTensorEnv:
             self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
 
     def _obs(self):
-        obs = torch.randn(self.num_envs * self.agents, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
+        if self.device.type == 'cuda':
+            # one generation pass (N(1, 3^2) written once) instead of randn + mul + add: 28 MB instead
+            # of 140 MB of traffic per step at 65,536 x 108 - the env should not evict the rollout's own
+            # rewards / values / done flags from the Infinity Cache before the GAE launch reads them
+            obs = torch.empty(self.num_envs * self.agents, self.obs_dim, device=self.device).normal_(
+                1.0, 3.0, generator=self.gen)
+        else:
+            obs = torch.randn(self.num_envs * self.agents, self.obs_dim, device=self.device, generator=self.gen) * 3.0 + 1.0
         if self.state_dim > 0:
             states = torch.randn(self.num_envs, self.state_dim, device=self.device, generator=self.gen) * 2.0 - 0.5
             return {'obs': obs, 'states': states}

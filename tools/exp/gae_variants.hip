@@ -396,6 +396,18 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL((gae_var_kernel<32, MOM, WAVES, PW>), dim3((N / 64 + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
 #define RUNVAR(MOM, WAVES, label) report(label, time_it([&](int i) { auto& s = sets[i % nsets]; \
       hipLaunchKernelGGL((gae_var_kernel<32, MOM, WAVES>), dim3((N / 64 + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, 0, s.r, s.v, s.d, s.lv, s.ld, s.o0, s.o1, s.part, N, 0.99f, 0.9405f); }, iters));
+    if (nsets == 16 && !pmc) {
+      // mixed residency (round 2): which side costs the cold penalty - the 18.9 MB of inputs or the
+      // 16.8 MB of outputs?  inputs rotate over 16 sets (cold) while the outputs stay in one set (warm), and v.v.
+      report("product: inputs COLD, outputs WARM", time_it([&](int i) { auto& a = sets[i % nsets]; auto& b = sets[0];
+        rlg_gae_envmajor_fused(a.r, a.v, a.d, a.lv, a.ld, b.o0, b.o1, b.part, N, H, 0.99f, 0.9405f, nullptr); }, iters));
+      report("product: inputs WARM, outputs COLD", time_it([&](int i) { auto& a = sets[0]; auto& b = sets[i % nsets];
+        rlg_gae_envmajor_fused(a.r, a.v, a.d, a.lv, a.ld, b.o0, b.o1, b.part, N, H, 0.99f, 0.9405f, nullptr); }, iters));
+      report("nomom 4w: inputs COLD, outputs WARM", time_it([&](int i) { auto& a = sets[i % nsets]; auto& b = sets[0];
+        hipLaunchKernelGGL((gae_var_kernel<32, 0, 4>), dim3(N / 64 / 4), dim3(256), 0, 0, a.r, a.v, a.d, a.lv, a.ld, b.o0, b.o1, b.part, N, 0.99f, 0.9405f); }, iters));
+      report("nomom 4w: inputs WARM, outputs COLD", time_it([&](int i) { auto& a = sets[0]; auto& b = sets[i % nsets];
+        hipLaunchKernelGGL((gae_var_kernel<32, 0, 4>), dim3(N / 64 / 4), dim3(256), 0, 0, a.r, a.v, a.d, a.lv, a.ld, b.o0, b.o1, b.part, N, 0.99f, 0.9405f); }, iters));
+    }
     RUNVAR(0, 1, "var nomom 1wave/blk");
     RUNVAR(1, 1, "var f64mom 1wave/blk");
     RUNVAR(2, 1, "var f32mom 1wave/blk");
