@@ -397,6 +397,25 @@ int rlg_lstm_seq_backward(const float* gates, const float* c_all, const float* c
                           const unsigned char* dones_or_null, const float* w_hh, const float* d_out,
                           float* d_gates, int num_seqs, int seq_len, int hidden, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * In-graph gradient all-reduce over peer-mapped device memory (csrc/ipc_allreduce.hip)
+ *   replaces dist.all_reduce(SUM) of the flattened gradients in A2CBase.trancate_gradients_and_step
+ *   (rl_games/common/a2c_common.py:493-509) and of the minibatch KL (:1559-1560, carried in a tail
+ *   slot of the same arena).  One process per GPU: rlg_ipc_comm_create allocates the rank's staging
+ *   memory and returns its hipIpcMemHandle_t (rlg_ipc_handle_bytes() bytes); the host exchanges the
+ *   handles (any channel), rlg_ipc_comm_connect maps the peers; rlg_ipc_allreduce_sum is then ONE
+ *   kernel launch (no host sync, capturable in a HIP graph) that leaves the identical rank-ordered
+ *   sum in `data` on every rank.  A peer that never arrives makes the launch give up after a few
+ *   seconds (rlg_ipc_comm_status reports its ordinal) instead of hanging the device.
+ * ---------------------------------------------------------------------------------- */
+int rlg_ipc_handle_bytes(void);
+int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_out, void* handle_out);
+int rlg_ipc_comm_connect(void* comm, const void* all_handles /* world x handle bytes, rank-major */);
+int rlg_ipc_comm_fine_grained(void* comm);
+int rlg_ipc_allreduce_sum(void* comm, float* data, long long n, void* stream);
+int rlg_ipc_comm_status(void* comm, unsigned* launches_out, unsigned* timed_out_launch_out);
+int rlg_ipc_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,14 @@ _PROTOTYPES = {
     'rlg_act_bwd_num_blocks': [_c_ll, _c_int],
     'rlg_act_bwd_colsum': [_P, _P, _P, _c_ll, _c_int, _c_ll, _c_int, _P, _c_int, _P],
     'rlg_colsum_finalize': [_P, _c_int, _c_int, _P, _c_int, _P],
+    # ipc_allreduce.hip
+    'rlg_ipc_handle_bytes': [],
+    'rlg_ipc_comm_create': [_c_int, _c_int, _c_ll, ctypes.POINTER(_P), _P],
+    'rlg_ipc_comm_connect': [_P, ctypes.c_char_p],
+    'rlg_ipc_comm_fine_grained': [_P],
+    'rlg_ipc_allreduce_sum': [_P, _P, _c_ll, _P],
+    'rlg_ipc_comm_status': [_P, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)],
+    'rlg_ipc_comm_destroy': [_P],
     # optim.hip
     'rlg_grad_norm_num_blocks': [_c_ll],
     'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P, _P],

@@ -392,6 +392,7 @@ class A2CAgent:
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_epoch = None
         self._graph_failed = False
+        self._ipc_comm = None
         self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
         self._rnn_state_store = None
         self._eager_epochs = 0
@@ -1080,11 +1081,34 @@ class A2CAgent:
         if eng is None:
             torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
 
+    def _native_comm(self):
+        """The in-graph IPC all-reduce (csrc/ipc_allreduce.hip), created on first use; None when
+        `native_allreduce: False` or the peers' memory cannot be mapped (then RCCL is used)."""
+        if self._ipc_comm is False:
+            return None
+        if self._ipc_comm is None:
+            self._ipc_comm = False
+            if self.multi_gpu and self.config.get('native_allreduce', True):
+                try:
+                    from .ipc_allreduce import IpcAllReduce
+                    self._ipc_comm = IpcAllReduce(self.optimizer.flat_grads.numel(), self.ppo_device)
+                except Exception as e:
+                    print(f'rl_games_amd: native all-reduce unavailable ({type(e).__name__}: {e}); using RCCL')
+                    self._ipc_comm = False
+        return self._ipc_comm or None
+
+    def _all_reduce_grads(self):
+        """Gradients + KL slot, one collective (a2c_common.py:493-509, :1559-1560)."""
+        comm = self._native_comm()
+        if comm is not None:
+            comm.all_reduce_sum(self.optimizer.flat_grads)      # a plain kernel launch: capturable
+        else:
+            rdist.all_reduce_sum(self.optimizer.flat_grads)
+
     def trancate_gradients_and_step(self):
         """a2c_common.py:493-514 (+ the per-minibatch lr control of :1557-1563)."""
-        opt = self.optimizer
         if self.multi_gpu:
-            rdist.all_reduce_sum(opt.flat_grads)       # gradients + KL slot, one collective
+            self._all_reduce_grads()
         self._optimizer_kernels()
 
     def _optimizer_kernels(self):
@@ -1150,7 +1174,7 @@ class A2CAgent:
             self._graph_opt = self._capture(self._optimizer_kernels)
         g.replay()
         if self.multi_gpu:
-            rdist.all_reduce_sum(self.optimizer.flat_grads)
+            self._all_reduce_grads()
         self._graph_opt.replay()
         self.optimizer.step_count += 1
 
@@ -1168,6 +1192,8 @@ class A2CAgent:
             def body():
                 for i in range(nmb):
                     self._forward_loss_backward(self.dataset[i], self._graph_rows[i])
+                    if self.multi_gpu:
+                        self._all_reduce_grads()          # native in-graph collective only (see train_epoch)
                     self._optimizer_kernels()
             self._graph_epoch = self._capture(body)
         self._graph_epoch.replay()
@@ -1210,7 +1236,8 @@ class A2CAgent:
                 try:
                     self.set_train()
                     host_between = self.schedule_type == 'per_minibatch' and not device_schedule
-                    if not self.multi_gpu and not host_between and self.config.get('mini_epoch_graph', True):
+                    in_graph_comm = (not self.multi_gpu) or self._native_comm() is not None
+                    if in_graph_comm and not host_between and self.config.get('mini_epoch_graph', True):
                         self._graph_mini_epoch(nmb)
                         done = nmb
                     else:
@@ -1262,6 +1289,11 @@ class A2CAgent:
         if self.schedule_type == 'standard_epoch':
             self._host_schedule(float(torch.stack(kls).mean().item()))
         self.sync_running_stats()
+        if self._ipc_comm:
+            _, timed_out = self._ipc_comm.status()
+            if timed_out:
+                raise RuntimeError(f'in-graph all-reduce: launch {timed_out} gave up waiting for a peer rank '
+                                   f'(a rank stalled for ~10 s or died); gradients of this epoch are invalid')
         self._eager_epochs += 0 if use_graphs else 1
         if device_schedule:
             # one host read per epoch: [lr the last minibatch was stepped with, lr for the next one]

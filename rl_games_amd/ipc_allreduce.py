@@ -1,0 +1,75 @@
+"""In-graph gradient all-reduce over peer-mapped device memory (csrc/ipc_allreduce.hip).
+
+One process per GPU; every rank allocates its staging buffers through the C ABI, the ranks exchange
+the 64-byte hipIpcMemHandle_t of those buffers once through the existing torch.distributed group
+(RCCL or gloo - only used for this hand-shake), map each other's memory and from then on call
+`all_reduce_sum(flat_tensor)`: ONE kernel launch on the current stream, no host synchronisation, safe
+to capture in a HIP graph.  Replaces dist.all_reduce of the flat gradient arena
+(rl_games/common/a2c_common.py:493-509, KL slot :1559-1560) for the <= 1 MB arenas of the
+BASELINE configs; the RCCL path (rl_games_amd.distributed.all_reduce_sum) stays available behind the
+same agent call (`native_allreduce: False`).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class IpcAllReduce:
+    def __init__(self, numel, device, rank=None, world=None, group=None):
+        lib = _lib.load()
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.numel = int(numel)
+        self.device = torch.device(device)
+        nb = lib.rlg_ipc_handle_bytes()
+        handle = (ctypes.c_char * nb)()
+        comm = ctypes.c_void_p()
+        self._comm = None
+        # Every step below is collective: a rank that fails still takes part in the exchange, and the
+        # ranks agree on the outcome, so either all of them end up with a working communicator or all raise.
+        with torch.cuda.device(self.device):
+            err = lib.rlg_ipc_comm_create(self.rank, self.world, self.numel, ctypes.byref(comm), handle)
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle) if err == 0 else None, group=group)
+            if err == 0:
+                self._comm = comm
+            if any(h is None for h in handles):
+                self.close()
+                raise _lib.HipLibraryError(f'rlg_ipc_comm_create failed on a rank (local hipError_t {err})')
+            err = lib.rlg_ipc_comm_connect(self._comm, b''.join(handles))
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err, group=group)     # also: every rank has mapped every buffer
+            if any(oks):
+                self.close()
+                raise _lib.HipLibraryError(f'rlg_ipc_comm_connect failed on a rank (hipError_t per rank: {oks})')
+        self.fine_grained = bool(lib.rlg_ipc_comm_fine_grained(self._comm))
+
+    def all_reduce_sum(self, t):
+        """In place, on torch's current stream.  `t`: contiguous fp32 CUDA tensor of <= numel elements."""
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() > self.numel:
+            raise ValueError('IpcAllReduce: contiguous fp32 tensor of at most the planned size expected')
+        _lib.require_gpu(t, 'all_reduce_sum')
+        _lib.check(_lib.load().rlg_ipc_allreduce_sum(self._comm, t.data_ptr(), t.numel(),
+                                                     _lib.stream_handle(t.device)), 'rlg_ipc_allreduce_sum')
+        return t
+
+    def status(self):
+        """(launches completed, ordinal of a launch that gave up waiting for a peer or 0).  Synchronises."""
+        torch.cuda.synchronize(self.device)
+        a, b = ctypes.c_uint(), ctypes.c_uint()
+        _lib.check(_lib.load().rlg_ipc_comm_status(self._comm, ctypes.byref(a), ctypes.byref(b)), 'rlg_ipc_comm_status')
+        return int(a.value), int(b.value)
+
+    def close(self):
+        if getattr(self, '_comm', None) is not None:
+            _lib.load().rlg_ipc_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

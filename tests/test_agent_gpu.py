@@ -470,6 +470,33 @@ def test_two_rank_bench_on_one_gpu():
     assert out['value'] > 0 and out['roofline']['launches'] == 1
 
 
+def _run_two_ranks(script_args, timeout=600, nproc=2):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RLG_TEST_SINGLE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
+    return subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('nproc', [2, 4])
+def test_ipc_allreduce_between_processes_on_one_gpu(nproc):
+    """The in-graph all-reduce kernel (hipIpc-mapped peer staging buffers, device-side flags) between
+    2 and 4 processes sharing this box's GPU: eager and HIP-graph-replayed launches, every rank
+    bit-identical to the rank-ordered fp32 sum."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_ipc_check.py')], nproc=nproc)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert 'IPC_ALLREDUCE_CHECK ok' in res.stdout
+
+
 @pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss'])
 def test_central_value_update_matches_reference_epoch(golden, variant):
     """Central (asymmetric) value function: the update phase against golden vectors
