@@ -310,7 +310,20 @@ __global__ __launch_bounds__(1024) void ppo_loss_finalize_kernel(
     const int c = c0 + col_in_pass;
     double s = 0.0;
     if (c < W) {
-      for (int b = slice; b < nblocks; b += 32) s += partials[static_cast<long long>(b) * W + c];
+      // four independent loads in flight per thread (the launch is a chain of L2 round trips otherwise);
+      // the summation order is fixed, so the result does not depend on timing
+      int b = slice;
+      for (; b + 96 < nblocks; b += 128) {
+        const double v0 = partials[static_cast<long long>(b) * W + c];
+        const double v1 = partials[static_cast<long long>(b + 32) * W + c];
+        const double v2 = partials[static_cast<long long>(b + 64) * W + c];
+        const double v3 = partials[static_cast<long long>(b + 96) * W + c];
+        s += v0;
+        s += v1;
+        s += v2;
+        s += v3;
+      }
+      for (; b < nblocks; b += 32) s += partials[static_cast<long long>(b) * W + c];
     }
     part[slice][col_in_pass] = s;
     __syncthreads();
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(
 extern "C" {
 
 int rlg_ppo_loss_num_blocks(int minibatch) { return (minibatch + rlg::kLossRows - 1) / rlg::kLossRows; }
+
 
 int rlg_ppo_loss_partials_per_block(int actions) { return rlg::kLossScalars + 2 * actions; }
 
