@@ -16,8 +16,8 @@
 //     vector belongs to block e.  One 4/8/16-byte load per lane feeds BO MFMA operands, a wave load
 //     reads 4 rows x 64*BO contiguous bytes, and the epilogue stores BI consecutive floats per lane;
 //   * 16-wide blocks and the {64, 32, 16} tile widths keep the tile padding at 5 % (32x32 blocks: 36 %);
-//   * split-K over workgroups (k-slice z of EVERY tile has blockIdx = ... + z, so with ksplit a multiple
-//     of 8 a slice of rows is only ever touched by one XCD and stays in its L2) and over the 4 waves
+//   * split-K over workgroups (ordered so that a K-slice of rows is only ever touched by one XCD, which
+//     takes all tiles of a slice before the next slice - the slice stays in that XCD's L2) and over the 4 waves
 //     of a workgroup (combined through LDS, each wave finishing a quarter of the tile); per-slice
 //     partial tiles go to a workspace, one finalise kernel sums them in a fixed order (deterministic,
 //     no atomics) and writes W.grad;
@@ -220,11 +220,23 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
     if (static_cast<int>(blockIdx.x) >= args.layer[k].block_begin) l = k;
   }
   const DwLayer& L = args.layer[l];
-  // blockIdx = begin + tile * ksplit + z: the k-slice index is the fastest, so slice z of every tile
-  // runs on XCD (begin + z) % 8 when ksplit % 8 == 0
+  // Workgroup order inside a layer: id = ((z / 8) * tiles + tile) * 8 + (z % 8).  Workgroup b runs on
+  // XCD b % 8, so K-slice z (a band of rows of dZ and X) is only ever touched by XCD z % 8, and that
+  // XCD takes ALL tiles of one slice before the next one: the band (1.2 MB for the 200x400 layer at
+  // 64 slices) stays in its 4 MB L2 while the tiles re-read it, instead of 8 bands competing for it.
   const int local = blockIdx.x - L.block_begin;
-  const int t = local / L.ksplit;
-  const int z = local - t * L.ksplit;
+  const int tiles = L.tiles_o * L.tiles_i;
+  int t, z;
+  if ((L.ksplit & 7) == 0) {
+    const int zlo = local & 7;
+    const int q = local >> 3;
+    const int zhi = q / tiles;
+    t = q - zhi * tiles;
+    z = zhi * 8 + zlo;
+  } else {
+    t = local / L.ksplit;
+    z = local - t * L.ksplit;
+  }
   const int to = t / L.tiles_i;
   const int ti = t - to * L.tiles_i;
   const int o0 = L.o_start[to], i0 = L.i_start[ti];
