@@ -143,7 +143,7 @@ def test_full_train_epoch_runs_and_matches_oracle_on_same_rollout():
             a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
             r = ref[k]
             for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
-                assert np.isclose(got.item(), r[key].item(), rtol=1e-4, atol=5e-6), (k, key, got.item(), r[key].item())
+                assert np.isclose(got.item(), r[key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), r[key].item())
             k += 1
     assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
     # a complete train_epoch through the public entry point
@@ -273,8 +273,10 @@ def test_lstm_update_matches_reference_epoch(golden, manual_lstm):
             a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
             rows.append(torch.stack([a, c, e, kl, b]).clone())
     rows = torch.stack(rows).cpu()
-    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-4, atol=5e-6)
-    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-4, atol=5e-6)
+    # 1e-5 like the MLP goldens; the absolute floor covers minibatch means of +-O(1) terms (see
+    # tests/test_headline_gpu.py)
+    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6)
     assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
     kls = rows[:, 3].reshape(agent.mini_epochs_num, len(agent.dataset)).mean(1)
     assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-3, atol=1e-7)
@@ -393,7 +395,7 @@ def test_masked_rows_path_matches_oracle():
             a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
             r = ref[k]
             for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
-                assert np.isclose(got.item(), r[key].item(), rtol=1e-4, atol=5e-6), (k, key, got.item(), r[key].item())
+                assert np.isclose(got.item(), r[key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), r[key].item())
             k += 1
     assert agent.model.value_mean_std.count.item() == oracle.model.value_stats['count'].item()
     assert agent.model.value_mean_std.count.item() == 1 + 2 * int(mask.sum().item())
@@ -732,7 +734,7 @@ def test_odd_shapes_match_oracle_epoch(N, H, obs_dim, act_dim, units, mbs):
             res = agent.train_actor_critic(agent.dataset[i])
             for got, key in ((res[0], 'a_loss'), (res[1], 'c_loss'), (res[2], 'entropy'), (res[3], 'kl'),
                              (res[8], 'b_loss')):
-                assert np.isclose(got.item(), ref[k][key].item(), rtol=2e-4, atol=1e-5), (k, key, got.item(), ref[k][key].item())
+                assert np.isclose(got.item(), ref[k][key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), ref[k][key].item())
             k += 1
     assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
     final = agent.model.state_dict()
