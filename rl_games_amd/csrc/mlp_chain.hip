@@ -31,6 +31,7 @@
 // LDS tile of a layer with `nb` 16-feature blocks: [nb][G][64 lanes][4] floats (nb*G KiB).
 
 #include "rlg_device.hpp"
+#include <type_traits>
 
 namespace rlg {
 
@@ -101,9 +102,10 @@ __device__ __forceinline__ float chain_act_grad(float h, int act) {
   return 1.0f;
 }
 
-// A wave's share of one layer: `nunits` output units, unit j = the 16-feature block ob_of(j) for the NG
-// row groups g_of(j) .. g_of(j)+NG-1:
-//   [request the first batch of unit j+1];  pre(j);  acc[g] = sum over the KC k-chunks of  A(ob, chunk) x B(chunk, group);  epi(j, acc)
+// A wave's share of one layer: `nunits` output units, unit j = the NF consecutive 16-feature blocks
+// ob_of(j) .. ob_of(j)+NF-1 for the NG row groups g_of(j) .. g_of(j)+NG-1 (NF > 1 shares the B fragments
+// and spreads the per-unit costs - epilogue, K tail, hand-over to the next unit - over NF times the MFMAs):
+//   [request the first batch of unit j+1];  pre(j);  acc[f][g] = sum over the KC k-chunks of  A(ob+f, chunk) x B(chunk, group);  epi(j, acc)
 // (pre: loads the epilogue will need, issued before the unit's MFMAs)
 // kTransposedA = false: A[i][k] = W[ob*16 + i][k]        (forward, W row-major [out=i][in=k], ld = K)
 // kTransposedA = true : A[i][k] = W[k][ob*16 + i]        (backward, W row-major [out=k][in=i], ld = I)
@@ -118,7 +120,7 @@ __device__ __forceinline__ float chain_act_grad(float h, int act) {
 // reads to two MFMAs before theirs): pin the order issue-loads / MFMA group / issue-loads / ...
 #define RLG_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int NG, bool kTransposedA, class ObOf, class GOf, class Pre, class Epi>
+template <int NG, int NF, bool kTransposedA, class ObOf, class GOf, class Pre, class Epi>
 __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, const float* in_tile, int G,
                                             int nunits, ObOf ob_of, GOf g_of, Pre pre, Epi epi,
                                             long long* dbg = nullptr, int dbg_wave = 0, int* dbg_slot = nullptr) {
@@ -129,9 +131,9 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
   const int rem = KC & 3;
   const unsigned astep = kTransposedA ? static_cast<unsigned>(16 * ld * 4) : 64u;
   const int bstride = G * 256;
-  auto a_base = [&](int j) -> unsigned {
+  auto a_base = [&](int j, int f) -> unsigned {
     if (j >= nunits) return kOob;
-    const int i = ob_of(j) * 16 + (lane & 15);
+    const int i = (ob_of(j) + f) * 16 + (lane & 15);
     if (i >= I) return kOob;
     return kTransposedA ? static_cast<unsigned>(((4 * (lane >> 4)) * ld + i) * 4)
                         : static_cast<unsigned>((i * ld + 4 * (lane >> 4)) * 4);
@@ -155,46 +157,65 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
     for (int g = 0; g < NG; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p + g * 256);
   };
 
-  unsigned abase = a_base(0);
-  const float* bp = b_base(0);
-  f32x4 cur[4], nxt[4];
+  unsigned abase[NF];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) cur[u] = load_a(abase, u);
+  for (int f = 0; f < NF; ++f) abase[f] = a_base(0, f);
+  const float* bp = b_base(0);
+  f32x4 cur[4][NF], nxt[4][NF];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[u][f] = load_a(abase[f], u);
+  }
   f32x4 b0[NG], b1[NG];
   load_b(b0, bp);
 
   for (int j = 0; j < nunits; ++j) {
-    const unsigned abase_n = a_base(j + 1);
+    unsigned abase_n[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) abase_n[f] = a_base(j + 1, f);
     const float* bp_n = b_base(j + 1);
     // the first batch of the NEXT unit is requested now: it has this whole unit to arrive
-    f32x4 nn[4];
+    f32x4 nn[4][NF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) nn[u] = load_a(abase_n, u);
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) nn[u][f] = load_a(abase_n[f], u);
+    }
     pre(j);
-    f32x4 acc[NG];
+    f32x4 acc[NF][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // NG == 1: a second accumulator takes the odd steps (40-cycle dependent-issue latency vs 32-cycle
-    // issue), folded in before the epilogue - a fixed order, so still deterministic
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[f][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // NG == NF == 1: a second accumulator takes the odd steps (40-cycle dependent-issue latency vs
+    // 32-cycle issue), folded in before the epilogue - a fixed order, so still deterministic
     f32x4 acc_odd = {0.0f, 0.0f, 0.0f, 0.0f};
-    // one k-chunk = 4 MFMA steps x NG groups; the fragment reads of the following chunk are issued
-    // after step 0, so that a wait for THIS chunk's fragments never includes them
-    auto mfma_head = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
+    // one k-chunk = 4 MFMA steps x NF blocks x NG groups; the fragment reads of the following chunk are
+    // issued after step 0, so that a wait for THIS chunk's fragments never includes them
+    auto mfma_head = [&](const f32x4 (&av)[NF], const f32x4 (&bv)[NG]) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[g][0], acc[g], 0, 0, 0);
+      for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[g][0], acc[f][g], 0, 0, 0);
+      }
     };
-    auto mfma_rest = [&](const f32x4& av, const f32x4 (&bv)[NG]) {
-      if constexpr (NG == 1) {
-        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[0][1], acc_odd, 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[0][2], acc[0], 0, 0, 0);
-        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[0][3], acc_odd, 0, 0, 0);
+    auto mfma_rest = [&](const f32x4 (&av)[NF], const f32x4 (&bv)[NG]) {
+      if constexpr (NG == 1 && NF == 1) {
+        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][1], bv[0][1], acc_odd, 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][2], bv[0][2], acc[0][0], 0, 0, 0);
+        acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][3], bv[0][3], acc_odd, 0, 0, 0);
       } else {
 #pragma unroll
         for (int s = 1; s < 4; ++s) {
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+          for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+              acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][s], bv[g][s], acc[f][g], 0, 0, 0);
+          }
         }
       }
     };
@@ -202,7 +223,10 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
       const int c = bi * 4;
       const bool wraps = (c + 4 >= KC);                 // the following chunk belongs to the next unit
 #pragma unroll
-      for (int u = 0; u < 4; ++u) nxt[u] = load_a(wraps ? kOob : abase, c + 4 + u);
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) nxt[u][f] = load_a(wraps ? kOob : abase[f], c + 4 + u);
+      }
       mfma_head(cur[0], b0);
       RLG_PIN();
       load_b(b1, bp + (c + 1) * bstride);
@@ -228,7 +252,10 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
       mfma_rest(cur[3], b1);
       RLG_PIN();
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[u][f] = nxt[u][f];
+      }
     }
     if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the full batches
     if (rem != 0) {
@@ -280,17 +307,24 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = nn[u];
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) cur[u][f] = nn[u][f];
+    }
     // The next unit's first fragments (requested at the start of this unit) are claimed HERE, in front of the
     // epilogue: hipcc would otherwise place the copy - and its s_waitcnt vmcnt(0) - at the top of
     // the next unit, behind the epilogue's global stores, and wait for those as well.
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(cur[u]));
-    if constexpr (NG == 1) acc[0] += acc_odd;
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(cur[u][f]));
+    }
+    if constexpr (NG == 1 && NF == 1) acc[0][0] += acc_odd;
     if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the tail + claim of the next fragments
     epi(j, acc);
     if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the epilogue
-    abase = abase_n;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) abase[f] = abase_n[f];
     bp = bp_n;
   }
 }
@@ -464,21 +498,24 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     const bool h_on = l_h != nullptr;
     const bool h_fast = pin_s(static_cast<int>(h_on && vec4_ok(l_h, l_ldh) && (l_out & 3) == 0)) != 0;
     // bias of the unit's 4 features: requested before the unit's MFMAs (pre), used in its epilogue
-    f32x4 biasv = {0.0f, 0.0f, 0.0f, 0.0f};
+    // blocks per unit (whole blocks), the rest as one smaller unit.  G = 2 runs two workgroups per CU (two
+    // waves per SIMD): 3 blocks per unit would push it past 256 registers and halve the occupancy.
+    constexpr int kNF = (G == 2) ? 2 : 3;
+    f32x4 biasv[kNF];
     const bool bias_fast = pin_s(static_cast<int>(aligned16(l_bias) && (l_out & 3) == 0)) != 0;
-    auto load_bias = [&](int ob) {
+    auto load_bias = [&](int ob, int slot) {
       const int f = ob * 16 + 4 * (lane >> 4);
+      biasv[slot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (bias_fast) {
-        biasv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (f < l_out) biasv = *reinterpret_cast<const f32x4*>(l_bias + f);
+        if (f < l_out) biasv[slot] = *reinterpret_cast<const f32x4*>(l_bias + f);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) biasv[e] = (f + e < l_out) ? l_bias[f + e] : 0.0f;
+        for (int e = 0; e < 4; ++e) biasv[slot][e] = (f + e < l_out) ? l_bias[f + e] : 0.0f;
       }
     };
-    auto epilogue = [&](int ob, int g, const f32x4& accv) {
+    auto epilogue = [&](int ob, int g, const f32x4& accv, const f32x4& bias) {
       const int f = ob * 16 + 4 * (lane >> 4);
-      const f32x4 v = chain_act4(accv + biasv, l_act);
+      const f32x4 v = chain_act4(accv + bias, l_act);
       if (!last) *reinterpret_cast<f32x4*>(tout + ((ob * G + g) * 64 + lane) * 4) = v;
       const long long row = row0 + g * 16 + (lane & 15);
       if (h_fast) {
@@ -487,27 +524,42 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
         store_row4(l_h, l_ldh, row, f, l_out, v, false);
       }
     };
-    // whole blocks: all G row groups, one weight stream per block
-    chain_units<G, false>(
-        wr, l_out, l_in, l_in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
-        [&](int j) { load_bias(wave * full + j); },
-        [&](int j, const f32x4 (&acc)[G]) {
+    // whole blocks: all G row groups, one weight stream per block; kNF blocks per unit
+    auto whole = [&](auto nf_tag, int first_ob, int nunits, bool stamps) {
+      constexpr int NF = decltype(nf_tag)::value;
+      chain_units<G, NF, false>(
+          wr, l_out, l_in, l_in, tin, G, nunits, [&](int j) { return first_ob + j * NF; }, [&](int) { return 0; },
+          [&](int j) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) epilogue(wave * full + j, g, acc[g]);
-        },
-        (L < 2) ? a.dbg : nullptr, wave, &stamp);
+            for (int f = 0; f < NF; ++f) load_bias(first_ob + j * NF + f, f);
+          },
+          [&](int j, const f32x4 (&acc)[NF][G]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+              for (int g = 0; g < G; ++g) epilogue(first_ob + j * NF + f, g, acc[f][g], biasv[f]);
+            }
+          },
+          stamps ? a.dbg : nullptr, wave, &stamp);
+    };
+    {
+      const int units = full / kNF, left = full - units * kNF;
+      whole(std::integral_constant<int, kNF>{}, wave * full, units, L < 2);
+      if (kNF == 3 && left == 2) whole(std::integral_constant<int, 2>{}, wave * full + units * kNF, 1, false);
+      else if (left >= 1) whole(std::integral_constant<int, 1>{}, wave * full + units * kNF, 1, false);
+    }
     chain_stamp(a.dbg, wave, stamp);
     // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
     const int rem_first = full * kChainWaves;
     const int rem_units = (NOB - rem_first) * G;
     const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
-    chain_units<1, false>(
+    chain_units<1, 1, false>(
         wr, l_out, l_in, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
         [&](int j) { return (wave + j * kChainWaves) % G; },
-        [&](int j) { load_bias(rem_first + (wave + j * kChainWaves) / G); },
-        [&](int j, const f32x4 (&acc)[1]) {
+        [&](int j) { load_bias(rem_first + (wave + j * kChainWaves) / G, 0); },
+        [&](int j, const f32x4 (&acc)[1][1]) {
           const int u = wave + j * kChainWaves;
-          epilogue(rem_first + u / G, u % G, acc[0]);
+          epilogue(rem_first + u / G, u % G, acc[0][0], biasv[0]);
         });
     chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
@@ -613,20 +665,37 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
       }
     };
 
-    f32x4 hval[G];
-    chain_units<G, true>(
-        wr, width, l_out, l_in, tin, G, full, [&](int j) { return wave * full + j; }, [&](int) { return 0; },
-        [&](int j) {
+    // blocks per unit (whole blocks); the H fragments of a unit live in registers.  G = 4 runs two
+    // workgroups per CU in this direction and must stay under 256 registers: one block per unit.
+    constexpr int kNF = (G == 4) ? 1 : 2;
+    f32x4 hval[kNF][G];
+    auto whole = [&](auto nf_tag, int first_ob, int nunits) {
+      constexpr int NF = decltype(nf_tag)::value;
+      chain_units<G, NF, true>(
+          wr, width, l_out, l_in, tin, G, nunits, [&](int j) { return first_ob + j * NF; }, [&](int) { return 0; },
+          [&](int j) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) hval[g] = load_h(wave * full + j, g);
-        },
-        [&](int j, const f32x4 (&acc)[G]) {
-          const int ob = wave * full + j;
-          f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int f = 0; f < NF; ++f) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) s += epilogue(ob, g, ob * G + g, keep_tile, acc[g], hval[g]);
-          colsum_store(ob, s);
-        });
+              for (int g = 0; g < G; ++g) hval[f][g] = load_h(first_ob + j * NF + f, g);
+            }
+          },
+          [&](int j, const f32x4 (&acc)[NF][G]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              const int ob = first_ob + j * NF + f;
+              f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+              for (int g = 0; g < G; ++g) s += epilogue(ob, g, ob * G + g, keep_tile, acc[f][g], hval[f][g]);
+              colsum_store(ob, s);
+            }
+          });
+    };
+    {
+      const int units = full / kNF, left = full - units * kNF;
+      whole(std::integral_constant<int, kNF>{}, wave * full, units);
+      if (left == 1) whole(std::integral_constant<int, 1>{}, wave * full + units * kNF, 1);
+    }
     // remainder blocks, one row group at a time.  The groups of such a block belong to different
     // waves, so every unit leaves its fragment in the output tile (at its normal place when the tile
     // feeds the next step, else in the first slots) and, after the barrier, one wave per block adds
@@ -635,17 +704,17 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
     const int rem_blocks = NOB - rem_first;
     const int rem_units = rem_blocks * G;
     const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
-    chain_units<1, true>(
+    chain_units<1, 1, true>(
         wr, width, l_out, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
         [&](int j) { return (wave + j * kChainWaves) % G; },
         [&](int j) {
           const int u = wave + j * kChainWaves;
-          hval[0] = load_h(rem_first + u / G, u % G);
+          hval[0][0] = load_h(rem_first + u / G, u % G);
         },
-        [&](int j, const f32x4 (&acc)[1]) {
+        [&](int j, const f32x4 (&acc)[1][1]) {
           const int u = wave + j * kChainWaves;
           const int ob = rem_first + u / G, g = u % G;
-          epilogue(ob, g, keep_tile ? ob * G + g : u, true, acc[0], hval[0]);
+          epilogue(ob, g, keep_tile ? ob * G + g : u, true, acc[0][0], hval[0][0]);
         });
     __syncthreads();
     if (bpart != nullptr) {
