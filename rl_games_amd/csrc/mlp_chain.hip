@@ -343,8 +343,17 @@ __device__ __forceinline__ T* pin_s(T* ptr) {
   return reinterpret_cast<T*>(pin_s(reinterpret_cast<long long>(ptr)));
 }
 
-// activation of a fragment: one wave-uniform switch per fragment, not per element
+// activation of a fragment: one wave-uniform switch per fragment, not per element.  HACT >= 0: the
+// launch knows that every layer is either HACT or identity (the usual network: one hidden activation,
+// linear heads) - the kernel then carries one activation body instead of all of them (48 inlined
+// tanhf bodies pushed the G = 4 forward past the 64 KiB instruction cache); HACT = kChAny: per layer.
+constexpr int kChAny = -1;
+template <int HACT>
 __device__ __forceinline__ f32x4 chain_act4(f32x4 v, int act) {
+  if constexpr (HACT != kChAny) {
+    if (act == kChIdentity) return v;
+    act = HACT;
+  }
   if (act == kChElu) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : __expf(v[e]) - 1.0f;
@@ -403,7 +412,7 @@ __device__ __forceinline__ bool vec4_ok(const void* p, long long ld) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int G>
+template <int G, int HACT>
 __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = lane_id();
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     };
     auto epilogue = [&](int ob, int g, const f32x4& accv, const f32x4& bias) {
       const int f = ob * 16 + 4 * (lane >> 4);
-      const f32x4 v = chain_act4(accv + bias, l_act);
+      const f32x4 v = chain_act4<HACT>(accv + bias, l_act);
       if (!last) *reinterpret_cast<f32x4*>(tout + ((ob * G + g) * 64 + lane) * 4) = v;
       const long long row = row0 + g * 16 + (lane & 15);
       if (h_fast) {
@@ -800,21 +809,35 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
   return 0;
 }
 
-template <int G, bool kBackward>
-static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+static bool g_chain_prepared = false;     // rlg_mlp_chain_prepare raised the LDS limit of every kernel
+
+template <int G, bool kBackward, int HACT>
+static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st) {
   const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
-  auto kern = kBackward ? mlp_chain_bwd_kernel<G> : mlp_chain_fwd_kernel<G>;
-  if (lds_bytes > 64 * 1024) {
-    static bool raised[2] = {false, false};
-    if (!raised[kBackward ? 1 : 0]) {
+  auto kern = kBackward ? mlp_chain_bwd_kernel<G> : mlp_chain_fwd_kernel<G, HACT>;
+  if (lds_bytes > 64 * 1024 && !g_chain_prepared) {
+    static bool raised = false;          // one flag per instantiation = per kernel
+    if (!raised) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return static_cast<int>(e);
-      raised[kBackward ? 1 : 0] = true;
+      raised = true;
     }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kChainThreads), static_cast<size_t>(lds_bytes), st, args);
   RLG_RETURN_LAUNCH_STATUS();
+}
+
+template <int G, bool kBackward>
+static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+  if constexpr (!kBackward) {
+    // forward: the ELU-or-identity network (every BASELINE configuration) gets its own instance
+    bool elu_only = true;
+    for (int L = 0; L < args.num_layers; ++L)
+      elu_only = elu_only && (args.layer[L].act == kChElu || args.layer[L].act == kChIdentity);
+    if (elu_only) return chain_launch_as<G, false, kChElu>(args, lds_bytes, st);
+  }
+  return chain_launch_as<G, kBackward, kChAny>(args, lds_bytes, st);
 }
 
 }  // namespace rlg
@@ -836,14 +859,19 @@ int rlg_mlp_chain_num_blocks(long long rows, int groups) {
 // Raises the dynamic-LDS limit of every chain kernel once, outside any stream capture (the launchers
 // would otherwise do it lazily on the first launch that needs more than 64 KiB).
 int rlg_mlp_chain_prepare(void) {
+  using namespace rlg;
+  if (g_chain_prepared) return 0;
   const void* kernels[] = {
-      reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<1>), reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<2>),
-      reinterpret_cast<const void*>(rlg::mlp_chain_fwd_kernel<4>), reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<1>),
-      reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<2>), reinterpret_cast<const void*>(rlg::mlp_chain_bwd_kernel<4>)};
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChElu>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChAny>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChAny>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4>)};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return static_cast<int>(e);
   }
+  g_chain_prepared = true;
   return 0;
 }
 

@@ -164,6 +164,28 @@ def test_dw_odd_shapes_match_fp64(rows):
         _close(grad, t64, lib32)
 
 
+@pytest.mark.parametrize('nblocks', [1, 17, 128, 300, 513])
+def test_dw_finalize_bias_column_sums(nblocks):
+    """Bias gradients ride along in the finalise launch: out[c] = sum over the per-block fp64 partial
+    rows the backward kernels leave behind (any row count, widths that are no multiples of 16)."""
+    from rl_games_amd import ops
+    g = torch.Generator().manual_seed(nblocks)
+    rows = 64
+    shapes = [(20, 12)]
+    dz = torch.randn(rows, 20, generator=g).to(DEV)
+    x = torch.randn(rows, 12, generator=g).to(DEV)
+    grad = torch.empty(20, 12, device=DEV)
+    widths = [400, 100, 22, 7]
+    parts = [torch.randn(nblocks * w, generator=g, dtype=torch.float64).to(DEV) for w in widths]
+    outs = [torch.full((w,), float('nan'), device=DEV) for w in widths]
+    plan = ops.MlpDwPlan(shapes, rows, DEV)
+    plan.launch([(dz, x, grad)], [(parts[k], nblocks, widths[k], outs[k]) for k in range(len(widths))])
+    assert torch.allclose(grad.double(), dz.double().t() @ x.double(), rtol=1e-5, atol=1e-5)
+    for p, w, o in zip(parts, widths, outs):
+        want = p.view(nblocks, w).sum(0)
+        assert torch.allclose(o.double(), want, rtol=1e-6, atol=1e-6 * max(1.0, want.abs().max().item()))
+
+
 def test_engine_fused_chain_equals_per_layer_engine():
     """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
     gradients in the arena, on a BASELINE config #2 shaped network."""

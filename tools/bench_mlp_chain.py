@@ -112,6 +112,14 @@ def main():
             t = timeit(lambda: plan.launch(jobs), args.reps)
             print(f'  dW (16x16x4 MFMA, target_blocks {tb}, ksplit {[plan.plan(k)[3] for k in range(plan.n)]})  {t:8.1f} us  '
                   f'{2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
+            # as the engine launches it: bias gradients (column sums of the backward launch's
+            # per-block fp64 partials) ride along in the finalise kernel
+            nblk = chain.num_blocks(rows, 1, 0)
+            cparts = [torch.randn(nblk * u, dtype=torch.float64, device=dev) for u in units]
+            couts = [torch.empty(u, device=dev) for u in units]
+            colsums = [(cparts[k], nblk, units[k], couts[k]) for k in range(len(units))]
+            t = timeit(lambda: plan.launch(jobs, colsums), args.reps)
+            print(f'     + bias column sums of {nblk} partial rows in the finalise launch   {t:8.1f} us')
 
         if args.no_lib:
             continue
