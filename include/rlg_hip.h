@@ -159,6 +159,14 @@ int rlg_column_moments_num_blocks(long long rows, int cols);
 int rlg_column_moments(const float* x, const float* row_mask_or_null, long long rows, int cols,
                        double* partials, int num_blocks, void* stream);
 
+/* The same moments for num_segments consecutive bands of rows_per_segment rows in two launches -
+ * the minibatches of one epoch, which every mini-epoch revisits unchanged (rl_games/common/
+ * datasets.py:57-75: fixed slices): table[seg][2*cols+1] = {sum[cols], sumsq[cols], rows}.
+ * partials: scratch of num_segments * num_blocks * (2*cols+1) doubles.  rlg_mlp_chain_forward folds
+ * a table row into the running state in its prologue. */
+int rlg_column_moments_segments(const float* x, long long rows_per_segment, int cols, int num_segments,
+                                double* partials, int num_blocks, double* table, void* stream);
+
 /* Chan merge of the batch moments into the fp64/int64 running state (running_mean_std.py:
  * 55-67).  mode 0: population variance, count += rows (:74-75,:83); mode 1: masked moments
  * of get_mean_var_with_masks, count += rows (:72,:83); mode 2: moments of the selected rows
@@ -373,7 +381,16 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           const int* in_features, const int* out_features, const int* acts,
                           float* const* act_out, const long long* act_ld, const float* x, long long ldx,
                           const double* rms_mean_or_null, const double* rms_var, float rms_eps,
-                          float* xn_out_or_null, long long rows, int groups, void* stream);
+                          float* xn_out_or_null,
+                          /* training-mode RunningMeanStd.forward (rl_games/algos_torch/running_mean_std.py:
+                           * 69-84, called from models.py:54-56): fold this minibatch's column moments
+                           * rms_batch = {sum[in], sumsq[in], rows} (rlg_column_moments_segments) into the
+                           * state BEFORE normalising; the new state goes to the *_out buffers, which must
+                           * differ from the inputs (every workgroup folds from the old state).  NULL
+                           * rms_batch: normalise with the state as it is. */
+                          const double* rms_batch_or_null, const long long* rms_count,
+                          double* rms_mean_out, double* rms_var_out, long long* rms_count_out,
+                          long long rows, int groups, void* stream);
 int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const int* in_features,
                            const int* out_features, const int* acts, const float* const* act_in,
                            const long long* act_ld, const float* d_out, long long ld_dout,

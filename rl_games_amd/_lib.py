@@ -49,6 +49,7 @@ _PROTOTYPES = {
     # running_stats.hip
     'rlg_column_moments_num_blocks': [_c_ll, _c_int],
     'rlg_column_moments': [_P, _P, _c_ll, _c_int, _P, _c_int, _P],
+    'rlg_column_moments_segments': [_P, _c_ll, _c_int, _c_int, _P, _c_int, _P, _P],
     'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P, _P],
     'rlg_rms_apply': [_P, _P, _c_ll, _c_int, _P, _P, _c_float, _c_int, _P],
     'rlg_prepare_stats_bytes': [],
@@ -73,8 +74,8 @@ _PROTOTYPES = {
     'rlg_mlp_chain_num_blocks': [_c_ll, _c_int],
     'rlg_mlp_chain_lds_bytes': [_c_int, _P, _P, _c_int, _c_int],
     'rlg_mlp_chain_debug_stamps': [_P],
-    'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P, _c_ll,
-                              _c_int, _P],
+    'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
+                              _P, _P, _P, _P, _P, _c_ll, _c_int, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _c_ll, _c_int, _P],
     'rlg_lstm_supported': [_c_int],
     'rlg_lstm_seq_forward': [_P] * 10 + [_c_int, _c_int, _c_int, _P],

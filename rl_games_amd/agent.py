@@ -392,6 +392,8 @@ class A2CAgent:
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_epoch = None
         self._graph_failed = False
+        self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
+        self._fold_index = None
         self._ipc_comm = None
         self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
         self._rnn_state_store = None
@@ -1027,9 +1029,15 @@ class A2CAgent:
                 if eng.chain is not None:
                     if not obs_batch.is_contiguous():
                         obs_batch = obs_batch.contiguous()
+                    rms, fold = self._obs_rms(), None
                     if self.normalize_input and self.model.running_mean_std.training:
-                        self.model.running_mean_std.update(obs_batch)   # statistics first (models.py:54-56)
-                    heads = eng.forward_obs(obs_batch, self._obs_rms(), self._obs_eps())
+                        if self._fold_index is not None:
+                            # statistics first (models.py:54-56), in the launch's prologue, from the
+                            # epoch's precomputed minibatch moments
+                            rms, fold = self.model.running_mean_std.fold_buffers(self._fold_index)
+                        else:
+                            self.model.running_mean_std.update(obs_batch)
+                    heads = eng.forward_obs(obs_batch, rms, self._obs_eps(), rms_fold=fold)
                     obs_n = None
                 elif self.normalize_input:                              # updates the obs statistics
                     out = self._obs_norm_mb[:obs_batch.shape[0]] if self._obs_norm_mb is not None else None
@@ -1121,6 +1129,31 @@ class A2CAgent:
                  schedule=schedule, kl_scale=scale)
 
     # ------------------------------------------------------------------ HIP graphs
+    def _with_fold(self, mb_index, fn, *args):
+        """Run fn with the minibatch index visible to _forward_loss_backward (the in-kernel statistics
+        fold needs it); a no-op wrapper when the epoch has no precomputed minibatch moments."""
+        self._fold_index = mb_index if self._fold_ready else None
+        try:
+            return fn(*args)
+        finally:
+            self._fold_index = None
+
+    def _prepare_obs_fold(self):
+        """Once per epoch, after prepare_dataset: column moments of every minibatch's observations in
+        two launches (instead of a moments + a merge launch in each of the epoch's optimiser steps)."""
+        self._fold_ready = False
+        eng = self._engine
+        if (eng is None or eng.chain is None or not self.normalize_input or self.is_rnn
+                or not self.config.get('fold_obs_stats', True)):
+            return
+        obs = self.dataset.values_dict.get('obs')
+        if not torch.is_tensor(obs) or obs.dim() != 2 or not obs.is_contiguous() or obs.dtype != torch.float32:
+            return
+        if obs.shape[0] != len(self.dataset) * self.minibatch_size:
+            return
+        self.model.running_mean_std.precompute_minibatch_moments(obs, self.minibatch_size)
+        self._fold_ready = True
+
     def _graph_signature(self):
         """Everything a captured minibatch graph bakes in: dataset storage addresses and the
         scalar hyper-parameters passed by value to the kernels."""
@@ -1134,7 +1167,8 @@ class A2CAgent:
                  getattr(s, 'lr_multiplier', None))
         return (ptrs, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
                 self.bound_loss_type, self.clip_value, self.use_smooth_clamp, self.grad_norm,
-                self.truncate_grads, self.schedule_type, self.is_adaptive_lr, sched, self.world_size)
+                self.truncate_grads, self.schedule_type, self.is_adaptive_lr, sched, self.world_size,
+                self._fold_ready and self.model.running_mean_std._mb_table.data_ptr())
 
     def _graphs_usable(self):
         return (self._hip_graphs and self._engine is not None and self._eager_epochs >= 1
@@ -1169,7 +1203,8 @@ class A2CAgent:
         g = self._graphs.get(i)
         if g is None:
             item = self.dataset[i]
-            g = self._graphs[i] = self._capture(lambda: self._forward_loss_backward(item, self._graph_rows[i]))
+            g = self._graphs[i] = self._capture(lambda: self._with_fold(i, self._forward_loss_backward, item,
+                                                                       self._graph_rows[i]))
         if self._graph_opt is None:
             self._graph_opt = self._capture(self._optimizer_kernels)
         g.replay()
@@ -1191,10 +1226,12 @@ class A2CAgent:
         if self._graph_epoch is None:
             def body():
                 for i in range(nmb):
-                    self._forward_loss_backward(self.dataset[i], self._graph_rows[i])
+                    self._with_fold(i, self._forward_loss_backward, self.dataset[i], self._graph_rows[i])
                     if self.multi_gpu:
                         self._all_reduce_grads()          # native in-graph collective only (see train_epoch)
                     self._optimizer_kernels()
+                if self._fold_ready:
+                    self.model.running_mean_std.fold_sync(nmb)
             self._graph_epoch = self._capture(body)
         self._graph_epoch.replay()
         self.optimizer.step_count += nmb
@@ -1218,6 +1255,7 @@ class A2CAgent:
         self.curr_frames = batch_dict.pop('played_frames')
         self.prepare_dataset(batch_dict)
         self.algo_observer.after_steps()
+        self._prepare_obs_fold()
 
         a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
         if self.has_central_value:                                   # a2c_common.py:1536-1537
@@ -1232,14 +1270,16 @@ class A2CAgent:
         for mini_ep in range(self.mini_epochs_num):
             first = self._mb_index
             done = 0                     # minibatches of this mini-epoch already stepped
+            fold_synced = False
             if use_graphs:
                 try:
                     self.set_train()
                     host_between = self.schedule_type == 'per_minibatch' and not device_schedule
                     in_graph_comm = (not self.multi_gpu) or self._native_comm() is not None
                     if in_graph_comm and not host_between and self.config.get('mini_epoch_graph', True):
-                        self._graph_mini_epoch(nmb)
+                        self._graph_mini_epoch(nmb)      # (the statistics hand-back is part of the graph)
                         done = nmb
+                        fold_synced = True
                     else:
                         for i in range(nmb):
                             self._graph_minibatch(i)
@@ -1267,7 +1307,7 @@ class A2CAgent:
                 if self.is_discrete and done == 0:    # a2c_common.py:1263 (no-op unless `permute`)
                     self.dataset.apply_permutation()
                 for i in range(done, nmb):
-                    res = self.train_actor_critic(self.dataset[i])
+                    res = self._with_fold(i, self.train_actor_critic, self.dataset[i])
                     a_loss, c_loss, entropy, kl, last_lr, lr_mul = res[:6]
                     b_loss = res[8] if len(res) > 8 else None
                     a_losses.append(a_loss)
@@ -1277,6 +1317,8 @@ class A2CAgent:
                         b_losses.append(b_loss)
                     if self.schedule_type == 'per_minibatch' and not device_schedule:
                         self._host_schedule(None if not self.is_adaptive_lr else float(kl.item()))
+            if self._fold_ready and not fold_synced:
+                self.model.running_mean_std.fold_sync(nmb)
             av_kls = self._mb_scalars[first:self._mb_index, 4].mean()
             if self.multi_gpu:
                 rdist.all_reduce_sum(av_kls)
@@ -1288,6 +1330,7 @@ class A2CAgent:
                 self.model.running_mean_std.eval()
         if self.schedule_type == 'standard_epoch':
             self._host_schedule(float(torch.stack(kls).mean().item()))
+        self._fold_ready = False
         self.sync_running_stats()
         if self._ipc_comm:
             _, timed_out = self._ipc_comm.status()

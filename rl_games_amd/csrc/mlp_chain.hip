@@ -61,6 +61,14 @@ struct ChainArgs {
   const double* rms_mean;      // forward: RunningMeanStd state (fp64) or nullptr
   const double* rms_var;
   float rms_eps;
+  // forward, training: fold this minibatch's column moments {sum[in], sumsq[in], rows} into the state
+  // first (RunningMeanStd.forward in training mode updates, then normalises) - every block folds for
+  // itself, block 0 publishes the new state to the OTHER buffer set (the next launch reads that one)
+  const double* rms_batch;     // or nullptr: normalise with the state as it is
+  const long long* rms_count;
+  double* rms_mean_out;
+  double* rms_var_out;
+  long long* rms_count_out;
   float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
   long long rows;
   int lds_b_floats;            // start of the second LDS region, in floats
@@ -475,8 +483,25 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     if (norm) {
       // mean32 / denom exactly like rms_apply_kernel mode 0 (running_mean_std.py:112-113)
       for (int f = threadIdx.x; f < in0; f += kChainThreads) {
-        tile_b[f] = static_cast<float>(a.rms_mean[f]);
-        tile_b[in0p + f] = sqrt_rn(static_cast<float>(a.rms_var[f]) + a.rms_eps);
+        double mean = a.rms_mean[f], var = a.rms_var[f];
+        if (a.rms_batch) {
+          // rms_update_kernel mode 0: population moments of the minibatch, rounded to fp32 like the
+          // reference's input.mean / input.var, Chan merge in fp64 (running_mean_std.py:55-67,:74-83)
+          const double n = fmax(a.rms_batch[2 * in0], 1.0);
+          double bm = a.rms_batch[f] / n;
+          double bv = fmax(a.rms_batch[in0 + f] / n - bm * bm, 0.0);
+          bm = static_cast<double>(static_cast<float>(bm));
+          bv = static_cast<double>(static_cast<float>(bv));
+          const long long old_count = *a.rms_count;
+          chan_merge(mean, var, static_cast<double>(old_count), bm, bv, static_cast<double>(a.rows));
+          if (blockIdx.x == 0) {
+            a.rms_mean_out[f] = mean;
+            a.rms_var_out[f] = var;
+            if (f == 0) *a.rms_count_out = old_count + a.rows;
+          }
+        }
+        tile_b[f] = static_cast<float>(mean);
+        tile_b[in0p + f] = sqrt_rn(static_cast<float>(var) + a.rms_eps);
       }
       __syncthreads();
     }
@@ -893,6 +918,8 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           const int* in_features, const int* out_features, const int* acts,
                           float* const* act_out, const long long* act_ld, const float* x, long long ldx,
                           const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                          const double* rms_batch, const long long* rms_count, double* rms_mean_out,
+                          double* rms_var_out, long long* rms_count_out,
                           long long rows, int groups, void* stream) {
   using namespace rlg;
   if (rows <= 0) return 0;
@@ -909,6 +936,16 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   args.rms_mean = rms_mean;
   args.rms_var = rms_mean ? rms_var : nullptr;
   args.rms_eps = rms_eps;
+  args.rms_batch = rms_mean ? rms_batch : nullptr;
+  if (args.rms_batch) {
+    if (!rms_count || !rms_mean_out || !rms_var_out || !rms_count_out || rms_mean_out == rms_mean ||
+        rms_var_out == rms_var || rms_count_out == rms_count)
+      return static_cast<int>(hipErrorInvalidValue);      // the fold publishes into a second buffer set
+  }
+  args.rms_count = rms_count;
+  args.rms_mean_out = rms_mean_out;
+  args.rms_var_out = rms_var_out;
+  args.rms_count_out = rms_count_out;
   args.xn = xn_out;
   args.rows = rows;
   args.dbg = g_chain_dbg;
@@ -945,6 +982,10 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
   args.ldx = ld_dout;
   args.rms_mean = args.rms_var = nullptr;
   args.rms_eps = 0.0f;
+  args.rms_batch = nullptr;
+  args.rms_count = nullptr;
+  args.rms_mean_out = args.rms_var_out = nullptr;
+  args.rms_count_out = nullptr;
   args.xn = nullptr;
   args.rows = rows;
   const int G = pick_groups(rows, groups, 1);

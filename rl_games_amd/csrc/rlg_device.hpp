@@ -71,6 +71,21 @@ __device__ __forceinline__ bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
+// running_mean_std.py:55-67, operands promoted exactly as torch does: batch_mean / batch_var
+// are fp32 tensors (input.mean / input.var of an fp32 input), the state is fp64.
+__device__ __forceinline__ void chan_merge(double& mean, double& var, double count_f,
+                                           double batch_mean, double batch_var, double batch_count) {
+  const double tot = count_f + batch_count;
+  const double delta = batch_mean - mean;
+  const double new_mean = mean + delta * batch_count / tot;
+  const double m_a = var * count_f;
+  const double m_b = batch_var * batch_count;
+  const double M2 = m_a + m_b + delta * delta * count_f * batch_count / tot;
+  mean = new_mean;
+  var = M2 / tot;
+}
+
+
 }  // namespace rlg
 
 // Host-side launch check used by every extern "C" entry point: launchers never

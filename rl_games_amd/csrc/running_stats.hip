@@ -58,7 +58,10 @@ __global__ __launch_bounds__(kMomBlock) void column_moments_kernel(
   const int wave = wave_id();
   const long long gwave = static_cast<long long>(blockIdx.x) * kMomWaves + wave;
   const long long nwaves = static_cast<long long>(gridDim.x) * kMomWaves;
-  double* out = partials + static_cast<long long>(blockIdx.x) * (2 * C + 1);
+  // blockIdx.y = segment: consecutive bands of `rows` rows (the minibatches of an epoch), own partial rows
+  x += static_cast<long long>(blockIdx.y) * rows * C;
+  if (row_mask) row_mask += static_cast<long long>(blockIdx.y) * rows;
+  double* out = partials + (static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * (2 * C + 1);
   double* block_acc = smem + kMomWaves * kWave * 2 * UNIT;       // [2*C + 1]
   for (int i = threadIdx.x; i < 2 * C + 1; i += kMomBlock) block_acc[i] = 0.0;
   __syncthreads();
@@ -138,23 +141,31 @@ __global__ __launch_bounds__(kMomBlock) void column_moments_kernel(
   for (int i = threadIdx.x; i < 2 * C + 1; i += kMomBlock) out[i] = block_acc[i];
 }
 
+// table[seg][j] = sum over the per-block partial rows of segment seg, in block order (deterministic):
+// one {sum[C], sumsq[C], count} row per minibatch, folded later by the fused forward's prologue.
+__global__ __launch_bounds__(256) void moments_rows_kernel(const double* __restrict__ partials, int nblocks,
+                                                           int W, double* __restrict__ table) {
+  const double* src = partials + static_cast<long long>(blockIdx.x) * nblocks * W;
+  for (int j = threadIdx.x; j < W; j += blockDim.x) {
+    double s = 0.0;
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[static_cast<long long>(b + u) * W + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; ++b) s += src[static_cast<long long>(b) * W + j];
+    table[static_cast<long long>(blockIdx.x) * W + j] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // (2) finalise: fold partial sums into the running state (Chan merge, fp64)
 // ---------------------------------------------------------------------------------
 
-// running_mean_std.py:55-67, operands promoted exactly as torch does: batch_mean / batch_var
-// are fp32 tensors (input.mean / input.var of an fp32 input), the state is fp64.
-__device__ __forceinline__ void chan_merge(double& mean, double& var, double count_f,
-                                           double batch_mean, double batch_var, double batch_count) {
-  const double tot = count_f + batch_count;
-  const double delta = batch_mean - mean;
-  const double new_mean = mean + delta * batch_count / tot;
-  const double m_a = var * count_f;
-  const double m_b = batch_var * batch_count;
-  const double M2 = m_a + m_b + delta * delta * count_f * batch_count / tot;
-  mean = new_mean;
-  var = M2 / tot;
-}
+// chan_merge (running_mean_std.py:55-67) lives in rlg_device.hpp: the fused forward folds with it too.
 
 // mode 0: unmasked  - population variance, batch_count = rows            (:74-75, :83)
 // mode 1: masked    - mean/var of get_mean_var_with_masks (unbiased, denominators clamped,
@@ -475,6 +486,32 @@ int rlg_column_moments(const float* x, const float* row_mask_or_null, long long 
     hipLaunchKernelGGL((column_moments_kernel<1>), dim3(num_blocks), dim3(kMomBlock), shm, st, x,
                        row_mask_or_null, rows, cols, partials);
   }
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+// Column moments of `num_segments` consecutive bands of rows_per_segment rows (the minibatches of an
+// epoch) in two launches: table[seg] = {sum[cols], sumsq[cols], rows}.  `partials` is scratch of
+// num_segments * num_blocks * (2*cols+1) doubles.
+int rlg_column_moments_segments(const float* x, long long rows_per_segment, int cols, int num_segments,
+                                double* partials, int num_blocks, double* table, void* stream) {
+  using namespace rlg;
+  if (rows_per_segment <= 0 || cols <= 0 || num_segments <= 0 || num_segments > 65535 || num_blocks <= 0)
+    return static_cast<int>(hipErrorInvalidValue);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (cols % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int unit = vec ? 4 : 1;
+  const size_t shm = (static_cast<size_t>(kMomWaves) * kWave * 2 * unit + 2 * cols + 1) * sizeof(double);
+  if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+  const dim3 grid(num_blocks, num_segments);
+  if (vec) {
+    hipLaunchKernelGGL((column_moments_kernel<4>), grid, dim3(kMomBlock), shm, st, x,
+                       static_cast<const float*>(nullptr), rows_per_segment, cols, partials);
+  } else {
+    hipLaunchKernelGGL((column_moments_kernel<1>), grid, dim3(kMomBlock), shm, st, x,
+                       static_cast<const float*>(nullptr), rows_per_segment, cols, partials);
+  }
+  hipLaunchKernelGGL(moments_rows_kernel, dim3(num_segments), dim3(256), 0, st, partials, num_blocks,
+                     2 * cols + 1, table);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -199,17 +199,19 @@ class ManualMLP:
         return heads
 
     @torch.no_grad()
-    def forward_obs(self, obs, rms=None, eps=1e-5, keep=True):
+    def forward_obs(self, obs, rms=None, eps=1e-5, keep=True, rms_fold=None):
         """Fused chain: obs [rows, in] RAW observations; rms = (running_mean, running_var) fp64 or None
         (normalize_input off).  One launch: normalise -> hidden layers -> heads.  keep=True retains
         the activations and the normalised observations for backward(); keep=False (rollout,
-        get_values) writes nothing but the heads, so it cannot disturb a pending backward."""
+        get_values) writes nothing but the heads, so it cannot disturb a pending backward.
+        rms_fold: RunningMeanStd.fold_buffers() - the statistics update of a training forward happens
+        in the launch's prologue."""
         rows = obs.shape[0]
         heads = self.heads[:rows]
         if keep:
             acts = [h[:rows] for h in self.Hs]
             xn = self.xn[:rows] if rms is not None else None
-            self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn)
+            self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn, rms_fold=rms_fold)
             self._x = xn if rms is not None else obs
             self._rows, self._last = rows, acts[-1]
             self._pending_backward = True

@@ -35,6 +35,41 @@ class RunningMeanStd(nn.Module):
         self.register_buffer('running_var', torch.ones(in_size, dtype=torch.float64))
         self.register_buffer('count', torch.ones((), dtype=torch.int64))
         self._partials = None
+        # fused training forward (csrc/mlp_chain.hip): per-minibatch moments of the epoch's dataset and
+        # the second state buffer set the in-kernel fold publishes into (plain attributes - checkpoints
+        # only ever see running_mean / running_var / count)
+        self._mb_table = self._mb_scratch = None
+        self._shadow = None
+
+    # ---- in-kernel fold (rlg_mlp_chain_forward's rms_batch arguments) -----------------------------
+    def precompute_minibatch_moments(self, obs, minibatch_rows):
+        """Column moments of every minibatch of the epoch in two launches.  The dataset's minibatches
+        are fixed row slices (rl_games/common/datasets.py:57-75) that all mini-epochs revisit, so the
+        batch statistics RunningMeanStd.forward recomputes on every visit are the same numbers."""
+        self._mb_table, self._mb_scratch = ops.column_moments_segments(
+            obs, minibatch_rows, self._mb_table, self._mb_scratch)
+        return self._mb_table
+
+    def fold_buffers(self, mb_index):
+        """(rms, rms_fold) for the fused forward of minibatch `mb_index`: the state goes back and forth
+        between the registered buffers and a second set - even minibatches read the registered ones
+        and publish into the other set, odd ones the reverse (a pure function of the index: captured
+        graphs and the eager path agree without any host-side mirror).  `fold_sync(nmb)` follows the
+        last minibatch of a mini-epoch."""
+        if self._shadow is None or self._shadow[0].device != self.running_mean.device:
+            self._shadow = (torch.empty_like(self.running_mean), torch.empty_like(self.running_var),
+                            torch.empty_like(self.count))
+        official = (self.running_mean, self.running_var, self.count)
+        cur, nxt = (official, self._shadow) if mb_index % 2 == 0 else (self._shadow, official)
+        return (cur[0], cur[1]), (self._mb_table[mb_index], cur[2], nxt[0], nxt[1], nxt[2])
+
+    def fold_sync(self, num_minibatches):
+        """After the last minibatch of a mini-epoch: an odd number of folds leaves the state in the
+        second set - three tiny copies bring it back to the registered buffers."""
+        if num_minibatches % 2:
+            self.running_mean.copy_(self._shadow[0])
+            self.running_var.copy_(self._shadow[1])
+            self.count.copy_(self._shadow[2])
 
     def _cols(self):
         return self.running_mean.numel()

@@ -147,6 +147,29 @@ def column_moments(x, mask=None, partials=None):
     return partials, nb
 
 
+def column_moments_segments(x, rows_per_segment, table=None, scratch=None):
+    """x [segments * rows_per_segment, C] fp32 contiguous -> table [segments, 2C+1] fp64 =
+    {sum[C], sumsq[C], rows} per band of rows (the minibatches of an epoch); two launches.
+    Returns (table, scratch) so that callers can keep both between epochs."""
+    lib = _lib.load()
+    x2 = x.reshape(x.shape[0], -1)
+    total, C = x2.shape
+    rps = int(rows_per_segment)
+    if rps <= 0 or total % rps != 0:
+        raise ValueError(f'{total} rows are not a whole number of {rps}-row segments')
+    segs = total // rps
+    nb = column_moments_blocks(rps, C)
+    W = 2 * C + 1
+    if table is None or table.numel() != segs * W or table.device != x.device:
+        table = torch.empty((segs, W), dtype=F64, device=x.device)
+    if scratch is None or scratch.numel() < segs * nb * W or scratch.device != x.device:
+        scratch = torch.empty(segs * nb * W, dtype=F64, device=x.device)
+    _lib.check(lib.rlg_column_moments_segments(_need(x2, F32, 'x'), rps, C, segs, _need(scratch, F64, 'scratch'),
+                                               nb, _need(table, F64, 'table'), _stream(x)),
+               'rlg_column_moments_segments')
+    return table, scratch
+
+
 _tickets = {}
 
 
@@ -489,10 +512,13 @@ class MlpChain:
     def num_blocks(self, rows, direction, requested=0):
         return _lib.load().rlg_mlp_chain_num_blocks(int(rows), self.groups(rows, direction, requested))
 
-    def forward(self, x, heads, act_out=None, rms=None, eps=1e-5, xn_out=None, groups=0):
+    def forward(self, x, heads, act_out=None, rms=None, eps=1e-5, xn_out=None, groups=0, rms_fold=None):
         """x [rows, in0] (row stride free), heads [rows, out_last] out.  act_out: per hidden layer a
         [rows, out_l] tensor or None.  rms = (running_mean, running_var) fp64 -> the observations are
-        normalised on the way in (xn_out [rows, in0] optionally receives them)."""
+        normalised on the way in (xn_out [rows, in0] optionally receives them).  rms_fold =
+        (moments_row [2*in0+1] fp64, count int64, mean_out, var_out, count_out): training-mode
+        RunningMeanStd - the minibatch's moments are folded into the state first, the new state is
+        written to the *_out tensors (a second buffer set)."""
         rows = x.shape[0]
         n = self.n
         outs = list(act_out) if act_out is not None else [None] * (n - 1)
@@ -505,9 +531,18 @@ class MlpChain:
         mean = var = None
         if rms is not None:
             mean, var = _need(rms[0], F64, 'running_mean'), _need(rms[1], F64, 'running_var')
+        fold = [None] * 5
+        if rms_fold is not None:
+            if rms is None:
+                raise ValueError('rms_fold needs rms')
+            row, cnt, mean_o, var_o, cnt_o = rms_fold
+            if row.numel() != 2 * self.ins[0] + 1:
+                raise ValueError('rms_fold: moments row of 2*in0+1 doubles expected')
+            fold = [_need(row, F64, 'moments row'), _need(cnt, torch.int64, 'count'), _need(mean_o, F64, 'mean out'),
+                    _need(var_o, F64, 'var out'), _need(cnt_o, torch.int64, 'count out')]
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
-            mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), rows,
+            mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
             self.groups(rows, 0, groups), _stream(x)), 'rlg_mlp_chain_forward')
 
     def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0):

@@ -186,6 +186,54 @@ def test_dw_finalize_bias_column_sums(nblocks):
         assert torch.allclose(o.double(), want, rtol=1e-6, atol=1e-6 * max(1.0, want.abs().max().item()))
 
 
+@pytest.mark.parametrize('in_dim,mb_rows,nmb', [(108, 4096, 3), (60, 1000, 4), (13, 37, 5)])
+def test_forward_folds_minibatch_moments_like_running_mean_std(in_dim, mb_rows, nmb):
+    """Training-mode RunningMeanStd.forward = update, then normalise (running_mean_std.py:69-84).  The
+    fused forward folds the epoch's precomputed minibatch moments in its prologue; the state and the
+    normalised observations must follow the stand-alone update + apply kernels step by step."""
+    from rl_games_amd import ops
+    from rl_games_amd.normalizers import RunningMeanStd
+    layers, g = _net(in_dim, [32], 5, 'elu', seed=in_dim)
+    chain = ops.MlpChain(layers, DEV)
+    obs = (2.5 * torch.randn(nmb * mb_rows, in_dim, generator=g) + 0.7).to(DEV)
+    a, b = RunningMeanStd(in_dim).to(DEV), RunningMeanStd(in_dim).to(DEV)
+    for m in (a, b):
+        m.running_mean.copy_(torch.linspace(-1, 1, in_dim, dtype=torch.float64))
+        m.running_var.copy_(torch.linspace(0.5, 2, in_dim, dtype=torch.float64))
+        m.count.fill_(777)
+    table = a.precompute_minibatch_moments(obs, mb_rows)
+    want = torch.cat([obs.double().view(nmb, mb_rows, in_dim).sum(1),
+                      (obs.double() ** 2).view(nmb, mb_rows, in_dim).sum(1),
+                      torch.full((nmb, 1), float(mb_rows), dtype=torch.float64, device=DEV)], dim=1)
+    assert torch.allclose(table, want, rtol=1e-12, atol=1e-9)
+    for i in range(nmb):
+        x = obs[i * mb_rows:(i + 1) * mb_rows]
+        rms, fold = a.fold_buffers(i)
+        heads = torch.empty(mb_rows, 5, device=DEV)
+        xn = torch.empty(mb_rows, in_dim, device=DEV)
+        chain.forward(x, heads, rms=rms, eps=a.epsilon, xn_out=xn, rms_fold=fold)
+        b.train()
+        xn_ref = b(x)                                        # update + apply kernels
+        heads_ref = torch.empty(mb_rows, 5, device=DEV)
+        chain.forward(xn_ref, heads_ref)
+        new_mean, new_var, new_count = fold[2], fold[3], fold[4]
+        assert new_count.item() == b.count.item() == 777 + (i + 1) * mb_rows
+        assert torch.allclose(new_mean, b.running_mean, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(new_var, b.running_var, rtol=1e-12, atol=1e-13)
+        # same fp32 mean / denominator unless the 1e-12 state difference crosses a rounding boundary
+        assert torch.allclose(xn, xn_ref, rtol=0, atol=1e-6)
+        assert (xn != xn_ref).float().mean().item() < 1e-3
+        assert torch.allclose(heads, heads_ref, rtol=1e-5, atol=1e-5)
+    a.fold_sync(nmb)
+    assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(a.running_var, b.running_var, rtol=1e-12, atol=1e-13)
+    assert a.count.item() == b.count.item()
+    # the fold needs a second buffer set
+    with pytest.raises(RuntimeError):
+        chain.forward(obs[:mb_rows], heads, rms=(a.running_mean, a.running_var),
+                      rms_fold=(table[0], a.count, a.running_mean, a.running_var, a.count))
+
+
 def test_engine_fused_chain_equals_per_layer_engine():
     """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
     gradients in the arena, on a BASELINE config #2 shaped network."""
