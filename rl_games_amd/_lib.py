@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librlg_hip.so')
+# RLG_HIP_LIB: another build of the same ABI (A/B measurements of kernel variants, tools only)
+LIB_PATH = os.environ.get('RLG_HIP_LIB') or os.path.join(_HERE, 'librlg_hip.so')
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int

@@ -36,6 +36,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kDwMaxLayers = 8;
 constexpr int kDwMaxTiles = 16;    // tiles per dimension of one layer (<= 1024 features in 64-wide tiles)
 constexpr int kDwBatch = 4;        // k-steps (of 4 rows) per prefetch batch
+#ifndef RLG_DW_SETS
+#define RLG_DW_SETS 3
+#endif
+constexpr int kDwSets = RLG_DW_SETS;   // register sets: kDwSets-1 batches of loads in flight
 
 struct DwLayer {
   const float* dz;     // [rows, lda]
@@ -127,25 +131,52 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(dw_get<BO>(av, a), dw_get<BI>(bv, b), acc[a][b], 0, 0, 0);
     }
   };
+  // Full batches: kDwSets register sets, kDwSets-1 batches of loads in flight while one issues its
+  // MFMAs.  All tiles of a K-slice stream their band of rows at the same time, so every load of a
+  // workgroup sees first-touch (HBM / Infinity Cache) latency even when the line counts as an L2 hit:
+  // with one batch of look-ahead (~1-1.7 us of MFMAs at two waves per SIMD) the waves spent 74 % of
+  // their cycles in s_waitcnt (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).  Straight-line structure with
+  // statically named sets and unconditional loads, so hipcc's vmcnt bookkeeping stays exact.
   int s = s_begin;
-  if (s + kDwBatch <= s_full_end) {
-    VA a_cur[kDwBatch], a_nxt[kDwBatch];
-    VB b_cur[kDwBatch], b_nxt[kDwBatch];
-    load_batch(a_cur, b_cur);
-    s += kDwBatch;
-    while (s + kDwBatch <= s_full_end) {
-      load_batch(a_nxt, b_nxt);             // in flight while the MFMAs of the current batch issue
-      RLG_DW_PIN();
+  const int nb = (s_full_end > s_begin) ? (s_full_end - s_begin) / kDwBatch : 0;
+  auto mfma_batch = [&](const VA (&av)[kDwBatch], const VB (&bv)[kDwBatch]) {
+    RLG_DW_PIN();
 #pragma unroll
-      for (int u = 0; u < kDwBatch; ++u) mfma_step(a_cur[u], b_cur[u]);
-      RLG_DW_PIN();
+    for (int u = 0; u < kDwBatch; ++u) mfma_step(av[u], bv[u]);
+    RLG_DW_PIN();
+  };
+  {
+    VA av[kDwSets][kDwBatch];
+    VB bv[kDwSets][kDwBatch];
+    // the pipelined section takes (kDwSets-1) + kDwSets*m batches (ONE way in and out: with several
+    // exits hipcc stops accumulating in place and spills); the batches that do not fit are issued the
+    // plain way first.  Set indices are compile-time constants after unrolling.
+    const int plain = (nb >= kDwSets - 1) ? (nb - (kDwSets - 1)) % kDwSets : nb;
+    const bool piped = nb - plain >= kDwSets - 1;
+    if (piped) {
 #pragma unroll
-      for (int u = 0; u < kDwBatch; ++u) { a_cur[u] = a_nxt[u]; b_cur[u] = b_nxt[u]; }
-      s += kDwBatch;
+      for (int j = 0; j < kDwSets - 1; ++j) load_batch(av[j], bv[j]);
     }
+    // (requested right behind the pipeline's first batches: one cold round trip covers them all)
+#pragma unroll 1
+    for (int e = 0; e < plain; ++e) {
+      load_batch(av[kDwSets - 1], bv[kDwSets - 1]);
+      mfma_batch(av[kDwSets - 1], bv[kDwSets - 1]);
+    }
+    if (piped) {
+#pragma unroll 1
+      for (int t = plain + kDwSets - 1; t < nb; t += kDwSets) {
 #pragma unroll
-    for (int u = 0; u < kDwBatch; ++u) mfma_step(a_cur[u], b_cur[u]);
+        for (int j = 0; j < kDwSets; ++j) {
+          load_batch(av[(j + kDwSets - 1) % kDwSets], bv[(j + kDwSets - 1) % kDwSets]);
+          mfma_batch(av[j], bv[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kDwSets - 1; ++j) mfma_batch(av[j], bv[j]);
+    }
   }
+  s += nb * kDwBatch;
   // tail steps (and the ragged last rows): predicated, zero-filled
   for (; s < s_end; ++s) {
     const long long r = 4LL * s + kq;
