@@ -164,6 +164,9 @@ def main():
     # GEMM solution selection: shipped TunableOp file; shapes missing from it (other library
     # versions) are tuned during the untimed warm-up epochs.
     params['config']['gemm_tuning_online'] = args.warmup >= 1
+    # A/B measurements of optional code paths (tools/gpu_r2_call*.sh): RLG_BENCH_CONFIG='{"fused_loss": false}'
+    overrides = json.loads(os.environ.get('RLG_BENCH_CONFIG', '{}'))
+    params['config'].update(overrides)
     torch.manual_seed(42 + rank)
     agent = A2CAgent('bench', params)
     agent.init_tensors()

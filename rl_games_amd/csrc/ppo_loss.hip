@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kLossThreads) void ppo_loss_kernel(LossArgs p) {
   float* row_w = row_g + kLossRows;           // [256]  inv_count * mask of the row
   float* col_sigma = row_w + kLossRows;       // [A]
   float* col_logstd = col_sigma + A;          // [A]
-  double* red = reinterpret_cast<double*>(col_logstd + A);  // float offset is even -> 8 B aligned
+  float* col_ent = col_logstd + A;            // [A]  entropy term of the column (the same for every row)
+  double* red = reinterpret_cast<double*>(
+      (reinterpret_cast<uintptr_t>(col_ent + A) + 7) & ~static_cast<uintptr_t>(7));
 
   const int tid = threadIdx.x;
   const long long row0 = static_cast<long long>(blockIdx.x) * kLossRows;
@@ -101,7 +103,10 @@ __global__ __launch_bounds__(kLossThreads) void ppo_loss_kernel(LossArgs p) {
   for (int a = tid; a < A; a += kLossThreads) {
     const float ls = p.logstd[a];
     col_logstd[a] = ls;
-    col_sigma[a] = expf(ls);                                                  // models.py:296
+    const float sg = expf(ls);                                                // models.py:296
+    col_sigma[a] = sg;
+    // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale) - once per column, not once per row and column
+    col_ent[a] = 1.4189385332046727f + logf(sg);
   }
   __syncthreads();
 
@@ -159,8 +164,7 @@ __global__ __launch_bounds__(kLossThreads) void ppo_loss_kernel(LossArgs p) {
       s_kl += t_kl[tid * AP + a];
       s_b += t_b[tid * AP + a];
       s_ls += col_logstd[a];
-      // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale)
-      s_ent += 1.4189385332046727f + logf(col_sigma[a]);
+      s_ent += col_ent[a];
     }
     // neglogp                                                                models.py:361-364
     const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
@@ -606,7 +610,7 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   p.bound_kind = bound_kind;
   p.write_back = write_back;
   const int AP = actions_num | 1;
-  size_t shm = (static_cast<size_t>(3) * kLossRows * AP + 2 * kLossRows + 2 * actions_num + 2) * sizeof(float);
+  size_t shm = (static_cast<size_t>(3) * kLossRows * AP + 2 * kLossRows + 3 * actions_num + 4) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
   const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossThreads / kWave)
                                  ? static_cast<size_t>(8) * actions_num
