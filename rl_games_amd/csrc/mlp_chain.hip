@@ -31,13 +31,14 @@
 // LDS tile of a layer with `nb` 16-feature blocks: [nb][G][64 lanes][4] floats (nb*G KiB).
 
 #include "rlg_device.hpp"
+
+#include <cstdlib>
 #include <type_traits>
 
 namespace rlg {
 
 constexpr int kChainMaxLayers = 8;
-constexpr int kChainWaves = 4;
-constexpr int kChainThreads = 64 * kChainWaves;
+constexpr int kChainWideBlocks = 384;   // up to this many 16-row workgroups run with 8 waves instead of 4
 constexpr unsigned kOob = 0x40000000u;     // byte offset far outside every weight buffer
 
 enum : int { kChIdentity = 0, kChElu = 1, kChRelu = 2, kChTanh = 3 };
@@ -81,7 +82,7 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ void chain_stamp(long long* dbg, int wave, int& slot) {
   if (dbg != nullptr) {
     const long long t = __builtin_amdgcn_s_memtime();
-    if (lane_id() == 0 && slot < 32) dbg[(static_cast<long long>(blockIdx.x) * kChainWaves + wave) * 32 + slot] = t;
+    if (lane_id() == 0 && slot < 32 && wave < 4) dbg[(static_cast<long long>(blockIdx.x) * 4 + wave) * 32 + slot] = t;
     ++slot;
   }
 }
@@ -200,6 +201,16 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
     // NG == NF == 1: a second accumulator takes the odd steps (40-cycle dependent-issue latency vs
     // 32-cycle issue), folded in before the epilogue - a fixed order, so still deterministic
     f32x4 acc_odd = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Accumulators live in AGPRs.  The 8-wave instances (256-register budget) otherwise get VGPR-form
+    // MFMAs, and hipcc (ROCm 7.2) then retargets the LAST MFMA of a K tail to the registers of the
+    // merge point behind the tail switch - partially overlapping its own SrcC (v[16:19] <- v[18:21]):
+    // undefined by the ISA, fragment registers 2 and 3 came out wrong for K <= 32.
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) asm volatile("" : "+a"(acc[f][g]));
+    }
+    asm volatile("" : "+a"(acc_odd));
     // one k-chunk = 4 MFMA steps x NF blocks x NG groups; the fragment reads of the following chunk are
     // issued after step 0, so that a wait for THIS chunk's fragments never includes them
     auto mfma_head = [&](const f32x4 (&av)[NF], const f32x4 (&bv)[NG]) {
@@ -420,8 +431,8 @@ __device__ __forceinline__ bool vec4_ok(const void* p, long long ld) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int G, int HACT>
-__global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs a) {
+template <int G, int HACT, int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = lane_id();
   const int wave = wave_id_uniform();
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     auto load_frags = [&](int u0) {
 #pragma unroll
       for (int k = 0; k < kProBatch; ++k) {
-        const int u = u0 + k * kChainWaves;
+        const int u = u0 + k * W;
         const int c = u / G;
         const int g = u - c * G;
         const long long row = row0 + g * 16 + (lane & 15);
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     auto put_frags = [&](int u0) {
 #pragma unroll
       for (int k = 0; k < kProBatch; ++k) {
-        const int u = u0 + k * kChainWaves;
+        const int u = u0 + k * W;
         if (u < nfrag) {
           const int c = u / G;
           const int g = u - c * G;
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     load_frags(wave);
     if (norm) {
       // mean32 / denom exactly like rms_apply_kernel mode 0 (running_mean_std.py:112-113)
-      for (int f = threadIdx.x; f < in0; f += kChainThreads) {
+      for (int f = threadIdx.x; f < in0; f += (64 * W)) {
         double mean = a.rms_mean[f], var = a.rms_var[f];
         if (a.rms_batch) {
           // rms_update_kernel mode 0: population moments of the minibatch, rounded to fp32 like the
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
       __syncthreads();
     }
     put_frags(wave);
-    for (int u0 = wave + kChainWaves * kProBatch; u0 < nfrag; u0 += kChainWaves * kProBatch) {
+    for (int u0 = wave + W * kProBatch; u0 < nfrag; u0 += W * kProBatch) {
       load_frags(u0);
       put_frags(u0);
     }
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     const long long n_rows = pin_s(a.rows);
     const rsrc_t wr = make_rsrc(a.layer[L].w, static_cast<unsigned>(l_in) * l_out * 4u);
     const int NOB = (l_out + 15) >> 4;
-    const int full = NOB / kChainWaves;
+    const int full = NOB / W;
     // fast path: every fragment inside the matrix is one aligned 16-byte store
     const bool h_on = l_h != nullptr;
     const bool h_fast = pin_s(static_cast<int>(h_on && vec4_ok(l_h, l_ldh) && (l_out & 3) == 0)) != 0;
@@ -584,15 +595,15 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
     }
     chain_stamp(a.dbg, wave, stamp);
     // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
-    const int rem_first = full * kChainWaves;
+    const int rem_first = full * W;
     const int rem_units = (NOB - rem_first) * G;
-    const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
+    const int my_rem = (rem_units > wave) ? (rem_units - wave + W - 1) / W : 0;
     chain_units<1, 1, false>(
-        wr, l_out, l_in, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
-        [&](int j) { return (wave + j * kChainWaves) % G; },
-        [&](int j) { load_bias(rem_first + (wave + j * kChainWaves) / G, 0); },
+        wr, l_out, l_in, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * W) / G; },
+        [&](int j) { return (wave + j * W) % G; },
+        [&](int j) { load_bias(rem_first + (wave + j * W) / G, 0); },
         [&](int j, const f32x4 (&acc)[1][1]) {
-          const int u = wave + j * kChainWaves;
+          const int u = wave + j * W;
           epilogue(rem_first + u / G, u % G, acc[0][0], biasv[0]);
         });
     chain_stamp(a.dbg, wave, stamp);
@@ -608,8 +619,8 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_fwd_kernel(ChainArgs 
 // backward (dX chain): layer[num_layers-1] is the head, its dZ is `x` (d heads) itself.
 // For L = num_layers-1 .. 1:  dZ_{L-1} = (dZ_L W_L) * act'_{L-1}(H_{L-1});  layer 0 needs no dX.
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs a) {
+template <int G, int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = lane_id();
   const int wave = wave_id_uniform();
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
     const int w = a.layer[a.num_layers - 1].out;
     const int KC0 = (w + 15) >> 4;
     const bool xv = vec4_ok(a.x, a.ldx);
-    for (int u = wave; u < KC0 * G; u += kChainWaves) {
+    for (int u = wave; u < KC0 * G; u += W) {
       const int c = u / G;
       const int g = u - c * G;
       const long long row = row0 + g * 16 + (lane & 15);
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
     const rsrc_t wr = make_rsrc(a.layer[L].w, static_cast<unsigned>(l_in) * l_out * 4u);
     const int width = l_in;                     // == layer[L-1].out
     const int NOB = (width + 15) >> 4;
-    const int full = NOB / kChainWaves;
+    const int full = NOB / W;
     const bool keep_tile = (L - 1 >= 1);        // dZ_0 feeds nothing further down
     const bool fast = pin_s(static_cast<int>(vec4_ok(p_h, p_ldh) && vec4_ok(p_dz, p_lddz) && (width & 3) == 0)) != 0;
     double* bpart = pin_s(a.layer[L - 1].bias_partials);
@@ -734,25 +745,25 @@ __global__ __launch_bounds__(kChainThreads) void mlp_chain_bwd_kernel(ChainArgs 
     // waves, so every unit leaves its fragment in the output tile (at its normal place when the tile
     // feeds the next step, else in the first slots) and, after the barrier, one wave per block adds
     // the G groups in order.
-    const int rem_first = full * kChainWaves;
+    const int rem_first = full * W;
     const int rem_blocks = NOB - rem_first;
     const int rem_units = rem_blocks * G;
-    const int my_rem = (rem_units > wave) ? (rem_units - wave + kChainWaves - 1) / kChainWaves : 0;
+    const int my_rem = (rem_units > wave) ? (rem_units - wave + W - 1) / W : 0;
     chain_units<1, 1, true>(
-        wr, width, l_out, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * kChainWaves) / G; },
-        [&](int j) { return (wave + j * kChainWaves) % G; },
+        wr, width, l_out, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * W) / G; },
+        [&](int j) { return (wave + j * W) % G; },
         [&](int j) {
-          const int u = wave + j * kChainWaves;
+          const int u = wave + j * W;
           hval[0][0] = load_h(rem_first + u / G, u % G);
         },
         [&](int j, const f32x4 (&acc)[1][1]) {
-          const int u = wave + j * kChainWaves;
+          const int u = wave + j * W;
           const int ob = rem_first + u / G, g = u % G;
           epilogue(ob, g, keep_tile ? ob * G + g : u, true, acc[0][0], hval[0][0]);
         });
     __syncthreads();
     if (bpart != nullptr) {
-      for (int rb = wave; rb < rem_blocks; rb += kChainWaves) {
+      for (int rb = wave; rb < rem_blocks; rb += W) {
         const int slot0 = keep_tile ? (rem_first + rb) * G : rb * G;
         f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int g = 0; g < G; ++g) s += *reinterpret_cast<const f32x4*>(tout + ((slot0 + g) * 64 + lane) * 4);
@@ -836,33 +847,62 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
 
 static bool g_chain_prepared = false;     // rlg_mlp_chain_prepare raised the LDS limit of every kernel
 
-template <int G, bool kBackward, int HACT>
+template <int G, bool kBackward, int HACT, int W>
 static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st) {
   const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
-  auto kern = kBackward ? mlp_chain_bwd_kernel<G> : mlp_chain_fwd_kernel<G, HACT>;
+  const void* kern;
+  if constexpr (kBackward) kern = reinterpret_cast<const void*>(mlp_chain_bwd_kernel<G, W>);
+  else kern = reinterpret_cast<const void*>(mlp_chain_fwd_kernel<G, HACT, W>);
   if (lds_bytes > 64 * 1024 && !g_chain_prepared) {
     static bool raised = false;          // one flag per instantiation = per kernel
     if (!raised) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return static_cast<int>(e);
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kChainThreads), static_cast<size_t>(lds_bytes), st, args);
+  if constexpr (kBackward) {
+    hipLaunchKernelGGL((mlp_chain_bwd_kernel<G, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
+                       args);
+  } else {
+    hipLaunchKernelGGL((mlp_chain_fwd_kernel<G, HACT, W>), dim3(grid), dim3(64 * W),
+                       static_cast<size_t>(lds_bytes), st, args);
+  }
   RLG_RETURN_LAUNCH_STATUS();
 }
 
-template <int G, bool kBackward>
-static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+// Waves per workgroup.  Small minibatches (one data-parallel rank's 4,096 rows: 256 workgroups of 16
+// rows, at most one or two per CU) are bound by the serial chain of a workgroup, not by MFMA
+// throughput: 8 waves halve each wave's share of every layer and put two waves on every SIMD.
+static int chain_waves(int G, long long rows) {
+  static const int forced = [] {
+    const char* e = std::getenv("RLG_CHAIN_WAVES");      // tools: A/B measurements
+    return e ? std::atoi(e) : 0;
+  }();
+  if (G != 1) return 4;
+  if (forced == 4 || forced == 8) return forced;
+  const long long grid = (rows + 15) / 16;
+  return grid <= kChainWideBlocks ? 8 : 4;
+}
+
+template <int G, bool kBackward, int W>
+static int chain_launch_w(const ChainArgs& args, int lds_bytes, hipStream_t st) {
   if constexpr (!kBackward) {
     // forward: the ELU-or-identity network (every BASELINE configuration) gets its own instance
     bool elu_only = true;
     for (int L = 0; L < args.num_layers; ++L)
       elu_only = elu_only && (args.layer[L].act == kChElu || args.layer[L].act == kChIdentity);
-    if (elu_only) return chain_launch_as<G, false, kChElu>(args, lds_bytes, st);
+    if (elu_only) return chain_launch_as<G, false, kChElu, W>(args, lds_bytes, st);
   }
-  return chain_launch_as<G, kBackward, kChAny>(args, lds_bytes, st);
+  return chain_launch_as<G, kBackward, kChAny, W>(args, lds_bytes, st);
+}
+
+template <int G, bool kBackward>
+static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+  if constexpr (G == 1) {
+    if (chain_waves(1, args.rows) == 8) return chain_launch_w<1, kBackward, 8>(args, lds_bytes, st);
+  }
+  return chain_launch_w<G, kBackward, 4>(args, lds_bytes, st);
 }
 
 }  // namespace rlg
@@ -887,11 +927,12 @@ int rlg_mlp_chain_prepare(void) {
   using namespace rlg;
   if (g_chain_prepared) return 0;
   const void* kernels[] = {
-      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChElu>),
-      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny>),
-      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChAny>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChAny>),
-      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2>),
-      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4>)};
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu, 4>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChElu, 4>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChElu, 4>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny, 4>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChAny, 4>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChAny, 4>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny, 8>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2, 4>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 8>)};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return static_cast<int>(e);

@@ -108,7 +108,13 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
 #pragma unroll
   for (int a = 0; a < BO; ++a) {
 #pragma unroll
-    for (int b = 0; b < BI; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < BI; ++b) {
+      acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      // accumulators in AGPRs: with VGPR-form MFMAs hipcc (ROCm 7.2) allocates destinations that
+      // partially overlap SrcC / contain SrcA (v[8:11] <- v8, v35, v[10:13]) in the pipelined loop;
+      // the same pattern produced wrong fragment halves in mlp_chain.hip's 8-wave instance
+      asm volatile("" : "+a"(acc[a][b]));
+    }
   }
   // row pointers of this lane, advanced by one batch (16 rows) at a time
   const long long step_a = 4 * L.lda, step_b = 4 * L.ldb;

@@ -32,7 +32,9 @@
 
 namespace rlg {
 
-constexpr int kLossRows = 64;      // rows per block (one LDS tile set)
+constexpr int kLossRows = 64;      // rows per block (one LDS tile set) ...
+constexpr int kLossRowsSmall = 16; // ... and for minibatches of at most kLossSmallBatch rows: a tile is a chain of
+constexpr int kLossSmallBatch = 8192;   // short phases, so a small minibatch wants more, smaller tiles
 constexpr int kLossThreads = 256;  // threads per block: all walk the tile, the first kLossRows own a row
 constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
 
@@ -79,24 +81,25 @@ __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) 
   return (4.0f * e) * (s * s);
 }
 
+template <int kRows>
 __global__ __launch_bounds__(kLossThreads) void ppo_loss_kernel(LossArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int A = p.A;
   const int AP = A | 1;                       // odd row stride: conflict-free row walks
   float* t_z2 = lds;                          // [256][AP]  z^2, later g*(1-z^2)
-  float* t_kl = t_z2 + kLossRows * AP;        // [256][AP]
-  float* t_b = t_kl + kLossRows * AP;         // [256][AP]
-  float* row_g = t_b + kLossRows * AP;        // [256]  d loss / d neglogp of the row
-  float* row_w = row_g + kLossRows;           // [256]  inv_count * mask of the row
-  float* col_sigma = row_w + kLossRows;       // [A]
+  float* t_kl = t_z2 + kRows * AP;        // [256][AP]
+  float* t_b = t_kl + kRows * AP;         // [256][AP]
+  float* row_g = t_b + kRows * AP;        // [256]  d loss / d neglogp of the row
+  float* row_w = row_g + kRows;           // [256]  inv_count * mask of the row
+  float* col_sigma = row_w + kRows;       // [A]
   float* col_logstd = col_sigma + A;          // [A]
   float* col_ent = col_logstd + A;            // [A]  entropy term of the column (the same for every row)
   double* red = reinterpret_cast<double*>(
       (reinterpret_cast<uintptr_t>(col_ent + A) + 7) & ~static_cast<uintptr_t>(7));
 
   const int tid = threadIdx.x;
-  const long long row0 = static_cast<long long>(blockIdx.x) * kLossRows;
-  const int rows = static_cast<int>(min(static_cast<long long>(kLossRows), p.mb - row0));
+  const long long row0 = static_cast<long long>(blockIdx.x) * kRows;
+  const int rows = static_cast<int>(min(static_cast<long long>(kRows), p.mb - row0));
   const long long e0 = row0 * A;              // first element of the tile
   const int tile_elems = rows * A;
 
@@ -564,7 +567,10 @@ __global__ __launch_bounds__(256) void value_loss_kernel(
 
 extern "C" {
 
-int rlg_ppo_loss_num_blocks(int minibatch) { return (minibatch + rlg::kLossRows - 1) / rlg::kLossRows; }
+int rlg_ppo_loss_num_blocks(int minibatch) {
+  const int rows = minibatch <= rlg::kLossSmallBatch ? rlg::kLossRowsSmall : rlg::kLossRows;
+  return (minibatch + rows - 1) / rows;
+}
 
 
 int rlg_ppo_loss_partials_per_block(int actions) { return rlg::kLossScalars + 2 * actions; }
@@ -610,7 +616,8 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   p.bound_kind = bound_kind;
   p.write_back = write_back;
   const int AP = actions_num | 1;
-  size_t shm = (static_cast<size_t>(3) * kLossRows * AP + 2 * kLossRows + 3 * actions_num + 4) * sizeof(float);
+  const int tile_rows = minibatch <= kLossSmallBatch ? kLossRowsSmall : kLossRows;
+  size_t shm = (static_cast<size_t>(3) * tile_rows * AP + 2 * tile_rows + 3 * actions_num + 4) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
   const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossThreads / kWave)
                                  ? static_cast<size_t>(8) * actions_num
@@ -618,8 +625,13 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   shm += red_doubles * sizeof(double);
   if (shm > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const int grid = rlg_ppo_loss_num_blocks(minibatch);
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(kLossThreads), shm,
-                     static_cast<hipStream_t>(stream), p);
+  if (tile_rows == kLossRows) {
+    hipLaunchKernelGGL(ppo_loss_kernel<kLossRows>, dim3(grid), dim3(kLossThreads), shm,
+                       static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(ppo_loss_kernel<kLossRowsSmall>, dim3(grid), dim3(kLossThreads), shm,
+                       static_cast<hipStream_t>(stream), p);
+  }
   RLG_RETURN_LAUNCH_STATUS();
 }
 

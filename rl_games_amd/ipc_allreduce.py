@@ -46,6 +46,31 @@ class IpcAllReduce:
                 self.close()
                 raise _lib.HipLibraryError(f'rlg_ipc_comm_connect failed on a rank (hipError_t per rank: {oks})')
         self.fine_grained = bool(lib.rlg_ipc_comm_fine_grained(self._comm))
+        self._self_test(group)
+
+    def _self_test(self, group):
+        """Two known-answer all-reduces (one per staging slot) before the communicator is handed out:
+        mapping peers' memory can succeed on a topology where the flags or the data do not become visible
+        across devices in time.  Collective like the rest of the set-up - all ranks keep the communicator
+        or all raise (the agent then uses RCCL)."""
+        n = min(self.numel, 4096)
+        ok = True
+        try:
+            for it in range(2):
+                t = torch.arange(n, dtype=torch.float32, device=self.device) * 0.5 + float(self.rank + 1 + it)
+                self.all_reduce_sum(t)
+                want = torch.arange(n, dtype=torch.float32, device=self.device) * (0.5 * self.world) + float(
+                    self.world * (self.world + 1) // 2 + it * self.world)
+                ok = ok and bool(torch.equal(t, want))
+            _, timed_out = self.status()
+            ok = ok and timed_out == 0
+        except Exception:
+            ok = False
+        oks = [None] * self.world
+        dist.all_gather_object(oks, ok, group=group)
+        if not all(oks):
+            self.close()
+            raise _lib.HipLibraryError(f'in-graph all-reduce self-test failed (per rank: {oks})')
 
     def all_reduce_sum(self, t):
         """In place, on torch's current stream.  `t`: contiguous fp32 CUDA tensor of <= numel elements."""

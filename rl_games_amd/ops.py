@@ -573,10 +573,13 @@ class MlpDwPlan:
     step.  Raises NotImplementedError when a shape is outside the kernel's envelope (callers use
     the library GEMMs then)."""
 
-    def __init__(self, shapes, rows, device, target_blocks=1024):
+    def __init__(self, shapes, rows, device, target_blocks=None):
         import ctypes
         lib = _lib.load()
         n = len(shapes)
+        if target_blocks is None:
+            # K-slices per layer: a rank's 4,096-row minibatch has too few rows per slice at 32 slices
+            target_blocks = 1024 if int(rows) > 8192 else 256
         self.rows, self.n, self.shapes = int(rows), n, [tuple(s) for s in shapes]
         self._plans = (ctypes.c_int * (4 * n))()
         self.workspaces = []

