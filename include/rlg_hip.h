@@ -6,7 +6,7 @@
  * its own; every entry point below therefore replaces a *Python* function or method of
  * the reference, cited as `file:line` relative to the reference checkout.  The binding a
  * reference maintainer would add is a ctypes stub; the in-tree host
- * code (rl_games_amd/*.py) is that binding.
+ * code (the .py files of rl_games_amd/) is that binding.
  *
  * Conventions (all entry points):
  *   - plain device pointers + explicit sizes/strides, scalars by value, no torch types;
@@ -345,11 +345,26 @@ int rlg_mlp_linear_act_backward(const float* dz, long long lddz, const float* w,
 long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4);
 /* colsum_* (num_colsums may be 0): bias gradients `grad_output.sum(0)` finished in the same finalise
  * launch from the per-block fp64 column sums of rlg_act_bwd_colsum (partials [blocks][cols]). */
+/* The arguments of rlg_ppo_loss_finalize as a struct: rlg_mlp_dw_launch can fold the loss partials in
+ * its finalise launch (a few extra workgroups next to the weight-gradient ones) instead of a launch of
+ * its own - the head-bias / logstd gradients, the loss scalars and the KL are then ready when the
+ * weight gradients are. */
+typedef struct rlg_loss_finalize_desc {
+  const double* partials;
+  int num_blocks, actions_num, minibatch, masked;
+  float critic_coef, entropy_coef, bounds_coef;
+  float* scalars8;
+  float* d_logstd;
+  float* kl_slot_or_null;
+  float* d_mu_bias_or_null;
+  float* d_value_bias_or_null;
+} rlg_loss_finalize_desc;
+
 int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
                       float* const* grad, const int* out_features, const int* in_features,
                       const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
                       const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                      void* stream);
+                      const rlg_loss_finalize_desc* loss_finalize_or_null, void* stream);
 
 /* ---- the MLP as one vertically fused chain on f32 MFMA (csrc/mlp_chain.hip) ------------------
  * forward : heads = head(act(... act(norm(x) W_0^T + b_0) ...)) for a row tile, every layer in ONE

@@ -68,7 +68,7 @@ _PROTOTYPES = {
     'rlg_mlp_linear_act_forward': [_P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_linear_act_backward': [_P, _c_ll, _P, _P, _P, _c_ll, _c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
-    'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P],
+    'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P, _P],
     # mlp_chain.hip
     'rlg_mlp_chain_prepare': [],
     'rlg_mlp_chain_groups': [_c_ll, _c_int, _c_int],
@@ -143,6 +143,16 @@ def load():
         fn.restype = _c_ll if name in _RETURNS_LONG_LONG else _c_int
     _lib = lib
     return lib
+
+
+class LossFinalizeDesc(ctypes.Structure):
+    """rlg_loss_finalize_desc (include/rlg_hip.h): the arguments of rlg_ppo_loss_finalize, for launches
+    that fold the loss partials alongside their own work (rlg_mlp_dw_launch)."""
+    _fields_ = [('partials', ctypes.c_void_p), ('num_blocks', ctypes.c_int), ('actions_num', ctypes.c_int),
+                ('minibatch', ctypes.c_int), ('masked', ctypes.c_int), ('critic_coef', ctypes.c_float),
+                ('entropy_coef', ctypes.c_float), ('bounds_coef', ctypes.c_float), ('scalars8', ctypes.c_void_p),
+                ('d_logstd', ctypes.c_void_p), ('kl_slot_or_null', ctypes.c_void_p),
+                ('d_mu_bias_or_null', ctypes.c_void_p), ('d_value_bias_or_null', ctypes.c_void_p)]
 
 
 def check(err, what):

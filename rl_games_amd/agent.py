@@ -1081,11 +1081,16 @@ class A2CAgent:
                 input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
                 self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
                 self.use_smooth_clamp, kind, True, mask, mask_sum)
-            ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
-                                  coef_c, self.entropy_coef, coef_b, row, net.sigma.grad,
-                                  opt.kl_slot, mu_bias_grad, value_bias_grad)
-            if eng is not None:
-                eng.backward(d_heads)
+            fin = (self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
+                   coef_c, self.entropy_coef, coef_b, row, net.sigma.grad,
+                   opt.kl_slot, mu_bias_grad, value_bias_grad)
+            if eng is not None and self.config.get('fold_loss_finalize', True):
+                # the loss partials are folded by the weight-gradient finalise launch (one launch less)
+                eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin))
+            else:
+                ops.ppo_loss_finalize(*fin)
+                if eng is not None:
+                    eng.backward(d_heads)
         if eng is None:
             torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
 

@@ -28,6 +28,7 @@
 // replaces; only the summation order differs.
 
 #include "rlg_device.hpp"
+#include "rlg_hip.h"
 
 namespace rlg {
 
@@ -292,6 +293,91 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
 #undef RLG_DW_CASE
 }
 
+// The PPO loss partials ride along too (what ppo_loss_finalize_kernel does in a launch of its own,
+// csrc/ppo_loss.hip): block 0 of the item folds the 7 scalar columns (losses, KL, sum of d values),
+// every further block 8 of the 2A vector columns (d logstd terms, column sums of d mu) plus the
+// mask-sum column it needs.  16 column slots x 16 row slices per block, 8 loads in flight per thread,
+// slices combined in a fixed order.
+constexpr int kLfScalars = 7;      // = kLossScalars of ppo_loss.hip (layout of a partial row)
+constexpr int kLfCols = 8;         // vector columns per block
+struct LossFinalizeItem {
+  rlg_loss_finalize_desc d;
+  int num_blocks;                  // 0: no item
+};
+
+__device__ __forceinline__ void loss_finalize_block(const rlg_loss_finalize_desc& d, int b, double (*part)[17]) {
+  const int A = d.actions_num;
+  const int W = kLfScalars + 2 * A;
+  const int slot = threadIdx.x & 15;
+  const int slice = threadIdx.x >> 4;
+  // column of this slot: block 0 = the scalars; block b > 0 = vector columns 8(b-1).. and, in slot 8, the mask sum
+  int c = -1;
+  if (b == 0) {
+    if (slot < kLfScalars) c = slot;
+  } else if (slot < kLfCols) {
+    c = kLfScalars + kLfCols * (b - 1) + slot;
+    if (c >= W) c = -1;
+  } else if (slot == kLfCols) {
+    c = 5;
+  }
+  double s = 0.0;
+  if (c >= 0) {
+    const double* src = d.partials + c;
+    int r = slice;
+    for (; r + 7 * 16 < d.num_blocks; r += 8 * 16) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[static_cast<long long>(r + u * 16) * W];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < d.num_blocks; r += 16) s += src[static_cast<long long>(r) * W];
+  }
+  part[slice][slot] = s;
+  __syncthreads();
+  if (slice == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][slot];
+    part[16][slot] = t;                   // column totals of this block
+  }
+  __syncthreads();
+  const double msum = part[16][b == 0 ? 5 : kLfCols];
+  const double denom = d.masked ? fmax(msum, 1.0) : static_cast<double>(d.minibatch);
+  if (b > 0) {
+    // d loss / d logstd_a = sum_i g_i (1 - z^2)  -  entropy_coef * sum_i w_i   (d ent/d logstd = 1)
+    if (slice == 0 && slot < kLfCols && c >= 0) {
+      const float w_total = static_cast<float>(msum / denom);
+      const int a = c - kLfScalars;
+      if (a < A) {
+        d.d_logstd[a] = static_cast<float>(part[16][slot]) - d.entropy_coef * w_total;
+      } else if (d.d_mu_bias_or_null) {
+        d.d_mu_bias_or_null[a - A] = static_cast<float>(part[16][slot]);   // bias grad of the mu head
+      }
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    const float a_loss = static_cast<float>(part[16][0] / denom);
+    const float c_loss = static_cast<float>(part[16][1] / denom);
+    const float ent = static_cast<float>(part[16][2] / denom);
+    const float b_loss = static_cast<float>(part[16][3] / denom);
+    const float kl = static_cast<float>(part[16][4] / denom);
+    // loss = a + 0.5*c*critic_coef - entropy*entropy_coef + b*bounds_coef   a2c_continuous.py:133
+    const float loss = ((a_loss + (0.5f * c_loss) * d.critic_coef) - ent * d.entropy_coef) + b_loss * d.bounds_coef;
+    d.scalars8[0] = a_loss;
+    d.scalars8[1] = c_loss;
+    d.scalars8[2] = ent;
+    d.scalars8[3] = b_loss;
+    d.scalars8[4] = kl;
+    d.scalars8[5] = loss;
+    d.scalars8[6] = static_cast<float>(msum);
+    d.scalars8[7] = 0.0f;
+    if (d.kl_slot_or_null) *d.kl_slot_or_null = kl;
+    if (d.d_value_bias_or_null) *d.d_value_bias_or_null = static_cast<float>(part[16][6]);   // bias grad of the value head
+  }
+}
+
 // grad[e] = sum_z partial[z][e].  A block covers kFinElems consecutive float4 elements (a 256-byte
 // span per slice) with kFinGroups z-groups: group g sums the slices z = g, g+16, ... (up to 4 loads
 // in flight per thread), the groups are combined through LDS in a fixed order, so the result does
@@ -300,15 +386,21 @@ constexpr int kFinElems = 16;
 constexpr int kFinGroups = 16;
 constexpr int kCsCols = 16;       // bias-gradient blocks: columns x row-slices of the per-block partials
 constexpr int kCsSlices = 16;
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs) {
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf) {
   __shared__ f32x4 part[kFinGroups][kFinElems];
-  if (static_cast<int>(blockIdx.x) < cs.num_blocks) {
+  if (static_cast<int>(blockIdx.x) < lf.num_blocks) {
+    __shared__ double lpart[17][17];
+    loss_finalize_block(lf.d, blockIdx.x, lpart);
+    return;
+  }
+  const int blk = blockIdx.x - lf.num_blocks;      // colsum blocks, then the weight-gradient blocks
+  if (blk < cs.num_blocks) {
     // ---- bias-gradient blocks: kCsCols columns x kCsSlices row-slices per block; a thread sums the
     //      rows slice, slice + 16, ... with 8 independent loads in flight (the per-block partials of
     //      the backward launch are a few hundred rows - one dependent load per row would dominate
     //      this whole launch: 29 us -> 13 us in the update step), slices combined in a fixed order
     __shared__ double cpart[kCsSlices][kCsCols + 1];
-    int b = blockIdx.x;
+    int b = blk;
     int item = 0;
 #pragma unroll 1
     for (int k = 0; k < cs.count; ++k) {
@@ -346,7 +438,7 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
   }
   int l = 0;
   int base = 0;
-  const int fin_block = blockIdx.x - cs.num_blocks;
+  const int fin_block = blk - cs.num_blocks;
 #pragma unroll 1
   for (int k = 0; k < args.num_layers; ++k) {
     const int n4 = (args.layer[k].No * args.layer[k].Mi) >> 2;
@@ -451,7 +543,7 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       float* const* grad, const int* out_features, const int* in_features,
                       const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
                       const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                      void* stream) {
+                      const rlg_loss_finalize_desc* loss_finalize, void* stream) {
   using namespace rlg;
   if (num_layers <= 0 || num_layers > kDwMaxLayers || rows <= 0 || num_colsums < 0 ||
       num_colsums > kDwMaxLayers)
@@ -493,9 +585,18 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     cs_blocks += (colsum_cols[k] + kCsCols - 1) / kCsCols;
   }
   cs.num_blocks = cs_blocks;
+  LossFinalizeItem lf = {};
+  if (loss_finalize) {
+    lf.d = *loss_finalize;
+    if (!lf.d.partials || lf.d.num_blocks <= 0 || lf.d.actions_num < 0 || !lf.d.scalars8 ||
+        (lf.d.actions_num > 0 && !lf.d.d_logstd))
+      return static_cast<int>(hipErrorInvalidValue);
+    lf.num_blocks = 1 + (2 * lf.d.actions_num + kLfCols - 1) / kLfCols;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
-  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(fin_blocks + cs_blocks), dim3(256), 0, st, args, cs);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(lf.num_blocks + cs_blocks + fin_blocks), dim3(256), 0, st, args, cs,
+                     lf);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -226,12 +226,14 @@ class ManualMLP:
         return heads[:, self.V:]
 
     @torch.no_grad()
-    def backward(self, d_heads):
+    def backward(self, d_heads, loss_finalize=None):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
         finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
         chain waits for - are then ONE f32-MFMA launch for all layers (csrc/mlp_dw.hip), or the
-        library GEMMs when a shape is outside that kernel's envelope / `mfma_dw` is off."""
+        library GEMMs when a shape is outside that kernel's envelope / `mfma_dw` is off.
+        loss_finalize: ops.loss_finalize_desc(...) - folded in the weight-gradient finalise launch when
+        there is one, launched on its own otherwise."""
         rows = self._rows
         L = len(self.linears)
         self._pending_backward = False
@@ -248,7 +250,7 @@ class ManualMLP:
                 lin = self.linears[l]
                 jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            self._weight_grads(jobs, rows, colsums)
+            self._weight_grads(jobs, rows, colsums, loss_finalize)
             return
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
@@ -285,9 +287,9 @@ class ManualMLP:
                 d_prev = self.dA[l - 1][:rows]
                 torch.mm(d, lin.weight, out=d_prev)
                 d = d_prev
-        self._weight_grads(jobs, rows, colsums)
+        self._weight_grads(jobs, rows, colsums, loss_finalize)
 
-    def _weight_grads(self, jobs, rows, colsums=()):
+    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None):
         """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
@@ -311,12 +313,15 @@ class ManualMLP:
                     plan = False
                 self._dw_plans[key] = plan
             if plan:
-                plan.launch(fast, colsums)              # bias gradients finished in the same finalise launch
+                plan.launch(fast, colsums, loss_finalize)   # bias gradients (and the loss partials) finished in the same finalise launch
                 colsums = ()
+                loss_finalize = None
                 self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run
             else:
                 slow = slow + fast
                 fast = []
+        if loss_finalize is not None:
+            ops.ppo_loss_finalize_from(loss_finalize, jobs[0][2].device)
         for part, nb, cols, out in colsums:
             ops.colsum_finalize(part, nb, cols, out)
         self.last_dw_path = 'mfma' if fast else 'library'

@@ -376,6 +376,24 @@ def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, crit
         _opt(d_value_bias, F32, 'd_value_bias'), _stream(partials)), 'rlg_ppo_loss_finalize')
 
 
+def loss_finalize_desc(partials, num_blocks, actions_num, minibatch, masked, critic_coef, entropy_coef,
+                       bounds_coef, scalars, d_logstd, kl_slot=None, d_mu_bias=None, d_value_bias=None):
+    """The arguments of ppo_loss_finalize as an rlg_loss_finalize_desc: MlpDwPlan.launch(loss_finalize=...)
+    folds the loss partials in its finalise launch; ppo_loss_finalize_from(desc) is the stand-alone launch."""
+    return _lib.LossFinalizeDesc(
+        _need(partials, F64, 'partials'), int(num_blocks), int(actions_num), int(minibatch), 1 if masked else 0,
+        float(np.float32(critic_coef)), float(np.float32(entropy_coef)), float(np.float32(bounds_coef)),
+        _need(scalars, F32, 'scalars'), _need(d_logstd, F32, 'd_logstd'), _opt(kl_slot, F32, 'kl_slot'),
+        _opt(d_mu_bias, F32, 'd_mu_bias'), _opt(d_value_bias, F32, 'd_value_bias'))
+
+
+def ppo_loss_finalize_from(desc, device):
+    _lib.check(_lib.load().rlg_ppo_loss_finalize(
+        desc.partials, desc.num_blocks, desc.actions_num, desc.minibatch, desc.masked, desc.critic_coef,
+        desc.entropy_coef, desc.bounds_coef, desc.scalars8, desc.d_logstd, desc.kl_slot_or_null,
+        desc.d_mu_bias_or_null, desc.d_value_bias_or_null, _lib.stream_handle(device)), 'rlg_ppo_loss_finalize')
+
+
 # ------------------------------------------------------------------ manual MLP backward
 
 ACT_KINDS = {'None': 0, None: 0, 'elu': 1, 'relu': 2, 'tanh': 3}
@@ -600,9 +618,10 @@ class MlpDwPlan:
     def plan(self, k):
         return tuple(self._plans[4 * k:4 * k + 4])
 
-    def launch(self, jobs, colsums=()):
+    def launch(self, jobs, colsums=(), loss_finalize=None):
         """jobs: (dz, x, grad) per planned layer.  colsums: optional (partials fp64 [blocks*cols],
-        blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch."""
+        blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch.
+        loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well."""
         import ctypes
         if len(jobs) != self.n:
             raise ValueError('job count does not match the plan')
@@ -626,7 +645,9 @@ class MlpDwPlan:
             self._grad[k] = _need(grad, F32, 'grad')
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
-                                                 cs_cols, cs_out, _lib.stream_handle(self._device)),
+                                                 cs_cols, cs_out,
+                                                 None if loss_finalize is None else ctypes.addressof(loss_finalize),
+                                                 _lib.stream_handle(self._device)),
                    'rlg_mlp_dw_launch')
 
 

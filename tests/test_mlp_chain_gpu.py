@@ -234,6 +234,41 @@ def test_forward_folds_minibatch_moments_like_running_mean_std(in_dim, mb_rows, 
                       rms_fold=(table[0], a.count, a.running_mean, a.running_var, a.count))
 
 
+@pytest.mark.parametrize('nblocks,A', [(512, 21), (64, 8), (1, 1), (300, 33), (77, 0)])
+def test_dw_finalize_folds_loss_partials_like_ppo_loss_finalize(nblocks, A):
+    """The weight-gradient finalise launch can fold the PPO loss partials (rlg_loss_finalize_desc): same
+    scalars, KL, d logstd and head-bias gradients as the stand-alone rlg_ppo_loss_finalize."""
+    from rl_games_amd import ops
+    g = torch.Generator().manual_seed(nblocks + A)
+    W = 7 + 2 * A
+    partials = torch.randn(nblocks, W, generator=g, dtype=torch.float64)
+    partials[:, 5] = torch.rand(nblocks, generator=g, dtype=torch.float64) * 64     # mask sums
+    partials = partials.to(DEV)
+    mb = nblocks * 64
+    dz = torch.randn(64, 20, generator=g).to(DEV)
+    x = torch.randn(64, 12, generator=g).to(DEV)
+    grad = torch.empty(20, 12, device=DEV)
+    plan = ops.MlpDwPlan([(20, 12)], 64, DEV)
+    out = {}
+    for masked in (False, True):
+        for fused in (True, False):
+            scalars = torch.full((8,), float('nan'), device=DEV)
+            d_logstd = torch.full((max(A, 1),), float('nan'), device=DEV)
+            kl = torch.full((1,), float('nan'), device=DEV)
+            dmb = torch.full((max(A, 1),), float('nan'), device=DEV)
+            dvb = torch.full((1,), float('nan'), device=DEV)
+            args = (partials, nblocks, A, mb, masked, 2.0, 0.01, 1e-4, scalars, d_logstd, kl, dmb, dvb)
+            if fused:
+                plan.launch([(dz, x, grad)], loss_finalize=ops.loss_finalize_desc(*args))
+            else:
+                ops.ppo_loss_finalize(*args)
+            out[fused] = (scalars, d_logstd[:A], kl, dmb[:A], dvb)
+        for got, ref in zip(out[True], out[False]):
+            assert torch.isfinite(got).all()
+            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7 * max(1.0, ref.abs().max().item() if ref.numel() else 1.0))
+    assert torch.allclose(grad.double(), dz.double().t() @ x.double(), rtol=1e-5, atol=1e-5)
+
+
 def test_engine_fused_chain_equals_per_layer_engine():
     """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
     gradients in the arena, on a BASELINE config #2 shaped network."""
