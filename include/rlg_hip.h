@@ -364,7 +364,14 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       float* const* grad, const int* out_features, const int* in_features,
                       const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
                       const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                      const rlg_loss_finalize_desc* loss_finalize_or_null, void* stream);
+                      const rlg_loss_finalize_desc* loss_finalize_or_null,
+                      /* optional by-product: norm_partials[b] = sum (g * grad_scale)^2 over the gradient
+                       * elements finalise block b wrote (*finalize_blocks_out blocks, host int) - the input of
+                       * rlg_adam_step's clipping when THIS launch produces every gradient of the arena and
+                       * nothing touches them before Adam (single GPU); it then also advances step_counter
+                       * like rlg_grad_sumsq does. */
+                      double* norm_partials_or_null, float grad_scale, long long* step_counter_or_null,
+                      int* finalize_blocks_out_or_null, void* stream);
 
 /* ---- the MLP as one vertically fused chain on f32 MFMA (csrc/mlp_chain.hip) ------------------
  * forward : heads = head(act(... act(norm(x) W_0^T + b_0) ...)) for a row tile, every layer in ONE

@@ -393,6 +393,9 @@ class A2CAgent:
         self._graph_epoch = None
         self._graph_failed = False
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
+        self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
+        self._fin_norm_partials = None
+        self._norm_ready = None       # (partials, count) when the finalise launch produced the gradient norm
         self._fold_index = None
         self._ipc_comm = None
         self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
@@ -1085,8 +1088,14 @@ class A2CAgent:
                    coef_c, self.entropy_coef, coef_b, row, net.sigma.grad,
                    opt.kl_slot, mu_bias_grad, value_bias_grad)
             if eng is not None and self.config.get('fold_loss_finalize', True):
-                # the loss partials are folded by the weight-gradient finalise launch (one launch less)
-                eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin))
+                # the loss partials are folded by the weight-gradient finalise launch (one launch less),
+                # and - single GPU, every gradient of the arena written by that launch - the sums of
+                # squares for clip_grad_norm_ with them (another one)
+                norm = None
+                if self._norm_in_finalize():
+                    norm = (self._fin_norm_partials, 1.0, opt.step_counter)
+                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm)
+                self._norm_ready = (self._fin_norm_partials, nb) if nb else None
             else:
                 ops.ppo_loss_finalize(*fin)
                 if eng is not None:
@@ -1124,6 +1133,20 @@ class A2CAgent:
             self._all_reduce_grads()
         self._optimizer_kernels()
 
+    def _norm_in_finalize(self):
+        """The weight-gradient finalise launch may leave the gradient-norm partials (and advance the Adam
+        step counter) when it writes EVERY gradient of the arena and nothing touches them before Adam."""
+        ok = self._fin_norm_ok
+        if ok is None:
+            eng = self._engine
+            ok = (not self.multi_gpu and eng is not None and eng.chain is not None and not self.is_rnn
+                  and self.config.get('norm_in_finalize', True)
+                  and eng.gradient_elements() == self.optimizer.numel)
+            if ok:
+                self._fin_norm_partials = torch.zeros(1 << 15, dtype=torch.float64, device=self.ppo_device)
+            self._fin_norm_ok = ok
+        return ok
+
     def _optimizer_kernels(self):
         opt = self.optimizer
         scale = 1.0 / self.world_size if self.multi_gpu else 1.0
@@ -1131,7 +1154,8 @@ class A2CAgent:
         if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
             schedule = self.scheduler.device_rule()
         opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
-                 schedule=schedule, kl_scale=scale)
+                 schedule=schedule, kl_scale=scale, norm_ready=self._norm_ready)
+        self._norm_ready = None
 
     # ------------------------------------------------------------------ HIP graphs
     def _with_fold(self, mb_index, fn, *args):

@@ -305,7 +305,9 @@ struct LossFinalizeItem {
   int num_blocks;                  // 0: no item
 };
 
-__device__ __forceinline__ void loss_finalize_block(const rlg_loss_finalize_desc& d, int b, double (*part)[17]) {
+// Returns this thread's share of sum (g * grad_scale)^2 over the gradient elements it wrote.
+__device__ __forceinline__ double loss_finalize_block(const rlg_loss_finalize_desc& d, int b, double (*part)[17],
+                                                      float grad_scale) {
   const int A = d.actions_num;
   const int W = kLfScalars + 2 * A;
   const int slot = threadIdx.x & 15;
@@ -349,13 +351,18 @@ __device__ __forceinline__ void loss_finalize_block(const rlg_loss_finalize_desc
     if (slice == 0 && slot < kLfCols && c >= 0) {
       const float w_total = static_cast<float>(msum / denom);
       const int a = c - kLfScalars;
+      float g = 0.0f;
       if (a < A) {
-        d.d_logstd[a] = static_cast<float>(part[16][slot]) - d.entropy_coef * w_total;
+        g = static_cast<float>(part[16][slot]) - d.entropy_coef * w_total;
+        d.d_logstd[a] = g;
       } else if (d.d_mu_bias_or_null) {
-        d.d_mu_bias_or_null[a - A] = static_cast<float>(part[16][slot]);   // bias grad of the mu head
+        g = static_cast<float>(part[16][slot]);
+        d.d_mu_bias_or_null[a - A] = g;                                     // bias grad of the mu head
       }
+      g *= grad_scale;
+      return static_cast<double>(g) * static_cast<double>(g);
     }
-    return;
+    return 0.0;
   }
   if (threadIdx.x == 0) {
     const float a_loss = static_cast<float>(part[16][0] / denom);
@@ -374,9 +381,24 @@ __device__ __forceinline__ void loss_finalize_block(const rlg_loss_finalize_desc
     d.scalars8[6] = static_cast<float>(msum);
     d.scalars8[7] = 0.0f;
     if (d.kl_slot_or_null) *d.kl_slot_or_null = kl;
-    if (d.d_value_bias_or_null) *d.d_value_bias_or_null = static_cast<float>(part[16][6]);   // bias grad of the value head
+    if (d.d_value_bias_or_null) {
+      const float g = static_cast<float>(part[16][6]);                      // bias grad of the value head
+      *d.d_value_bias_or_null = g;
+      return static_cast<double>(g * grad_scale) * static_cast<double>(g * grad_scale);
+    }
   }
+  return 0.0;
 }
+
+// Optional by-product of the finalise launch: per-block sums of (g * grad_scale)^2 over every gradient
+// element the launch writes - what grad_sumsq_kernel (csrc/optim.hip) computes in a launch of its own for
+// clip_grad_norm_ (a2c_common.py:510-512).  Valid when this launch produces ALL gradients of the arena
+// and nothing modifies them before the Adam launch (single GPU).  Also advances the Adam step counter.
+struct NormItem {
+  double* partials;          // [gridDim.x] or nullptr
+  long long* step_counter;   // or nullptr
+  float grad_scale;
+};
 
 // grad[e] = sum_z partial[z][e].  A block covers kFinElems consecutive float4 elements (a 256-byte
 // span per slice) with kFinGroups z-groups: group g sums the slices z = g, g+16, ... (up to 4 loads
@@ -386,15 +408,15 @@ constexpr int kFinElems = 16;
 constexpr int kFinGroups = 16;
 constexpr int kCsCols = 16;       // bias-gradient blocks: columns x row-slices of the per-block partials
 constexpr int kCsSlices = 16;
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf) {
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf,
+                                                              NormItem nrm) {
   __shared__ f32x4 part[kFinGroups][kFinElems];
+  double sq = 0.0;                                 // this thread's share of sum (g * grad_scale)^2
+  const int blk = blockIdx.x - lf.num_blocks;      // colsum blocks, then the weight-gradient blocks
   if (static_cast<int>(blockIdx.x) < lf.num_blocks) {
     __shared__ double lpart[17][17];
-    loss_finalize_block(lf.d, blockIdx.x, lpart);
-    return;
-  }
-  const int blk = blockIdx.x - lf.num_blocks;      // colsum blocks, then the weight-gradient blocks
-  if (blk < cs.num_blocks) {
+    sq = loss_finalize_block(lf.d, blockIdx.x, lpart, nrm.grad_scale);
+  } else if (blk < cs.num_blocks) {
     // ---- bias-gradient blocks: kCsCols columns x kCsSlices row-slices per block; a thread sums the
     //      rows slice, slice + 16, ... with 8 independent loads in flight (the per-block partials of
     //      the backward launch are a few hundred rows - one dependent load per row would dominate
@@ -432,10 +454,11 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
       double t = cpart[0][cl];
 #pragma unroll
       for (int k = 1; k < kCsSlices; ++k) t += cpart[k][cl];
-      cs.out[item][col] = static_cast<float>(t);
+      const float gv = static_cast<float>(t);
+      cs.out[item][col] = gv;
+      sq = static_cast<double>(gv * nrm.grad_scale) * static_cast<double>(gv * nrm.grad_scale);
     }
-    return;
-  }
+  } else {
   int l = 0;
   int base = 0;
   const int fin_block = blk - cs.num_blocks;
@@ -474,6 +497,22 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
 #pragma unroll
     for (int k = 1; k < kFinGroups; ++k) t += part[k][el];
     reinterpret_cast<f32x4*>(L.grad)[e] = t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gv = t[k] * nrm.grad_scale;
+      sq = fma(static_cast<double>(gv), static_cast<double>(gv), sq);
+    }
+  }
+  }
+  if (nrm.partials) {                                // (uniform: every thread of the block gets here)
+    __shared__ double nscratch[256 / kWave];
+    double one[1] = {sq};
+    __syncthreads();
+    block_sum<1, 256>(one, nscratch);
+    if (threadIdx.x == 0) {
+      nrm.partials[blockIdx.x] = one[0];
+      if (blockIdx.x == 0 && nrm.step_counter) *nrm.step_counter += 1;
+    }
   }
 }
 
@@ -543,7 +582,8 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       float* const* grad, const int* out_features, const int* in_features,
                       const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
                       const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                      const rlg_loss_finalize_desc* loss_finalize, void* stream) {
+                      const rlg_loss_finalize_desc* loss_finalize, double* norm_partials, float grad_scale,
+                      long long* step_counter, int* finalize_blocks_out, void* stream) {
   using namespace rlg;
   if (num_layers <= 0 || num_layers > kDwMaxLayers || rows <= 0 || num_colsums < 0 ||
       num_colsums > kDwMaxLayers)
@@ -595,8 +635,10 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
+  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
+  if (finalize_blocks_out) *finalize_blocks_out = lf.num_blocks + cs_blocks + fin_blocks;
   hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(lf.num_blocks + cs_blocks + fin_blocks), dim3(256), 0, st, args, cs,
-                     lf);
+                     lf, nrm);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -110,14 +110,19 @@ class FlatAdam(FlatArena):
         return used, nxt
 
     # ------------------------------------------------------------------ step
-    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
+    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None):
         """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
-        driven by the KL in `kl_slot` (times kl_scale)."""
+        driven by the KL in `kl_slot` (times kl_scale).  norm_ready = (partials fp64, count): the
+        launch that wrote the gradients already left the per-block sums of (g * grad_scale)^2 AND advanced
+        the device step counter (ops.MlpDwPlan.launch(norm=...)) - no grad_sumsq launch."""
         self.step_count += 1
-        # always launched: it also advances the device step counter the Adam kernel reads
-        ops.grad_sumsq(self.grads, grad_scale, self.norm_partials, self.step_counter)
-        partials = self.norm_partials if max_norm is not None else None
+        if norm_ready is None:
+            # it also advances the device step counter the Adam kernel reads
+            ops.grad_sumsq(self.grads, grad_scale, self.norm_partials, self.step_counter)
+            partials = self.norm_partials if max_norm is not None else None
+        else:
+            partials = norm_ready[0][:norm_ready[1]] if max_norm is not None else None
         kw = {}
         kind = 0
         if schedule is not None:

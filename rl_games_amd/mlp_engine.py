@@ -219,6 +219,12 @@ class ManualMLP:
             self.chain.forward(obs, heads, rms=rms, eps=eps)
         return heads
 
+    def gradient_elements(self):
+        """Number of arena gradient elements that backward() + the loss finalise produce on the fused
+        path: trunk weights and biases, the fused head matrix, the head biases and logstd."""
+        n = sum(l.weight.numel() + l.bias.numel() for l in self.linears)
+        return n + self.head_w_grad.numel() + (self.V + self.A) + self.A
+
     def values_view(self, heads):
         return heads[:, :self.V]
 
@@ -226,14 +232,16 @@ class ManualMLP:
         return heads[:, self.V:]
 
     @torch.no_grad()
-    def backward(self, d_heads, loss_finalize=None):
+    def backward(self, d_heads, loss_finalize=None, norm=None):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
         finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
         chain waits for - are then ONE f32-MFMA launch for all layers (csrc/mlp_dw.hip), or the
         library GEMMs when a shape is outside that kernel's envelope / `mfma_dw` is off.
         loss_finalize: ops.loss_finalize_desc(...) - folded in the weight-gradient finalise launch when
-        there is one, launched on its own otherwise."""
+        there is one, launched on its own otherwise.  norm = (partials, grad_scale, step_counter): see
+        ops.MlpDwPlan.launch; returns the number of valid norm partials, or None when the gradient norm
+        was not produced (a gradient of this step did not come out of that launch)."""
         rows = self._rows
         L = len(self.linears)
         self._pending_backward = False
@@ -250,8 +258,7 @@ class ManualMLP:
                 lin = self.linears[l]
                 jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            self._weight_grads(jobs, rows, colsums, loss_finalize)
-            return
+            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm)
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
@@ -287,13 +294,14 @@ class ManualMLP:
                 d_prev = self.dA[l - 1][:rows]
                 torch.mm(d, lin.weight, out=d_prev)
                 d = d_prev
-        self._weight_grads(jobs, rows, colsums, loss_finalize)
+        return self._weight_grads(jobs, rows, colsums, loss_finalize)
 
-    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None):
+    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None):
         """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
         fast, slow = [], []
+        norm_blocks = None
         if self.mfma_dw:
             for job in jobs:
                 g = job[2]
@@ -313,7 +321,12 @@ class ManualMLP:
                     plan = False
                 self._dw_plans[key] = plan
             if plan:
-                plan.launch(fast, colsums, loss_finalize)   # bias gradients (and the loss partials) finished in the same finalise launch
+                # bias gradients (and the loss partials) finished in the same finalise launch; the gradient
+                # norm as well when every gradient of the step is written there
+                whole = norm is not None and not slow and loss_finalize is not None
+                norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
+                if not whole:
+                    norm_blocks = None
                 colsums = ()
                 loss_finalize = None
                 self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run
@@ -328,3 +341,4 @@ class ManualMLP:
         self.last_dw_library_jobs = len(slow)
         for dz, x, g in slow:
             torch.mm(dz.t(), x, out=g)
+        return norm_blocks

@@ -618,10 +618,22 @@ class MlpDwPlan:
     def plan(self, k):
         return tuple(self._plans[4 * k:4 * k + 4])
 
-    def launch(self, jobs, colsums=(), loss_finalize=None):
+    def finalize_blocks(self, colsums=(), loss_finalize=None):
+        """Workgroups of the finalise launch (= entries of the optional norm partials)."""
+        n = sum((No * Mi // 4 + 15) // 16 for No, Mi in self.shapes)
+        n += sum((int(c[2]) + 15) // 16 for c in colsums)
+        if loss_finalize is not None:
+            n += 1 + (2 * loss_finalize.actions_num + 7) // 8
+        return n
+
+    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None):
         """jobs: (dz, x, grad) per planned layer.  colsums: optional (partials fp64 [blocks*cols],
         blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch.
-        loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well."""
+        loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well.
+        norm = (partials fp64 [>= finalise blocks], grad_scale, step_counter int64 [1]): the finalise
+        launch also leaves per-block sums of (g * grad_scale)^2 and advances the Adam step counter (what
+        grad_sumsq does) - only meaningful when this launch writes every gradient of the arena.
+        Returns the number of finalise blocks (= valid entries of the norm partials)."""
         import ctypes
         if len(jobs) != self.n:
             raise ValueError('job count does not match the plan')
@@ -634,6 +646,11 @@ class MlpDwPlan:
             cs_cols = (ctypes.c_int * nc)(*[int(c[2]) for c in colsums])
         else:
             cs_part = cs_out = cs_blocks = cs_cols = None
+        nfin = ctypes.c_int(0)
+        if norm is not None:
+            need = self.finalize_blocks(colsums, loss_finalize)
+            if norm[0].numel() < need:
+                raise ValueError(f'norm partials: {need} entries needed, {norm[0].numel()} given')
         for k, (dz, x, grad) in enumerate(jobs):
             No, Mi = self.shapes[k]
             if tuple(dz.shape) != (self.rows, No) or tuple(x.shape) != (self.rows, Mi) or \
@@ -647,8 +664,12 @@ class MlpDwPlan:
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
                                                  cs_cols, cs_out,
                                                  None if loss_finalize is None else ctypes.addressof(loss_finalize),
-                                                 _lib.stream_handle(self._device)),
+                                                 None if norm is None else _need(norm[0], F64, 'norm partials'),
+                                                 1.0 if norm is None else float(np.float32(norm[1])),
+                                                 None if norm is None else _need(norm[2], torch.int64, 'step_counter'),
+                                                 ctypes.byref(nfin), _lib.stream_handle(self._device)),
                    'rlg_mlp_dw_launch')
+        return nfin.value
 
 
 # ------------------------------------------------------------------ recurrent policy (LSTM)

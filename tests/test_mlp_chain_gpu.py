@@ -267,6 +267,19 @@ def test_dw_finalize_folds_loss_partials_like_ppo_loss_finalize(nblocks, A):
             assert torch.isfinite(got).all()
             assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7 * max(1.0, ref.abs().max().item() if ref.numel() else 1.0))
     assert torch.allclose(grad.double(), dz.double().t() @ x.double(), rtol=1e-5, atol=1e-5)
+    # by-product: per-block sums of (g * scale)^2 over every element the launch wrote + the step counter
+    cparts = torch.randn(5 * 36, generator=g, dtype=torch.float64).to(DEV)
+    cout = torch.empty(36, device=DEV)
+    colsums = [(cparts, 5, 36, cout)]
+    desc = ops.loss_finalize_desc(*args)
+    norm_partials = torch.full((plan.finalize_blocks(colsums, desc) + 3,), float('nan'), dtype=torch.float64, device=DEV)
+    counter = torch.tensor([41], dtype=torch.int64, device=DEV)
+    nb = plan.launch([(dz, x, grad)], colsums, desc, norm=(norm_partials, 0.5, counter))
+    assert nb == plan.finalize_blocks(colsums, desc) and counter.item() == 42
+    written = [grad.reshape(-1), cout, d_logstd[:A], dmb[:A], dvb]
+    want = sum(((0.5 * t).double() ** 2).sum() for t in written)
+    assert torch.isfinite(norm_partials[:nb]).all() and torch.isnan(norm_partials[nb:]).all()
+    assert torch.allclose(norm_partials[:nb].sum(), want, rtol=1e-12)
 
 
 def test_engine_fused_chain_equals_per_layer_engine():
