@@ -30,6 +30,8 @@
 
 #include "rlg_device.hpp"
 
+#include <cstdlib>
+
 namespace rlg {
 
 constexpr int kLossRows = 64;      // rows per block (one LDS tile set) ...
@@ -79,6 +81,15 @@ __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) 
   const float e = expf(t);
   const float s = 1.0f / (1.0f + e);
   return (4.0f * e) * (s * s);
+}
+
+static int loss_tile_rows(int minibatch) {
+  static const int forced = [] {
+    const char* e = std::getenv("RLG_LOSS_ROWS");       // tools: A/B measurements (16 / 32 / 64)
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  return minibatch <= kLossSmallBatch ? kLossRowsSmall : kLossRows;
 }
 
 template <int kRows>
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(
 extern "C" {
 
 int rlg_ppo_loss_num_blocks(int minibatch) {
-  const int rows = minibatch <= rlg::kLossSmallBatch ? rlg::kLossRowsSmall : rlg::kLossRows;
+  const int rows = rlg::loss_tile_rows(minibatch);
   return (minibatch + rows - 1) / rows;
 }
 
@@ -616,7 +627,7 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   p.bound_kind = bound_kind;
   p.write_back = write_back;
   const int AP = actions_num | 1;
-  const int tile_rows = minibatch <= kLossSmallBatch ? kLossRowsSmall : kLossRows;
+  const int tile_rows = loss_tile_rows(minibatch);
   size_t shm = (static_cast<size_t>(3) * tile_rows * AP + 2 * tile_rows + 3 * actions_num + 4) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
   const size_t red_doubles = static_cast<size_t>(8) * actions_num > kLossScalars * (kLossThreads / kWave)
@@ -627,6 +638,9 @@ int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values
   const int grid = rlg_ppo_loss_num_blocks(minibatch);
   if (tile_rows == kLossRows) {
     hipLaunchKernelGGL(ppo_loss_kernel<kLossRows>, dim3(grid), dim3(kLossThreads), shm,
+                       static_cast<hipStream_t>(stream), p);
+  } else if (tile_rows == 32) {
+    hipLaunchKernelGGL(ppo_loss_kernel<32>, dim3(grid), dim3(kLossThreads), shm,
                        static_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(ppo_loss_kernel<kLossRowsSmall>, dim3(grid), dim3(kLossThreads), shm,
