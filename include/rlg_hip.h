@@ -452,6 +452,13 @@ int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_o
 int rlg_ipc_comm_connect(void* comm, const void* all_handles /* world x handle bytes, rank-major */);
 int rlg_ipc_comm_fine_grained(void* comm);
 int rlg_ipc_allreduce_sum(void* comm, float* data, long long n, void* stream);
+/* The same launch with a by-product: norm_partials[rlg_ipc_allreduce_norm_blocks()] = per-workgroup sums of
+ * (reduced x * grad_scale)^2 over the first norm_n elements (the gradients; the arena's tail slots are not),
+ * and *step_counter += 1 - what rlg_grad_sumsq would compute in a launch of its own after the collective
+ * (clip_grad_norm_ of the averaged gradients, a2c_common.py:498-512). */
+int rlg_ipc_allreduce_norm_blocks(void);
+int rlg_ipc_allreduce_sum_norm(void* comm, float* data, long long n, double* norm_partials, long long norm_n,
+                               float grad_scale, long long* step_counter_or_null, void* stream);
 int rlg_ipc_comm_status(void* comm, unsigned* launches_out, unsigned* timed_out_launch_out);
 int rlg_ipc_comm_destroy(void* comm);
 

@@ -98,6 +98,8 @@ _PROTOTYPES = {
     'rlg_ipc_comm_connect': [_P, ctypes.c_char_p],
     'rlg_ipc_comm_fine_grained': [_P],
     'rlg_ipc_allreduce_sum': [_P, _P, _c_ll, _P],
+    'rlg_ipc_allreduce_norm_blocks': [],
+    'rlg_ipc_allreduce_sum_norm': [_P, _P, _c_ll, _P, _c_ll, _c_float, _P, _P],
     'rlg_ipc_comm_status': [_P, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)],
     'rlg_ipc_comm_destroy': [_P],
     # optim.hip

@@ -395,7 +395,8 @@ class A2CAgent:
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
         self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
         self._fin_norm_partials = None
-        self._norm_ready = None       # (partials, count) when the finalise launch produced the gradient norm
+        self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
+        self._ar_norm_partials = None
         self._fold_index = None
         self._ipc_comm = None
         self._rollout_graphs, self._rollout_graph_key, self._rollout_static = {}, None, None
@@ -1123,7 +1124,16 @@ class A2CAgent:
         """Gradients + KL slot, one collective (a2c_common.py:493-509, :1559-1560)."""
         comm = self._native_comm()
         if comm is not None:
-            comm.all_reduce_sum(self.optimizer.flat_grads)      # a plain kernel launch: capturable
+            # a plain kernel launch: capturable.  The reduced gradients pass through its registers, so it
+            # also leaves the sums of squares clip_grad_norm_ needs (no grad_sumsq launch behind it).
+            opt = self.optimizer
+            norm = None
+            if self.config.get('norm_in_allreduce', True):
+                if self._ar_norm_partials is None:
+                    self._ar_norm_partials = torch.zeros(comm.norm_blocks(), dtype=torch.float64, device=self.ppo_device)
+                norm = (self._ar_norm_partials, opt.numel, 1.0 / self.world_size, opt.step_counter)
+                self._norm_ready = (self._ar_norm_partials, comm.norm_blocks())
+            comm.all_reduce_sum(opt.flat_grads, norm=norm)
         else:
             rdist.all_reduce_sum(self.optimizer.flat_grads)
 
@@ -1234,11 +1244,14 @@ class A2CAgent:
             item = self.dataset[i]
             g = self._graphs[i] = self._capture(lambda: self._with_fold(i, self._forward_loss_backward, item,
                                                                        self._graph_rows[i]))
-        if self._graph_opt is None:
-            self._graph_opt = self._capture(self._optimizer_kernels)
         g.replay()
         if self.multi_gpu:
             self._all_reduce_grads()
+        if self._graph_opt is None:
+            # captured AFTER the launches that may already have produced the gradient norm (the weight-gradient
+            # finalise on one GPU, the native all-reduce on several): the graph then carries no grad_sumsq
+            self._graph_opt = self._capture(self._optimizer_kernels)
+        self._norm_ready = None
         self._graph_opt.replay()
         self.optimizer.step_count += 1
 

@@ -40,7 +40,18 @@ struct IpcPeers {
   int rank, world;
 };
 
-__global__ __launch_bounds__(kIpcThreads) void ipc_allreduce_kernel(IpcPeers p, float* __restrict__ data, long long n) {
+// Optional by-product (what grad_sumsq_kernel of csrc/optim.hip computes in a launch of its own):
+// norm.partials[block] = sum over the block's share of the first norm.n REDUCED elements of
+// (x * grad_scale)^2, and the Adam step counter advanced - the reduced gradients pass through registers here.
+struct IpcNorm {
+  double* partials;            // [kIpcBlocks] or nullptr
+  long long n;                 // leading elements that are gradients (the arena's tail slots are not)
+  long long* step_counter;     // or nullptr
+  float grad_scale;
+};
+
+__global__ __launch_bounds__(kIpcThreads) void ipc_allreduce_kernel(IpcPeers p, float* __restrict__ data, long long n,
+                                                                    IpcNorm norm) {
   __shared__ unsigned s_epoch;
   if (threadIdx.x == 0) s_epoch = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   __syncthreads();
@@ -83,15 +94,36 @@ __global__ __launch_bounds__(kIpcThreads) void ipc_allreduce_kernel(IpcPeers p, 
   __syncthreads();
 
   // ---- reduce, rank order 0 .. P-1 on every rank
+  double sq = 0.0;
   for (long long i = tid; i < n4; i += nthreads) {
     f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.stage[par][0]) + i);
     for (int q = 1; q < p.world; ++q) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.stage[par][q]) + i);
     reinterpret_cast<f32x4*>(data)[i] = s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (4 * i + k < norm.n) {
+        const float g = s[k] * norm.grad_scale;
+        sq = fma(static_cast<double>(g), static_cast<double>(g), sq);
+      }
+    }
   }
   for (long long i = (n4 << 2) + tid; i < n; i += nthreads) {
     float s = __builtin_nontemporal_load(p.stage[par][0] + i);
     for (int q = 1; q < p.world; ++q) s += __builtin_nontemporal_load(p.stage[par][q] + i);
     data[i] = s;
+    if (i < norm.n) {
+      const float g = s * norm.grad_scale;
+      sq = fma(static_cast<double>(g), static_cast<double>(g), sq);
+    }
+  }
+  if (norm.partials) {
+    __shared__ double nscratch[kIpcThreads / kWave];
+    double one[1] = {sq};
+    block_sum<1, kIpcThreads>(one, nscratch);
+    if (threadIdx.x == 0) {
+      norm.partials[blockIdx.x] = one[0];
+      if (blockIdx.x == 0 && norm.step_counter) *norm.step_counter += 1;
+    }
   }
 
   // ---- the last workgroup to finish advances the launch ordinal
@@ -188,8 +220,27 @@ int rlg_ipc_allreduce_sum(void* comm, float* data, long long n, void* stream) {
   IpcComm* c = static_cast<IpcComm*>(comm);
   if (!c->connected || n <= 0 || n > c->capacity || reinterpret_cast<uintptr_t>(data) % 16 != 0)
     return static_cast<int>(hipErrorInvalidValue);
+  IpcNorm none = {nullptr, 0, nullptr, 1.0f};
   hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(kIpcBlocks), dim3(kIpcThreads), 0, static_cast<hipStream_t>(stream),
-                     c->peers, data, n);
+                     c->peers, data, n, none);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_ipc_allreduce_norm_blocks(void) { return rlg::kIpcBlocks; }
+
+// The same launch, which also leaves norm_partials[rlg_ipc_allreduce_norm_blocks()] = per-block sums of
+// (reduced x * grad_scale)^2 over the first norm_n elements and advances step_counter - the inputs of
+// rlg_adam_step's gradient clipping, i.e. rlg_grad_sumsq without its launch.
+int rlg_ipc_allreduce_sum_norm(void* comm, float* data, long long n, double* norm_partials, long long norm_n,
+                               float grad_scale, long long* step_counter_or_null, void* stream) {
+  using namespace rlg;
+  IpcComm* c = static_cast<IpcComm*>(comm);
+  if (!c->connected || n <= 0 || n > c->capacity || reinterpret_cast<uintptr_t>(data) % 16 != 0 || !norm_partials ||
+      norm_n < 0 || norm_n > n)
+    return static_cast<int>(hipErrorInvalidValue);
+  IpcNorm norm = {norm_partials, norm_n, step_counter_or_null, grad_scale};
+  hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(kIpcBlocks), dim3(kIpcThreads), 0, static_cast<hipStream_t>(stream),
+                     c->peers, data, n, norm);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -72,14 +72,30 @@ class IpcAllReduce:
             self.close()
             raise _lib.HipLibraryError(f'in-graph all-reduce self-test failed (per rank: {oks})')
 
-    def all_reduce_sum(self, t):
-        """In place, on torch's current stream.  `t`: contiguous fp32 CUDA tensor of <= numel elements."""
+    def all_reduce_sum(self, t, norm=None):
+        """In place, on torch's current stream.  `t`: contiguous fp32 CUDA tensor of <= numel elements.
+        norm = (partials fp64 [>= norm_blocks()], n_grads, grad_scale, step_counter int64 [1]): the launch
+        also leaves the per-block sums of (reduced x * grad_scale)^2 over the first n_grads elements and
+        advances the Adam step counter (FlatAdam.step(norm_ready=(partials, norm_blocks())))."""
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() > self.numel:
             raise ValueError('IpcAllReduce: contiguous fp32 tensor of at most the planned size expected')
         _lib.require_gpu(t, 'all_reduce_sum')
-        _lib.check(_lib.load().rlg_ipc_allreduce_sum(self._comm, t.data_ptr(), t.numel(),
-                                                     _lib.stream_handle(t.device)), 'rlg_ipc_allreduce_sum')
+        lib = _lib.load()
+        if norm is None:
+            _lib.check(lib.rlg_ipc_allreduce_sum(self._comm, t.data_ptr(), t.numel(), _lib.stream_handle(t.device)),
+                       'rlg_ipc_allreduce_sum')
+        else:
+            partials, n_grads, scale, counter = norm
+            if partials.dtype != torch.float64 or partials.numel() < self.norm_blocks() or counter.dtype != torch.int64:
+                raise ValueError('IpcAllReduce: norm partials fp64 [norm_blocks] and an int64 step counter expected')
+            _lib.check(lib.rlg_ipc_allreduce_sum_norm(self._comm, t.data_ptr(), t.numel(), partials.data_ptr(),
+                                                      int(n_grads), float(scale), counter.data_ptr(),
+                                                      _lib.stream_handle(t.device)), 'rlg_ipc_allreduce_sum_norm')
         return t
+
+    @staticmethod
+    def norm_blocks():
+        return _lib.load().rlg_ipc_allreduce_norm_blocks()
 
     def status(self):
         """(launches completed, ordinal of a launch that gave up waiting for a peer or 0).  Synchronises."""

@@ -52,8 +52,21 @@ for rep in range(3):
     torch.cuda.synchronize()
     for k in range(4):
         ok &= bool(torch.equal(outs[k].cpu(), expected(100 + 10 * rep + k, N)))
+# by-product: per-block sums of (reduced x * scale)^2 over the leading n_grads elements + the step counter
+partials = torch.full((comm.norm_blocks() + 2,), float('nan'), dtype=torch.float64, device=dev)
+counter = torch.tensor([7], dtype=torch.int64, device=dev)
+n_grads = N - 4                                         # the arena's tail slots do not count
+for it in range(200, 203):
+    t.copy_(contribution(rank, it, N))
+    comm.all_reduce_sum(t, norm=(partials, n_grads, 1.0 / world, counter))
+    want = expected(it, N)
+    ok &= bool(torch.equal(t.cpu(), want))
+    sq = ((want[:n_grads] * (1.0 / world)).double() ** 2).sum()
+    ok &= bool(torch.allclose(partials[:comm.norm_blocks()].sum().cpu(), sq, rtol=1e-12))
+    ok &= bool(torch.isnan(partials[comm.norm_blocks():]).all())
+ok &= counter.item() == 10
 launches, timed_out = comm.status()
-ok &= (timed_out == 0) and launches0 == 2 and launches == launches0 + 40 + 12
+ok &= (timed_out == 0) and launches0 == 2 and launches == launches0 + 40 + 12 + 3
 flag = torch.tensor([1.0 if ok else 0.0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
