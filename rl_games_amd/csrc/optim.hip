@@ -69,7 +69,18 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   __shared__ double scratch[kOptBlock / kWave];
   double sq[1] = {0.0};
   if (a.norm_partials) {
-    for (int b = threadIdx.x; b < a.norm_blocks; b += kOptBlock) sq[0] += a.norm_partials[b];
+    // (a few thousand entries when the weight-gradient finalise launch produced them: 4 loads in flight per
+    //  thread, fixed order - every block computes the same sum)
+    int b = threadIdx.x;
+    for (; b + 3 * kOptBlock < a.norm_blocks; b += 4 * kOptBlock) {
+      const double v0 = a.norm_partials[b], v1 = a.norm_partials[b + kOptBlock];
+      const double v2 = a.norm_partials[b + 2 * kOptBlock], v3 = a.norm_partials[b + 3 * kOptBlock];
+      sq[0] += v0;
+      sq[0] += v1;
+      sq[0] += v2;
+      sq[0] += v3;
+    }
+    for (; b < a.norm_blocks; b += kOptBlock) sq[0] += a.norm_partials[b];
     block_sum<1, kOptBlock>(sq, scratch);
   }
   if (threadIdx.x == 0) {
