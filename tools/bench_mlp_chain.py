@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--no-lib', action='store_true', help='skip the library comparison rows')
     ap.add_argument('--phases', action='store_true', help='per-phase shader-clock breakdown of the forward')
     ap.add_argument('--groups', type=int, nargs='+', default=[4, 2, 1])
+    ap.add_argument('--act', default='elu', help='hidden activation: elu / relu / tanh / None')
     ap.add_argument('--dw-blocks', type=int, nargs='+', default=[256, 512, 1024])
     args = ap.parse_args()
     from rl_games_amd import ops
@@ -47,7 +48,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     layers, last = [], in_dim
     for u in units + [out_dim]:
-        layers.append(((torch.randn(u, last, generator=g) / last ** 0.5).to(dev), (0.1 * torch.randn(u, generator=g)).to(dev), 'elu'))
+        layers.append(((torch.randn(u, last, generator=g) / last ** 0.5).to(dev), (0.1 * torch.randn(u, generator=g)).to(dev), args.act))
         last = u
     layers[-1] = (layers[-1][0], layers[-1][1], 'None')
     chain = ops.MlpChain(layers, dev)
