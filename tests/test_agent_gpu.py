@@ -828,6 +828,40 @@ def test_hip_graph_replays_are_bit_identical_to_eager_training(cfg):
     assert res[0][5] == res[1][5]
 
 
+@pytest.mark.parametrize('graphs', [True, False])
+def test_folded_launches_match_the_separate_ones(graphs):
+    """The launches that round 2 merged away - observation statistics folded in the forward's prologue
+    (with an ODD number of minibatches: the state ends a mini-epoch in the second buffer set), loss
+    partials and gradient-norm partials folded by the weight-gradient finalise - against the same agent
+    with every one of them as its own launch.  Only summation orders differ."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for folded in (True, False):
+        params = configs.tiny(num_actors=96, horizon=8, hip_graphs=graphs, fold_obs_stats=folded,
+                              fold_loss_finalize=folded, norm_in_finalize=folded)
+        params['config']['minibatch_size'] = 256                      # 768 rows -> 3 minibatches
+        torch.manual_seed(11)
+        agent = A2CAgent('f', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(4):
+            agent.update_epoch()
+            agent.train_epoch()
+        assert len(agent.dataset) == 3
+        assert bool(agent._fin_norm_ok) == folded
+        m = agent.model.running_mean_std
+        res.append((m.running_mean.clone(), m.running_var.clone(), m.count.clone(),
+                    agent.optimizer.flat_params.clone(), agent.optimizer.last_and_next_lr()))
+    a, b = res
+    assert a[2].item() == b[2].item() == 1 + 4 * 2 * 768              # every minibatch of every mini-epoch counted
+    assert torch.allclose(a[0], b[0], rtol=1e-9, atol=1e-12) and torch.allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
+    assert a[4] == b[4]                                               # same learning-rate trajectory
+    bad = ~torch.isclose(a[3], b[3], rtol=1e-3, atol=1e-6)
+    assert bad.float().mean().item() <= 0.01
+    assert (a[3] - b[3]).abs().max().item() <= 2.1 * 24 * 1e-2       # 24 Adam steps at lr <= max_lr
+
+
 @pytest.mark.parametrize('kind', ['mlp', 'lstm', 'discrete', 'central_value'])
 def test_two_rank_training_keeps_ranks_in_sync(kind):
     """2 ranks on this box's single GPU (RLG_TEST_SINGLE_GPU=1: gloo collectives), different data per
