@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--phases', action='store_true', help='per-phase shader-clock breakdown of the forward')
     ap.add_argument('--groups', type=int, nargs='+', default=[4, 2, 1])
     ap.add_argument('--act', default='elu', help='hidden activation: elu / relu / tanh / None')
+    ap.add_argument('--cold-x', type=int, default=0, help='rotate the forward input over this many buffers (cold observations)')
     ap.add_argument('--dw-blocks', type=int, nargs='+', default=[256, 512, 1024])
     args = ap.parse_args()
     from rl_games_amd import ops
@@ -71,6 +72,16 @@ def main():
             parts = [torch.empty(nblk * u, dtype=torch.float64, device=dev) for u in units]
             t = timeit(lambda: chain.forward(x, heads, act_out=acts, rms=(mean, var), xn_out=xn, groups=G), args.reps)
             print(f'  G={G} forward train   {t:8.1f} us  {2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
+            if args.cold_x > 1:
+                xs = [x.clone() for _ in range(args.cold_x)]
+                state = {'k': 0}
+
+                def cold():
+                    state['k'] = (state['k'] + 1) % len(xs)
+                    chain.forward(xs[state['k']], heads, act_out=acts, rms=(mean, var), xn_out=xn, groups=G)
+                t = timeit(cold, args.reps)
+                print(f'  G={G} forward train, observations rotating over {len(xs)} buffers  {t:8.1f} us')
+                del xs
             t = timeit(lambda: chain.forward(x, heads, rms=(mean, var), groups=G), args.reps)
             print(f'  G={G} forward infer   {t:8.1f} us  {2e-6 * rows * macs_f / t:6.1f} TFLOP/s')
             if args.phases:
