@@ -413,11 +413,39 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           const double* rms_batch_or_null, const long long* rms_count,
                           double* rms_mean_out, double* rms_var_out, long long* rms_count_out,
                           long long rows, int groups, void* stream);
+/* Arguments of the clipped-PPO loss (the parameter list of rlg_ppo_loss_fused as a struct): with a
+ * non-NULL descriptor the BACKWARD launch evaluates the loss of its own row tile in front of its
+ * prologue - no separate loss launch - i.e. it first writes d mu / d values (which must be views of the
+ * d_out buffer this launch then reads), the mu/sigma write-back and one row of partials per workgroup
+ * (rlg_mlp_chain_num_blocks(rows, resolved backward groups) rows of rlg_ppo_loss_partials_per_block
+ * doubles).  minibatch must equal rows. */
+typedef struct rlg_ppo_loss_desc {
+  const float* mu;            /* [rows, A] view, row stride ld_mu */
+  const float* logstd;        /* [A] */
+  const float* values;        /* [rows] view, stride ld_values */
+  const float* actions;       /* [rows, A] */
+  const float* old_neglogp;   /* [rows] */
+  const float* advantages;
+  const float* old_values;
+  const float* returns;
+  float* old_mu;              /* [rows, A] read, then overwritten when write_back */
+  float* old_sigma;
+  const float* mask_or_null;
+  const float* mask_sum_or_null;
+  float* d_mu;                /* [rows, A] view, row stride ld_d_mu */
+  float* d_values;            /* [rows] view, stride ld_d_values */
+  double* partials;
+  int minibatch, actions_num;
+  int ld_mu, ld_values, ld_d_mu, ld_d_values;
+  float e_clip, critic_coef, bounds_coef;
+  int clip_value, use_smooth_clamp, bound_kind, write_back;
+} rlg_ppo_loss_desc;
+
 int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const int* in_features,
                            const int* out_features, const int* acts, const float* const* act_in,
                            const long long* act_ld, const float* d_out, long long ld_dout,
                            float* const* dz_out, const long long* dz_ld, double* const* bias_partials_or_null,
-                           long long rows, int groups, void* stream);
+                           const rlg_ppo_loss_desc* ppo_loss_or_null, long long rows, int groups, void* stream);
 
 /* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
  * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state

@@ -78,7 +78,7 @@ _PROTOTYPES = {
     'rlg_mlp_chain_debug_stamps': [_P],
     'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                               _P, _P, _P, _P, _P, _c_ll, _c_int, _P],
-    'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _c_ll, _c_int, _P],
+    'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P],
     'rlg_lstm_supported': [_c_int],
     'rlg_lstm_seq_forward': [_P] * 10 + [_c_int, _c_int, _c_int, _P],
     'rlg_lstm_seq_backward': [_P] * 7 + [_c_int, _c_int, _c_int, _P],
@@ -146,6 +146,16 @@ def load():
         fn.restype = _c_ll if name in _RETURNS_LONG_LONG else _c_int
     _lib = lib
     return lib
+
+
+class PpoLossDesc(ctypes.Structure):
+    """rlg_ppo_loss_desc (include/rlg_hip.h): the PPO-loss arguments of a fused backward launch."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in (
+        'mu', 'logstd', 'values', 'actions', 'old_neglogp', 'advantages', 'old_values', 'returns', 'old_mu',
+        'old_sigma', 'mask_or_null', 'mask_sum_or_null', 'd_mu', 'd_values', 'partials')]
+        + [(n, ctypes.c_int) for n in ('minibatch', 'actions_num', 'ld_mu', 'ld_values', 'ld_d_mu', 'ld_d_values')]
+        + [(n, ctypes.c_float) for n in ('e_clip', 'critic_coef', 'bounds_coef')]
+        + [(n, ctypes.c_int) for n in ('clip_value', 'use_smooth_clamp', 'bound_kind', 'write_back')])
 
 
 class LossFinalizeDesc(ctypes.Structure):

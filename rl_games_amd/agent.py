@@ -426,8 +426,9 @@ class A2CAgent:
         self._d_mu = torch.empty(mb, A, dtype=torch.float32, device=dev)
         self._d_val = torch.empty(mb, dtype=torch.float32, device=dev)
         self._loss_blocks = ops.ppo_loss_blocks(mb)
-        self._loss_partials = torch.empty(self._loss_blocks, ops.ppo_loss_partials_per_block(A),
-                                          dtype=torch.float64, device=dev)
+        # (a fused backward launch leaves one row per 16 / 32 / 64-row workgroup)
+        self._loss_partials = torch.empty(max(self._loss_blocks, (mb + 15) // 16),
+                                          ops.ppo_loss_partials_per_block(A), dtype=torch.float64, device=dev)
 
     def _rollout_fields(self):
         return ['actions', 'neglogpacs', 'values', 'mus', 'sigmas']
@@ -1077,25 +1078,37 @@ class A2CAgent:
         # (c_loss = zeros, a2c_continuous.py:112-115) - a zero coefficient removes it from loss and grads
         coef_c = self.critic_coef if self.has_value_loss else 0.0
         with torch.no_grad():
-            ops.ppo_loss_fused(
-                mu.detach(), logstd.detach(), values.detach().reshape(mb, -1)[:, 0] if eng is not None
-                else values.detach().reshape(-1), input_dict['actions'],
-                input_dict['old_logp_actions'], input_dict['advantages'],
-                input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
-                input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
-                self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
-                self.use_smooth_clamp, kind, True, mask, mask_sum)
-            fin = (self._loss_partials, ops.ppo_loss_blocks(mb), A, mb, mask is not None,
+            loss_args = (mu.detach(), logstd.detach(),
+                         values.detach().reshape(mb, -1)[:, 0] if eng is not None else values.detach().reshape(-1),
+                         input_dict['actions'], input_dict['old_logp_actions'], input_dict['advantages'],
+                         input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
+                         input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
+                         self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
+                         self.use_smooth_clamp, kind, True, mask, mask_sum)
+            fold = eng is not None and self.config.get('fold_loss_finalize', True)
+            # Large minibatches on the fused chain: the backward launch evaluates the loss of its own row
+            # tiles first (no loss launch; one partial row per backward workgroup).  Small ones keep the
+            # stand-alone kernel - their backward runs 8 waves per workgroup, the loss tile is written for 4.
+            in_backward = (fold and eng.chain is not None and self.config.get('loss_in_backward', True)
+                           and eng.chain.groups(mb, 1) >= 2)
+            if in_backward:
+                loss_blocks = eng.chain.num_blocks(mb, 1)
+                ppo = ops.ppo_loss_desc(*loss_args)
+            else:
+                loss_blocks = ops.ppo_loss_blocks(mb)
+                ppo = None
+                ops.ppo_loss_fused(*loss_args)
+            fin = (self._loss_partials, loss_blocks, A, mb, mask is not None,
                    coef_c, self.entropy_coef, coef_b, row, net.sigma.grad,
                    opt.kl_slot, mu_bias_grad, value_bias_grad)
-            if eng is not None and self.config.get('fold_loss_finalize', True):
+            if fold:
                 # the loss partials are folded by the weight-gradient finalise launch (one launch less),
                 # and - single GPU, every gradient of the arena written by that launch - the sums of
                 # squares for clip_grad_norm_ with them (another one)
                 norm = None
                 if self._norm_in_finalize():
                     norm = (self._fin_norm_partials, 1.0, opt.step_counter)
-                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm)
+                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo)
                 self._norm_ready = (self._fin_norm_partials, nb) if nb else None
             else:
                 ops.ppo_loss_finalize(*fin)

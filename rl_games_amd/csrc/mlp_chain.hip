@@ -31,6 +31,8 @@
 // LDS tile of a layer with `nb` 16-feature blocks: [nb][G][64 lanes][4] floats (nb*G KiB).
 
 #include "rlg_device.hpp"
+#include "ppo_loss_tile.hpp"
+#include "rlg_hip.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -73,7 +75,8 @@ struct ChainArgs {
   float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
   long long rows;
   int lds_b_floats;            // start of the second LDS region, in floats
-  long long* dbg;              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
+  long long* dbg;
+  int with_loss;               // backward: evaluate the PPO loss of the tile first (LossArgs)              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
 };
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
@@ -620,13 +623,22 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
 // For L = num_layers-1 .. 1:  dZ_{L-1} = (dZ_L W_L) * act'_{L-1}(H_{L-1});  layer 0 needs no dX.
 // ------------------------------------------------------------------------------------------------
 template <int G, int W>
-__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a) {
+__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, LossArgs loss) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
   float* tile_a = lds;
   float* tile_b = lds + a.lds_b_floats;
+
+  // ---- the PPO loss of this row tile first (training steps): d heads = d loss / d (value, mu) of the rows,
+  //      the mu / sigma write-back and the tile's partial sums; the tile regions are still free
+  if constexpr (W == 4) {
+    if (a.with_loss) {
+      ppo_loss_tile<16 * G>(loss, lds, blockIdx.x);
+      __syncthreads();          // d heads written by this workgroup are visible to it
+    }
+  }
 
   // ---- prologue: d heads tile -> LDS -----------------------------------------------------------
   {
@@ -842,13 +854,14 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
   }
   args.num_layers = num_layers;
   args.dbg = nullptr;
+  args.with_loss = 0;
   return 0;
 }
 
 static bool g_chain_prepared = false;     // rlg_mlp_chain_prepare raised the LDS limit of every kernel
 
 template <int G, bool kBackward, int HACT, int W>
-static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss) {
   const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
   const void* kern;
   if constexpr (kBackward) kern = reinterpret_cast<const void*>(mlp_chain_bwd_kernel<G, W>);
@@ -862,8 +875,9 @@ static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st)
     }
   }
   if constexpr (kBackward) {
+    LossArgs none = {};
     hipLaunchKernelGGL((mlp_chain_bwd_kernel<G, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
-                       args);
+                       args, loss ? *loss : none);
   } else {
     hipLaunchKernelGGL((mlp_chain_fwd_kernel<G, HACT, W>), dim3(grid), dim3(64 * W),
                        static_cast<size_t>(lds_bytes), st, args);
@@ -886,23 +900,24 @@ static int chain_waves(int G, long long rows) {
 }
 
 template <int G, bool kBackward, int W>
-static int chain_launch_w(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+static int chain_launch_w(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss) {
   if constexpr (!kBackward) {
     // forward: the ELU-or-identity network (every BASELINE configuration) gets its own instance
     bool elu_only = true;
     for (int L = 0; L < args.num_layers; ++L)
       elu_only = elu_only && (args.layer[L].act == kChElu || args.layer[L].act == kChIdentity);
-    if (elu_only) return chain_launch_as<G, false, kChElu, W>(args, lds_bytes, st);
+    if (elu_only) return chain_launch_as<G, false, kChElu, W>(args, lds_bytes, st, loss);
   }
-  return chain_launch_as<G, kBackward, kChAny, W>(args, lds_bytes, st);
+  return chain_launch_as<G, kBackward, kChAny, W>(args, lds_bytes, st, loss);
 }
 
 template <int G, bool kBackward>
-static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss = nullptr) {
   if constexpr (G == 1) {
-    if (chain_waves(1, args.rows) == 8) return chain_launch_w<1, kBackward, 8>(args, lds_bytes, st);
+    // (the loss tile is written for 256 threads: a launch that carries the loss stays at 4 waves)
+    if (loss == nullptr && chain_waves(1, args.rows) == 8) return chain_launch_w<1, kBackward, 8>(args, lds_bytes, st, loss);
   }
-  return chain_launch_w<G, kBackward, 4>(args, lds_bytes, st);
+  return chain_launch_w<G, kBackward, 4>(args, lds_bytes, st, loss);
 }
 
 }  // namespace rlg
@@ -1005,7 +1020,7 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
                            const int* out_features, const int* acts, const float* const* act_in,
                            const long long* act_ld, const float* d_out, long long ld_dout,
                            float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
-                           long long rows, int groups, void* stream) {
+                           const rlg_ppo_loss_desc* ppo_loss, long long rows, int groups, void* stream) {
   using namespace rlg;
   if (rows <= 0) return 0;
   if (num_layers < 2) return static_cast<int>(hipErrorInvalidValue);
@@ -1031,13 +1046,53 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
   args.rows = rows;
   const int G = pick_groups(rows, groups, 1);
   int b_floats = 0;
-  const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 1, &b_floats);
+  int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 1, &b_floats);
   if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);
   args.lds_b_floats = b_floats;
+  LossArgs loss = {};
+  args.with_loss = ppo_loss ? 1 : 0;
+  if (ppo_loss) {
+    const rlg_ppo_loss_desc& d = *ppo_loss;
+    if (d.minibatch != rows || d.actions_num <= 0 || (d.mask_or_null && !d.mask_sum_or_null) || !d.partials ||
+        !d.mu || !d.values || !d.d_mu || !d.d_values)
+      return static_cast<int>(hipErrorInvalidValue);
+    loss.mu = d.mu;
+    loss.logstd = d.logstd;
+    loss.values = d.values;
+    loss.actions = d.actions;
+    loss.old_neglogp = d.old_neglogp;
+    loss.advantages = d.advantages;
+    loss.old_values = d.old_values;
+    loss.returns = d.returns;
+    loss.old_mu = d.old_mu;
+    loss.old_sigma = d.old_sigma;
+    loss.mask = d.mask_or_null;
+    loss.mask_sum = d.mask_sum_or_null;
+    loss.d_mu = d.d_mu;
+    loss.d_values = d.d_values;
+    loss.partials = d.partials;
+    loss.mb = d.minibatch;
+    loss.A = d.actions_num;
+    loss.ld_mu = d.ld_mu;
+    loss.ld_val = d.ld_values;
+    loss.ld_dmu = d.ld_d_mu;
+    loss.ld_dval = d.ld_d_values;
+    loss.e_clip = d.e_clip;
+    loss.critic_coef = d.critic_coef;
+    loss.bounds_coef = d.bounds_coef;
+    loss.clip_value = d.clip_value;
+    loss.smooth = d.use_smooth_clamp;
+    loss.bound_kind = d.bound_kind;
+    loss.write_back = d.write_back;
+    const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, d.actions_num));
+    if (need > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (need > lds_bytes) lds_bytes = need;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (G == 4) return chain_launch<4, true>(args, lds_bytes, st);
-  if (G == 2) return chain_launch<2, true>(args, lds_bytes, st);
-  return chain_launch<1, true>(args, lds_bytes, st);
+  const LossArgs* lp = ppo_loss ? &loss : nullptr;
+  if (G == 4) return chain_launch<4, true>(args, lds_bytes, st, lp);
+  if (G == 2) return chain_launch<2, true>(args, lds_bytes, st, lp);
+  return chain_launch<1, true>(args, lds_bytes, st, lp);
 }
 
 }  // extern "C"

@@ -1,0 +1,292 @@
+// The clipped-PPO loss of one tile of minibatch rows: device code shared by the stand-alone kernel of
+// ppo_loss.hip (see there for what it replaces) and the fused backward kernel of mlp_chain.hip.
+#pragma once
+
+#include "rlg_device.hpp"
+
+namespace rlg {
+
+constexpr int kLossRows = 64;      // rows per block (one LDS tile set) ...
+constexpr int kLossRowsSmall = 16; // ... and for minibatches of at most kLossSmallBatch rows: a tile is a chain of
+constexpr int kLossSmallBatch = 8192;   // short phases, so a small minibatch wants more, smaller tiles
+constexpr int kLossThreads = 256;  // threads per block: all walk the tile, the first kLossRows own a row
+constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
+
+struct LossArgs {
+  // network outputs
+  const float* mu;         // [mb, A]
+  const float* logstd;     // [A]
+  const float* values;     // [mb]
+  // minibatch slices of the dataset
+  const float* actions;    // [mb, A]
+  const float* old_neglogp;  // [mb]
+  const float* advantages;   // [mb]
+  const float* old_values;   // [mb]
+  const float* returns;      // [mb]
+  float* old_mu;           // [mb, A]  read, then overwritten with mu     (update_mu_sigma)
+  float* old_sigma;        // [mb, A]  read, then overwritten with sigma
+  const float* mask;       // [mb] or nullptr (rnn_masks)
+  const float* mask_sum;   // device scalar sum(mask) for this minibatch, or nullptr
+  // outputs
+  float* d_mu;             // [mb, A]
+  float* d_values;         // [mb]
+  double* partials;        // [gridDim.x][kLossScalars + 2A]: scalars | d logstd terms | sum_rows d_mu
+  int mb, A;
+  int ld_mu, ld_val, ld_dmu, ld_dval;   // row strides (elements) of mu / values / d_mu / d_values
+  float e_clip, critic_coef, bounds_coef;
+  int clip_value;          // default_critic_loss clip flag
+  int smooth;              // use_smooth_clamp
+  int bound_kind;          // 0 none (coef None), 1 'bound', 2 'regularisation'
+  int write_back;          // overwrite old_mu/old_sigma with the new policy's
+};
+
+__device__ __forceinline__ float smooth_clamp_f(float x, float mi, float mx) {
+  // 1/(1 + exp((-(x-mi)/(mx-mi)+0.5)*4)) * (mx-mi) + mi          common_losses.py:32-36
+  const float t = ((-(x - mi) / (mx - mi)) + 0.5f) * 4.0f;
+  return (1.0f / (1.0f + expf(t))) * (mx - mi) + mi;
+}
+
+__device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) {
+  // d/dx of the above: s = 1/(1+e^t), ds/dt = -e^t s^2, dt/dx = -4/(mx-mi)  ->  4 e^t s^2.
+  // (4 s (1-s) is the same number but cancels catastrophically once s -> 1.)
+  const float t = ((-(x - mi) / (mx - mi)) + 0.5f) * 4.0f;
+  const float e = expf(t);
+  const float s = 1.0f / (1.0f + e);
+  return (4.0f * e) * (s * s);
+}
+
+// One tile of kRows rows (the tile_index-th of the minibatch) by the 256 threads of a workgroup; `lds`:
+// ppo_loss_lds_bytes(kRows, A) bytes, 16-byte aligned.  Called by ppo_loss_kernel and by the fused backward
+// kernel in front of its own prologue (csrc/mlp_chain.hip: d heads of the tile are then already there).
+template <int kRows>
+__device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int tile_index) {
+  static_assert(kRows <= kLossThreads, "one thread per row in phase 2");
+  const int A = p.A;
+  const int AP = A | 1;                       // odd row stride: conflict-free row walks
+  float* t_z2 = lds;                          // [256][AP]  z^2, later g*(1-z^2)
+  float* t_kl = t_z2 + kRows * AP;        // [256][AP]
+  float* t_b = t_kl + kRows * AP;         // [256][AP]
+  float* row_g = t_b + kRows * AP;        // [256]  d loss / d neglogp of the row
+  float* row_w = row_g + kRows;           // [256]  inv_count * mask of the row
+  float* col_sigma = row_w + kRows;       // [A]
+  float* col_logstd = col_sigma + A;          // [A]
+  float* col_ent = col_logstd + A;            // [A]  entropy term of the column (the same for every row)
+  double* red = reinterpret_cast<double*>(
+      (reinterpret_cast<uintptr_t>(col_ent + A) + 7) & ~static_cast<uintptr_t>(7));
+
+  const int tid = threadIdx.x;
+  const long long row0 = static_cast<long long>(tile_index) * kRows;
+  const int rows = static_cast<int>(min(static_cast<long long>(kRows), p.mb - row0));
+  const long long e0 = row0 * A;              // first element of the tile
+  const int tile_elems = rows * A;
+
+  for (int a = tid; a < A; a += kLossThreads) {
+    const float ls = p.logstd[a];
+    col_logstd[a] = ls;
+    const float sg = expf(ls);                                                // models.py:296
+    col_sigma[a] = sg;
+    // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale) - once per column, not once per row and column
+    col_ent[a] = 1.4189385332046727f + logf(sg);
+  }
+  __syncthreads();
+
+  const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
+  float denom_count = static_cast<float>(p.mb);
+  if (p.mask) denom_count = fmaxf(*p.mask_sum, 1.0f);                         // torch_ext.py:165
+
+  // ------------------------------ phase 1: element-wise ------------------------------
+  {
+    int r = tid / A, a = tid - r * A;
+    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossThreads) {
+      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
+      const float x = p.actions[e0 + e];
+      const float omu = p.old_mu[e0 + e];
+      const float osg = p.old_sigma[e0 + e];
+      const float sg = col_sigma[a];
+      const float z = (x - mu) / sg;                                          // models.py:362
+      t_z2[r * AP + a] = z * z;
+      // policy_kl(p0 = new, p1 = old)                                        torch_ext.py:28-31
+      const float c1 = logf(osg / sg + 1e-5f);
+      const float dm = omu - mu;
+      const float c2 = (sg * sg + dm * dm) / (2.0f * (osg * osg + 1e-5f));
+      t_kl[r * AP + a] = (c1 + c2) + (-0.5f);
+      float b = 0.0f;
+      if (p.bound_kind == 1) {                                                // a2c_continuous.py:248-253
+        const float hi_t = fmaxf(mu - 1.1f, 0.0f);
+        const float lo_t = fminf(mu + 1.1f, 0.0f);
+        b = lo_t * lo_t + hi_t * hi_t;
+      } else if (p.bound_kind == 2) {                                         // :241-246
+        b = mu * mu;
+      }
+      t_b[r * AP + a] = b;
+      if (p.write_back) {                                                     // datasets.py:42-43
+        p.old_mu[e0 + e] = mu;
+        p.old_sigma[e0 + e] = sg;
+      }
+      a += da;
+      r += dr;
+      if (a >= A) {
+        a -= A;
+        r += 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------ phase 2: one thread per row ------------------------
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (tid < rows) {
+    const long long i = row0 + tid;
+    float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      s_z2 += t_z2[tid * AP + a];
+      s_kl += t_kl[tid * AP + a];
+      s_b += t_b[tid * AP + a];
+      s_ls += col_logstd[a];
+      s_ent += col_ent[a];
+    }
+    // neglogp                                                                models.py:361-364
+    const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
+    const float adv = p.advantages[i];
+    const float ratio = expf(p.old_neglogp[i] - nlp);                         // common_losses.py:75
+    const float surr1 = adv * ratio;
+    float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
+    if (p.smooth) {
+      l2 = adv * smooth_clamp_f(ratio, lo, hi);
+      dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
+    } else {
+      l2 = adv * fminf(fmaxf(ratio, lo), hi);
+      dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    }
+    const float n1 = -surr1, n2 = -l2;
+    const float a_loss = fmaxf(n1, n2);                                       // :78
+    // torch.max backward: the larger branch takes the gradient, equal branches split it
+    float w1, w2;
+    if (n1 > n2) {
+      w1 = 1.0f;
+      w2 = 0.0f;
+    } else if (n2 > n1) {
+      w1 = 0.0f;
+      w2 = 1.0f;
+    } else {
+      w1 = 0.5f;
+      w2 = 0.5f;
+    }
+    // d a_loss / d ratio = -adv*(w1 + w2*dl2) ; d ratio / d nlp = -ratio
+    const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
+
+    // critic                                                                 common_losses.py:20-27
+    const float v = p.values[i * p.ld_val], vo = p.old_values[i], R = p.returns[i];
+    float c_loss, g_v;
+    if (p.clip_value) {
+      const float delta = v - vo;
+      const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+      const float d1 = v - R, d2 = vclip - R;
+      const float c1 = d1 * d1, c2 = d2 * d2;
+      c_loss = fmaxf(c1, c2);
+      const float in = (delta >= -p.e_clip && delta <= p.e_clip) ? 1.0f : 0.0f;
+      if (c1 > c2) {
+        g_v = 2.0f * d1;
+      } else if (c2 > c1) {
+        g_v = 2.0f * d2 * in;
+      } else {
+        g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
+      }
+    } else {
+      const float d = R - v;
+      c_loss = d * d;
+      g_v = -2.0f * d;
+    }
+
+    const float m = p.mask ? p.mask[i] : 1.0f;
+    const float w = m / denom_count;          // d(mean)/d(element)
+    row_g[tid] = g_nlp * w;
+    row_w[tid] = w;
+    const float dv = (0.5f * p.critic_coef) * g_v * w;                        // a2c_continuous.py:133
+    p.d_values[i * p.ld_dval] = dv;
+    acc[6] = static_cast<double>(dv);
+    acc[0] = static_cast<double>(a_loss) * m;
+    acc[1] = static_cast<double>(c_loss) * m;
+    acc[2] = static_cast<double>(s_ent) * m;
+    acc[3] = static_cast<double>(s_b) * m;
+    acc[4] = static_cast<double>(s_kl) * m;
+    acc[5] = m;
+  }
+  block_sum<kLossScalars, kLossThreads>(acc, red);
+  double* out = p.partials + static_cast<long long>(tile_index) * (kLossScalars + 2 * A);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < kLossScalars; ++k) out[k] = acc[k];
+  }
+  __syncthreads();   // row_g / row_w visible; also fences the reuse of `red`
+
+  // ------------------------------ phase 3: d mu, logstd terms -------------------------
+  {
+    int r = tid / A, a = tid - r * A;
+    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kLossThreads) {
+      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
+      const float x = p.actions[e0 + e];
+      const float sg = col_sigma[a];
+      const float z = (x - mu) / sg;
+      float db = 0.0f;
+      if (p.bound_kind == 1) {
+        db = 2.0f * fminf(mu + 1.1f, 0.0f) + 2.0f * fmaxf(mu - 1.1f, 0.0f);
+      } else if (p.bound_kind == 2) {
+        db = 2.0f * mu;
+      }
+      // d nlp / d mu = -z / sigma
+      const float dmu = row_g[r] * (-(z / sg)) + (row_w[r] * p.bounds_coef) * db;
+      p.d_mu[(row0 + r) * p.ld_dmu + a] = dmu;
+      t_kl[r * AP + a] = dmu;                     // column sums -> bias gradient of the mu head
+      // d nlp / d logstd = 1 - z^2
+      t_z2[r * AP + a] = row_g[r] * (1.0f - z * z);
+      a += da;
+      r += dr;
+      if (a >= A) {
+        a -= A;
+        r += 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------ phase 4: column sums over the block's rows ----------
+  // two column sets (d logstd terms in t_z2, d mu in t_kl); 8 row groups x A columns each, then
+  // A threads fold the 8 partials (fixed order).
+  for (int set = 0; set < 2; ++set) {
+    const float* tile = set == 0 ? t_z2 : t_kl;
+    const int groups = 8;
+    const int per = (rows + groups - 1) / groups;
+    for (int j = tid; j < groups * A; j += kLossThreads) {
+      const int g = j / A, a = j - g * A;
+      double s = 0.0;
+      const int r_end = min(rows, (g + 1) * per);
+      for (int r = g * per; r < r_end; ++r) s += static_cast<double>(tile[r * AP + a]);
+      red[j] = s;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += kLossThreads) {
+      double s = 0.0;
+      for (int g = 0; g < groups; ++g) s += red[g * A + a];
+      out[kLossScalars + set * A + a] = s;
+    }
+    __syncthreads();
+  }
+}
+
+
+// LDS bytes of one ppo_loss_tile<rows>: 3 tiles [rows][A|1] + 2 row vectors + 3 column vectors (floats),
+// then the fp64 reduction scratch.
+inline size_t ppo_loss_lds_bytes(int rows, int A) {
+  const int AP = A | 1;
+  size_t shm = (static_cast<size_t>(3) * rows * AP + 2 * rows + 3 * A + 4) * sizeof(float);
+  shm = (shm + 7) & ~static_cast<size_t>(7);
+  const size_t red_doubles = static_cast<size_t>(8) * A > kLossScalars * (kLossThreads / kWave)
+                                 ? static_cast<size_t>(8) * A
+                                 : kLossScalars * (kLossThreads / kWave);
+  return shm + red_doubles * sizeof(double);
+}
+
+}  // namespace rlg

@@ -232,7 +232,7 @@ class ManualMLP:
         return heads[:, self.V:]
 
     @torch.no_grad()
-    def backward(self, d_heads, loss_finalize=None, norm=None):
+    def backward(self, d_heads, loss_finalize=None, norm=None, ppo_loss=None):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
         finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
@@ -241,7 +241,9 @@ class ManualMLP:
         loss_finalize: ops.loss_finalize_desc(...) - folded in the weight-gradient finalise launch when
         there is one, launched on its own otherwise.  norm = (partials, grad_scale, step_counter): see
         ops.MlpDwPlan.launch; returns the number of valid norm partials, or None when the gradient norm
-        was not produced (a gradient of this step did not come out of that launch)."""
+        was not produced (a gradient of this step did not come out of that launch).  ppo_loss
+        (ops.ppo_loss_desc, fused chain only): the backward launch evaluates the PPO loss first and so
+        produces d_heads itself."""
         rows = self._rows
         L = len(self.linears)
         self._pending_backward = False
@@ -251,7 +253,7 @@ class ManualMLP:
             acts = [h[:rows] for h in self.Hs]
             dzs = [d[:rows] for d in self.dA]
             parts = [p[:nblk * w.out_features] for p, w in zip(self.partials, self.linears)]
-            self.chain.backward(d_heads, acts, dzs, parts)
+            self.chain.backward(d_heads, acts, dzs, parts, ppo_loss=ppo_loss)
             jobs = [(d_heads, acts[-1], self.head_w_grad)]
             colsums = []
             for l in range(L - 1, -1, -1):

@@ -314,6 +314,28 @@ def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_val
         'rlg_ppo_loss_fused')
 
 
+def ppo_loss_desc(mu, logstd, values, actions, old_neglogp, advantages, old_values, returns,
+                  old_mu, old_sigma, d_mu, d_values, partials, e_clip, critic_coef, bounds_coef,
+                  clip_value=True, smooth=False, bound_kind=1, write_back=True, mask=None, mask_sum=None):
+    """The arguments of ppo_loss_fused as an rlg_ppo_loss_desc for MlpChain.backward(ppo_loss=...): the
+    backward launch evaluates the loss of each row tile in front of its own work.  d_mu / d_values must be
+    views of the d_heads tensor that backward then reads; partials needs MlpChain.num_blocks(rows, 1)
+    rows.  The descriptor keeps no tensor alive - the caller does (they are the step's static buffers)."""
+    mb, A = mu.shape
+    mu_p, ld_mu = _rows_view(mu, 'mu')
+    val_p, ld_val = _rows_view(values, 'values')
+    dmu_p, ld_dmu = _rows_view(d_mu, 'd_mu')
+    dval_p, ld_dval = _rows_view(d_values, 'd_values')
+    return _lib.PpoLossDesc(
+        mu_p, _need(logstd, F32, 'logstd'), val_p, _need(actions, F32, 'actions'),
+        _need(old_neglogp, F32, 'old_neglogp'), _need(advantages, F32, 'advantages'),
+        _need(old_values, F32, 'old_values'), _need(returns, F32, 'returns'), _need(old_mu, F32, 'old_mu'),
+        _need(old_sigma, F32, 'old_sigma'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), dmu_p, dval_p,
+        _need(partials, F64, 'partials'), mb, A, ld_mu, ld_val, ld_dmu, ld_dval,
+        float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(bounds_coef)),
+        1 if clip_value else 0, 1 if smooth else 0, bound_kind, 1 if write_back else 0)
+
+
 def value_loss(values, old_values, returns, d_values, partials, e_clip, clip_value=True, mask=None, mask_sum=None):
     """Central-value critic loss + its gradient; partials [ceil(mb/256), 7] for ppo_loss_finalize."""
     lib = _lib.load()
@@ -563,9 +585,11 @@ class MlpChain:
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
             self.groups(rows, 0, groups), _stream(x)), 'rlg_mlp_chain_forward')
 
-    def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0):
+    def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
-        dZ_l output; bias_partials: per hidden layer fp64 [num_blocks(rows, 1), out_l] or None."""
+        dZ_l output; bias_partials: per hidden layer fp64 [num_blocks(rows, 1), out_l] or None.
+        ppo_loss = ops.ppo_loss_desc(...): the launch first evaluates the PPO loss of its row tiles, i.e.
+        it produces d_heads itself (and the loss partials, the mu/sigma write-back)."""
         rows = d_heads.shape[0]
         n = self.n
         h = self._P(*([_need(t, F32, 'H', contiguous=False) for t in acts] + [None]))
@@ -578,7 +602,8 @@ class MlpChain:
         _lib.require_gpu(d_heads, 'd_heads')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
             n, self._w, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl,
-            bp, rows, self.groups(rows, 1, groups), _stream(d_heads)), 'rlg_mlp_chain_backward')
+            bp, None if ppo_loss is None else ctypes.addressof(ppo_loss), rows, self.groups(rows, 1, groups),
+            _stream(d_heads)), 'rlg_mlp_chain_backward')
 
 
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)

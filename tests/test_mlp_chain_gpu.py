@@ -282,6 +282,61 @@ def test_dw_finalize_folds_loss_partials_like_ppo_loss_finalize(nblocks, A):
     assert torch.allclose(norm_partials[:nb].sum(), want, rtol=1e-12)
 
 
+@pytest.mark.parametrize('rows,groups', [(32768, 0), (16384, 2), (1000, 4), (100, 2), (7, 1)])
+@pytest.mark.parametrize('variant', ['plain', 'smooth_reg_noclip'])
+def test_backward_evaluates_ppo_loss_like_the_loss_kernel(rows, groups, variant):
+    """Backward launch with a loss descriptor = rlg_ppo_loss_fused, then backward: the same per-row
+    arithmetic on the backward's 16 / 32 / 64-row tiles -> d heads, every dZ and the mu/sigma write-back
+    bit-identical, the reduced scalars and column sums equal up to fp64 summation order."""
+    from rl_games_amd import ops
+    A, V = 21, 1
+    layers, g = _net(108, [64, 32], V + A, 'elu', seed=rows)
+    chain = ops.MlpChain(layers, DEV)
+    x = torch.randn(rows, 108, generator=g).to(DEV)
+    logstd = (0.1 * torch.randn(A, generator=g) - 0.3).to(DEV)
+    heads = torch.empty(rows, V + A, device=DEV)
+    acts = [torch.empty(rows, u, device=DEV) for u in (64, 32)]
+    chain.forward(x, heads, act_out=acts, groups=groups)
+
+    def data():
+        gg = torch.Generator().manual_seed(rows + 1)
+        d = {'actions': torch.randn(rows, A, generator=gg), 'old_neglogp': 25 + torch.randn(rows, generator=gg),
+             'adv': torch.randn(rows, generator=gg), 'old_values': torch.randn(rows, generator=gg),
+             'returns': torch.randn(rows, generator=gg), 'old_mu': 0.3 * torch.randn(rows, A, generator=gg),
+             'old_sigma': 0.5 + torch.rand(rows, A, generator=gg)}
+        return {k: v.to(DEV) for k, v in d.items()}
+    kw = dict(clip_value=True, smooth=False, bound_kind=1)
+    if variant != 'plain':
+        kw = dict(clip_value=False, smooth=True, bound_kind=2)
+    out = {}
+    for fused in (True, False):
+        d = data()
+        d_heads = torch.full((rows, V + A), float('nan'), device=DEV)
+        dzs = [torch.full((rows, u), float('nan'), device=DEV) for u in (64, 32)]
+        nbw = chain.num_blocks(rows, 1, groups)
+        parts = [torch.empty(nbw * u, dtype=torch.float64, device=DEV) for u in (64, 32)]
+        nblk = nbw if fused else ops.ppo_loss_blocks(rows)
+        partials = torch.full((nblk, ops.ppo_loss_partials_per_block(A)), float('nan'), dtype=torch.float64, device=DEV)
+        args = (heads[:, V:], logstd, heads[:, 0], d['actions'], d['old_neglogp'], d['adv'], d['old_values'],
+                d['returns'], d['old_mu'], d['old_sigma'], d_heads[:, V:], d_heads[:, 0], partials, 0.2, 2.0, 1e-4)
+        if fused:
+            chain.backward(d_heads, acts, dzs, parts, groups=groups, ppo_loss=ops.ppo_loss_desc(*args, **kw))
+        else:
+            ops.ppo_loss_fused(*args, **kw)
+            chain.backward(d_heads, acts, dzs, parts, groups=groups)
+        scalars = torch.zeros(8, device=DEV)
+        d_logstd, kl = torch.zeros(A, device=DEV), torch.zeros(1, device=DEV)
+        d_mu_bias, d_v_bias = torch.zeros(A, device=DEV), torch.zeros(1, device=DEV)
+        ops.ppo_loss_finalize(partials, nblk, A, rows, False, 2.0, 0.0, 1e-4, scalars, d_logstd, kl, d_mu_bias, d_v_bias)
+        out[fused] = (d_heads, dzs[0], dzs[1], d['old_mu'], d['old_sigma'], scalars, d_logstd, d_mu_bias, d_v_bias)
+    for k in range(5):
+        assert torch.isfinite(out[True][k]).all()
+        assert torch.equal(out[True][k], out[False][k]), k
+    for k in range(5, 9):
+        ref = out[False][k]
+        assert torch.allclose(out[True][k], ref, rtol=1e-6, atol=1e-7 * max(1.0, ref.abs().max().item())), k
+
+
 def test_engine_fused_chain_equals_per_layer_engine():
     """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
     gradients in the arena, on a BASELINE config #2 shaped network."""
