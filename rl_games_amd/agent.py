@@ -1086,11 +1086,9 @@ class A2CAgent:
                          self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
                          self.use_smooth_clamp, kind, True, mask, mask_sum)
             fold = eng is not None and self.config.get('fold_loss_finalize', True)
-            # Large minibatches on the fused chain: the backward launch evaluates the loss of its own row
-            # tiles first (no loss launch; one partial row per backward workgroup).  Small ones keep the
-            # stand-alone kernel - their backward runs 8 waves per workgroup, the loss tile is written for 4.
-            in_backward = (fold and eng.chain is not None and self.config.get('loss_in_backward', True)
-                           and eng.chain.groups(mb, 1) >= 2)
+            # On the fused chain the backward launch evaluates the loss of its own row tiles first (no loss
+            # launch; one partial row per backward workgroup).
+            in_backward = fold and eng.chain is not None and self.config.get('loss_in_backward', True)
             if in_backward:
                 loss_blocks = eng.chain.num_blocks(mb, 1)
                 ppo = ops.ppo_loss_desc(*loss_args)

@@ -633,11 +633,14 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
 
   // ---- the PPO loss of this row tile first (training steps): d heads = d loss / d (value, mu) of the rows,
   //      the mu / sigma write-back and the tile's partial sums; the tile regions are still free
-  if constexpr (W == 4) {
-    if (a.with_loss) {
-      ppo_loss_tile<16 * G>(loss, lds, blockIdx.x);
-      __syncthreads();          // d heads written by this workgroup are visible to it
-    }
+  if (a.with_loss) {
+    ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x);
+    // The prologue below reads d heads that OTHER waves of this workgroup have just stored.  A workgroup
+    // barrier alone does not wait for global stores on gfx950 (hipcc emits no vmcnt(0) in front of
+    // s_barrier at workgroup scope) and the loads did overtake them (wrong dZ with 8 waves): the stores
+    // are completed and written back first.
+    __threadfence();
+    __syncthreads();
   }
 
   // ---- prologue: d heads tile -> LDS -----------------------------------------------------------
@@ -817,8 +820,11 @@ static int chain_lds(int num_layers, const int* in_features, const int* out_feat
     a_kb = (out_features[num_layers - 1] + 15) / 16;
     int flip = 0;
     for (int L = num_layers - 1; L >= 1; --L, flip ^= 1) {
-      // dZ_{L-1} tile; the last step (dZ_0 feeds nothing) only stages its <= 3 remainder blocks
-      const long long nb = (L >= 2) ? (in_features[L] + 15) / 16 : 3;
+      // dZ_{L-1} tile; the last step (dZ_0 feeds nothing) only stages its remainder blocks: at most 3 with
+      // 4 waves per workgroup, at most 7 with the 8 waves of the 16-row workgroups (G == 1)
+      const long long all = (in_features[L] + 15) / 16;
+      const long long rem_max = (G == 1) ? 7 : 3;
+      const long long nb = (L >= 2) ? all : (all < rem_max ? all : rem_max);
       if (flip == 0) b_kb = nb > b_kb ? nb : b_kb;
       else a_kb = nb > a_kb ? nb : a_kb;
     }
@@ -914,8 +920,7 @@ static int chain_launch_w(const ChainArgs& args, int lds_bytes, hipStream_t st, 
 template <int G, bool kBackward>
 static int chain_launch(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss = nullptr) {
   if constexpr (G == 1) {
-    // (the loss tile is written for 256 threads: a launch that carries the loss stays at 4 waves)
-    if (loss == nullptr && chain_waves(1, args.rows) == 8) return chain_launch_w<1, kBackward, 8>(args, lds_bytes, st, loss);
+    if (chain_waves(1, args.rows) == 8) return chain_launch_w<1, kBackward, 8>(args, lds_bytes, st, loss);
   }
   return chain_launch_w<G, kBackward, 4>(args, lds_bytes, st, loss);
 }
@@ -1084,7 +1089,7 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
     loss.smooth = d.use_smooth_clamp;
     loss.bound_kind = d.bound_kind;
     loss.write_back = d.write_back;
-    const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, d.actions_num));
+    const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, d.actions_num, 512));
     if (need > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (need > lds_bytes) lds_bytes = need;
   }

@@ -55,12 +55,12 @@ __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) 
   return (4.0f * e) * (s * s);
 }
 
-// One tile of kRows rows (the tile_index-th of the minibatch) by the 256 threads of a workgroup; `lds`:
+// One tile of kRows rows (the tile_index-th of the minibatch) by the kThreads threads of a workgroup; `lds`:
 // ppo_loss_lds_bytes(kRows, A) bytes, 16-byte aligned.  Called by ppo_loss_kernel and by the fused backward
 // kernel in front of its own prologue (csrc/mlp_chain.hip: d heads of the tile are then already there).
-template <int kRows>
+template <int kRows, int kThreads = kLossThreads>
 __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int tile_index) {
-  static_assert(kRows <= kLossThreads, "one thread per row in phase 2");
+  static_assert(kRows <= kThreads, "one thread per row in phase 2");
   const int A = p.A;
   const int AP = A | 1;                       // odd row stride: conflict-free row walks
   float* t_z2 = lds;                          // [256][AP]  z^2, later g*(1-z^2)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   const long long e0 = row0 * A;              // first element of the tile
   const int tile_elems = rows * A;
 
-  for (int a = tid; a < A; a += kLossThreads) {
+  for (int a = tid; a < A; a += kThreads) {
     const float ls = p.logstd[a];
     col_logstd[a] = ls;
     const float sg = expf(ls);                                                // models.py:296
@@ -97,8 +97,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   // ------------------------------ phase 1: element-wise ------------------------------
   {
     int r = tid / A, a = tid - r * A;
-    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
-    for (int e = tid; e < tile_elems; e += kLossThreads) {
+    const int dr = kThreads / A, da = kThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kThreads) {
       const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float omu = p.old_mu[e0 + e];
@@ -213,7 +213,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     acc[4] = static_cast<double>(s_kl) * m;
     acc[5] = m;
   }
-  block_sum<kLossScalars, kLossThreads>(acc, red);
+  block_sum<kLossScalars, kThreads>(acc, red);
   double* out = p.partials + static_cast<long long>(tile_index) * (kLossScalars + 2 * A);
   if (tid == 0) {
 #pragma unroll
@@ -224,8 +224,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   // ------------------------------ phase 3: d mu, logstd terms -------------------------
   {
     int r = tid / A, a = tid - r * A;
-    const int dr = kLossThreads / A, da = kLossThreads - dr * A;
-    for (int e = tid; e < tile_elems; e += kLossThreads) {
+    const int dr = kThreads / A, da = kThreads - dr * A;
+    for (int e = tid; e < tile_elems; e += kThreads) {
       const float mu = p.mu[(row0 + r) * p.ld_mu + a];
       const float x = p.actions[e0 + e];
       const float sg = col_sigma[a];
@@ -259,7 +259,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     const float* tile = set == 0 ? t_z2 : t_kl;
     const int groups = 8;
     const int per = (rows + groups - 1) / groups;
-    for (int j = tid; j < groups * A; j += kLossThreads) {
+    for (int j = tid; j < groups * A; j += kThreads) {
       const int g = j / A, a = j - g * A;
       double s = 0.0;
       const int r_end = min(rows, (g + 1) * per);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
       red[j] = s;
     }
     __syncthreads();
-    for (int a = tid; a < A; a += kLossThreads) {
+    for (int a = tid; a < A; a += kThreads) {
       double s = 0.0;
       for (int g = 0; g < groups; ++g) s += red[g * A + a];
       out[kLossScalars + set * A + a] = s;
@@ -279,13 +279,13 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 
 // LDS bytes of one ppo_loss_tile<rows>: 3 tiles [rows][A|1] + 2 row vectors + 3 column vectors (floats),
 // then the fp64 reduction scratch.
-inline size_t ppo_loss_lds_bytes(int rows, int A) {
+inline size_t ppo_loss_lds_bytes(int rows, int A, int threads = kLossThreads) {
   const int AP = A | 1;
   size_t shm = (static_cast<size_t>(3) * rows * AP + 2 * rows + 3 * A + 4) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
-  const size_t red_doubles = static_cast<size_t>(8) * A > kLossScalars * (kLossThreads / kWave)
+  const size_t red_doubles = static_cast<size_t>(8) * A > static_cast<size_t>(kLossScalars) * (threads / kWave)
                                  ? static_cast<size_t>(8) * A
-                                 : kLossScalars * (kLossThreads / kWave);
+                                 : static_cast<size_t>(kLossScalars) * (threads / kWave);
   return shm + red_doubles * sizeof(double);
 }
 

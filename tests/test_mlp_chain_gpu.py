@@ -51,6 +51,8 @@ SHAPES = [
     (13, [20, 36], 5, 'tanh'),              # nothing a multiple of 16, input not a multiple of 4
     (3, [64, 64], 2, 'relu'),               # Pendulum-sized observations
     (48, [32], 7, 'None'),
+    (12, [100, 52], 22, 'elu'),             # 7 output blocks of the first layer: all of them remainder blocks of an
+                                            # 8-wave workgroup (the backward stages them in LDS: sized for 7, not 3)
 ]
 
 

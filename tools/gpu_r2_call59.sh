@@ -1,0 +1,7 @@
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2c59
+mkdir -p $OUT
+python tools/exp/debug_loss_bwd.py 2>&1 | grep "rows" | grep -c "equal False"
+for v in 0 1; do
+  python -m pytest tests -m gpu -q --timeout 900 > $OUT/full_$v.log 2>&1
+  echo "== run $v rc=$?"; grep -n "passed\|failed\|Fatal\|^FAILED" $OUT/full_$v.log | head -8
+done
