@@ -637,9 +637,10 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
     ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x);
     // The prologue below reads d heads that OTHER waves of this workgroup have just stored.  A workgroup
     // barrier alone does not wait for global stores on gfx950 (hipcc emits no vmcnt(0) in front of
-    // s_barrier at workgroup scope) and the loads did overtake them (wrong dZ with 8 waves): the stores
-    // are completed and written back first.
-    __threadfence();
+    // s_barrier at workgroup scope) and the loads did overtake them (wrong dZ with 8 waves): every wave
+    // waits for its stores to be acknowledged by the L2 first.  (An agent-scope fence here - L2
+    // write-back + invalidate in every workgroup - cost 15 ms per epoch.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
