@@ -375,3 +375,18 @@ def test_engine_fused_chain_equals_per_layer_engine():
         if not torch.isfinite(gref).all():
             continue                                     # head biases come from the loss kernel
         assert torch.allclose(got, gref, rtol=1e-4, atol=1e-5 * max(1.0, gref.abs().max().item())), n
+
+
+def test_random_network_shapes_fuzz():
+    """tools/exp/fuzz_chain.py: 60 random (observation width, hidden widths, action count, activation, rows,
+    row groups) combinations - forward, backward with and without the loss tile, weight gradients - against
+    fp64 torch.  Guards the shape-dependent paths (remainder blocks of 4- and 8-wave workgroups, LDS region
+    sizes, ragged tiles) that the fixed shape list above cannot enumerate."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'exp', 'fuzz_chain.py'), '60', '3'],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert '0 bad of 60' in res.stdout, [l for l in res.stdout.splitlines() if 'BAD' in l][:5]
