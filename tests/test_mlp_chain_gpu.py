@@ -377,6 +377,47 @@ def test_engine_fused_chain_equals_per_layer_engine():
         assert torch.allclose(got, gref, rtol=1e-4, atol=1e-5 * max(1.0, gref.abs().max().item())), n
 
 
+def test_full_size_rows_are_computed_independently_of_their_position():
+    """Size-independent properties at the BASELINE size (65,536 rows, 108 -> [400, 200, 100] -> 22): a row's
+    forward / backward result does not depend on where the row sits (bit-exact under a row permutation: the
+    same MFMA sequence per row wherever its tile is), the weight gradients are a sum over rows (equal under
+    the permutation up to summation order, and linear in dZ), and every launch is deterministic."""
+    from rl_games_amd import ops
+    rows = 65536
+    layers, g = _net(108, [400, 200, 100], 22, 'elu', seed=65536)
+    chain = ops.MlpChain(layers, DEV)
+    x = torch.randn(rows, 108, generator=g).to(DEV)
+    d_heads = torch.randn(rows, 22, generator=g).to(DEV)
+    perm = torch.randperm(rows, generator=g).to(DEV)
+
+    def run(xx, dd):
+        heads = torch.empty(rows, 22, device=DEV)
+        acts = [torch.empty(rows, u, device=DEV) for u in (400, 200, 100)]
+        dzs = [torch.empty(rows, u, device=DEV) for u in (400, 200, 100)]
+        nb = chain.num_blocks(rows, 1)
+        parts = [torch.empty(nb * u, dtype=torch.float64, device=DEV) for u in (400, 200, 100)]
+        chain.forward(xx, heads, act_out=acts)
+        chain.backward(dd, acts, dzs, parts)
+        jobs = [(dd, acts[2], torch.empty(22, 100, device=DEV)), (dzs[2], acts[1], torch.empty(100, 200, device=DEV)),
+                (dzs[1], acts[0], torch.empty(200, 400, device=DEV)), (dzs[0], xx, torch.empty(400, 108, device=DEV))]
+        plan = ops.MlpDwPlan([tuple(j[2].shape) for j in jobs], rows, DEV)
+        plan.launch(jobs)
+        return heads, acts, dzs, [j[2] for j in jobs]
+    h0, a0, z0, w0 = run(x, d_heads)
+    h1, a1, z1, w1 = run(x[perm].contiguous(), d_heads[perm].contiguous())
+    assert torch.equal(h1, h0[perm])
+    for p, q in zip(a1 + z1, a0 + z0):
+        assert torch.equal(p, q[perm])
+    for p, q in zip(w1, w0):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-4 * q.abs().max().item())
+    h2, a2, z2, w2 = run(x, d_heads)                       # deterministic
+    assert torch.equal(h2, h0) and all(torch.equal(p, q) for p, q in zip(z2 + w2, z0 + w0))
+    # dW is linear in dZ: G(2 dZ) = 2 G(dZ) exactly (power-of-two scaling commutes with every rounding)
+    _, _, _, w3 = run(x, 2.0 * d_heads)
+    for p, q in zip(w3, w0):
+        assert torch.equal(p, 2.0 * q)
+
+
 def test_random_network_shapes_fuzz():
     """tools/exp/fuzz_chain.py: 60 random (observation width, hidden widths, action count, activation, rows,
     row groups) combinations - forward, backward with and without the loss tile, weight gradients - against
