@@ -136,6 +136,10 @@ int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logst
                             const double* value_mean_or_null, const double* value_var_or_null,
                             float eps, float* actions_out, float* values_out, float* buf_actions,
                             float* buf_mus, float* buf_sigmas, float* buf_neglogp, float* buf_values,
+                            /* optional [N, A]: rescale_actions(low, high, clamp(actions, -1, 1)) - what
+                             * preprocess_actions hands to the env when clip_actions is set
+                             * (a2c_common.py:725-733); act_low / act_high [A] */
+                            float* env_actions_out_or_null, const float* act_low, const float* act_high,
                             int num_envs, int horizon, int actions_num, int step, void* stream);
 
 /* play_steps_rnn zero-on-done: s[:, done_envs, :] = 0 (a2c_common.py:1150-1153).

@@ -46,7 +46,7 @@ _PROTOTYPES = {
     'rlg_episode_meters_update': [_P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P],
     'rlg_rnn_zero_done_states': [_P, _P, _c_int, _c_int, _c_int, _P],
     'rlg_rollout_policy_head': [_P, _c_int, _P, _P, _P, _P, _c_float, _P, _P, _P, _P, _P, _P, _P,
-                                _c_int, _c_int, _c_int, _c_int, _P],
+                                _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P],
     # running_stats.hip
     'rlg_column_moments_num_blocks': [_c_ll, _c_int],
     'rlg_column_moments': [_P, _P, _c_ll, _c_int, _P, _c_int, _P],

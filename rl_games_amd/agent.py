@@ -396,6 +396,7 @@ class A2CAgent:
         self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
         self._fin_norm_partials = None
         self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
+        self._roll_env_actions = None
         self._ar_norm_partials = None
         self._fold_index = None
         self._ipc_comm = None
@@ -773,17 +774,20 @@ class A2CAgent:
         if self.normalize_value:
             vm = self.model.value_mean_std
             vs, eps = (vm.running_mean, vm.running_var), vm.epsilon
+        env_actions = None
+        if self.clip_actions:
+            # clamp + rescale for the env ride along in the same launch (3 element-wise launches less per step)
+            if self._roll_env_actions is None or self._roll_env_actions.shape != self._roll_actions.shape:
+                self._roll_env_actions = torch.empty_like(self._roll_actions)
+            env_actions = (self._roll_env_actions, self.actions_low, self.actions_high)
         ops.rollout_policy_head(heads, self.model.a2c_network.sigma.data, self._roll_noise, vs, eps,
-                                self._roll_actions, self._roll_values, buf.storage, self.horizon_length, n)
+                                self._roll_actions, self._roll_values, buf.storage, self.horizon_length, n,
+                                env_actions=env_actions)
         # the buffer keeps the observation as the env delivered it (a2c_common.py:1000), not the
         # /255-preprocessed copy
         buf.store_step(n, {'obses': obs_raw if obs_raw.is_contiguous() else obs_raw.contiguous(), 'dones': dones})
         res = {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
-        if self.clip_actions:
-            res['env_actions'] = rescale_actions(self.actions_low, self.actions_high,
-                                                 torch.clamp(self._roll_actions, -1.0, 1.0))
-        else:
-            res['env_actions'] = self._roll_actions
+        res['env_actions'] = self._roll_env_actions if self.clip_actions else self._roll_actions
         if self.is_rnn:
             res['rnn_states'] = eng.last_states
         return res

@@ -275,6 +275,11 @@ struct PolicyHeadArgs {
   float* buf_sigmas;
   float* buf_neglogp;      // [N][H]
   float* buf_values;       // [N][H]
+  // optional: what goes to the env when clip_actions is set (a2c_common.py:725-733 preprocess_actions:
+  // rescale_actions(low, high, clamp(actions, -1, 1)), torch_ext.py rescale_actions)
+  float* env_actions_out;  // [N, A] or nullptr
+  const float* act_low;    // [A]
+  const float* act_high;   // [A]
   int N, H, A, step;
 };
 
@@ -323,6 +328,13 @@ __global__ __launch_bounds__(256) void rollout_policy_head_kernel(PolicyHeadArgs
     const float act = mu + sg * p.noise[e * p.A + a];
     const long long o = (e * p.H + p.step) * p.A + a;
     p.actions_out[e * p.A + a] = act;
+    if (p.env_actions_out) {
+      // d = (high - low) / 2, m = (high + low) / 2, clamp(act, -1, 1) * d + m - each op rounded like the
+      // reference's separate torch kernels
+      const float lo = p.act_low[a], hi = p.act_high[a];
+      const float d = (hi - lo) / 2.0f, m = (hi + lo) / 2.0f;
+      p.env_actions_out[e * p.A + a] = fminf(fmaxf(act, -1.0f), 1.0f) * d + m;
+    }
     p.buf_actions[o] = act;
     p.buf_mus[o] = mu;
     p.buf_sigmas[o] = sg;
@@ -445,9 +457,11 @@ int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logst
                             const double* value_mean_or_null, const double* value_var_or_null,
                             float eps, float* actions_out, float* values_out, float* buf_actions,
                             float* buf_mus, float* buf_sigmas, float* buf_neglogp, float* buf_values,
+                            float* env_actions_out, const float* act_low, const float* act_high,
                             int num_envs, int horizon, int actions_num, int step, void* stream) {
   if (num_envs <= 0) return 0;
   if (step < 0 || step >= horizon || actions_num <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (env_actions_out && (!act_low || !act_high)) return static_cast<int>(hipErrorInvalidValue);
   rlg::PolicyHeadArgs p;
   p.heads = heads;
   p.ld = ld_heads;
@@ -467,6 +481,9 @@ int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logst
   p.H = horizon;
   p.A = actions_num;
   p.step = step;
+  p.env_actions_out = env_actions_out;
+  p.act_low = act_low;
+  p.act_high = act_high;
   hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();

@@ -104,8 +104,9 @@ def episode_meters_update(ep_partials, horizon, num_blocks, value_size, max_size
 
 
 def rollout_policy_head(heads, logstd, noise, value_stats, eps, actions_out, values_out, storage, horizon,
-                        step):
-    """storage: ExperienceBuffer.storage (env-major fields).  value_stats = (mean, var) or None."""
+                        step, env_actions=None):
+    """storage: ExperienceBuffer.storage (env-major fields).  value_stats = (mean, var) or None.
+    env_actions = (out [N, A], low [A], high [A]): also rescale_actions(low, high, clamp(actions, -1, 1))."""
     lib = _lib.load()
     N, A = noise.shape
     vm = vv = None
@@ -117,6 +118,9 @@ def rollout_policy_head(heads, logstd, noise, value_stats, eps, actions_out, val
         _need(values_out, F32, 'values_out'), _need(storage['actions'], F32, 'actions'),
         _need(storage['mus'], F32, 'mus'), _need(storage['sigmas'], F32, 'sigmas'),
         _need(storage['neglogpacs'], F32, 'neglogpacs'), _need(storage['values'], F32, 'values'),
+        None if env_actions is None else _need(env_actions[0], F32, 'env actions'),
+        None if env_actions is None else _need(env_actions[1], F32, 'actions low'),
+        None if env_actions is None else _need(env_actions[2], F32, 'actions high'),
         N, horizon, A, step, _stream(heads)), 'rlg_rollout_policy_head')
 
 

@@ -249,6 +249,11 @@ def test_fused_rollout_step_matches_model_forward():
     assert torch.allclose(tb['values'][2], ref['values'], rtol=1e-5, atol=1e-5)
     assert torch.equal(tb['obses'][2], agent.obs['obs'])
     assert torch.equal(res['actions'], tb['actions'][2]) and torch.equal(res['values'], tb['values'][2])
+    # what goes to the env: preprocess_actions (a2c_common.py:725-733) = rescale(clamp(actions, -1, 1)), bit for bit
+    from rl_games_amd.agent import rescale_actions
+    assert agent.clip_actions
+    want = rescale_actions(agent.actions_low, agent.actions_high, torch.clamp(res['actions'], -1.0, 1.0))
+    assert torch.equal(res['env_actions'], want)
     assert torch.allclose(agent._fast_values(agent.obs).view(-1, 1), agent.get_values(agent.obs), rtol=1e-5, atol=1e-5)
 
 
