@@ -712,32 +712,47 @@ class A2CAgent:
 
     def _fast_policy_step(self, n):
         """Rollout forward of step n on the engine (see _policy_step_kernels).  From the second epoch
-        on the ~12 launches of a step are replayed as one HIP graph per step index: the env-owned
-        inputs (observations, done flags, recurrent state) are copied into static buffers first."""
+        on the launches of a step are replayed as one HIP graph per step index; its inputs must live at
+        fixed addresses: the buffer slot of the step (plain float observations) or static copies of the
+        env-owned tensors (recurrent policies, integer observations)."""
         if not self._rollout_graphs_usable():
             return self._policy_step_kernels(n, self.obs['obs'], self.dones, self.rnn_states)
         key = (id(self.experience_buffer), tuple(self.obs['obs'].shape), self.obs['obs'].dtype)
+        buf = self.experience_buffer
+        obs = self.obs['obs']
+        # Plain float observations without recurrent state: the step's observations / done flags go from the
+        # env's tensors straight into the buffer (the one launch that had to happen anyway) and the captured
+        # forward reads the observations from that buffer slot - no staging copies in front of the graph.
+        direct = (not self.is_rnn and obs.dtype == torch.float32 and obs.dim() == 2 and obs.is_contiguous()
+                  and torch.is_tensor(buf.storage['obses']) and self.config.get('rollout_obs_from_buffer', True))
         if self._rollout_graph_key != key:
             self._rollout_graphs.clear()
             self._rollout_graph_key = key
-            st = {'obs': torch.empty_like(self.obs['obs']).contiguous(), 'dones': torch.empty_like(self.dones)}
+            self._rollout_static = None
+        if direct:
+            buf.store_step(n, {'obses': obs, 'dones': self.dones})
+            args = (n, buf.storage['obses'][:, n, :], None, None, False)
+        else:
+            if self._rollout_static is None:
+                st = {'obs': torch.empty_like(obs).contiguous(), 'dones': torch.empty_like(self.dones)}
+                if self.is_rnn:
+                    st['rnn'] = [torch.empty_like(s) for s in self.rnn_states]
+                self._rollout_static = st
+            st = self._rollout_static
+            st['obs'].copy_(obs)
+            st['dones'].copy_(self.dones)
             if self.is_rnn:
-                st['rnn'] = [torch.empty_like(s) for s in self.rnn_states]
-            self._rollout_static = st
-        st = self._rollout_static
-        st['obs'].copy_(self.obs['obs'])
-        st['dones'].copy_(self.dones)
-        if self.is_rnn:
-            for dst, src in zip(st['rnn'], self.rnn_states):
-                dst.copy_(src)
-        entry = self._rollout_graphs.get(n)
+                for dst, src in zip(st['rnn'], self.rnn_states):
+                    dst.copy_(src)
+            args = (n, st['obs'], st['dones'], st.get('rnn'), True)
+        entry = self._rollout_graphs.get((n, direct))
         if entry is None:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
-                out = self._policy_step_kernels(n, st['obs'], st['dones'], st.get('rnn'))
-            entry = self._rollout_graphs[n] = (g, out)
+                out = self._policy_step_kernels(*args)
+            entry = self._rollout_graphs[(n, direct)] = (g, out)
         entry[0].replay()
         return entry[1]
 
@@ -745,15 +760,15 @@ class A2CAgent:
         return (self._hip_graphs and self.config.get('rollout_graphs', True) and self._eager_epochs >= 1
                 and not self._graph_failed and isinstance(self.obs['obs'], torch.Tensor))
 
-    def _policy_step_kernels(self, n, obs_raw, dones, rnn_states):
+    def _policy_step_kernels(self, n, obs_raw, dones, rnn_states, store=True):
         """obs normalise -> engine GEMMs -> fused policy-head kernel that also writes actions / mus /
         sigmas / neglogpacs / values of the step into the buffer -> obs + dones into the buffer ->
         action clamp/rescale for the env.  Same maths as get_action_values + update_data +
         preprocess_actions; no autograd, nothing that depends on the host."""
         eng, buf = self._engine, self.experience_buffer
         obs = self._preproc_obs(obs_raw)
-        if not obs.is_contiguous():
-            obs = obs.contiguous()
+        if not obs.is_contiguous() and (eng.chain is None or obs.stride(-1) != 1):
+            obs = obs.contiguous()          # (the fused forward takes any row stride: a buffer slot [:, n, :])
         rows = obs.shape[0]
         if eng.chain is not None:
             # normaliser + every layer + heads in one launch; nothing but the heads is written
@@ -785,7 +800,8 @@ class A2CAgent:
                                 env_actions=env_actions)
         # the buffer keeps the observation as the env delivered it (a2c_common.py:1000), not the
         # /255-preprocessed copy
-        buf.store_step(n, {'obses': obs_raw if obs_raw.is_contiguous() else obs_raw.contiguous(), 'dones': dones})
+        if store:
+            buf.store_step(n, {'obses': obs_raw if obs_raw.is_contiguous() else obs_raw.contiguous(), 'dones': dones})
         res = {'actions': self._roll_actions, 'values': self._roll_values.view(rows, 1)}
         res['env_actions'] = self._roll_env_actions if self.clip_actions else self._roll_actions
         if self.is_rnn:
