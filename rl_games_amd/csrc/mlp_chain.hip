@@ -40,6 +40,9 @@
 namespace rlg {
 
 constexpr int kChainMaxLayers = 8;
+// K-split scratch of the forward (partial fragments of 256 floats): G = 1: up to 2 units x 3 parts (8 waves) or
+// 4 x 1; G = 2: up to 2 units x 1 part; G = 4: no split (a remainder block already has one unit per wave)
+static inline int chain_split_floats(int G) { return (G == 1 ? 6 : (G == 2 ? 2 : 0)) * 256; }
 constexpr int kChainWideBlocks = 384;   // up to this many 16-row workgroups run with 8 waves instead of 4
 constexpr unsigned kOob = 0x40000000u;     // byte offset far outside every weight buffer
 
@@ -74,7 +77,9 @@ struct ChainArgs {
   long long* rms_count_out;
   float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
   long long rows;
-  int lds_b_floats;            // start of the second LDS region, in floats
+  int lds_b_floats;
+  int lds_split_floats;        // forward: offset of the K-split scratch (partial fragments of remainder units)
+  int no_ksplit;               // tools (RLG_CHAIN_KSPLIT=0): remainder units without the K-split            // start of the second LDS region, in floats
   long long* dbg;
   int with_loss;               // backward: evaluate the PPO loss of the tile first (LossArgs)              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
 };
@@ -135,10 +140,13 @@ __device__ __forceinline__ float chain_act_grad(float h, int act) {
 template <int NG, int NF, bool kTransposedA, class ObOf, class GOf, class Pre, class Epi>
 __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, const float* in_tile, int G,
                                             int nunits, ObOf ob_of, GOf g_of, Pre pre, Epi epi,
-                                            long long* dbg = nullptr, int dbg_wave = 0, int* dbg_slot = nullptr) {
+                                            long long* dbg = nullptr, int dbg_wave = 0, int* dbg_slot = nullptr,
+                                            int kc_begin = 0, int kc_end = -1) {
   if (nunits <= 0) return;
   const int lane = lane_id();
-  const int KC = (K + 15) >> 4;
+  // k-chunks [kc_begin, kc_end) of the reduction (default: all of them; a K-split unit takes a part)
+  const int kc_all = (K + 15) >> 4;
+  const int KC = (kc_end < 0 ? kc_all : kc_end) - kc_begin;
   const int nfull = KC >> 2;
   const int rem = KC & 3;
   const unsigned astep = kTransposedA ? static_cast<unsigned>(16 * ld * 4) : 64u;
@@ -147,12 +155,13 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
     if (j >= nunits) return kOob;
     const int i = (ob_of(j) + f) * 16 + (lane & 15);
     if (i >= I) return kOob;
-    return kTransposedA ? static_cast<unsigned>(((4 * (lane >> 4)) * ld + i) * 4)
-                        : static_cast<unsigned>((i * ld + 4 * (lane >> 4)) * 4);
+    const unsigned first = static_cast<unsigned>(kc_begin) * astep;
+    return first + (kTransposedA ? static_cast<unsigned>(((4 * (lane >> 4)) * ld + i) * 4)
+                                 : static_cast<unsigned>((i * ld + 4 * (lane >> 4)) * 4));
   };
   auto b_base = [&](int j) -> const float* {
     const int jj = (j < nunits) ? j : nunits - 1;
-    return in_tile + (g_of(jj) * 64 + lane) * 4;
+    return in_tile + kc_begin * bstride + (g_of(jj) * 64 + lane) * 4;
   };
   auto load_a = [&](unsigned base, int c) -> f32x4 {
     const unsigned off = (c < KC) ? base + static_cast<unsigned>(c) * astep : kOob;
@@ -600,6 +609,30 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
     // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
     const int rem_first = full * W;
     const int rem_units = (NOB - rem_first) * G;
+    // Fewer (block, row group) units than waves (the one remainder block of the 400- and 200-wide layers):
+    // the idle waves take a share of the reduction instead - `ksplit` waves per unit, each over a part
+    // of the k-chunks, partial fragments combined through LDS in a fixed order by the unit's first wave.
+    const int ksplit = (a.no_ksplit || rem_units <= 0) ? 1 : ((4 * rem_units <= W) ? 4 : ((2 * rem_units <= W) ? 2 : 1));
+    if (ksplit > 1) {
+      const bool active = wave < rem_units * ksplit;
+      const int bu = active ? wave % rem_units : 0;           // unit, part of its reduction
+      const int part = active ? wave / rem_units : 0;
+      const int ob = rem_first + bu / G, g = bu % G;
+      const int KCall = (l_in + 15) >> 4;
+      f32x4 held = {0.0f, 0.0f, 0.0f, 0.0f};
+      chain_units<1, 1, false>(
+          wr, l_out, l_in, l_in, tin, G, active ? 1 : 0, [&](int) { return ob; }, [&](int) { return g; },
+          [&](int) { if (part == 0) load_bias(ob, 0); },
+          [&](int, const f32x4 (&acc)[1][1]) { held = acc[0][0]; },
+          nullptr, 0, nullptr, (KCall * part) / ksplit, (KCall * (part + 1)) / ksplit);
+      float* scratch = lds + a.lds_split_floats;
+      if (active && part > 0) *reinterpret_cast<f32x4*>(scratch + ((bu * (ksplit - 1) + part - 1) * 64 + lane) * 4) = held;
+      __syncthreads();
+      if (active && part == 0) {
+        for (int q = 1; q < ksplit; ++q) held += *reinterpret_cast<const f32x4*>(scratch + ((bu * (ksplit - 1) + q - 1) * 64 + lane) * 4);
+        epilogue(ob, g, held, biasv[0]);
+      }
+    } else {
     const int my_rem = (rem_units > wave) ? (rem_units - wave + W - 1) / W : 0;
     chain_units<1, 1, false>(
         wr, l_out, l_in, l_in, tin, G, my_rem, [&](int j) { return rem_first + (wave + j * W) / G; },
@@ -609,6 +642,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
           const int u = wave + j * W;
           epilogue(rem_first + u / G, u % G, acc[0][0], biasv[0]);
         });
+    }
     chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
     chain_stamp(a.dbg, wave, stamp);
@@ -837,7 +871,9 @@ static int chain_lds(int num_layers, const int* in_features, const int* out_feat
   }
   if (b_floats == 0) b_floats = 4;
   *b_floats_out = static_cast<int>(a_floats);
-  const long long bytes = (a_floats + b_floats) * 4;
+  long long bytes = (a_floats + b_floats) * 4;
+  // forward: the K-split scratch behind the tile regions
+  if (direction == 0) bytes += chain_split_floats(G) * 4;
   return bytes <= 160 * 1024 ? static_cast<int>(bytes) : -1;
 }
 
@@ -1016,6 +1052,11 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 0, &b_floats);
   if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);
   args.lds_b_floats = b_floats;
+  args.lds_split_floats = lds_bytes / 4 - chain_split_floats(G);
+  {
+    static const int off = [] { const char* e = std::getenv("RLG_CHAIN_KSPLIT"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
+    args.no_ksplit = off;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (G == 4) return chain_launch<4, false>(args, lds_bytes, st);
   if (G == 2) return chain_launch<2, false>(args, lds_bytes, st);
