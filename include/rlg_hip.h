@@ -340,12 +340,17 @@ int rlg_mlp_linear_act_backward(const float* dz, long long lddz, const float* w,
                                 float* dz_prev, long long ldo, int rows, int out_features, int in_features,
                                 int act_kind, void* stream);
 
-/* ---- MLP weight gradients on f32 MFMA ------------------------------------------------------
+/* ---- MLP weight gradients on the matrix cores -----------------------------------------------
  * G_l [No, Mi] = dZ_l^T X_l for every nn.Linear of the policy MLP in ONE launch (+ one finalise
  * launch): replaces autograd's `grad_output.t().mm(input)` of A2CBuilder's layers
  * (rl_games/algos_torch/network_builder.py:118-147, heads :295-311; torch.nn.Linear backward).
+ * fp32 in, fp32 out, fp32 accumulation.  Products: split-bf16 (each fp32 product as six exact bf16 plane
+ * products on v_mfma_f32_16x16x32_bf16, truncation <= 3 * 2^-24 |x||y| - as accurate against fp64 as
+ * exact products) by default; RLG_DW_BF16=0 in the environment selects exact f32 products
+ * (v_mfma_f32_16x16x4_f32, 1.4x slower).
  * rlg_mlp_dw_plan fills plan4 = {bo, tiles_o, tiles_i, ksplit} for one layer and returns the
- * workspace size in floats (-1: shape unsupported, use the library GEMM). */
+ * workspace size in floats (-1: shape unsupported, use the library GEMM); target_blocks <= 0: the
+ * default workgroup count. */
 long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int target_blocks, int* plan4);
 /* colsum_* (num_colsums may be 0): bias gradients `grad_output.sum(0)` finished in the same finalise
  * launch from the per-block fp64 column sums of rlg_act_bwd_colsum (partials [blocks][cols]). */

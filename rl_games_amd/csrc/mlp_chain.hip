@@ -213,10 +213,11 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
     // NG == NF == 1: a second accumulator takes the odd steps (40-cycle dependent-issue latency vs
     // 32-cycle issue), folded in before the epilogue - a fixed order, so still deterministic
     f32x4 acc_odd = {0.0f, 0.0f, 0.0f, 0.0f};
-    // Accumulators live in AGPRs.  The 8-wave instances (256-register budget) otherwise get VGPR-form
-    // MFMAs, and hipcc (ROCm 7.2) then retargets the LAST MFMA of a K tail to the registers of the
-    // merge point behind the tail switch - partially overlapping its own SrcC (v[16:19] <- v[18:21]):
-    // undefined by the ISA, fragment registers 2 and 3 came out wrong for K <= 32.
+    // Accumulators live in AGPRs: every MFMA then accumulates in place and the VGPRs stay free for the
+    // operand fragments.  (History: the 8-wave backward instance once produced wrong fragment registers 2, 3
+    // for K <= 32 in VGPR form.  The cause was NOT the destination / source overlap suspected first - every
+    // overlap form is exact on gfx950, tools/exp/mfma_overlap_probe.hip - but a missing wait state between the
+    // last MFMA of a tail case and the first VALU read of its result, see the s_nop in front of the epilogue.)
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -350,6 +351,21 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
 #pragma unroll
       for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(cur[u][f]));
     }
+    // One more issue slot in front of the first read of an accumulator: gfx950 needs 10 wait states between
+    // v_mfma_f32_16x16x4_f32 and a VALU read of its result (40 cycles, NOT interlocked - a too-early read
+    // returns the old register contents), hipcc (ROCm 7.2) counts one short across the branch from a tail
+    // case to this merge point (tools/audit_mfma.py, tools/exp/mfma_valu_read_probe.hip).
+    // (The accumulators pass through the asm statements, which hipcc keeps in order: every AGPR read of the
+    // epilogue is issued behind the s_nop.)
+    asm volatile("s_nop 0" : "+a"(acc[0][0]));
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (f + g > 0) asm volatile("" : "+a"(acc[f][g]));
+      }
+    }
+    asm volatile("" : "+a"(acc_odd));
     if constexpr (NG == 1 && NF == 1) acc[0][0] += acc_odd;
     if (dbg != nullptr && j < 2) chain_stamp(dbg, dbg_wave, *dbg_slot);     // after the tail + claim of the next fragments
     epi(j, acc);

@@ -1,4 +1,4 @@
-// Weight-gradient GEMMs of the actor-critic MLP on f32 MFMA, all layers in ONE launch (gfx950).
+// Weight-gradient GEMMs of the actor-critic MLP on the matrix cores, all layers in ONE launch (gfx950).
 //
 //   G_l [No, Mi] = dZ_l^T X_l = sum over the minibatch rows r of  dZ_l[r, :]^T (x) X_l[r, :]
 //
@@ -24,8 +24,9 @@
 //   * loads are software-pipelined in batches of 4 k-steps (16 rows): the next batch is in flight
 //     while the 4*BO*BI MFMAs of the current one issue;
 //   * every layer of the MLP is a work item of the same launch (descriptor table).
-// Numerics: exact fp32 products, fp32 accumulation - same class as the library kernels it
-// replaces; only the summation order differs.
+// Numerics: fp32 accumulation of products that are exact (f32 form) or exact up to 3 * 2^-24 |x||y| (split-bf16
+// form, the default: six bf16 plane products per fp32 product on the 16x16x32 bf16 MFMA, see dw_split8) -
+// the same class as the library kernels it replaces; only the summation order differs.
 
 #include "rlg_device.hpp"
 #include "rlg_hip.h"
@@ -41,6 +42,16 @@ constexpr int kDwBatch = 4;        // k-steps (of 4 rows) per prefetch batch
 #define RLG_DW_SETS 3
 #endif
 constexpr int kDwSets = RLG_DW_SETS;   // register sets: kDwSets-1 batches of loads in flight
+constexpr int kDwSplitBatch = 8;       // k-steps per batch of the split-bf16 form (K = 32 of one bf16 MFMA)
+
+// RLG_DW_BF16=0 selects exact f32 products (the round-1 kernel: 1.3x slower, same accuracy class)
+static bool dw_split_products() {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_DW_BF16");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  return on;
+}
 
 struct DwLayer {
   const float* dz;     // [rows, lda]
@@ -83,7 +94,38 @@ template <int B> __device__ __forceinline__ typename DwVec<B>::type dw_zero() { 
 
 #define RLG_DW_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int BO, int BI>
+// ---- split-bf16 products: x = x0 + x1 + x2 with bf16 planes (exact: 3 x 8 significant bits); a product is
+// the sum of the 6 plane products of weight >= 2^-16 - each exact in fp32 - on v_mfma_f32_16x16x32_bf16
+// (12.8x the rate of the f32 MFMA, 2.1x for six of them).  The truncated terms are <= 3 * 2^-24 |x||y|, one
+// fp32 rounding: against fp64 the launch is as accurate as with exact f32 products and ~10x more accurate
+// than the library's fp32 GEMM (tools/exp/split_bf16_numerics.py, tools/exp/dw_bf16_check.py,
+// profiles/r2_dw_bf16x6.txt).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 floats (the lane's 8 k values of one 16-wide block) -> 3 planes of 8 packed bf16.  The conversion is
+// an asm statement so that hipcc keeps ONE v_cvt_pk_bf16_f32 (RNE) per pair (it otherwise converts the low
+// half a second time for the shift) and leaves the residuals as plain v_sub_f32 (no v_pk_add_f32 + moves).
+__device__ __forceinline__ void dw_split8(const float (&x)[8], u32x4 (&plane)[3]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lo = x[2 * q], hi = x[2 * q + 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      unsigned w;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+      plane[p][q] = w;
+      if (p < 2) {
+        lo -= __uint_as_float(w << 16);                  // exact: the residual has <= 16 (8) significant bits
+        hi -= __uint_as_float(w & 0xffff0000u);
+      }
+    }
+  }
+}
+
+// kSplit = false: exact f32 products (v_mfma_f32_16x16x4_f32).  kSplit = true: split-bf16 products, two
+// register sets of 32 rows.
+template <int BO, int BI, bool kSplit>
 __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int i0, int z, float* lds) {
   using VA = typename DwVec<BO>::type;
   using VB = typename DwVec<BI>::type;
@@ -111,10 +153,10 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
 #pragma unroll
     for (int b = 0; b < BI; ++b) {
       acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      // accumulators in AGPRs: with VGPR-form MFMAs hipcc (ROCm 7.2) allocates destinations that
-      // partially overlap SrcC / contain SrcA (v[8:11] <- v8, v35, v[10:13]) in the pipelined loop;
-      // the same pattern produced wrong fragment halves in mlp_chain.hip's 8-wave instance
-      asm volatile("" : "+a"(acc[a][b]));
+      // f32 form: accumulators pinned to AGPRs (keeps every MFMA in place and the 114 VGPRs for the three
+      // load sets).  Split form: NO AGPRs - hipcc halves the register budget of a kernel that uses any
+      // (128 + 128 at two workgroups per CU), and the two 64-register load sets + planes need ~244 VGPRs.
+      if constexpr (!kSplit) asm volatile("" : "+a"(acc[a][b]));
     }
   }
   // row pointers of this lane, advanced by one batch (16 rows) at a time
@@ -138,6 +180,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(dw_get<BO>(av, a), dw_get<BI>(bv, b), acc[a][b], 0, 0, 0);
     }
   };
+  if constexpr (!kSplit) {
   // Full batches: kDwSets register sets, kDwSets-1 batches of loads in flight while one issues its
   // MFMAs.  All tiles of a K-slice stream their band of rows at the same time, so every load of a
   // workgroup sees first-touch (HBM / Infinity Cache) latency even when the line counts as an L2 hit:
@@ -195,6 +238,99 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
     }
     mfma_step(av, bv);
   }
+  } else {
+    // split-bf16: a batch is 8 k-steps = the K = 32 of one bf16 MFMA; the lane's 8 k values of a block
+    // are element (block) of its 8 row vectors - A and B agree on the row order, which is all a sum needs
+    constexpr int S = 2;
+    constexpr int KB = kDwSplitBatch;
+    auto load8 = [&](VA (&av)[KB], VB (&bv)[KB]) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        av[u] = *reinterpret_cast<const VA*>(ra + u * step_a);
+        bv[u] = *reinterpret_cast<const VB*>(rb + u * step_b);
+      }
+      ra += KB * step_a;
+      rb += KB * step_b;
+    };
+    auto compute8 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
+      RLG_DW_PIN();
+      u32x4 pb[BI][3];
+#pragma unroll
+      for (int b = 0; b < BI; ++b) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], b);
+        dw_split8(x, pb[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < BO; ++a) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], a);
+        u32x4 pa[3];
+        dw_split8(x, pa);
+        // small terms first; consecutive MFMAs go to different accumulators
+        constexpr int kPa[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int kPb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+          for (int b = 0; b < BI; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa[kPa[t]]),
+                                                                __builtin_bit_cast(bf16x8, pb[b][kPb[t]]),
+                                                                acc[a][b], 0, 0, 0);
+        }
+      }
+      RLG_DW_PIN();
+    };
+    int s = s_begin;
+    const int nb = (s_full_end > s_begin) ? (s_full_end - s_begin) / KB : 0;
+    {
+      VA av[S][KB];
+      VB bv[S][KB];
+      const int plain = (nb >= S - 1) ? (nb - (S - 1)) % S : nb;
+      const bool piped = nb - plain >= S - 1;
+      if (piped) {
+#pragma unroll
+        for (int j = 0; j < S - 1; ++j) load8(av[j], bv[j]);
+      }
+#pragma unroll 1
+      for (int e = 0; e < plain; ++e) {
+        load8(av[S - 1], bv[S - 1]);
+        compute8(av[S - 1], bv[S - 1]);
+      }
+      if (piped) {
+#pragma unroll 1
+        for (int t = plain + S - 1; t < nb; t += S) {
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            load8(av[(j + S - 1) % S], bv[(j + S - 1) % S]);
+            compute8(av[j], bv[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < S - 1; ++j) compute8(av[j], bv[j]);
+      }
+    }
+    s += nb * KB;
+    // tail batches (and the ragged last rows): predicated, zero-filled
+#pragma unroll 1
+    for (; s < s_end; s += KB) {
+      VA av[KB];
+      VB bv[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const long long r = 4LL * (s + u) + kq;
+        av[u] = dw_zero<BO>();
+        bv[u] = dw_zero<BI>();
+        if (s + u < s_end && r < rows) {
+          av[u] = *reinterpret_cast<const VA*>(pa + r * L.lda);
+          bv[u] = *reinterpret_cast<const VB*>(pb + r * L.ldb);
+        }
+      }
+      compute8(av, bv);
+    }
+  }
 
   // ---- combine the 4 waves' K-slices through LDS.  Fragment q = a*BI + b; wave w finishes the PER
   //      consecutive fragments [w*PER, (w+1)*PER) - consecutive b of one a, so it stores PER
@@ -250,7 +386,8 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
+template <bool kSplit>
+__device__ __forceinline__ void mlp_dw_body(const DwArgs& args) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 16 * 64 * 4];     // 64 KiB
   int l = 0;
 #pragma unroll 1
@@ -280,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
   const int o0 = L.o_start[to], i0 = L.i_start[ti];
   const int bo = L.o_b[to], bi = L.i_b[ti];
 #define RLG_DW_CASE(BO_, BI_) \
-  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_>(L, args.rows, o0, i0, z, lds); return; }
+  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_, kSplit>(L, args.rows, o0, i0, z, lds); return; }
   RLG_DW_CASE(4, 4)
   RLG_DW_CASE(4, 2)
   RLG_DW_CASE(4, 1)
@@ -292,6 +429,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) {
   RLG_DW_CASE(1, 1)
 #undef RLG_DW_CASE
 }
+
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) { mlp_dw_body<false>(args); }
+__global__ __launch_bounds__(256, 2) void mlp_dw_bf16x6_kernel(DwArgs args) { mlp_dw_body<true>(args); }
 
 // The PPO loss partials ride along too (what ppo_loss_finalize_kernel does in a launch of its own,
 // csrc/ppo_loss.hip): block 0 of the item folds the 7 scalar columns (losses, KL, sum of d values),
@@ -548,7 +688,7 @@ static int dw_max_b(const void* p, long long ld, int width) {
 
 extern "C" {
 
-// Plans one layer: writes {0, tiles_o, tiles_i, ksplit} and returns the workspace floats needed,
+// Plans one layer (target_blocks <= 0: the default): writes {0, tiles_o, tiles_i, ksplit} and returns the workspace floats needed,
 // or -1 when the shape is not supported (caller falls back to the library GEMM).  The tile split
 // itself is recomputed at launch from the operand alignment; the counts here assume 16-byte aligned
 // operands with ld % 4 == 0 unless in/out features say otherwise.
@@ -565,10 +705,14 @@ long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int targe
   if (tiles_o < 0 || tiles_i < 0) return -1;
   // k-slices: a multiple of 8 (one XCD per slice of rows) with >= 2 prefetch batches per wave
   const int steps = (rows + 3) / 4;
+  const int batch = dw_split_products() ? kDwSplitBatch : kDwBatch;
+  // default workgroup count (32,768 rows: 80 us at 256 / 89 us at 1,024 in the split form, 171 / 119 us with
+  // f32 products, whose workgroups are 2.5x longer; a rank's 4,096-row minibatch wants <= 16 slices either way)
+  if (target_blocks <= 0) target_blocks = (dw_split_products() || rows <= 8192) ? 256 : 1024;
   int ksplit = 8;
-  while (ksplit * 2 <= 64 && steps / (ksplit * 2 * 4) >= 2 * kDwBatch && tiles_o * tiles_i * ksplit < target_blocks)
+  while (ksplit * 2 <= 64 && steps / (ksplit * 2 * 4) >= 2 * batch && tiles_o * tiles_i * ksplit < target_blocks)
     ksplit *= 2;
-  while (ksplit > 1 && steps / (ksplit * 4) < kDwBatch) ksplit /= 2;
+  while (ksplit > 1 && steps / (ksplit * 4) < batch) ksplit /= 2;
   plan4[0] = 0;
   plan4[1] = tiles_o;
   plan4[2] = tiles_i;
@@ -634,7 +778,8 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
     lf.num_blocks = 1 + (2 * lf.d.actions_num + kLfCols - 1) / kLfCols;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
+  if (dw_split_products()) hipLaunchKernelGGL(mlp_dw_bf16x6_kernel, dim3(blocks), dim3(256), 0, st, args);
+  else hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
   NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
   if (finalize_blocks_out) *finalize_blocks_out = lf.num_blocks + cs_blocks + fin_blocks;
   hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(lf.num_blocks + cs_blocks + fin_blocks), dim3(256), 0, st, args, cs,

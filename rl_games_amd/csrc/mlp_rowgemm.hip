@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256, 2) void mlp_rowgemm_kernel(RowGemmArgs p) {
     for (int b = 0; b < kRgMaxNB; ++b) b_cur[b] = b_nxt[b];
   }
   mfma_panel(a_cur, b_cur);
+  // One more issue slot in front of the first read of an accumulator: the MFMA result is not interlocked
+  // against VALU reads (18 wait states for this shape) and hipcc counts one short across the branches of
+  // the last panel (tools/audit_mfma.py; csrc/mlp_chain.hip has the measurements).
+  asm volatile("s_nop 0" : "+v"(acc[0]));
+#pragma unroll
+  for (int b = 1; b < kRgMaxNB; ++b) asm volatile("" : "+v"(acc[b]));
 
   // ---- epilogue: acc[b][q] is C[m0 + (q&3) + 8*(q>>2) + 4h][n0 + 32b + j]
 #pragma unroll

@@ -5,6 +5,8 @@ happens here - shapes/dtypes are checked and raw pointers are handed to librlg_h
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -625,8 +627,8 @@ class MlpDwPlan:
         lib = _lib.load()
         n = len(shapes)
         if target_blocks is None:
-            # K-slices per layer: a rank's 4,096-row minibatch has too few rows per slice at 32 slices
-            target_blocks = 1024 if int(rows) > 8192 else 256
+            # 0: the library's default workgroup count; RLG_DW_BLOCKS: A/B measurements of it (tools only)
+            target_blocks = max(int(os.environ.get('RLG_DW_BLOCKS') or 0), 0)
         self.rows, self.n, self.shapes = int(rows), n, [tuple(s) for s in shapes]
         self._plans = (ctypes.c_int * (4 * n))()
         self.workspaces = []

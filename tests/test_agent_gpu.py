@@ -887,3 +887,85 @@ def test_two_rank_training_keeps_ranks_in_sync(kind):
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert f'TWO_RANK_CHECK {kind} in_sync' in res.stdout
+
+
+class _HostVecEnv:
+    """A CPU vector env behind the IVecEnv seam (rl_games/common/ivecenv.py:1-36).  numpy=True hands out
+    what a gym-style CPU env does (float64 observations / rewards, bool dones, numpy actions expected,
+    a2c_common.py:663-673,:705-722); numpy=False hands the SAME numbers out as device tensors."""
+
+    def __init__(self, numpy_io, num_envs, obs_dim, act_dim=0, discrete_actions=None, autoreset_mode='same_step'):
+        self.inner = SyntheticTensorEnv(num_envs, obs_dim, act_dim, device='cpu', seed=77,
+                                        discrete_actions=discrete_actions, autoreset_mode=autoreset_mode)
+        self.numpy_io = numpy_io
+        self.action_kinds = set()
+
+    def _out(self, t, dtype=None):
+        if self.numpy_io:
+            a = t.numpy()
+            return a.astype(dtype) if dtype is not None else a
+        return t.to(DEV)
+
+    def reset(self):
+        return self._out(self.inner.reset(), np.float64)
+
+    def step(self, actions):
+        self.action_kinds.add(type(actions).__name__)
+        if self.numpy_io:
+            assert isinstance(actions, np.ndarray) and actions.shape[0] == self.inner.num_envs
+        obs, rewards, dones, infos = self.inner.step(None)
+        time_outs = infos['time_outs']
+        return (self._out(obs, np.float64), self._out(rewards, np.float64), self._out(dones.bool()),
+                {'time_outs': time_outs.numpy() if self.numpy_io else time_outs.to(DEV)})
+
+    def get_env_info(self):
+        return self.inner.get_env_info()
+
+    def __getattr__(self, name):          # has_action_masks, set_train_info, get_env_state ...
+        return getattr(self.inner, name)
+
+
+@pytest.mark.parametrize('kind', ['continuous', 'discrete'])
+def test_numpy_vec_env_plumbing_equals_the_tensor_env(kind):
+    """BASELINE.json config #1 as stated - a CPU env speaking numpy (cast_obs / env_step branches,
+    a2c_common.py:663-673,:705-722): two epochs on numpy observations / rewards / dones must leave the very
+    same parameters as the same numbers handed over as device tensors."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+
+    def run(numpy_io):
+        torch.manual_seed(5)
+        if kind == 'discrete':
+            params = configs.cartpole_discrete(num_actors=16, device=DEV)
+            env = _HostVecEnv(numpy_io, 16, 4, discrete_actions=2, autoreset_mode='next_step')
+            cls = DiscreteA2CAgent
+        else:
+            params = configs.tiny(num_actors=64, horizon=8, obs_dim=12, act_dim=3, device=DEV)
+            env = _HostVecEnv(numpy_io, 64, 12, 3)
+            cls = A2CAgent
+        params['config']['vec_env'] = env
+        params['config']['env_info'] = env.get_env_info()
+        params['config']['seed'] = 11
+        agent = cls('host_env', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        assert agent.is_tensor_obses == (not numpy_io)
+        assert agent.obs['obs'].dtype == torch.float32 and agent.obs['obs'].device.type == 'cuda'
+        results = []
+        for _ in range(2):
+            agent.epoch_num += 1
+            results.append(agent.train_epoch())
+        assert env.action_kinds == ({'ndarray'} if numpy_io else {'Tensor'})
+        return agent, results
+
+    a_np, r_np = run(True)
+    a_t, r_t = run(False)
+    for x, y in zip(r_np, r_t):
+        for u, v in zip(x[4] + x[5] + x[6] + x[7], y[4] + y[5] + y[6] + y[7]):     # losses, entropies, KLs
+            assert torch.isfinite(u).all() and torch.equal(u, v)
+    for (k, p), (_, q) in zip(a_np.model.state_dict().items(), a_t.model.state_dict().items()):
+        assert torch.equal(p, q), k
+    buf_np, buf_t = a_np.experience_buffer.tensor_dict, a_t.experience_buffer.tensor_dict
+    for k in ('obses', 'rewards', 'dones', 'actions'):
+        assert torch.equal(buf_np[k], buf_t[k]), k

@@ -61,10 +61,12 @@ def test_cpu_tensors_fail_loudly():
         compute_gae(x, x, torch.zeros(4, 2), torch.zeros(2, 1), torch.zeros(2), 0.99, 0.95)
 
 
-def test_no_mfma_destination_overlaps_a_source():
-    """Build audit (tools/audit_mfma.py): hipcc may allocate a VGPR-form v_mfma_f32_16x16x4_f32 whose
-    destination partially overlaps SrcC or contains SrcA/SrcB; on gfx950 that produced wrong result
-    halves.  The kernels pin accumulators to AGPRs; this fails if a build brings the pattern back."""
+def test_no_mfma_result_is_read_inside_its_hazard_window():
+    """Build audit (tools/audit_mfma.py): on gfx950 a VALU / LDS / store read of an MFMA result is NOT
+    interlocked (10 wait states for v_mfma_f32_16x16x4_f32, 8 for v_mfma_f32_16x16x32_bf16, measured with
+    tools/exp/mfma_valu_read_probe.hip) and hipcc counts one short across branches; the kernels carry an
+    explicit s_nop in front of their epilogues.  Fails if any control-flow path of a build reads a result
+    register too early."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('audit_mfma', os.path.join(ROOT, 'tools', 'audit_mfma.py'))
     mod = importlib.util.module_from_spec(spec)

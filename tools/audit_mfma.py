@@ -2,12 +2,26 @@
 
     python tools/audit_mfma.py [rl_games_amd/librlg_hip.so]
 
-hipcc (ROCm 7.2) may allocate the destination of a VGPR-form v_mfma_f32_16x16x4_f32 so that it
-PARTIALLY overlaps its own SrcC, or contains its SrcA / SrcB register (LLVM treats that as legal for
-128-bit results).  On gfx950 this produced wrong halves of the result fragment (found with the 8-wave
-instances of csrc/mlp_chain.hip: v_mfma v[16:19], v7, v17, v[18:21]).  The kernels pin their accumulators
-to AGPRs (asm volatile("" : "+a"(acc))), which keeps every MFMA in place; this audit fails if a build
-contains the pattern again.  Exit status 1 and a listing when it finds one."""
+What it guards.  On gfx950 the result registers of an MFMA must not be read by a non-MFMA instruction
+(VALU incl. v_accvgpr_read, LDS / global stores, addresses) - nor as SrcA / SrcB of another MFMA - before
+`passes + 2` (f32 operands) / `passes + 3` (bf16 / f16 / 8-bit operands) wait states have gone by; only the
+SrcC dependency of a following MFMA is interlocked by the hardware.  Measured with
+tools/exp/mfma_valu_read_probe.hip: v_mfma_f32_16x16x4_f32 needs 10 wait states before the first read of
+a result register other than the first one, v_mfma_f32_16x16x32_bf16 needs 8 before any read; earlier
+reads return the OLD register contents, silently.  hipcc (ROCm 7.2) inserts the s_nops in straight-line
+code but MISSED them across a branch: in the 8-wave backward instance of csrc/mlp_chain.hip the last
+MFMAs of a K-tail case were followed by `s_cbranch_execnz` to the merge point, whose first instruction
+(v_pk_add_f32 of accumulator registers 2,3) ran 2 wait states after the MFMA - fragment registers 2
+and 3 came out wrong for K <= 32 (tools/exp/chain_nopin_repro.py reproduces it).  The overlap of an MFMA
+destination with its own sources, suspected first, is harmless (tools/exp/mfma_overlap_probe.hip,
+mfma_chain_probe.hip: every form gives identical results, dependent chains included).
+
+The audit walks every control-flow path behind each MFMA (branch targets decoded from the
+disassembly) and fails on a read of a result register inside the window.  A wait state is one issue slot of the
+wave (4 cycles: the measured windows, 10 and 8, are the 40- and 32-cycle latencies of the two shapes); they
+are counted the way LLVM's hazard recognizer does - one per instruction, N + 1 for s_nop N - except that a
+following MFMA cannot start before the passes of the audited one have left the matrix core.  Exit status 1
+and a listing."""
 import os
 import re
 import shutil
@@ -17,19 +31,152 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-PAT = re.compile(r'(v_mfma\S*)\s+([av])\[(\d+):(\d+)\],\s*([^,\s]+),\s*([^,\s]+),\s*([av])\[(\d+):(\d+)\]')
+
+LINE = re.compile(r'^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):')
+REG = re.compile(r'\b([av])(?:\[(\d+):(\d+)\]|(\d+))')
+# passes of the MFMA shapes the kernels may use (4 cycles each); wait states = passes + 2 / + 3
+PASSES = (
+    (re.compile(r'v_mfma_f32_32x32x2_?f32'), 16, 2),
+    (re.compile(r'v_mfma_f32_16x16x4_?f32'), 8, 2),    # measured: 10
+    (re.compile(r'v_mfma_f32_32x32x1_'), 16, 2),
+    (re.compile(r'v_mfma_f32_16x16x1_'), 8, 2),
+    (re.compile(r'v_mfma_f32_4x4x1_'), 2, 2),
+    (re.compile(r'v_mfma_f32_32x32x16_'), 16, 3),
+    (re.compile(r'v_mfma_f32_16x16x32_'), 8, 0),      # measured: 8 (hipcc leaves 8)
+    (re.compile(r'v_mfma_f32_32x32x8_'), 16, 3),
+    (re.compile(r'v_mfma_f32_16x16x16_'), 8, 3),
+)
+STORES = ('global_store', 'buffer_store', 'flat_store', 'scratch_store', 'ds_write', 'ds_store', 'global_atomic',
+          'buffer_atomic', 'flat_atomic', 'ds_add', 'ds_max', 'ds_min')
+READS_DST = ('v_fmac', 'v_mac', 'v_pk_fmac', 'v_dot2c', 'v_dot4c', 'v_dot8c', 'v_movrel', 'v_writelane',
+             'v_cndmask')     # (v_cndmask listed only to stay conservative with tied forms)
 
 
-def _regs(tok):
-    m = re.match(r'([av])\[(\d+):(\d+)\]$', tok) or re.match(r'([av])(\d+)$', tok)
-    if not m:
-        return None
-    g = m.groups()
-    return (g[0], int(g[1]), int(g[-1]))
+def passes_of(mnemonic):
+    for pat, passes, _ in PASSES:
+        if pat.match(mnemonic):
+            return passes
+    return 1
+
+
+def _window(mnemonic):
+    for pat, passes, extra in PASSES:
+        if pat.match(mnemonic):
+            return passes + extra
+    return 19 if mnemonic.startswith('v_mfma') or mnemonic.startswith('v_smfmac') else 0
+
+
+def _regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        k, lo, hi, one = m.groups()
+        if one is not None:
+            out.add((k, int(one)))
+        else:
+            out.update((k, r) for r in range(int(lo), int(hi) + 1))
+    return out
+
+
+def _split_operands(ops):
+    return [o.strip() for o in ops.split(',')] if ops else []
+
+
+def _parse(text):
+    """-> list of functions, each a list of (address, mnemonic, operand text)."""
+    funcs, cur = [], None
+    for line in text.splitlines():
+        if re.match(r'^[0-9a-f]+ <.*>:$', line):
+            cur = []
+            funcs.append(cur)
+            continue
+        m = LINE.match(line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return funcs
+
+
+def _successors(func):
+    index = {addr: i for i, (addr, _, _) in enumerate(func)}
+    succ = []
+    for i, (addr, mn, ops) in enumerate(func):
+        s = []
+        if mn in ('s_endpgm', 's_setpc_b64', 's_swappc_b64'):
+            succ.append(s)
+            continue
+        if mn.startswith('s_branch') or mn.startswith('s_cbranch'):
+            simm = int(ops.split()[0])
+            if simm >= 1 << 15:
+                simm -= 1 << 16
+            t = index.get(addr + 4 + 4 * simm)
+            if t is not None:
+                s.append(t)
+            if mn.startswith('s_cbranch') and i + 1 < len(func):
+                s.append(i + 1)
+        elif i + 1 < len(func):
+            s.append(i + 1)
+        succ.append(s)
+    return succ
+
+
+def _sources_and_dests(mn, ops):
+    """-> (registers read, registers written) of a non-MFMA instruction (conservative)."""
+    o = _split_operands(ops)
+    if not o:
+        return set(), set()
+    if mn.startswith(STORES):
+        return _regs(ops), set()
+    dst = _regs(o[0])
+    src = set()
+    for t in o[1:]:
+        src |= _regs(t)
+    if mn.startswith(READS_DST):
+        src |= dst
+    return src, dst
+
+
+def audit_function(func):
+    """-> (number of MFMAs, [(mfma line, reader line, wait states)])."""
+    succ = _successors(func)
+    count, bad = 0, []
+    for i, (addr, mn, ops) in enumerate(func):
+        win = _window(mn)
+        if not win:
+            continue
+        count += 1
+        o = _split_operands(ops)
+        live0 = frozenset(_regs(o[0]))
+        # breadth-first over (instruction, wait states so far, result registers not yet overwritten)
+        seen, todo = set(), [(j, 0, live0) for j in succ[i]]
+        while todo:
+            j, ws, live = todo.pop()
+            if ws >= win or not live or (j, ws, live) in seen:
+                continue
+            seen.add((j, ws, live))
+            _, mn2, ops2 = func[j]
+            step = 1
+            if mn2 == 's_nop':
+                step = int(ops2.split()[0]) + 1
+            elif _window(mn2):
+                o2 = _split_operands(ops2)
+                if (_regs(o2[1]) | _regs(o2[2])) & live:      # SrcA / SrcB: not interlocked
+                    bad.append((f'{addr:x}: {mn} {ops}', f'{func[j][0]:x}: {mn2} {ops2}', ws))
+                    continue
+                live = live - _regs(o2[0]) if _regs(o2[0]) != set(live0) else live    # in place: same hazard class
+                # the next MFMA cannot start before the passes of this one are through the matrix core
+                step = max(passes_of(mn) - ws, 0) + 1
+            elif mn2.startswith(('v_', 'ds_', 'global_', 'buffer_', 'flat_', 'scratch_')):
+                src, dst = _sources_and_dests(mn2, ops2)
+                if src & live:
+                    bad.append((f'{addr:x}: {mn} {ops}', f'{func[j][0]:x}: {mn2} {ops2}', ws))
+                    continue
+                live = live - dst
+            for k in succ[j]:
+                todo.append((k, ws + step, live))
+    return count, bad
 
 
 def audit(lib_path):
-    """-> (number of MFMA instructions, [offending disassembly lines])."""
+    """-> (number of MFMA instructions, [offending 'mfma -> reader (wait states)' lines])."""
     work = tempfile.mkdtemp(prefix='rlg_audit_')
     try:
         local = os.path.join(work, os.path.basename(lib_path))
@@ -39,22 +186,12 @@ def audit(lib_path):
         if not objs:
             raise RuntimeError('no device code object found in ' + lib_path)
         count, bad = 0, []
-        for co in objs:
+        for co in sorted(objs):
             text = subprocess.run([OBJDUMP, '-d', co], check=True, capture_output=True, text=True).stdout
-            for line in text.splitlines():
-                m = PAT.search(line)
-                if not m:
-                    continue
-                count += 1
-                _, dk, d0, d1, sa, sb, ck, c0, c1 = m.groups()
-                d0, d1, c0, c1 = int(d0), int(d1), int(c0), int(c1)
-                partial = dk == ck and not (d1 < c0 or c1 < d0) and (d0, d1) != (c0, c1)
-                inside = False
-                for tok in (sa, sb):
-                    r = _regs(tok)
-                    inside = inside or (r is not None and r[0] == dk and not (r[2] < d0 or d1 < r[1]))
-                if partial or inside:
-                    bad.append(line.strip())
+            for func in _parse(text):
+                n, b = audit_function(func)
+                count += n
+                bad += [f'{m}  ->  {r}   ({ws} wait states)' for m, r, ws in b]
         return count, bad
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -63,7 +200,7 @@ def audit(lib_path):
 if __name__ == '__main__':
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'rl_games_amd', 'librlg_hip.so')
     n, bad = audit(path)
-    print(f'{path}: {n} MFMA instructions, {len(bad)} with a destination overlapping a source')
-    for b in bad:
+    print(f'{path}: {n} MFMA instructions, {len(bad)} result reads inside the hazard window')
+    for b in bad[:60]:
         print('   ', b)
     sys.exit(1 if bad else 0)
