@@ -25,7 +25,8 @@ Prints ONE JSON line on rank 0 with the contract keys plus
     `traffic` = HBM bytes per launch measured by rocprofv3 --pmc on THIS command
     (tools/gpu_pmc_bench_gae.sh writes profiles/gae_pmc_traffic.json; null if that file does not
     cover the workload),
-  * `roofline_mfma`: the weight-gradient launch against the dense fp32 MFMA peak,
+  * `roofline_mfma`: the weight-gradient launch against the dense MFMA peak of the instruction it issues
+    (bf16 for the default split-product form, with the fp32-equivalent rate beside it),
   * at N=1 `cpu_baseline`: the CPU port of the reference epoch (oracle/ppo_epoch_oracle.py) timed on
     this box's host cores on a bounded sample, at the reference's default threading AND on all
     cores, with the port -> untouched-reference calibration measured in the build container
@@ -46,6 +47,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; no sparsity)
 GAE_BYTES_PER_ENV_STEP = 17   # r 4 + v 4 + done 1 read, returns 4 + advantages 4 written
 
 WORKLOADS = {
@@ -234,12 +236,27 @@ def main():
         us = ev0.elapsed_time(ev1) * 1e3 / reps
         rows = jobs[0][0].shape[0]
         flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
-        mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch pair)',
-                'bound': 'mfma', 'achieved': flops / us / 1e6, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                'algorithmic_flops_per_launch': flops, 'avg_launch_us': us, 'launches': reps,
-                'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
-                        '(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); timed after the timed region'}
+        split = os.environ.get('RLG_DW_BF16', '1') != '0'
+        useful = flops / us / 1e6                               # fp32 products per second, as TFLOP/s
+        if split:
+            # six bf16 plane products per fp32 product (csrc/mlp_dw.hip): priced against the bf16 peak
+            mfma = {'kernel': 'rlg::mlp_dw_bf16x6_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one '
+                              'launch pair; fp32 products as six exact bf16 plane products)',
+                    'bound': 'mfma', 'achieved': 6.0 * useful, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': 6.0 * useful / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'algorithmic_flops_per_launch': 6.0 * flops, 'avg_launch_us': us, 'launches': reps,
+                    'fp32_equivalent_tflops': useful, 'fp32_equivalent_over_fp32_mfma_peak': useful / FP32_MFMA_PEAK_TFLOPS,
+                    'note': 'issued flops = 6 x useful 2*rows*sum(No*Mi) (tile padding not counted) against the dense '
+                            'bf16 MFMA peak (v_mfma_f32_16x16x32_bf16, MI355X_MICROARCH.md); fp32_equivalent_* = the '
+                            'useful fp32 products against the fp32 MFMA peak (157.3) that RLG_DW_BF16=0 would be '
+                            'priced on; timed after the timed region'}
+        else:
+            mfma = {'kernel': 'rlg::mlp_dw_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch pair)',
+                    'bound': 'mfma', 'achieved': useful, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': useful / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'algorithmic_flops_per_launch': flops, 'avg_launch_us': us, 'launches': reps,
+                    'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
+                            '(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); timed after the timed region'}
 
     traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
     try:
@@ -270,6 +287,9 @@ def main():
                 'lr_schedule': 'adaptive (device side)', 'mixed_precision': False,
                 'mlp': 'fused chain kernels' if (eng is not None and getattr(eng, 'chain', None) is not None)
                        else 'per-layer engine',
+                'weight_gradient_products': ('split-bf16 (six exact bf16 plane products per fp32 product, fp32 '
+                                             'accumulation; as accurate against fp64 as exact fp32 products)'
+                                             if os.environ.get('RLG_DW_BF16', '1') != '0' else 'exact fp32'),
             },
             'roofline': {
                 'kernel': f'rlg::gae_envmajor_kernel<{horizon},false> (GAE + returns + advantages + fp64 moments)',
