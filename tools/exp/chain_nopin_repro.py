@@ -1,5 +1,15 @@
 """Repro of the wrong dZ that the 8-wave backward instance produces when its MFMA accumulators are NOT
-pinned to AGPRs (tools/exp/_build/librlg_nopin.so via RLG_HIP_LIB): where are the wrong elements?"""
+pinned to AGPRs and no explicit s_nop precedes the epilogue: where are the wrong elements?
+
+Build the variant next to the product library and point RLG_HIP_LIB at it:
+    cd rl_games_amd/csrc
+    sed 's/asm volatile("" : "+a"(acc\[f\]\[g\]));/;/; s/asm volatile("" : "+a"(acc_odd));/;/; s/asm volatile("s_nop 0" : "+a"(acc\[0\]\[0\]));/;/' \
+        mlp_chain.hip > _v.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. -c _v.hip -o /tmp/v.o
+    hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v mlp_chain.o) /tmp/v.o -o ../../tools/exp/_build/librlg_nopin.so
+    RLG_HIP_LIB=$PWD/../../tools/exp/_build/librlg_nopin.so python ../../tools/exp/chain_nopin_repro.py
+(python tools/audit_mfma.py tools/exp/_build/librlg_nopin.so lists the reads inside the hazard window;
+profiles/r2_mfma_hazard_probes.txt has the output of both.)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rl_games_amd import ops
