@@ -431,3 +431,19 @@ def test_random_network_shapes_fuzz():
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     assert '0 bad of 60' in res.stdout, [l for l in res.stdout.splitlines() if 'BAD' in l][:5]
+
+
+def test_dw_exact_f32_product_form_passes_the_same_tests():
+    """The weight gradients default to split-bf16 products (csrc/mlp_dw.hip); RLG_DW_BF16=0 selects the
+    exact-f32 kernel.  The library reads the variable once per process, so the dW tests of this file and of
+    test_ops_gpu.py are re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLG_DW_BF16='0')
+    res = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_ops_gpu.py', 'tests/test_mlp_chain_gpu.py', '-q', '-m', 'gpu',
+                          '-k', 'dw and not exact_f32', '-p', 'no:cacheprovider'],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
+    assert ' passed' in res.stdout and 'failed' not in res.stdout, res.stdout[-500:]
