@@ -77,3 +77,56 @@ def test_no_mfma_result_is_read_inside_its_hazard_window():
     count, bad = mod.audit(_lib.LIB_PATH)
     assert count > 1000, count            # the fused MLP kernels are in there
     assert not bad, bad[:5]
+
+
+def _audit_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('audit_mfma', os.path.join(ROOT, 'tools', 'audit_mfma.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _listing(instrs):
+    """[(mnemonic, operands)] -> the (address, mnemonic, operands) form of audit_function, 4 bytes apart."""
+    return [(0x100 + 4 * i, mn, ops) for i, (mn, ops) in enumerate(instrs)]
+
+
+def test_mfma_audit_catches_the_hazards_it_is_meant_to():
+    """The audit itself, on hand-written listings: the sequence that produced wrong results on gfx950 (a
+    result read 2 wait states behind the MFMA, reached through a taken branch), its straight-line form, a
+    read as SrcA of another MFMA - and the forms that are fine (10 wait states, SrcC chains, overwritten
+    results, the 8-wait-state window of the bf16 shape)."""
+    mod = _audit_module()
+    mfma = ('v_mfma_f32_16x16x4_f32', 'v[16:19], v7, v17, v[16:19]')
+    read = ('v_pk_add_f32', 'v[0:1], v[14:15], v[18:19]')
+    # straight line, too early / late enough
+    n, bad = mod.audit_function(_listing([mfma, ('s_nop', '7'), read, ('s_endpgm', '')]))
+    assert n == 1 and len(bad) == 1 and bad[0][2] == 8
+    n, bad = mod.audit_function(_listing([mfma, ('s_nop', '9'), read, ('s_endpgm', '')]))
+    assert n == 1 and not bad
+    # the shape of the real defect: MFMA, taken branch over a block that has its own wait states, early read
+    prog = [mfma, ('s_cbranch_execnz', '3'), ('s_nop', '15'), ('v_mov_b32_e32', 'v40, v16'), ('s_endpgm', ''),
+            ('s_waitcnt', 'vmcnt(0)'), read, ('s_endpgm', '')]
+    n, bad = mod.audit_function(_listing(prog))
+    assert [b[2] for b in bad] == [2], bad                         # only the path through the branch is short
+    # SrcC of a following MFMA is interlocked; SrcA / SrcB are not
+    chain = [mfma, ('v_mfma_f32_16x16x4_f32', 'v[20:23], v8, v9, v[16:19]'), ('s_nop', '15'), ('s_nop', '15'), ('s_endpgm', '')]
+    assert not mod.audit_function(_listing(chain))[1]
+    as_a = [mfma, ('v_mfma_f32_16x16x4_f32', 'v[20:23], v16, v9, v[20:23]'), ('s_nop', '15'), ('s_nop', '15'), ('s_endpgm', '')]
+    assert len(mod.audit_function(_listing(as_a))[1]) == 1
+    # a result register that is overwritten first is no longer the MFMA's
+    over = [mfma, ('v_mov_b32_e32', 'v18, v1'), ('v_mov_b32_e32', 'v19, v1'), read, ('s_nop', '15'), ('s_endpgm', '')]
+    assert not mod.audit_function(_listing(over))[1]
+    # stores read their data operand; AGPR results are read by v_accvgpr_read
+    st = [mfma, ('s_nop', '3'), ('global_store_dwordx4', 'v[2:3], v[16:19], off'), ('s_endpgm', '')]
+    assert len(mod.audit_function(_listing(st))[1]) == 1
+    agpr = [('v_mfma_f32_16x16x4_f32', 'a[0:3], v7, v17, a[0:3]'), ('s_nop', '8'), ('v_accvgpr_read_b32', 'v5, a3'), ('s_endpgm', '')]
+    assert [b[2] for b in mod.audit_function(_listing(agpr))[1]] == [9]
+    # bf16 16x16x32: 8 wait states
+    bf = ('v_mfma_f32_16x16x32_bf16', 'v[16:19], v[4:7], v[8:11], v[16:19]')
+    assert len(mod.audit_function(_listing([bf, ('s_nop', '6'), read, ('s_endpgm', '')]))[1]) == 1
+    assert not mod.audit_function(_listing([bf, ('s_nop', '7'), read, ('s_endpgm', '')]))[1]
+    # an MFMA in between cannot start before the passes of the first one have left the matrix core
+    between = [mfma, ('v_mfma_f32_16x16x4_f32', 'v[24:27], v8, v9, v[24:27]'), ('s_nop', '0'), read, ('s_nop', '15'), ('s_nop', '15'), ('s_endpgm', '')]
+    assert not [b for b in mod.audit_function(_listing(between))[1] if b[0].startswith('100:')]
