@@ -1,22 +1,13 @@
+# PMC passes over the split-product weight-gradient launch (tools/bench_mlp_chain.py, 32,768 rows, default plan)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_dw
-mkdir -p $OUT
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o v -- python $GRAFT_REPO_ROOT/tools/bench_dw_mfma.py 32768 256 > /dev/null 2>&1
+rm -rf $OUT; mkdir -p $OUT
+CMD="python $GRAFT_REPO_ROOT/tools/bench_mlp_chain.py --rows 32768 --no-lib --dw-blocks 256 --groups 2 --reps 5"
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  D=$OUT/$(echo $C | tr ' ' '_' | cut -c1-40)
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o v -- $CMD > /dev/null 2>&1
+  rm -f $D/*kernel_trace.csv
 done
-python - <<'PY'
-import csv, os, collections, glob
-root = os.path.join(os.environ['GRAFT_REPO_ROOT'], 'gpurun_out/pmc_dw')
-for C in ('FETCH_SIZE', 'WRITE_SIZE'):
-    files = glob.glob(os.path.join(root, C, '*counter_collection.csv'))
-    if not files:
-        print(C, 'no counter file'); continue
-    rows = list(csv.DictReader(open(files[0])))
-    agg = collections.defaultdict(list)
-    for r in rows:
-        if r.get('Counter_Name') == C and 'mlp_dw' in r['Kernel_Name']:
-            agg[(r['Kernel_Name'][:40], r.get('Grid_Size', '?'))].append(float(r['Counter_Value']))
-    for k, v in sorted(agg.items()):
-        print(f'{C} {k[0]:40s} grid {k[1]:>8s} n={len(v)} mean={sum(v)/len(v):.1f} KiB min={min(v):.1f} max={max(v):.1f}')
-PY
-rm -rf $OUT/*/v_kernel_trace.csv
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT mlp_dw > $OUT/summary.txt
+rm -rf $OUT/*/
+cat $OUT/summary.txt
