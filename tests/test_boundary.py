@@ -130,3 +130,37 @@ def test_mfma_audit_catches_the_hazards_it_is_meant_to():
     # an MFMA in between cannot start before the passes of the first one have left the matrix core
     between = [mfma, ('v_mfma_f32_16x16x4_f32', 'v[24:27], v8, v9, v[24:27]'), ('s_nop', '0'), read, ('s_nop', '15'), ('s_nop', '15'), ('s_endpgm', '')]
     assert not [b for b in mod.audit_function(_listing(between))[1] if b[0].startswith('100:')]
+
+
+def test_dw_plan_defaults_follow_the_product_form():
+    """rlg_mlp_dw_plan is host code: the default workgroup target (target_blocks <= 0) gives the split-bf16
+    form (default) 16 / 16 / 32 / 64 K-slices for the BASELINE MLP at 32,768 rows and the exact-f32 form
+    (RLG_DW_BF16=0, read once per process) 64 each; a rank's 4,096-row minibatch never gets fewer than two
+    batches per wave."""
+    import ctypes
+    import subprocess
+    import sys
+    code = ('import ctypes, json; from rl_games_amd import _lib; lib = _lib.load(); out = {}\n'
+            'for rows in (32768, 4096, 64):\n'
+            '    ks = []\n'
+            '    for No, Mi in ((400, 108), (200, 400), (100, 200), (22, 100)):\n'
+            '        p = (ctypes.c_int * 4)(); need = lib.rlg_mlp_dw_plan(rows, No, Mi, 0, p)\n'
+            '        assert need == p[3] * No * Mi, (need, list(p))\n'
+            '        ks.append(p[3])\n'
+            '    out[rows] = ks\n'
+            'print(json.dumps(out))')
+    import json
+    got = {}
+    for form in ('1', '0'):
+        res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=120,
+                             env=dict(os.environ, RLG_DW_BF16=form))
+        assert res.returncode == 0, res.stderr[-1500:]
+        got[form] = {int(k): v for k, v in json.loads(res.stdout.strip().splitlines()[-1]).items()}
+    assert got['1'][32768] == [16, 16, 32, 64] and got['0'][32768] == [64, 64, 64, 64], got
+    for form, batch in (('1', 8), ('0', 4)):
+        for rows, ks in got[form].items():
+            steps = (rows + 3) // 4
+            assert all(k >= 1 and (k == 1 or steps // (k * 4) >= batch) for k in ks), (form, rows, ks)
+    from rl_games_amd import _lib
+    p = (ctypes.c_int * 4)()
+    assert _lib.load().rlg_mlp_dw_plan(64, 10, 7, 0, p) == -1        # 70 elements: not a multiple of 4
