@@ -1,3 +1,4 @@
+# (replaces the round-1 script of the same name - FETCH_SIZE / WRITE_SIZE over tools/bench_dw_mfma.py, profiles/r1_dw_pmc.txt)
 # PMC passes over the split-product weight-gradient launch (tools/bench_mlp_chain.py, 32,768 rows, default plan)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_dw
