@@ -1,0 +1,64 @@
+"""CPU: the arithmetic of the split-bf16 weight gradients (csrc/mlp_dw.hip: dw_split8 + six bf16 plane
+products per fp32 product, fp32 accumulation) restated with torch - the plane decomposition is exact and the
+truncated sum is as accurate against fp64 as a plain fp32 product.  (The kernel itself is checked against
+fp64 and the library on the GPU: tests/test_ops_gpu.py, tests/test_mlp_chain_gpu.py, tools/exp/dw_bf16_check.py.)"""
+import pytest
+import torch
+
+
+def _planes(t):
+    """x -> (x0, x1, x2): bf16 values (as fp32) by round-to-nearest-even of the running residual."""
+    out, r = [], t.clone()
+    for _ in range(3):
+        p = r.bfloat16().float()
+        out.append(p)
+        r = r - p                      # exact in fp32: the residual has <= 16 (8) significant bits
+    return out, r
+
+
+KEPT = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]      # order of the kernel: small terms first
+
+
+def _split_matmul(a, b):
+    (pa, _), (pb, _) = _planes(a), _planes(b)
+    acc = torch.zeros(a.shape[0], b.shape[1])
+    for i, j in KEPT:
+        acc += pa[i] @ pb[j]           # products of bf16 values are exact in fp32; fp32 accumulation
+    return acc
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e-4, 3e3])
+def test_three_bf16_planes_reproduce_an_fp32_value_exactly(scale):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(100000, generator=g) * scale * torch.exp(3.0 * torch.randn(100000, generator=g))
+    x[:4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-20])
+    planes, rest = _planes(x)
+    assert torch.equal(planes[0] + planes[1] + planes[2], x)
+    assert torch.count_nonzero(rest) == 0
+    # every plane is a bf16 value: 8 significant bits, the low 16 bits of its fp32 pattern are zero
+    for p in planes:
+        assert torch.all((p.view(torch.int32) & 0xFFFF) == 0)
+    # each plane is at most half an ulp (2^-8 relative) of the one above it
+    assert torch.all(planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-45)
+    assert torch.all(planes[2].abs() <= planes[1].abs() * 2.0 ** -8 + 1e-45)
+
+
+@pytest.mark.parametrize('rows,No,Mi', [(4096, 200, 400), (4096, 22, 100), (512, 64, 60)])
+def test_six_plane_products_are_as_accurate_as_an_fp32_product(rows, No, Mi):
+    """dW = dZ^T X on gradient-like / activation-like operands: error against fp64 relative to |dZ|^T |X|.
+    The dropped terms (x1 y2, x2 y1, x2 y2) are <= 3 * 2^-24 |x||y| per product - one fp32 rounding."""
+    g = torch.Generator().manual_seed(rows + No)
+    dz = torch.randn(rows, No, generator=g) * torch.exp(2.0 * torch.randn(rows, 1, generator=g)) * 1e-4
+    x = torch.nn.functional.elu(torch.randn(rows, Mi, generator=g))
+    ref = dz.double().t() @ x.double()
+    scale = dz.double().abs().t() @ x.double().abs()
+    err_split = ((_split_matmul(dz.t().contiguous(), x).double() - ref).abs() / scale)
+    err_fp32 = (((dz.t() @ x).double() - ref).abs() / scale)
+    # (absolute level: the fp32 ACCUMULATION of a few thousand heavy-tailed rows, common to both forms)
+    assert err_split.max() < 2e-6 and err_split.pow(2).mean().sqrt() < 3e-7
+    assert err_split.max() <= 1.5 * err_fp32.max() + 1e-8
+    assert err_split.pow(2).mean().sqrt() <= 1.5 * err_fp32.pow(2).mean().sqrt() + 1e-9
+    # three products only (x0 y0, x0 y1, x1 y0) would NOT do: an order of magnitude worse
+    (pa, _), (pb, _) = _planes(dz.t().contiguous()), _planes(x)
+    three = pa[0] @ pb[0] + pa[0] @ pb[1] + pa[1] @ pb[0]
+    assert ((three.double() - ref).abs() / scale).pow(2).mean().sqrt() > 5 * err_split.pow(2).mean().sqrt()
