@@ -23,6 +23,10 @@
 //     no atomics) and writes W.grad;
 //   * loads are software-pipelined in batches of 4 k-steps (16 rows): the next batch is in flight
 //     while the 4*BO*BI MFMAs of the current one issue;
+//   * the default form (split-bf16 products) keeps exactly this data movement: 8 k-steps (32 rows) make the
+//     K = 32 of one v_mfma_f32_16x16x32_bf16 - a lane's 8 k values of a block are element (block) of its 8
+//     row vectors, A and B agree on that order and a sum needs no more - split into three bf16 planes per
+//     operand in registers, 6*BO*BI MFMAs per batch;
 //   * every layer of the MLP is a work item of the same launch (descriptor table).
 // Numerics: fp32 accumulation of products that are exact (f32 form) or exact up to 3 * 2^-24 |x||y| (split-bf16
 // form, the default: six bf16 plane products per fp32 product on the 16x16x32 bf16 MFMA, see dw_split8) -
