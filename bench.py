@@ -1,8 +1,11 @@
 """bench.py - PPO env-steps/s of the MI355X hot path on BASELINE.json's headline workload.
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload humanoid|ant]
+    python bench.py --gpus 1 --steps K --warmup W [--workload humanoid|ant|lstm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    RLG_BENCH_CONFIG='{"native_allreduce": false}' ... bench.py --gpus N ...   (second row: RCCL gradient all-reduce
+        instead of the in-graph hipIpc kernel; '{"native_allreduce_two_phase": true}': its reduce-scatter + all-gather
+        variant).  tools/scale_check.sh runs the N = 1, 2, 4, 8 rows of both.
 
 One "step" = one full PPO epoch of rl_games' ContinuousA2CBase.train_epoch on a synthetic,
 device-resident workload: rollout with policy inference and every buffer write, GAE, dataset
@@ -12,6 +15,8 @@ preparation, every minibatch forward / fused loss / backward / clip / Adam / ada
       = 320 optimiser steps per epoch
   ant (BASELINE.json configs[1]): obs 60, act 8, 4,096 envs x horizon 16, MLP [256,128,64],
       minibatch 32,768, 4 mini-epochs
+  lstm (BASELINE.json configs[4]): LSTM policy, obs 3, act 1, 4,096 envs x seq_len 16, MLP [64,64] + LSTM 64,
+      minibatch 16,384, 4 mini-epochs
 Inputs are generated on the device (no PCIe in the timed region).  With N GPUs the envs (and the
 minibatch) are sharded N ways ("strong" scaling) with one gradient all-reduce per
 optimiser step.
@@ -27,14 +32,22 @@ Prints ONE JSON line on rank 0 with the contract keys plus
     cover the workload),
   * `roofline_mfma`: the weight-gradient launch against the dense MFMA peak of the instruction it issues
     (bf16 for the default split-product form, with the fp32-equivalent rate beside it),
+  * `roofline_fwd` / `roofline_bwd`: the two dominant kernels of the epoch (fused forward / fused backward chain,
+    csrc/mlp_chain.hip) against the dense fp32 MFMA peak: useful flops / mean launch duration over ALL their
+    launches of one eager epoch run after the timed region (HIP events bound to each dispatch, like the GAE
+    launch; inside the timed region they are nodes of a replayed HIP graph and cannot carry events),
+  * at N>1 `config.allreduce` ("ipc" | "ipc-two-phase" | "rccl": the collective that ran), `config.ipc_self_test`,
+    `config.ranks_in_sync`,
   * at N=1 `cpu_baseline`: the CPU port of the reference epoch (oracle/ppo_epoch_oracle.py) timed on
     this box's host cores on a bounded sample, at the reference's default threading AND on all
     cores, with the port -> untouched-reference calibration measured in the build container
     (profiles/cpu_baseline_calibration.json, tools/cpu_reference_baseline.py).
 """
 import argparse
+import datetime
 import json
 import os
+import signal
 import statistics
 import sys
 import time
@@ -57,6 +70,9 @@ WORKLOADS = {
     'ant': dict(envs=4096, horizon=16, minibatch=32768, mini_epochs=4, obs=60, act=8, units=[256, 128, 64],
                 desc='Ant-v5-shaped PPO epoch (BASELINE.json configs[1]): obs 60, act 8, 4096 envs x horizon 16 global, '
                      'MLP [256,128,64] elu, fixed sigma'),
+    'lstm': dict(envs=4096, horizon=16, minibatch=16384, mini_epochs=4, obs=3, act=1, units=[64, 64],
+                 desc='LSTM-policy PPO epoch (BASELINE.json configs[4], play_steps_rnn path): Pendulum-shaped obs 3, act 1, '
+                      '4096 envs x seq_len 16, MLP [64,64] elu + LSTM 64, fixed sigma'),
 }
 
 
@@ -65,6 +81,9 @@ def make_params(workload, num_actors, minibatch, device, multi_gpu=False):
     if workload == 'humanoid':
         return configs.humanoid_65536(num_actors=num_actors, minibatch_size=minibatch, device=device,
                                       multi_gpu=multi_gpu)
+    if workload == 'lstm':
+        return configs.pendulum_lstm_4096(num_actors=num_actors, minibatch_size=minibatch, device=device,
+                                          multi_gpu=multi_gpu)
     return configs.ant_4096(num_actors=num_actors, minibatch_size=minibatch, device=device, multi_gpu=multi_gpu)
 
 
@@ -116,6 +135,8 @@ def cpu_baseline(workload, sample_envs):
         'sample': f'{sample_envs} envs x {w["horizon"]} (1/{max(1, w["envs"] // sample_envs)} of the workload), same '
                   f'model / minibatch / mini-epochs, 1 warm-up + 2 timed epochs per row, host cores {cores}',
         'seconds_per_epoch': d['seconds_per_epoch'], 'rows': rows, 'calibration': calibration,
+        'host_cores': cores, 'host_cores_note': 'cores of THIS box; calibration.host_cores = the build container the '
+                                                'port -> reference factor was measured on',
         'rows_note': "'all_cores' uses min(host cores, 16) torch threads (more threads run this workload slower)",
     }
     if calibration is not None:
@@ -131,13 +152,29 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='humanoid')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-envs', type=int, default=0, help='0: 4096 (humanoid) / 1024 (ant)')
+    ap.add_argument('--cpu-sample-envs', type=int, default=0, help='0: 4096 (humanoid) / 1024 (ant, lstm)')
+    ap.add_argument('--max-seconds', type=int, default=1500, help='watchdog: the process exits non-zero with a '
+                    'message instead of hanging (a peer rank that died, a collective that never completes)')
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
+
+    def on_alarm(signum, frame):
+        sys.stderr.write(f'bench.py: watchdog - no result after {args.max_seconds} s (rank '
+                         f'{os.environ.get("RANK", "0")}); a rank died or a collective never completed. Aborting.\n')
+        sys.stderr.flush()
+        os._exit(3)
+    signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(args.max_seconds)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # dmabuf IPC is the only mode the driver supports (hipIpcGetMemHandle fails otherwise: RCCL and the
+    # in-graph all-reduce both need it); must be in the environment before the HIP runtime starts
+    if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') != '0':
+        sys.stderr.write('bench.py: overriding HSA_ENABLE_IPC_MODE_LEGACY=%s with 0 (dmabuf IPC)\n'
+                         % os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node '
@@ -153,7 +190,10 @@ def main():
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         import torch.distributed as dist
-        dist.init_process_group(rdist.backend_for(True), rank=rank, world_size=world)
+        # every collective of the set-up and of RCCL itself is bounded: a rank that died makes the others fail
+        # with a message instead of waiting for ever
+        dist.init_process_group(rdist.backend_for(True), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=min(600, args.max_seconds)))
 
     from rl_games_amd.agent import A2CAgent
     global_envs, horizon = w['envs'], w['horizon']
@@ -168,6 +208,9 @@ def main():
     params['config']['gemm_tuning_online'] = args.warmup >= 1
     # A/B measurements of optional code paths (tools/gpu_r2_call*.sh): RLG_BENCH_CONFIG='{"fused_loss": false}'
     overrides = json.loads(os.environ.get('RLG_BENCH_CONFIG', '{}'))
+    if multi:
+        # the in-graph all-reduce gives up (fail-safe, all ranks then raise) well inside the watchdog's bound
+        params['config'].setdefault('native_allreduce_timeout_s', 120.0)
     params['config'].update(overrides)
     torch.manual_seed(42 + rank)
     agent = A2CAgent('bench', params)
@@ -258,6 +301,41 @@ def main():
                     'note': 'useful flops 2*rows*sum(No*Mi) (tile padding not counted); dense fp32 MFMA peak '
                             '(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); timed after the timed region'}
 
+    # rooflines of the two dominant kernels: one more epoch, eagerly (no HIP graphs), every chain dispatch bracketed
+    # by HIP events; all ranks run it together (it contains the usual collectives)
+    chain_roof = {}
+    if eng is not None and getattr(eng, 'chain', None) is not None:
+        from rl_games_amd import ops
+        agent._hip_graphs = False
+        ops.chain_timers = {}
+        agent.update_epoch()
+        agent.train_epoch()
+        torch.cuda.synchronize()
+        timers, ops.chain_timers = ops.chain_timers, None
+        ins, outs = eng.chain.ins, eng.chain.outs
+        macs_f = sum(i * o for i, o in zip(ins, outs))
+        macs_b = sum(i * o for i, o in zip(ins[1:], outs[1:]))
+        mb_rows = global_mb // world
+        for key, kind, rows, macs, name in (
+                ('roofline_fwd', 'fwd_train', mb_rows, macs_f, 'rlg::mlp_chain_fwd_kernel (training forward: statistics '
+                 'fold + normalise + every layer + heads, activations written)'),
+                ('roofline_fwd_infer', 'fwd_infer', envs, macs_f, 'rlg::mlp_chain_fwd_kernel (rollout inference forward)'),
+                ('roofline_bwd', 'bwd_loss', mb_rows, macs_b, 'rlg::mlp_chain_bwd_kernel (PPO loss tile + dX chain + '
+                 'activation backward + bias partials)')):
+            each = [p.elapsed_us() for p in timers.get(kind, [])]
+            if not each:
+                continue
+            us = sum(each) / len(each)
+            tf = 2.0 * rows * macs / us / 1e6
+            chain_roof[key] = {
+                'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'rows': rows,
+                'algorithmic_flops_per_launch': 2.0 * rows * macs, 'avg_launch_us': us, 'launches': len(each),
+                'launch_us_min': min(each), 'launch_us_max': max(each),
+                'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
+                          'timed region (= rocprofv3 --kernel-trace begin/end); exact fp32 products on '
+                          'v_mfma_f32_16x16x4_f32, useful flops 2*rows*sum(in*out), tile padding not counted'}
+
     traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
     try:
         with open(os.path.join(ROOT, 'profiles', 'gae_pmc_traffic.json')) as f:
@@ -304,10 +382,23 @@ def main():
         }
         if mfma is not None:
             out['roofline_mfma'] = mfma
+        out.update(chain_roof)
         if in_sync is not None:
+            comm = agent._ipc_comm or None
             out['config']['ranks_in_sync'] = in_sync
+            out['config']['allreduce'] = (('ipc-two-phase' if comm.two_phase else 'ipc') if comm is not None else 'rccl')
+            out['config']['allreduce_note'] = (
+                'in-graph hipIpc all-reduce kernel (csrc/ipc_allreduce.hip), inside the mini-epoch HIP graph'
+                if comm is not None else 'RCCL all-reduce via torch.distributed between two graph replays per step'
+                + ('' if params['config'].get('native_allreduce', True) is False
+                   else ' (FALLBACK: the hipIpc communicator could not be created or failed its self-test)'))
+            out['config']['ipc_self_test'] = ('passed' if comm is not None else
+                                              ('not requested' if params['config'].get('native_allreduce', True) is False
+                                               else 'failed'))
+            out['config']['hsa_enable_ipc_mode_legacy'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample_envs or (4096 if args.workload == 'humanoid' else 1024)
+            signal.alarm(0)          # the CPU baseline is bounded by construction
             out['cpu_baseline'] = cpu_baseline(args.workload, sample)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))

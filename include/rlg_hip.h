@@ -185,6 +185,30 @@ int rlg_rms_update(const double* partials, int num_blocks, int cols, long long t
 int rlg_rms_apply(const float* x, float* y, long long rows, int cols, const double* running_mean,
                   const double* running_var, float eps, int mode, void* stream);
 
+/* Cross-rank synchronisation of ALL running normalisers of an agent, once per epoch (multi-GPU).
+ *   replaces rl_games/common/a2c_common.py: _running_stats_totals :43-47, seed_stats_sync_snapshot
+ *   :50-58, merge_rank_stats :61-93, broadcast_rank_stats :124-141; called from
+ *   A2CBase.sync_running_stats :782-808 and _seed_stats_sync_snapshots :766-780.
+ * The reference runs ~12 fp64 torch ops and THREE collectives per normaliser; here normaliser s
+ * (state: means[s] / vars[s] fp64 [dims[s]], counts[s] int64 scalar) is the segment
+ *   [count | first moments [dims[s]] | second moments [dims[s]]]
+ * of one flat fp64 buffer (segments back to back, rlg_stats_sync_flat_size doubles), so an epoch's
+ * exchange is pack -> ONE collective over the flat buffer -> apply.  num_segments <= 8.  Same fp64
+ * operations in the same order as the reference (bit-identical statistics for identical reduced
+ * sums); counts travel as doubles (exact below 2^53).  has_snapshot[s] == 0: the segment's whole
+ * history is rank-local (no merge yet, :72-74) - its base is zero.
+ * pack  mode 0: out = totals(state) - snapshot (this epoch's deltas);  mode 1: snapshot = totals(state)
+ *       (after loading a checkpoint; out unused);  mode 2: out = raw state [count, mean, var] (broadcast mode).
+ * apply mode 0: totals = snapshot + reduced;  mean = s1/n, var = max(s2/n - mean^2, 1e-8);  snapshot = totals;
+ *       mode 2: state = reduced (rank 0's raw state after a broadcast). */
+long long rlg_stats_sync_flat_size(int num_segments, const int* dims);
+int rlg_stats_sync_pack(int num_segments, double* const* means, double* const* vars, long long* const* counts,
+                        const int* dims, const int* has_snapshot, double* snapshot, double* out, int mode,
+                        void* stream);
+int rlg_stats_sync_apply(int num_segments, double* const* means, double* const* vars, long long* const* counts,
+                         const int* dims, const int* has_snapshot, double* snapshot, const double* reduced, int mode,
+                         void* stream);
+
 int rlg_prepare_stats_bytes(void);
 
 /* value_size==1 prepare_dataset statistics from the GAE kernel's partial moments: updates the
@@ -291,13 +315,16 @@ int rlg_grad_sumsq(const float* grads, long long n, float grad_scale, double* pa
  * norm_partials is given.  step = *step_counter is the 1-based Adam step (device word, advanced
  * by rlg_grad_sumsq); lr_slots[(step-1)&1] is the lr of this step, the other slot receives the next
  * lr (schedule_kind 1: KL-adaptive on *kl * kl_scale).  stats_out[4] = {total_norm, clip_coef,
- * lr_used, lr_next}.  No per-call host scalars: the pair replays from a captured HIP graph. */
+ * lr_used, lr_next}.  No per-call host scalars: the pair replays from a captured HIP graph.
+ * skip_flag_or_null: device word (rlg_ipc_comm_error_word); non-zero = the gradients are invalid
+ * (a failed in-graph all-reduce): parameters and moments stay untouched, the lr is carried over. */
 int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                   const double* norm_partials_or_null, int norm_blocks, float grad_scale,
                   float max_norm, double* lr_slots, const long long* step_counter, double beta1,
                   double beta2, double eps, double weight_decay, int schedule_kind,
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
-                  double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream);
+                  double max_lr, double lr_multiplier, float* stats_out_or_null,
+                  const unsigned* skip_flag_or_null, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Manual MLP backward helpers
@@ -408,6 +435,10 @@ int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* o
 /* tools only: the following forward launches record shader-clock stamps per phase into
  * buffer [blocks][4 waves][32] (int64); NULL switches it off. */
 int rlg_mlp_chain_debug_stamps(long long* buffer);
+/* HIP events (rlg_event_create) bound to the NEXT chain dispatch (forward or backward), one-shot; not for
+ * launches inside a graph capture.  bench.py's roofline_fwd / roofline_bwd. */
+int rlg_mlp_chain_time_next(void* ev_start, void* ev_stop);
+
 int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,
                           const int* in_features, const int* out_features, const int* acts,
                           float* const* act_out, const long long* act_ld, const float* x, long long ldx,
@@ -481,13 +512,23 @@ int rlg_lstm_seq_backward(const float* gates, const float* c_all, const float* c
  *   memory and returns its hipIpcMemHandle_t (rlg_ipc_handle_bytes() bytes); the host exchanges the
  *   handles (any channel), rlg_ipc_comm_connect maps the peers; rlg_ipc_allreduce_sum is then ONE
  *   kernel launch (no host sync, capturable in a HIP graph) that leaves the identical rank-ordered
- *   sum in `data` on every rank.  A peer that never arrives makes the launch give up after a few
- *   seconds (rlg_ipc_comm_status reports its ordinal) instead of hanging the device.
+ *   sum in `data` on every rank.  The wait for the peers is bounded by wall time (default 600 s,
+ *   RLG_IPC_TIMEOUT_S / rlg_ipc_comm_set_timeout; <= 0 = unbounded).  A launch that gives up, and every
+ *   launch after it, is fail-safe: zeros instead of a sum of stale data in `data`, the sticky error word
+ *   (rlg_ipc_comm_error_word) set - rlg_adam_step takes that word as its skip flag, so no parameter is
+ *   touched by invalid gradients - and rlg_ipc_comm_status reports the launch ordinal.
+ *   rlg_ipc_comm_create fails (the caller then uses RCCL) when the runtime has no fine-grained device
+ *   memory: the protocol needs mid-kernel visibility across devices.
+ *   Variant 1 (rlg_ipc_comm_set_variant / RLG_IPC_TWO_PHASE): reduce-scatter + all-gather - 2/P of the
+ *   bytes per xGMI link, two synchronisations; same bits as the one-shot variant.
  * ---------------------------------------------------------------------------------- */
 int rlg_ipc_handle_bytes(void);
 int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_out, void* handle_out);
 int rlg_ipc_comm_connect(void* comm, const void* all_handles /* world x handle bytes, rank-major */);
 int rlg_ipc_comm_fine_grained(void* comm);
+int rlg_ipc_comm_set_timeout(void* comm, double seconds);
+int rlg_ipc_comm_set_variant(void* comm, int two_phase);
+int rlg_ipc_comm_error_word(void* comm, unsigned** word_out);
 int rlg_ipc_allreduce_sum(void* comm, float* data, long long n, void* stream);
 /* The same launch with a by-product: norm_partials[rlg_ipc_allreduce_norm_blocks()] = per-workgroup sums of
  * (reduced x * grad_scale)^2 over the first norm_n elements (the gradients; the arena's tail slots are not),

@@ -471,6 +471,64 @@ def pooled_merge(state, snapshot, all_reduce_sum):
     return new_state, (n.clone(), s1.clone(), s2.clone())
 
 
+class StatsSyncOracle:
+    """CPU restatement of the flat-buffer form of the pooled merge that the product runs as two
+    kernels around one collective (rl_games_amd/distributed.py:StatsSync, csrc/running_stats.hip):
+    same interface as rl_games_amd.ops.StatsSyncKernels, arithmetic = stats_totals / pooled_merge above
+    (rl_games/common/a2c_common.py:43-93, :124-141) segment by segment.  Test infrastructure."""
+
+    PACK_DELTAS, PACK_SEED, PACK_STATE = 0, 1, 2
+    APPLY_MERGE, APPLY_STATE = 0, 2
+
+    def __init__(self, modules):
+        self.modules = list(modules)
+        self.dims = [int(m.running_mean.numel()) for m in self.modules]
+        self.offsets, off = [], 0
+        for d in self.dims:
+            self.offsets.append(off)
+            off += 1 + 2 * d
+        self.flat_size = off
+
+    def _state(self, m):
+        return {'count': m.count.detach().cpu(), 'running_mean': m.running_mean.detach().cpu(),
+                'running_var': m.running_var.detach().cpu()}
+
+    def pack(self, has_snapshot, snapshot, out, mode):
+        for m, d, o, has in zip(self.modules, self.dims, self.offsets, has_snapshot):
+            st = self._state(m)
+            if mode == self.PACK_STATE:
+                vals = (st['count'].double().reshape(1), st['running_mean'], st['running_var'])
+            else:
+                n, s1, s2 = stats_totals(st)
+                vals = (n.double().reshape(1), s1, s2)
+            flat = torch.cat([v.reshape(-1) for v in vals])
+            if mode == self.PACK_SEED:
+                snapshot[o:o + 1 + 2 * d] = flat.to(snapshot.device)
+            elif mode == self.PACK_DELTAS and has:
+                out[o:o + 1 + 2 * d] = (flat - snapshot[o:o + 1 + 2 * d].cpu()).to(out.device)
+            else:
+                out[o:o + 1 + 2 * d] = flat.to(out.device)
+
+    def apply(self, has_snapshot, snapshot, reduced, mode):
+        for m, d, o, has in zip(self.modules, self.dims, self.offsets, has_snapshot):
+            seg = reduced[o:o + 1 + 2 * d].cpu()
+            if mode == self.APPLY_STATE:
+                m.count.copy_(seg[0].to(torch.int64))
+                m.running_mean.copy_(seg[1:1 + d])
+                m.running_var.copy_(seg[1 + d:])
+                continue
+            base = snapshot[o:o + 1 + 2 * d].cpu() if has else torch.zeros(1 + 2 * d, dtype=torch.float64)
+            n = base[0] + seg[0]
+            s1 = base[1:1 + d] + seg[1:1 + d]
+            s2 = base[1 + d:] + seg[1 + d:]
+            mean = s1 / n
+            var = (s2 / n - mean ** 2).clamp_(min=1e-8)
+            m.count.copy_(n.to(torch.int64))
+            m.running_mean.copy_(mean)
+            m.running_var.copy_(var)
+            snapshot[o:o + 1 + 2 * d] = torch.cat([n.reshape(1), s1, s2]).to(snapshot.device)
+
+
 # --------------------------------------------------------------------------------------
 # a3 - per-step rollout glue
 # --------------------------------------------------------------------------------------

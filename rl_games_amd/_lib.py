@@ -53,6 +53,9 @@ _PROTOTYPES = {
     'rlg_column_moments_segments': [_P, _c_ll, _c_int, _c_int, _P, _c_int, _P, _P],
     'rlg_rms_update': [_P, _c_int, _c_int, _c_ll, _c_int, _P, _P, _P, _P, _P],
     'rlg_rms_apply': [_P, _P, _c_ll, _c_int, _P, _P, _c_float, _c_int, _P],
+    'rlg_stats_sync_flat_size': [_c_int, _P],
+    'rlg_stats_sync_pack': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
+    'rlg_stats_sync_apply': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _P],
     'rlg_prepare_stats_bytes': [],
     'rlg_triple_moments_num_blocks': [_c_ll],
     'rlg_triple_moments': [_P, _P, _P, _P, _c_ll, _P, _c_int, _P],
@@ -76,6 +79,7 @@ _PROTOTYPES = {
     'rlg_mlp_chain_num_blocks': [_c_ll, _c_int],
     'rlg_mlp_chain_lds_bytes': [_c_int, _P, _P, _c_int, _c_int],
     'rlg_mlp_chain_debug_stamps': [_P],
+    'rlg_mlp_chain_time_next': [_P, _P],
     'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                               _P, _P, _P, _P, _P, _c_ll, _c_int, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P],
@@ -97,6 +101,9 @@ _PROTOTYPES = {
     'rlg_ipc_comm_create': [_c_int, _c_int, _c_ll, ctypes.POINTER(_P), _P],
     'rlg_ipc_comm_connect': [_P, ctypes.c_char_p],
     'rlg_ipc_comm_fine_grained': [_P],
+    'rlg_ipc_comm_set_timeout': [_P, _c_double],
+    'rlg_ipc_comm_set_variant': [_P, _c_int],
+    'rlg_ipc_comm_error_word': [_P, ctypes.POINTER(_P)],
     'rlg_ipc_allreduce_sum': [_P, _P, _c_ll, _P],
     'rlg_ipc_allreduce_norm_blocks': [],
     'rlg_ipc_allreduce_sum_norm': [_P, _P, _c_ll, _P, _c_ll, _c_float, _P, _P],
@@ -107,7 +114,7 @@ _PROTOTYPES = {
     'rlg_grad_sumsq': [_P, _c_ll, _c_float, _P, _c_int, _P, _P],
     'rlg_adam_step': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
                       _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
-                      _c_double, _c_double, _c_double, _P, _P],
+                      _c_double, _c_double, _c_double, _P, _P, _P],
 }
 
 _lib = None
@@ -121,7 +128,7 @@ def exported_prototypes():
     return dict(_PROTOTYPES)
 
 
-_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan'}
+_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan', 'rlg_stats_sync_flat_size'}
 
 
 def load():

@@ -391,6 +391,8 @@ class A2CAgent:
         self._hip_graphs = bool(config.get('hip_graphs', True))
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_epoch = None
+        self._graph_norm_state = None
+        self.last_allreduce = None    # 'ipc' | 'rccl' once a multi-GPU step has run (bench.py reports it)
         self._graph_failed = False
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
         self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
@@ -1145,7 +1147,9 @@ class A2CAgent:
             if self.multi_gpu and self.config.get('native_allreduce', True):
                 try:
                     from .ipc_allreduce import IpcAllReduce
-                    self._ipc_comm = IpcAllReduce(self.optimizer.flat_grads.numel(), self.ppo_device)
+                    self._ipc_comm = IpcAllReduce(self.optimizer.flat_grads.numel(), self.ppo_device,
+                                                  timeout_s=self.config.get('native_allreduce_timeout_s'),
+                                                  two_phase=self.config.get('native_allreduce_two_phase'))
                 except Exception as e:
                     print(f'rl_games_amd: native all-reduce unavailable ({type(e).__name__}: {e}); using RCCL')
                     self._ipc_comm = False
@@ -1157,16 +1161,21 @@ class A2CAgent:
         if comm is not None:
             # a plain kernel launch: capturable.  The reduced gradients pass through its registers, so it
             # also leaves the sums of squares clip_grad_norm_ needs (no grad_sumsq launch behind it).
-            opt = self.optimizer
-            norm = None
-            if self.config.get('norm_in_allreduce', True):
-                if self._ar_norm_partials is None:
-                    self._ar_norm_partials = torch.zeros(comm.norm_blocks(), dtype=torch.float64, device=self.ppo_device)
-                norm = (self._ar_norm_partials, opt.numel, 1.0 / self.world_size, opt.step_counter)
-                self._norm_ready = (self._ar_norm_partials, comm.norm_blocks())
-            comm.all_reduce_sum(opt.flat_grads, norm=norm)
+            comm.all_reduce_sum(self.optimizer.flat_grads, norm=self._all_reduce_norm_plan(comm))
         else:
             rdist.all_reduce_sum(self.optimizer.flat_grads)
+        self.last_allreduce = 'ipc' if comm is not None else 'rccl'
+
+    def _all_reduce_norm_plan(self, comm):
+        """The `norm` argument of the native all-reduce launch; also tells the optimiser launch (eager or about
+        to be captured) that the gradient norm partials will be there.  Launches nothing."""
+        if comm is None or not self.config.get('norm_in_allreduce', True):
+            return None
+        opt = self.optimizer
+        if self._ar_norm_partials is None:
+            self._ar_norm_partials = torch.zeros(comm.norm_blocks(), dtype=torch.float64, device=self.ppo_device)
+        self._norm_ready = (self._ar_norm_partials, comm.norm_blocks())
+        return (self._ar_norm_partials, opt.numel, 1.0 / self.world_size, opt.step_counter)
 
     def trancate_gradients_and_step(self):
         """a2c_common.py:493-514 (+ the per-minibatch lr control of :1557-1563)."""
@@ -1184,7 +1193,10 @@ class A2CAgent:
                   and self.config.get('norm_in_finalize', True)
                   and eng.gradient_elements() == self.optimizer.numel)
             if ok:
-                self._fin_norm_partials = torch.zeros(1 << 15, dtype=torch.float64, device=self.ppo_device)
+                # one entry per finalise workgroup: ~ one per 64 weights + the bias / loss blocks (MlpDwPlan.
+                # finalize_blocks); a plan that still needs more falls back to grad_sumsq (mlp_engine._weight_grads)
+                entries = max(1 << 15, eng.gradient_elements() // 64 + 8192)
+                self._fin_norm_partials = torch.zeros(entries, dtype=torch.float64, device=self.ppo_device)
             self._fin_norm_ok = ok
         return ok
 
@@ -1194,8 +1206,11 @@ class A2CAgent:
         schedule = None
         if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
             schedule = self.scheduler.device_rule()
+        # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
+        # are invalid (a peer never arrived) changes nothing
+        skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
         opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
-                 schedule=schedule, kl_scale=scale, norm_ready=self._norm_ready)
+                 schedule=schedule, kl_scale=scale, norm_ready=self._norm_ready, skip_flag=skip)
         self._norm_ready = None
 
     # ------------------------------------------------------------------ HIP graphs
@@ -1275,13 +1290,19 @@ class A2CAgent:
             item = self.dataset[i]
             g = self._graphs[i] = self._capture(lambda: self._with_fold(i, self._forward_loss_backward, item,
                                                                        self._graph_rows[i]))
+            self._graph_norm_state = self._norm_ready      # what the captured launches will have produced
+        if self._graph_opt is None:
+            # Captured BEFORE anything of this minibatch runs (a failed capture then leaves minibatch i untouched
+            # for the eager path), knowing which launch in front of it produces the gradient norm - the
+            # weight-gradient finalise on one GPU, the native all-reduce on several - so that the graph carries no
+            # grad_sumsq of its own.
+            self._norm_ready = self._graph_norm_state
+            if self.multi_gpu:
+                self._all_reduce_norm_plan(self._native_comm())
+            self._graph_opt = self._capture(self._optimizer_kernels)
         g.replay()
         if self.multi_gpu:
             self._all_reduce_grads()
-        if self._graph_opt is None:
-            # captured AFTER the launches that may already have produced the gradient norm (the weight-gradient
-            # finalise on one GPU, the native all-reduce on several): the graph then carries no grad_sumsq
-            self._graph_opt = self._capture(self._optimizer_kernels)
         self._norm_ready = None
         self._graph_opt.replay()
         self.optimizer.step_count += 1
@@ -1406,10 +1427,18 @@ class A2CAgent:
         self._fold_ready = False
         self.sync_running_stats()
         if self._ipc_comm:
+            # one host read per epoch; the verdict is collective, so that every rank raises in the same epoch
+            # instead of one rank leaving the others to hang in their next collective
             _, timed_out = self._ipc_comm.status()
-            if timed_out:
-                raise RuntimeError(f'in-graph all-reduce: launch {timed_out} gave up waiting for a peer rank '
-                                   f'(a rank stalled for ~10 s or died); gradients of this epoch are invalid')
+            flag = torch.tensor([float(timed_out != 0)], device=self.ppo_device)
+            import torch.distributed as dist
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() != 0:
+                raise RuntimeError(f'in-graph all-reduce: a launch gave up waiting for a peer rank (this rank: '
+                                   f'launch {timed_out or "none"}); the optimiser steps behind it were skipped on the '
+                                   f'rank that gave up - parameters may differ between ranks, aborting on all ranks. '
+                                   f'Raise native_allreduce_timeout_s / RLG_IPC_TIMEOUT_S for legitimately long rank '
+                                   f'skews, or set native_allreduce: False to use RCCL.')
         self._eager_epochs += 0 if use_graphs else 1
         if device_schedule:
             # one host read per epoch: [lr the last minibatch was stepped with, lr for the next one]
@@ -1440,23 +1469,36 @@ class A2CAgent:
                 mods.append(cv_model.value_mean_std)
         return mods
 
+    def _stats_sync(self):
+        """One StatsSync over every normaliser of the agent (actor + central value): an epoch's exchange is
+        two launches and ONE collective (csrc/running_stats.hip, distributed.StatsSync)."""
+        mods = self._stats_sync_modules()
+        if not mods:
+            return None
+        sync = getattr(self, '_stats_sync_obj', None)
+        if sync is None or not sync.covers(mods):
+            sync = self._stats_sync_obj = rdist.StatsSync(mods)
+        return sync
+
     def _seed_stats_sync_snapshots(self):
+        """a2c_common.py:766-780: restored statistics are shared history, not fresh per-rank data."""
         if not self.multi_gpu or not self.multi_gpu_sync_stats or self.multi_gpu_sync_stats_mode == 'broadcast':
             return
-        for m in self._stats_sync_modules():
-            rdist.seed_stats_sync_snapshot(m)
+        sync = self._stats_sync()
+        if sync is not None:
+            sync.seed()
 
     def sync_running_stats(self):
         """a2c_common.py:782-808."""
         if not self.multi_gpu or not self.multi_gpu_sync_stats:
             return
-        import torch.distributed as dist
-        if self.multi_gpu_sync_stats_mode == 'broadcast':
-            for m in self._stats_sync_modules():
-                rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+        sync = self._stats_sync()
+        if sync is None:
             return
-        for m in self._stats_sync_modules():
-            rdist.merge_rank_stats(m, rdist.all_reduce_sum)
+        if self.multi_gpu_sync_stats_mode == 'broadcast':
+            sync.adopt_rank0(rdist.broadcast_from_rank0)
+        else:
+            sync.merge(rdist.all_reduce_sum)
 
     # ================================================================== weights / checkpoints
     def get_stats_weights(self, model_stats=False):
@@ -1577,8 +1619,9 @@ class A2CAgent:
         dist.broadcast(self.optimizer.flat_params, 0)
         if self.has_central_value:
             dist.broadcast(self.central_value_net.optimizer.flat_params, 0)
-        for m in self._stats_sync_modules():
-            rdist.broadcast_rank_stats(m, lambda t: dist.broadcast(t, src=0))
+        sync = self._stats_sync()
+        if sync is not None:
+            sync.adopt_rank0(rdist.broadcast_from_rank0)
         self._seed_stats_sync_snapshots()
 
     # ================================================================== training loop

@@ -37,8 +37,16 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Timing-only ablations for tools/ablate_chain.sh (-DRLG_ABL=mask builds a library that computes WRONG results and
+// shows what a phase costs): 1 no bias/activation maths, 2 no global stores of the epilogues, 4 no epilogue at all,
+// 8 no remainder units, 16 no barriers between layers, 32 no prologue loads, 64 no weight traffic (A loads out of range)
+#ifndef RLG_ABL
+#define RLG_ABL 0
+#endif
+
 namespace rlg {
 
+constexpr int kAbl = RLG_ABL;
 constexpr int kChainMaxLayers = 8;
 // K-split scratch of the forward (partial fragments of 256 floats): G = 1: up to 2 units x 3 parts (8 waves) or
 // 4 x 1; G = 2: up to 2 units x 1 part; G = 4: no split (a remainder block already has one unit per wave)
@@ -152,7 +160,7 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
   const unsigned astep = kTransposedA ? static_cast<unsigned>(16 * ld * 4) : 64u;
   const int bstride = G * 256;
   auto a_base = [&](int j, int f) -> unsigned {
-    if (j >= nunits) return kOob;
+    if (j >= nunits || (kAbl & 64)) return kOob;
     const int i = (ob_of(j) + f) * 16 + (lane & 15);
     if (i >= I) return kOob;
     const unsigned first = static_cast<unsigned>(kc_begin) * astep;
@@ -428,12 +436,22 @@ __device__ __forceinline__ f32x4 chain_act_grad4(f32x4 d, f32x4 h, int act) {
   return d;
 }
 
+// Pointers that went through pin_s (an integer round trip) have lost their address space: hipcc then emits FLAT
+// loads / stores, which count on lgkmcnt as well and turn every later LDS wait into lgkmcnt(0).  All arrays
+// of these kernels are global memory: say so at the access.
+template <class T>
+using glob_t = T __attribute__((address_space(1)));
+template <class T>
+__device__ __forceinline__ glob_t<T>* as_global(T* p) { return (glob_t<T>*)p; }
+template <class T>
+__device__ __forceinline__ const glob_t<T>* as_global(const T* p) { return (const glob_t<T>*)p; }
+
 // 4 consecutive features [f, f+4) of row `row` of a row-major array, masked to `width`
 __device__ __forceinline__ void store_row4(float* base, long long ld, long long row, int f, int width,
                                            const f32x4& v, bool vec_ok) {
-  float* p = base + row * ld + f;
+  glob_t<float>* p = as_global(base + row * ld + f);
   if (vec_ok && f + 4 <= width) {
-    *reinterpret_cast<f32x4*>(p) = v;
+    *(glob_t<f32x4>*)p = v;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -443,8 +461,8 @@ __device__ __forceinline__ void store_row4(float* base, long long ld, long long 
 }
 __device__ __forceinline__ f32x4 load_row4(const float* base, long long ld, long long row, int f, int width,
                                            bool vec_ok) {
-  const float* p = base + row * ld + f;
-  if (vec_ok && f + 4 <= width) return *reinterpret_cast<const f32x4*>(p);
+  const glob_t<float>* p = as_global(base + row * ld + f);
+  if (vec_ok && f + 4 <= width) return *(const glob_t<f32x4>*)p;
   f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
         const int g = u - c * G;
         const long long row = row0 + g * 16 + (lane & 15);
         xin[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (u < nfrag && row < a.rows) xin[k] = load_row4(a.x, a.ldx, row, c * 16 + 4 * (lane >> 4), in0, xv);
+        if (!(kAbl & 32) && u < nfrag && row < a.rows) xin[k] = load_row4(a.x, a.ldx, row, c * 16 + 4 * (lane >> 4), in0, xv);
       }
     };
     auto put_frags = [&](int u0) {
@@ -580,19 +598,21 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
       const int f = ob * 16 + 4 * (lane >> 4);
       biasv[slot] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (bias_fast) {
-        if (f < l_out) biasv[slot] = *reinterpret_cast<const f32x4*>(l_bias + f);
+        if (f < l_out) biasv[slot] = *(const glob_t<f32x4>*)as_global(l_bias + f);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) biasv[slot][e] = (f + e < l_out) ? l_bias[f + e] : 0.0f;
+        for (int e = 0; e < 4; ++e) biasv[slot][e] = (f + e < l_out) ? as_global(l_bias)[f + e] : 0.0f;
       }
     };
     auto epilogue = [&](int ob, int g, const f32x4& accv, const f32x4& bias) {
       const int f = ob * 16 + 4 * (lane >> 4);
-      const f32x4 v = chain_act4<HACT>(accv + bias, l_act);
+      if ((kAbl & 4) && n_rows >= 0) return;
+      const f32x4 v = (kAbl & 1) ? accv : chain_act4<HACT>(accv + bias, l_act);
       if (!last) *reinterpret_cast<f32x4*>(tout + ((ob * G + g) * 64 + lane) * 4) = v;
       const long long row = row0 + g * 16 + (lane & 15);
+      if ((kAbl & 2) && !last) return;
       if (h_fast) {
-        if (row < n_rows && f < l_out) *reinterpret_cast<f32x4*>(l_h + row * l_ldh + f) = v;
+        if (row < n_rows && f < l_out) *(glob_t<f32x4>*)as_global(l_h + row * l_ldh + f) = v;
       } else if (h_on && row < n_rows) {
         store_row4(l_h, l_ldh, row, f, l_out, v, false);
       }
@@ -624,7 +644,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
     chain_stamp(a.dbg, wave, stamp);
     // remainder blocks: dealt out per (block, row group) so that every wave gets the same share
     const int rem_first = full * W;
-    const int rem_units = (NOB - rem_first) * G;
+    const int rem_units = (kAbl & 8) ? 0 : (NOB - rem_first) * G;
     // Fewer (block, row group) units than waves (the one remainder block of the 400- and 200-wide layers):
     // the idle waves take a share of the reduction instead - `ksplit` waves per unit, each over a part
     // of the k-chunks, partial fragments combined through LDS in a fixed order by the unit's first wave.
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
         });
     }
     chain_stamp(a.dbg, wave, stamp);
-    __syncthreads();
+    if (!(kAbl & 16)) __syncthreads();
     chain_stamp(a.dbg, wave, stamp);
     float* t = tin;
     tin = tout;
@@ -735,21 +755,24 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
     auto epilogue = [&](int ob, int g, int slot, bool to_lds, const f32x4& accv, const f32x4& hval) -> f32x4 {
       const int f = ob * 16 + 4 * (lane >> 4);
       const long long row = row0 + g * 16 + (lane & 15);
-      f32x4 v = chain_act_grad4(accv, hval, p_act);
+      if ((kAbl & 4) && n_rows >= 0) return accv;
+      f32x4 v = (kAbl & 1) ? accv : chain_act_grad4(accv, hval, p_act);
       if (row >= n_rows) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (to_lds) *reinterpret_cast<f32x4*>(tout + (slot * 64 + lane) * 4) = v;
+      if (kAbl & 2) return v;
       if (fast) {
-        if (row < n_rows && f < width) *reinterpret_cast<f32x4*>(p_dz + row * p_lddz + f) = v;
+        if (row < n_rows && f < width) *(glob_t<f32x4>*)as_global(p_dz + row * p_lddz + f) = v;
       } else if (row < n_rows) {
         store_row4(p_dz, p_lddz, row, f, width, v, false);
       }
       return v;
     };
     auto load_h = [&](int ob, int g) -> f32x4 {
+      if (kAbl & 4) return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       const int f = ob * 16 + 4 * (lane >> 4);
       const long long row = row0 + g * 16 + (lane & 15);
       if (fast) {
-        if (row < n_rows && f < width) return *reinterpret_cast<const f32x4*>(p_h + row * p_ldh + f);
+        if (row < n_rows && f < width) return *(const glob_t<f32x4>*)as_global(p_h + row * p_ldh + f);
         return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
       if (row < n_rows) return load_row4(p_h, p_ldh, row, f, width, false);
@@ -771,7 +794,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
         const int f = ob * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (f + e < width) bpart[f + e] = static_cast<double>(s[e]);
+          if (f + e < width) as_global(bpart)[f + e] = static_cast<double>(s[e]);
         }
       }
     };
@@ -812,7 +835,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
     // feeds the next step, else in the first slots) and, after the barrier, one wave per block adds
     // the G groups in order.
     const int rem_first = full * W;
-    const int rem_blocks = NOB - rem_first;
+    const int rem_blocks = (kAbl & 8) ? 0 : NOB - rem_first;
     const int rem_units = rem_blocks * G;
     const int my_rem = (rem_units > wave) ? (rem_units - wave + W - 1) / W : 0;
     chain_units<1, 1, true>(
@@ -827,7 +850,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
           const int ob = rem_first + u / G, g = u % G;
           epilogue(ob, g, keep_tile ? ob * G + g : u, true, acc[0][0], hval[0][0]);
         });
-    __syncthreads();
+    if (!(kAbl & 16)) __syncthreads();
     if (bpart != nullptr) {
       for (int rb = wave; rb < rem_blocks; rb += W) {
         const int slot0 = keep_tile ? (rem_first + rb) * G : rb * G;
@@ -918,6 +941,9 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
 }
 
 static bool g_chain_prepared = false;     // rlg_mlp_chain_prepare raised the LDS limit of every kernel
+// rlg_mlp_chain_time_next: HIP events bound to the NEXT chain dispatch (its begin / end timestamps, what
+// rocprofv3 --kernel-trace reports); one-shot, bench.py's roofline_fwd / roofline_bwd
+static hipEvent_t g_chain_ev_start = nullptr, g_chain_ev_stop = nullptr;
 
 template <int G, bool kBackward, int HACT, int W>
 static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss) {
@@ -933,13 +959,23 @@ static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st,
       raised = true;
     }
   }
+  hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+  g_chain_ev_start = g_chain_ev_stop = nullptr;
   if constexpr (kBackward) {
     LossArgs none = {};
-    hipLaunchKernelGGL((mlp_chain_bwd_kernel<G, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
-                       args, loss ? *loss : none);
+    if (ev0 != nullptr)
+      hipExtLaunchKernelGGL((mlp_chain_bwd_kernel<G, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
+                            ev0, ev1, 0, args, loss ? *loss : none);
+    else
+      hipLaunchKernelGGL((mlp_chain_bwd_kernel<G, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
+                         args, loss ? *loss : none);
   } else {
-    hipLaunchKernelGGL((mlp_chain_fwd_kernel<G, HACT, W>), dim3(grid), dim3(64 * W),
-                       static_cast<size_t>(lds_bytes), st, args);
+    if (ev0 != nullptr)
+      hipExtLaunchKernelGGL((mlp_chain_fwd_kernel<G, HACT, W>), dim3(grid), dim3(64 * W),
+                            static_cast<size_t>(lds_bytes), st, ev0, ev1, 0, args);
+    else
+      hipLaunchKernelGGL((mlp_chain_fwd_kernel<G, HACT, W>), dim3(grid), dim3(64 * W),
+                         static_cast<size_t>(lds_bytes), st, args);
   }
   RLG_RETURN_LAUNCH_STATUS();
 }
@@ -1019,6 +1055,14 @@ int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* o
   int b = 0;
   if (num_layers < 1 || num_layers > rlg::kChainMaxLayers) return -1;
   return rlg::chain_lds(num_layers, in_features, out_features, groups, direction, &b);
+}
+
+// The next rlg_mlp_chain_forward / _backward launch (not inside a graph capture) is bracketed by these two HIP
+// events (rlg_event_create); one-shot.  bench.py: in-epoch launch durations of the two dominant kernels.
+int rlg_mlp_chain_time_next(void* ev_start, void* ev_stop) {
+  rlg::g_chain_ev_start = static_cast<hipEvent_t>(ev_start);
+  rlg::g_chain_ev_stop = static_cast<hipEvent_t>(ev_stop);
+  return 0;
 }
 
 static long long* g_chain_dbg = nullptr;

@@ -61,6 +61,8 @@ struct AdamArgs {
   float kl_scale;          // 1/world_size when kl holds a cross-rank SUM
   double kl_threshold, min_lr, max_lr, lr_multiplier;
   float* stats_out;        // [4]: total_norm, clip_coef, lr used, lr next
+  const unsigned* skip_flag;  // device word or nullptr; non-zero: the gradients are invalid (a failed in-graph
+                              // all-reduce) - nothing is updated, the learning rate is carried over unchanged
 };
 
 __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   }
   __syncthreads();
   const float clip = sh_clip;
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
   const long long step = *a.step_counter;
   const int cur = static_cast<int>((step - 1) & 1);
   const double lr = a.lr_slots[cur];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   const float eps = static_cast<float>(a.eps);
   const float wd = static_cast<float>(a.weight_decay);
 
-  for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < a.n;
+  for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < a.n && !skip;
        i += static_cast<long long>(gridDim.x) * kOptBlock) {
     float g = (a.grads[i] * a.grad_scale) * clip;
     a.grads[i] = g;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double next = lr;
-    if (a.schedule_kind == 1) {
+    if (a.schedule_kind == 1 && !skip) {
       // AdaptiveScheduler.update, python-float arithmetic                 schedulers.py:27-33
       const double kl = static_cast<double>(*a.kl * a.kl_scale);
       if (kl > 2.0 * a.kl_threshold) next = fmax(lr / a.lr_multiplier, a.min_lr);
@@ -171,7 +174,8 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   float max_norm, double* lr_slots, const long long* step_counter, double beta1,
                   double beta2, double eps, double weight_decay, int schedule_kind,
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
-                  double max_lr, double lr_multiplier, float* stats_out_or_null, void* stream) {
+                  double max_lr, double lr_multiplier, float* stats_out_or_null,
+                  const unsigned* skip_flag_or_null, void* stream) {
   using namespace rlg;
   if (n <= 0 || !step_counter) return static_cast<int>(hipErrorInvalidValue);
   if (schedule_kind == 1 && !kl_or_null) return static_cast<int>(hipErrorInvalidValue);
@@ -199,6 +203,7 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
   a.max_lr = max_lr;
   a.lr_multiplier = lr_multiplier;
   a.stats_out = stats_out_or_null;
+  a.skip_flag = skip_flag_or_null;
   long long grid = (n + kOptBlock * kOptVec - 1) / (kOptBlock * kOptVec);
   if (grid < 1) grid = 1;
   if (grid > 1024) grid = 1024;

@@ -458,6 +458,105 @@ __global__ __launch_bounds__(256) void prepare_apply_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-rank synchronisation of the running normalisers (multi-GPU, once per epoch).
+// replaces rl_games/common/a2c_common.py: _running_stats_totals :43-47, seed_stats_sync_snapshot :50-58,
+// merge_rank_stats :61-93, broadcast_rank_stats :124-141 - there a dozen tiny fp64 torch ops and THREE
+// collectives per normaliser; here every normaliser of the agent is a segment [count | sum or mean[D] |
+// sum of squares or var[D]] of ONE flat fp64 buffer: pack launch -> one collective -> apply launch.
+// Arithmetic: the reference's fp64 ops in the reference's order, one rounding each (-ffp-contract=off);
+// the count travels as a double (exact below 2^53).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStatsMaxSegments = 8;
+
+struct StatsSegments {
+  double* mean[kStatsMaxSegments];
+  double* var[kStatsMaxSegments];
+  long long* count[kStatsMaxSegments];
+  long long offset[kStatsMaxSegments];     // first double of the segment in the flat buffers
+  int dim[kStatsMaxSegments];
+  int has_snapshot[kStatsMaxSegments];
+  int num;
+};
+
+// totals of a state (a2c_common.py:43-47): count, mean * count, (var + mean^2) * count
+__device__ __forceinline__ void stats_totals(const StatsSegments& sg, int s, int i, double& value) {
+  const double n = static_cast<double>(*sg.count[s]);
+  if (i == 0) {
+    value = n;
+  } else if (i <= sg.dim[s]) {
+    value = sg.mean[s][i - 1] * n;
+  } else {
+    const double m = sg.mean[s][i - 1 - sg.dim[s]];
+    value = (sg.var[s][i - 1 - sg.dim[s]] + m * m) * n;
+  }
+}
+
+// mode 0: out = totals - snapshot   (the epoch's deltas, :72-77; a segment without snapshot sends its totals)
+// mode 1: snapshot = totals         (seed after a checkpoint load, :50-58; `out` unused)
+// mode 2: out = raw state [count, mean, var]  (broadcast mode, :124-141)
+__global__ __launch_bounds__(256) void stats_sync_pack_kernel(StatsSegments sg, double* snapshot, double* out, int mode) {
+  for (int s = 0; s < sg.num; ++s) {
+    const int len = 1 + 2 * sg.dim[s];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+      const long long at = sg.offset[s] + i;
+      if (mode == 2) {
+        const int D = sg.dim[s];
+        out[at] = i == 0 ? static_cast<double>(*sg.count[s]) : (i <= D ? sg.mean[s][i - 1] : sg.var[s][i - 1 - D]);
+        continue;
+      }
+      double cur;
+      stats_totals(sg, s, i, cur);
+      if (mode == 1) snapshot[at] = cur;
+      else out[at] = sg.has_snapshot[s] ? cur - snapshot[at] : cur;
+    }
+  }
+}
+
+// mode 0: totals = snapshot + reduced deltas -> state, snapshot = totals   (:78-93)
+// mode 2: state = reduced (rank 0's raw state)
+// Two passes per segment inside one launch are avoided by recomputing n per thread: every element only needs
+// the segment's count slot and, for the variance, the matching first-moment slot.
+__global__ __launch_bounds__(256) void stats_sync_apply_kernel(StatsSegments sg, double* snapshot, const double* reduced,
+                                                               int mode) {
+  for (int s = 0; s < sg.num; ++s) {
+    const int D = sg.dim[s];
+    const long long o = sg.offset[s];
+    const bool based = sg.has_snapshot[s] != 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= D; i += gridDim.x * blockDim.x) {
+      if (mode == 2) {
+        if (i == 0) *sg.count[s] = static_cast<long long>(reduced[o]);
+        else {
+          sg.mean[s][i - 1] = reduced[o + i];
+          sg.var[s][i - 1] = reduced[o + D + i];
+        }
+        continue;
+      }
+      // base + delta with the reference's zero base for a segment without snapshot (0.0 + x is exact)
+      const double n = (based ? snapshot[o] : 0.0) + reduced[o];
+      if (i == 0) continue;                         // the count is written last (below), by its own thread
+      const double s1 = (based ? snapshot[o + i] : 0.0) + reduced[o + i];
+      const double s2 = (based ? snapshot[o + D + i] : 0.0) + reduced[o + D + i];
+      const double mean = s1 / n;
+      double var = s2 / n - mean * mean;
+      var = var < 1e-8 ? 1e-8 : var;                // clamp_(min=1e-8); a NaN passes through like torch's clamp
+      sg.mean[s][i - 1] = mean;
+      sg.var[s][i - 1] = var;
+      snapshot[o + i] = s1;
+      snapshot[o + D + i] = s2;
+    }
+  }
+  // counts: after every thread of the grid has read snapshot[o] (one block only - see the launcher)
+  __syncthreads();
+  if (mode == 0 && threadIdx.x < sg.num && blockIdx.x == 0) {
+    const int s = threadIdx.x;
+    const long long o = sg.offset[s];
+    const double n = (sg.has_snapshot[s] ? snapshot[o] : 0.0) + reduced[o];
+    *sg.count[s] = static_cast<long long>(n);
+    snapshot[o] = n;
+  }
+}
+
 }  // namespace rlg
 
 extern "C" {
@@ -606,6 +705,55 @@ int rlg_prepare_apply(const float* values, const float* returns, const float* ad
                      static_cast<hipStream_t>(stream), values, returns, advantages, values_out,
                      returns_out, advantages_out, b4, batch, flags,
                      static_cast<const rlg::PrepareStats*>(stats));
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+static int stats_segments_fill(rlg::StatsSegments& sg, int num_segments, double* const* means, double* const* vars,
+                               long long* const* counts, const int* dims, const int* has_snapshot) {
+  if (num_segments < 1 || num_segments > rlg::kStatsMaxSegments) return 1;
+  long long off = 0;
+  for (int s = 0; s < num_segments; ++s) {
+    if (!means[s] || !vars[s] || !counts[s] || dims[s] < 1) return 1;
+    sg.mean[s] = means[s];
+    sg.var[s] = vars[s];
+    sg.count[s] = counts[s];
+    sg.dim[s] = dims[s];
+    sg.has_snapshot[s] = has_snapshot ? has_snapshot[s] : 1;
+    sg.offset[s] = off;
+    off += 1 + 2LL * dims[s];
+  }
+  sg.num = num_segments;
+  return 0;
+}
+
+long long rlg_stats_sync_flat_size(int num_segments, const int* dims) {
+  long long n = 0;
+  for (int s = 0; s < num_segments; ++s) n += 1 + 2LL * dims[s];
+  return n;
+}
+
+int rlg_stats_sync_pack(int num_segments, double* const* means, double* const* vars, long long* const* counts,
+                        const int* dims, const int* has_snapshot, double* snapshot, double* out, int mode,
+                        void* stream) {
+  rlg::StatsSegments sg;
+  if (stats_segments_fill(sg, num_segments, means, vars, counts, dims, has_snapshot) || mode < 0 || mode > 2 ||
+      (mode != 2 && !snapshot) || (mode != 1 && !out))
+    return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(rlg::stats_sync_pack_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sg, snapshot,
+                     out, mode);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_stats_sync_apply(int num_segments, double* const* means, double* const* vars, long long* const* counts,
+                         const int* dims, const int* has_snapshot, double* snapshot, const double* reduced, int mode,
+                         void* stream) {
+  rlg::StatsSegments sg;
+  if (stats_segments_fill(sg, num_segments, means, vars, counts, dims, has_snapshot) || (mode != 0 && mode != 2) ||
+      !reduced || (mode == 0 && !snapshot))
+    return static_cast<int>(hipErrorInvalidValue);
+  // ONE workgroup: the count slot of the snapshot is read by every thread and rewritten behind a barrier
+  hipLaunchKernelGGL(rlg::stats_sync_apply_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sg, snapshot,
+                     reduced, mode);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -7,7 +7,10 @@ The reference's collectives and what replaces them:
   C6 broadcast of [lr, entropy_coef] + 2x .item() (:564-576)
       -> ONE in-place all_reduce(SUM) of the flat gradient arena whose tail slot carries the
          KL; every rank then derives the same learning rate on device (csrc/optim.hip).
-  C7 merge_rank_stats / broadcast_rank_stats     (:61-93, :124-141)   -> same maths below
+  C7 merge_rank_stats / broadcast_rank_stats     (:61-93, :124-141)
+      -> StatsSync below: every normaliser of the agent is a segment of ONE flat fp64 buffer;
+         pack launch, ONE collective, apply launch per epoch (the reference: three collectives and a
+         dozen small fp64 torch ops per normaliser).  Kernels: csrc/running_stats.hip.
   C2 parameter broadcast, C8 exit flag            -> broadcast of the flat arena / a scalar.
 Payloads are <= 1 MB: latency bound, so fewer collectives matter more than bandwidth.
 """
@@ -53,47 +56,93 @@ def all_reduce_sum(t):
     return t
 
 
-def stats_totals(m):
-    """(count, sum x, sum x^2) equivalent of a RunningMeanStd state (a2c_common.py:43-47)."""
-    return (m.count.clone(), m.running_mean * m.count, (m.running_var + m.running_mean ** 2) * m.count)
-
-
-def seed_stats_sync_snapshot(m):
-    """After loading stats from a checkpoint: what is there is shared history
-    (a2c_common.py:50-58)."""
-    m._stats_sync_snapshot = tuple(t.clone() for t in stats_totals(m))
-
-
-def merge_rank_stats(m, all_reduce):
-    """Pooled cross-rank merge of one RunningMeanStd via summed per-epoch moment DELTAS against
-    the last merged snapshot (a2c_common.py:61-93).  `all_reduce(t)` must SUM t in place."""
-    cur = stats_totals(m)
-    prev = getattr(m, '_stats_sync_snapshot', None)
-    if prev is None:
-        deltas = [c.clone() for c in cur]
-        base = [torch.zeros_like(c) for c in cur]
-    else:
-        deltas = [c - p for c, p in zip(cur, prev)]
-        base = prev
-    for t in deltas:
-        all_reduce(t)
-    n = base[0] + deltas[0]
-    s1 = base[1] + deltas[1]
-    s2 = base[2] + deltas[2]
-    m.count.copy_(n)
-    m.running_mean.copy_(s1 / n)
-    m.running_var.copy_((s2 / n - m.running_mean ** 2).clamp_(min=1e-8))
-    m._stats_sync_snapshot = (n.clone(), s1.clone(), s2.clone())
-
-
-def broadcast_rank_stats(m, broadcast):
-    """Every rank adopts rank 0's statistics (a2c_common.py:124-141)."""
-    broadcast(m.count)
-    broadcast(m.running_mean)
-    broadcast(m.running_var)
+def broadcast_from_rank0(t):
+    dist.broadcast(t, src=0)
+    return t
 
 
 def resolve_stats_sync_mode(mode):
-    if mode not in STATS_SYNC_MODES:
-        raise ValueError(f"multi_gpu_sync_stats_mode must be one of {STATS_SYNC_MODES}, got '{mode}'")
-    return mode
+    if mode in STATS_SYNC_MODES:
+        return mode
+    raise ValueError(f"multi_gpu_sync_stats_mode must be one of {STATS_SYNC_MODES}, got '{mode}'")
+
+
+class StatsSync:
+    """Cross-rank synchronisation of a set of RunningMeanStd modules (row a19; behaviour of
+    rl_games/common/a2c_common.py:43-141, tested like tests/test_multigpu_stats_sync.py).
+
+    pooled mode (`merge`): every rank contributes the moment totals it accumulated since the last
+    merge - count, sum x, sum x^2 of each normaliser, i.e. totals(state) minus the totals right
+    after the previous merge (the "snapshot"; absent = the whole history is rank-local) - the
+    summed deltas are added to the shared snapshot and turned back into mean / var.  History that
+    all ranks already share (previous merges, a loaded checkpoint -> `seed`) is therefore counted
+    once, not world_size times.
+    broadcast mode (`adopt_rank0`): stateless, every rank takes rank 0's state.
+
+    Layout: normaliser s with D_s features owns 1 + 2*D_s consecutive doubles of the flat buffers
+    `deltas` / `snapshot`: [count | D_s first moments | D_s second moments].  One collective moves
+    all of them.  `kernels` does the arithmetic on the device (ops.StatsSyncKernels: no host
+    fallback); the CPU functional tests inject the oracle's restatement of the same layout."""
+
+    def __init__(self, modules, kernels=None):
+        self.modules = list(modules)
+        if not self.modules:
+            raise ValueError('StatsSync needs at least one normaliser')
+        if kernels is None:
+            from . import ops
+            kernels = ops.StatsSyncKernels(self.modules)
+        self.kernels = kernels
+        ref = self.modules[0].running_mean
+        size = kernels.flat_size
+        self.snapshot = torch.zeros(size, dtype=torch.float64, device=ref.device)
+        self.deltas = torch.zeros(size, dtype=torch.float64, device=ref.device)
+        self.has_snapshot = [False] * len(self.modules)
+
+    def covers(self, modules):
+        modules = list(modules)
+        return len(modules) == len(self.modules) and all(a is b for a, b in zip(modules, self.modules))
+
+    def seed(self):
+        """The current state is shared history (a checkpoint was loaded on every rank)."""
+        k = self.kernels
+        k.pack(self.has_snapshot, self.snapshot, self.deltas, k.PACK_SEED)
+        self.has_snapshot = [True] * len(self.modules)
+
+    def merge(self, all_reduce):
+        """`all_reduce(t)` must SUM the fp64 tensor t in place across ranks."""
+        k = self.kernels
+        k.pack(self.has_snapshot, self.snapshot, self.deltas, k.PACK_DELTAS)
+        all_reduce(self.deltas)
+        k.apply(self.has_snapshot, self.snapshot, self.deltas, k.APPLY_MERGE)
+        self.has_snapshot = [True] * len(self.modules)
+
+    def adopt_rank0(self, broadcast):
+        """`broadcast(t)` must overwrite the fp64 tensor t with rank 0's in place."""
+        k = self.kernels
+        k.pack(self.has_snapshot, self.snapshot, self.deltas, k.PACK_STATE)
+        broadcast(self.deltas)
+        k.apply(self.has_snapshot, self.snapshot, self.deltas, k.APPLY_STATE)
+
+
+def _sync_of(m):
+    """The single-module StatsSync behind the reference's per-module function seams."""
+    sync = getattr(m, '_stats_sync', None)
+    if sync is None or not sync.covers([m]):
+        sync = StatsSync([m])
+        m._stats_sync = sync
+    return sync
+
+
+def seed_stats_sync_snapshot(m):
+    """Function seam of a2c_common.py:50-58 for one normaliser."""
+    _sync_of(m).seed()
+
+
+def merge_rank_stats(m, all_reduce):
+    """Function seam of a2c_common.py:61-93 for one normaliser (one collective instead of three)."""
+    _sync_of(m).merge(all_reduce)
+
+
+def broadcast_rank_stats(m, broadcast):
+    """Function seam of a2c_common.py:124-141 for one normaliser (one collective instead of three)."""
+    _sync_of(m).adopt_rank0(broadcast)

@@ -110,12 +110,14 @@ class FlatAdam(FlatArena):
         return used, nxt
 
     # ------------------------------------------------------------------ step
-    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None):
+    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None, skip_flag=None):
         """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
         driven by the KL in `kl_slot` (times kl_scale).  norm_ready = (partials fp64, count): the
         launch that wrote the gradients already left the per-block sums of (g * grad_scale)^2 AND advanced
-        the device step counter (ops.MlpDwPlan.launch(norm=...)) - no grad_sumsq launch."""
+        the device step counter (ops.MlpDwPlan.launch(norm=...)) - no grad_sumsq launch.  skip_flag: device
+        address of the in-graph all-reduce's error word (IpcAllReduce.error_word): a step behind a failed
+        collective leaves parameters, moments and learning rate untouched."""
         self.step_count += 1
         if norm_ready is None:
             # it also advances the device step counter the Adam kernel reads
@@ -133,7 +135,8 @@ class FlatAdam(FlatArena):
                       grad_scale, 0.0 if max_norm is None else max_norm, self.lr_slots,
                       self.step_counter, betas=self.betas, eps=self.eps,
                       weight_decay=self.weight_decay, schedule_kind=kind,
-                      kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats, **kw)
+                      kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats,
+                      skip_flag=skip_flag, **kw)
 
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):

@@ -18,7 +18,9 @@ from . import _lib
 
 
 class IpcAllReduce:
-    def __init__(self, numel, device, rank=None, world=None, group=None):
+    def __init__(self, numel, device, rank=None, world=None, group=None, timeout_s=None, two_phase=None):
+        """timeout_s: bound of a launch's wait for its peers (None: RLG_IPC_TIMEOUT_S or 600 s; <= 0: unbounded).
+        two_phase: reduce-scatter + all-gather variant (None: RLG_IPC_TWO_PHASE or the one-shot variant)."""
         lib = _lib.load()
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -45,7 +47,15 @@ class IpcAllReduce:
             if any(oks):
                 self.close()
                 raise _lib.HipLibraryError(f'rlg_ipc_comm_connect failed on a rank (hipError_t per rank: {oks})')
-        self.fine_grained = bool(lib.rlg_ipc_comm_fine_grained(self._comm))
+        self.fine_grained = bool(lib.rlg_ipc_comm_fine_grained(self._comm))     # (creation fails without it)
+        if timeout_s is not None:
+            lib.rlg_ipc_comm_set_timeout(self._comm, float(timeout_s))
+        self.two_phase = bool(two_phase) if two_phase is not None else False
+        if two_phase is not None:
+            lib.rlg_ipc_comm_set_variant(self._comm, int(bool(two_phase)))
+        word = ctypes.c_void_p()
+        lib.rlg_ipc_comm_error_word(self._comm, ctypes.byref(word))
+        self.error_word = int(word.value)      # device address: FlatAdam.step(skip_flag=...)
         self._self_test(group)
 
     def _self_test(self, group):

@@ -325,7 +325,10 @@ class ManualMLP:
             if plan:
                 # bias gradients (and the loss partials) finished in the same finalise launch; the gradient
                 # norm as well when every gradient of the step is written there
-                whole = norm is not None and not slow and loss_finalize is not None
+                # (a norm buffer that is too small for this plan's finalise grid: the caller's grad_sumsq
+                #  launch takes over instead of an error in the middle of an epoch)
+                whole = (norm is not None and not slow and loss_finalize is not None
+                         and norm[0].numel() >= plan.finalize_blocks(colsums, loss_finalize))
                 norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
                 if not whole:
                     norm_blocks = None

@@ -211,6 +211,46 @@ def rms_apply(x, running_mean, running_var, eps, mode=0, out=None):
     return out
 
 
+class StatsSyncKernels:
+    """Device side of distributed.StatsSync: the normalisers' state tensors as the pointer tables of
+    rlg_stats_sync_pack / rlg_stats_sync_apply (include/rlg_hip.h)."""
+
+    PACK_DELTAS, PACK_SEED, PACK_STATE = 0, 1, 2
+    APPLY_MERGE, APPLY_STATE = 0, 2
+
+    def __init__(self, modules):
+        import ctypes
+        n = len(modules)
+        self.device = modules[0].running_mean.device
+        self._keep = [(m.running_mean, m.running_var, m.count) for m in modules]
+        self.dims = [int(m.running_mean.numel()) for m in modules]
+        self._means = (ctypes.c_void_p * n)(*[_need(m.running_mean, F64, 'running_mean') for m in modules])
+        self._vars = (ctypes.c_void_p * n)(*[_need(m.running_var, F64, 'running_var') for m in modules])
+        self._counts = (ctypes.c_void_p * n)(*[_need(m.count, torch.int64, 'count') for m in modules])
+        self._dims = (ctypes.c_int * n)(*self.dims)
+        self._n = n
+        self._ctypes = ctypes
+        self.flat_size = int(_lib.load().rlg_stats_sync_flat_size(n, ctypes.cast(self._dims, ctypes.c_void_p)))
+
+    def _tables(self, has_snapshot):
+        c = self._ctypes
+        flags = (c.c_int * self._n)(*[int(bool(h)) for h in has_snapshot])
+        return (self._n, c.cast(self._means, c.c_void_p), c.cast(self._vars, c.c_void_p),
+                c.cast(self._counts, c.c_void_p), c.cast(self._dims, c.c_void_p), c.cast(flags, c.c_void_p)), flags
+
+    def pack(self, has_snapshot, snapshot, out, mode):
+        args, keep = self._tables(has_snapshot)
+        _lib.check(_lib.load().rlg_stats_sync_pack(*args, _need(snapshot, F64, 'snapshot'),
+                                                   _need(out, F64, 'out'), mode, _stream(out)),
+                   'rlg_stats_sync_pack')
+
+    def apply(self, has_snapshot, snapshot, reduced, mode):
+        args, keep = self._tables(has_snapshot)
+        _lib.check(_lib.load().rlg_stats_sync_apply(*args, _need(snapshot, F64, 'snapshot'),
+                                                    _need(reduced, F64, 'reduced'), mode, _stream(reduced)),
+                   'rlg_stats_sync_apply')
+
+
 PREP_NORM_VALUE = 1
 PREP_NORM_ADV = 2
 PREP_FREEZE_CRITIC = 4
@@ -466,7 +506,8 @@ def grad_sumsq(grads, grad_scale, partials, step_counter=None):
 def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max_norm, lr_slots,
               step_counter, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
               kl=None, kl_scale=1.0, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2,
-              lr_multiplier=1.5, stats_out=None):
+              lr_multiplier=1.5, stats_out=None, skip_flag=None):
+    """skip_flag: device address (int) of the in-graph all-reduce's error word, or None."""
     lib = _lib.load()
     _lib.check(lib.rlg_adam_step(
         _need(params, F32, 'params'), _need(grads, F32, 'grads'), _need(exp_avg, F32, 'exp_avg'),
@@ -476,7 +517,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
         _need(step_counter, torch.int64, 'step_counter'),
         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), schedule_kind,
         _opt(kl, F32, 'kl'), float(np.float32(kl_scale)), float(kl_threshold), float(min_lr),
-        float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), _stream(params)),
+        float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), skip_flag, _stream(params)),
         'rlg_adam_step')
 
 
@@ -519,6 +560,18 @@ def mlp_linear_act_backward(dz, w, z_prev, dz_prev, act_kind=0):
 
 
 # ------------------------------------------------------------------ fused MLP chain (MFMA, LDS-resident)
+
+chain_timers = None     # bench.py: {'fwd': [...], 'bwd': [...]} of gae.HipEventPair, one per eager chain launch
+
+
+def _time_chain_launch(kind):
+    if chain_timers is None or torch.cuda.is_current_stream_capturing():
+        return
+    from .gae import HipEventPair
+    ev = HipEventPair()
+    chain_timers.setdefault(kind, []).append(ev)
+    _lib.check(_lib.load().rlg_mlp_chain_time_next(ev.start, ev.stop), 'rlg_mlp_chain_time_next')
+
 
 class MlpChain:
     """The whole MLP (hidden layers + the fused value|mu head as the last layer) as ONE forward and
@@ -586,6 +639,7 @@ class MlpChain:
                 raise ValueError('rms_fold: moments row of 2*in0+1 doubles expected')
             fold = [_need(row, F64, 'moments row'), _need(cnt, torch.int64, 'count'), _need(mean_o, F64, 'mean out'),
                     _need(var_o, F64, 'var out'), _need(cnt_o, torch.int64, 'count out')]
+        _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
@@ -606,6 +660,7 @@ class MlpChain:
         if bias_partials is not None:
             bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
         _lib.require_gpu(d_heads, 'd_heads')
+        _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
             n, self._w, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl,
             bp, None if ppo_loss is None else ctypes.addressof(ppo_loss), rows, self.groups(rows, 1, groups),

@@ -3,9 +3,10 @@
   * the flat gradient arena + KL tail slot through ONE all_reduce(SUM) equals the reference's
     cat -> all_reduce -> /world -> copy-back (a2c_common.py:493-509) plus its separate KL
     all-reduce (:1560) - checked against per-rank gradients computed independently;
-  * merge_rank_stats (pooled moment deltas, a2c_common.py:61-93) reproduces the statistics of
-    the pooled stream exactly like the reference's own test
-    (tests/test_multigpu_stats_sync.py:20-33, :97-115), and does not re-count shared history;
+  * distributed.StatsSync (pooled moment deltas, a2c_common.py:61-93, all normalisers in ONE collective)
+    reproduces the statistics of the pooled stream exactly like the reference's own test
+    (tests/test_multigpu_stats_sync.py:20-33, :97-115), does not re-count shared history, and equals the
+    reference's per-module merge_rank_stats bit for bit;
   * broadcast mode leaves every rank with rank 0's statistics.
 """
 import os
@@ -86,41 +87,66 @@ def _grad_worker(rank, world):
         off += n
 
 
+def _sync(mods):
+    """The product's host orchestration (flat layout, one collective, snapshot bookkeeping) with the
+    oracle's arithmetic standing in for the two device kernels (there is no GPU in this test)."""
+    from rl_games_amd import distributed as rdist
+    return rdist.StatsSync(mods, kernels=O.StatsSyncOracle(mods))
+
+
 def _stats_worker(rank, world):
     from rl_games_amd import distributed as rdist
     g = torch.Generator().manual_seed(7)
     data = [torch.randn(200 + 50 * r, 4, generator=g) * (1 + r) + r for r in range(world)]
-    m = _Stats(4)
+    vdata = [torch.randn(300 + 10 * r, 1, generator=g) * 3 - r for r in range(world)]
+    m, v = _Stats(4), _Stats(1)
     m.feed(data[rank])
-    rdist.merge_rank_stats(m, rdist.all_reduce_sum)
+    v.feed(vdata[rank])
+    sync = _sync([m, v])
+    calls = []
+
+    def counted_all_reduce(t):
+        calls.append(t.numel())
+        return rdist.all_reduce_sum(t)
+    sync.merge(counted_all_reduce)
+    assert calls == [(1 + 2 * 4) + (1 + 2 * 1)]          # ONE collective for both normalisers
     # pooled reference: prior (count 1, mean 0, var 1) per rank + all samples
-    n = sum(d.shape[0] for d in data) + world
-    s1 = sum(d.double().sum(0) for d in data)
-    s2 = sum((d.double() ** 2).sum(0) for d in data) + world * 1.0
-    mean = s1 / n
-    var = s2 / n - mean ** 2
-    assert m.count.item() == n
-    assert torch.allclose(m.running_mean, mean, atol=1e-5)
-    assert torch.allclose(m.running_var, var, atol=1e-4)
+    for mod, chunks in ((m, data), (v, vdata)):
+        n = sum(d.shape[0] for d in chunks) + world
+        s1 = sum(d.double().sum(0) for d in chunks)
+        s2 = sum((d.double() ** 2).sum(0) for d in chunks) + world * 1.0
+        mean = s1 / n
+        var = s2 / n - mean ** 2
+        assert mod.count.item() == n
+        assert torch.allclose(mod.running_mean, mean, atol=1e-5)
+        assert torch.allclose(mod.running_var, var, atol=1e-4)
+    n = m.count.item()
     # second epoch: only the NEW data is summed across ranks (no geometric count growth)
     extra = [torch.randn(100, 4, generator=g) for _ in range(world)]
     m.feed(extra[rank])
-    rdist.merge_rank_stats(m, rdist.all_reduce_sum)
+    sync.merge(rdist.all_reduce_sum)
     assert m.count.item() == n + 100 * world
+    # every rank ends with the same statistics, bit for bit
+    gathered = [torch.zeros_like(m.running_mean) for _ in range(world)]
+    dist.all_gather(gathered, m.running_mean)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
     # restored stats are shared history: seeding the snapshot must stop them being re-summed
     m2 = _Stats(4)
     m2.feed(data[0])
-    rdist.seed_stats_sync_snapshot(m2)
-    before = m2.count.item()
-    rdist.merge_rank_stats(m2, rdist.all_reduce_sum)
-    assert m2.count.item() == before
+    s2_ = _sync([m2])
+    s2_.seed()
+    before = (m2.count.item(), m2.running_mean.clone(), m2.running_var.clone())
+    s2_.merge(rdist.all_reduce_sum)
+    assert m2.count.item() == before[0]
+    assert torch.allclose(m2.running_mean, before[1], atol=1e-12) and torch.allclose(m2.running_var, before[2], atol=1e-9)
     # broadcast mode
     m3 = _Stats(4)
     m3.feed(data[rank])
-    rdist.broadcast_rank_stats(m3, lambda t: dist.broadcast(t, src=0))
+    _sync([m3]).adopt_rank0(rdist.broadcast_from_rank0)
     ref = _Stats(4)
     ref.feed(data[0])
-    assert torch.equal(m3.running_mean, ref.running_mean) and m3.count.item() == ref.count.item()
+    assert torch.equal(m3.running_mean, ref.running_mean) and torch.equal(m3.running_var, ref.running_var)
+    assert m3.count.item() == ref.count.item()
 
 
 def test_flat_arena_allreduce_two_ranks():
@@ -133,15 +159,53 @@ def test_running_stats_merge_two_ranks():
 
 def test_merge_with_injected_collective():
     """tests/test_multigpu_stats_sync.py:14-17 style: emulate two identical ranks with t.mul_(2)."""
-    from rl_games_amd import distributed as rdist
     m = _Stats(3)
     x = torch.randn(500, 3, generator=torch.Generator().manual_seed(1))
     m.feed(x)
     mean, var = m.running_mean.clone(), m.running_var.clone()
-    rdist.merge_rank_stats(m, lambda t: t.mul_(2))
+    _sync([m]).merge(lambda t: t.mul_(2))
     assert m.count.item() == 2 * 501
     assert torch.allclose(m.running_mean, mean, atol=1e-12)
     assert torch.allclose(m.running_var, var, atol=1e-9)
+
+
+def test_flat_merge_equals_reference_per_module_merge():
+    """The flat-buffer merge (one collective for all normalisers) against the REFERENCE's own
+    merge_rank_stats / seed_stats_sync_snapshot (imported when /root/reference exists, else the oracle's
+    pooled_merge restatement), bit for bit over three epochs."""
+    import sys
+    fake_world = 3
+    try:
+        sys.path.insert(0, '/root/reference')
+        from rl_games.common.a2c_common import merge_rank_stats as ref_merge
+    except Exception:
+        ref_merge = None
+    finally:
+        if sys.path[0] == '/root/reference':
+            sys.path.pop(0)
+    g = torch.Generator().manual_seed(3)
+    ours = [_Stats(5), _Stats(1)]
+    theirs = [_Stats(5), _Stats(1)]
+    sync = _sync(ours)
+    snaps = [None, None]
+    for epoch in range(3):
+        for k, d in enumerate((5, 1)):
+            x = torch.randn(64, d, generator=g) * (k + 2) + epoch
+            ours[k].feed(x)
+            theirs[k].feed(x)
+        sync.merge(lambda t: t.mul_(fake_world))
+        for k, m in enumerate(theirs):
+            if ref_merge is not None:
+                ref_merge(m, lambda t: t.mul_(fake_world))
+            else:
+                st = {'count': m.count, 'running_mean': m.running_mean, 'running_var': m.running_var}
+                new, snaps[k] = O.pooled_merge(st, snaps[k], lambda t: t.mul_(fake_world))
+                m.count.copy_(new['count'])
+                m.running_mean.copy_(new['running_mean'])
+                m.running_var.copy_(new['running_var'])
+        for a, b in zip(ours, theirs):
+            assert a.count.item() == b.count.item()
+            assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
 
 
 def test_stats_sync_mode_validation():

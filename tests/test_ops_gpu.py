@@ -541,3 +541,92 @@ def test_mlp_rowgemm_forward_and_backward_match_torch(rows, N, K, act):
         ops.mlp_linear_act_backward(dz, w, None, out2)
         e2 = (out2.double() - dz.double() @ w.double()).abs().max().item()
         assert e2 <= max(4 * ((dz @ w).double() - dz.double() @ w.double()).abs().max().item(), 1e-6)
+
+
+# ----------------------------------------------------------------------------- cross-rank statistics sync (a19)
+
+def _gpu_stats(dims, seed):
+    from rl_games_amd.normalizers import RunningMeanStd
+    gen = g(seed)
+    mods = []
+    for d in dims:
+        m = RunningMeanStd((d,)).to(DEV)
+        m.running_mean.copy_(torch.randn(d, generator=gen, dtype=torch.float64) * 3)
+        m.running_var.copy_(torch.rand(d, generator=gen, dtype=torch.float64) * 5 + 0.01)
+        m.count.fill_(int(torch.randint(1, 10 ** 7, (1,), generator=gen)))
+        mods.append(m)
+    return mods
+
+
+class _CpuStats:
+    def __init__(self, m):
+        self.running_mean, self.running_var, self.count = m.running_mean.cpu().clone(), m.running_var.cpu().clone(), m.count.cpu().clone()
+
+
+@pytest.mark.parametrize('dims', [(108, 1), (3,), (60, 1, 17, 1), (1000,)])
+def test_stats_sync_kernels_bit_exact_vs_oracle(dims):
+    """rlg_stats_sync_pack / _apply (all normalisers in one flat fp64 buffer) against the oracle's restatement of
+    a2c_common.py:43-93, :124-141: three epochs of pooled merges with an emulated 4-rank collective, a seed in
+    between, then the broadcast path - statistics, snapshot and counts bit for bit (same fp64 ops, same order)."""
+    from rl_games_amd import distributed as rdist
+    mods = _gpu_stats(dims, seed=len(dims))
+    refs = [_CpuStats(m) for m in mods]
+    ours = rdist.StatsSync(mods)
+    theirs = rdist.StatsSync(refs, kernels=O.StatsSyncOracle(refs))
+    gen = g(11)
+
+    def fake_all_reduce(t):             # 4 ranks: the other three contribute 3.5x of this rank's deltas
+        t.mul_(4.5)
+
+    for epoch in range(3):
+        for m, r in zip(mods, refs):
+            dm = torch.randn(r.running_mean.shape, generator=gen, dtype=torch.float64) * 0.1
+            dv = torch.rand(r.running_var.shape, generator=gen, dtype=torch.float64)
+            for t in (m, r):
+                t.running_mean.add_(dm.to(t.running_mean.device))
+                t.running_var.add_(dv.to(t.running_var.device))
+                t.count.add_(4096 * (epoch + 1))
+        if epoch == 1:
+            ours.seed()
+            theirs.seed()
+        ours.merge(fake_all_reduce)
+        theirs.merge(fake_all_reduce)
+        assert torch.equal(ours.deltas.cpu(), theirs.deltas) and torch.equal(ours.snapshot.cpu(), theirs.snapshot)
+        for m, r in zip(mods, refs):
+            assert m.count.item() == r.count.item()
+            assert torch.equal(m.running_mean.cpu(), r.running_mean) and torch.equal(m.running_var.cpu(), r.running_var)
+    # broadcast mode: "rank 0" hands over a different state
+    other = [(torch.randn_like(r.running_mean), torch.rand_like(r.running_var) + 1, 12345 + i) for i, r in enumerate(refs)]
+
+    def fake_broadcast(t):
+        off = 0
+        for mean, var, n in other:
+            d = mean.numel()
+            t[off] = float(n)
+            t[off + 1:off + 1 + d] = mean.to(t.device)
+            t[off + 1 + d:off + 1 + 2 * d] = var.to(t.device)
+            off += 1 + 2 * d
+    ours.adopt_rank0(fake_broadcast)
+    for m, (mean, var, n) in zip(mods, other):
+        assert m.count.item() == n and torch.equal(m.running_mean.cpu(), mean) and torch.equal(m.running_var.cpu(), var)
+
+
+def test_stats_sync_function_seams_and_clamp():
+    """The reference's per-module function names stay callable (merge_rank_stats / seed_stats_sync_snapshot /
+    broadcast_rank_stats); a variance that cancels below 1e-8 is clamped like `.clamp_(min=1e-8)`."""
+    from rl_games_amd import distributed as rdist
+    (m,) = _gpu_stats((4,), seed=5)
+    m.running_mean.fill_(1e6)
+    m.running_var.fill_(1e-12)
+    m.count.fill_(1000)
+    rdist.merge_rank_stats(m, lambda t: t.mul_(2))
+    assert m.count.item() == 2000
+    assert torch.all(m.running_var >= 1e-8) and torch.allclose(m.running_mean, torch.full_like(m.running_mean, 1e6))
+    before = (m.running_mean.clone(), m.running_var.clone(), m.count.item())
+    rdist.seed_stats_sync_snapshot(m)
+    rdist.merge_rank_stats(m, lambda t: t.mul_(2))          # nothing new since the seed: deltas are zero
+    assert m.count.item() == before[2] and torch.equal(m.running_mean, before[0])
+    rdist.broadcast_rank_stats(m, lambda t: t)
+    assert m.count.item() == before[2] and torch.equal(m.running_mean, before[0]) and torch.equal(m.running_var, m.running_var)
+    with pytest.raises(ValueError):
+        rdist.StatsSync([])
