@@ -307,6 +307,7 @@ def main():
     if eng is not None and getattr(eng, 'chain', None) is not None:
         from rl_games_amd import ops
         agent._hip_graphs = False
+        agent.kernel_timers = None        # (the GAE launch of this extra epoch is not part of `roofline`)
         ops.chain_timers = {}
         agent.update_epoch()
         agent.train_epoch()

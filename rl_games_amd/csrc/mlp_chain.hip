@@ -34,12 +34,15 @@
 #include "ppo_loss_tile.hpp"
 #include "rlg_hip.h"
 
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 // Timing-only ablations for tools/ablate_chain.sh (-DRLG_ABL=mask builds a library that computes WRONG results and
 // shows what a phase costs): 1 no bias/activation maths, 2 no global stores of the epilogues, 4 no epilogue at all,
-// 8 no remainder units, 16 no barriers between layers, 32 no prologue loads, 64 no weight traffic (A loads out of range)
+// 8 no remainder units, 16 no barriers between layers, 32 no prologue loads, 64 no weight traffic (A loads out of range),
+// 128 (pipelined kernels) no LDS reads of the B fragments
 #ifndef RLG_ABL
 #define RLG_ABL 0
 #endif
@@ -88,6 +91,11 @@ struct ChainArgs {
   int lds_b_floats;
   int lds_split_floats;        // forward: offset of the K-split scratch (partial fragments of remainder units)
   int no_ksplit;               // tools (RLG_CHAIN_KSPLIT=0): remainder units without the K-split            // start of the second LDS region, in floats
+  // pipelined kernels: ONE buffer resource over every weight matrix and bias vector (the flat parameter arena)
+  const float* w_base;
+  unsigned w_bytes;
+  unsigned w_off[kChainMaxLayers];     // byte offset of layer[L].w from w_base
+  unsigned b_off[kChainMaxLayers];     // byte offset of layer[L].bias from w_base (forward)
   long long* dbg;
   int with_loss;               // backward: evaluate the PPO loss of the tile first (LossArgs)              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
 };
@@ -477,19 +485,12 @@ __device__ __forceinline__ bool vec4_ok(const void* p, long long ld) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int G, int HACT, int W>
-__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = lane_id();
-  const int wave = wave_id_uniform();
-  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
-  float* tile_a = lds;
-  float* tile_b = lds + a.lds_b_floats;
-  int stamp = 0;
-  chain_stamp(a.dbg, wave, stamp);
-
-  // ---- prologue: observation tile -> LDS (fragment layout), normalised on the way -----------------
-  {
+// Forward prologue of a workgroup of W waves that owns 16 * G rows from row0 on: observation tile -> LDS (fragment
+// layout) in tile_a, normalised on the way (RunningMeanStd state folded first when a.rms_batch is given; the
+// mean / denominator scratch lives in tile_b), normalised observations written to a.xn.  Ends with a barrier.
+template <int G, int W>
+__device__ __forceinline__ void chain_fwd_prologue(const ChainArgs& a, float* tile_a, float* tile_b, long long row0, int lane,
+                                                   int wave, int& stamp) {
     const int in0 = a.layer[0].in;
     const int in0p = (in0 + 3) & ~3;
     const bool norm = a.rms_mean != nullptr;
@@ -569,7 +570,21 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
     }
     chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
-  }
+}
+
+template <int G, int HACT, int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
+  float* tile_a = lds;
+  float* tile_b = lds + a.lds_b_floats;
+  int stamp = 0;
+  chain_stamp(a.dbg, wave, stamp);
+
+  // ---- prologue: observation tile -> LDS (fragment layout), normalised on the way -----------------
+  chain_fwd_prologue<G, W>(a, tile_a, tile_b, row0, lane, wave, stamp);
   chain_stamp(a.dbg, wave, stamp);
 
   // ---- the layers ---------------------------------------------------------------------------------
@@ -685,6 +700,326 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
     float* t = tin;
     tin = tout;
     tout = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined forward for large minibatches: 64-row workgroups (G = 4), 4 waves = one per SIMD.
+//
+// What the ablation builds of the unit-structured kernel above showed (tools/ablate_chain.sh,
+// profiles/r3_chain_ablation.txt; 32,768 rows): of its 131 us, 20 are epilogues that no MFMA overlaps at one
+// wave per SIMD, 10 the inefficiency of the remainder units (a cold weight fetch and a barrier behind a handful of
+// MFMAs each), 12 weight-fetch latency at the head of every chain_units call.  This kernel keeps ONE stream of
+// chunk steps going per wave and layer instead:
+//   * a unit is ONE 16-feature output block for all four row groups (4 accumulators), or - the last NOB mod 4
+//     blocks of a layer - one block for ONE row group (every wave takes a different group: same MFMA count for all);
+//     both kinds are steps of the same stream, so the remainder units inherit the weight prefetch of their
+//     predecessors.  Four chunk slots of A fragments are in flight; a slot is refilled right behind the MFMAs that
+//     consumed it with the chunk four steps ahead - of this unit, else of the NEXT unit, else of the next LAYER'S
+//     first unit (weights do not depend on the barrier), so no weight latency is ever exposed after the first unit;
+//   * a finished unit's accumulators are copied aside (16 moves) and its epilogue - bias, activation, LDS write,
+//     global store - runs as four pieces inside the first four chunk steps of the following unit;
+//   * every global access is a buffer instruction: one resource over all weights and biases (the flat parameter
+//     arena), one per activation output with the row range as its bound, so the ragged last tile needs no masks
+//     and the addresses are 32-bit lane offsets.
+// Same products in the same order as mlp_chain_fwd_kernel<4>: the results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(std::declval<rsrc_t>(), 0u, 0, 0));
+__device__ __forceinline__ void buf_store4(rsrc_t r, unsigned off, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+// bound of a resource over the (at most) tile_rows rows of a [rows, ld] fp32 array that are left from its base on
+__device__ __forceinline__ unsigned tile_bytes(long long rows_left, long long tile_rows, long long ld) {
+  const long long r = rows_left < tile_rows ? rows_left : tile_rows;
+  return static_cast<unsigned>(r * ld * 4);
+}
+
+struct PipeGeo {
+  int in, out, KC, full, nrem, rem_first, nunits;
+  unsigned w_off;
+};
+
+template <int G, int HACT>
+__global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
+  constexpr int W = 4;
+  using WholeTag = std::integral_constant<int, G>;
+  using OneTag = std::integral_constant<int, 1>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const int q4 = 4 * (lane >> 4);
+  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
+  float* tile_a = lds;
+  float* tile_b = lds + a.lds_b_floats;
+  const rsrc_t wr = make_rsrc(a.w_base, a.w_bytes);
+  const int num_layers = pin_s(a.num_layers);
+  const long long n_rows = pin_s(a.rows);
+
+  auto geo = [&](int L) -> PipeGeo {
+    PipeGeo g;
+    if (L >= num_layers) {
+      g.in = g.out = g.KC = g.full = g.nrem = g.rem_first = g.nunits = 0;
+      g.w_off = kOob;
+      return g;
+    }
+    g.in = pin_s(a.layer[L].in);
+    g.out = pin_s(a.layer[L].out);
+    g.w_off = static_cast<unsigned>(pin_s(static_cast<int>(a.w_off[L])));
+    g.KC = (g.in + 15) >> 4;
+    const int NOB = (g.out + 15) >> 4;
+    g.full = NOB / W;
+    g.rem_first = g.full * W;
+    // the remaining blocks are dealt out per (block, row group): unit u = wave + 4 j -> block u / G, group u % G
+    const int rem_units = (NOB - g.rem_first) * G;
+    g.nrem = rem_units > wave ? (rem_units - wave + W - 1) / W : 0;
+    g.nunits = g.full + g.nrem;
+    return g;
+  };
+  auto unit_ob = [&](const PipeGeo& g, int idx) -> int {
+    return idx < g.full ? wave * g.full + idx : g.rem_first + (wave + W * (idx - g.full)) / G;
+  };
+  auto rem_group = [&](int r) -> int { return (wave + W * r) % G; };
+  // per-lane byte offset of chunk 0 of block ob's weight rows; out-of-range rows read zero
+  auto a_base = [&](const PipeGeo& g, int ob) -> unsigned {
+    const int i = ob * 16 + (lane & 15);
+    return (!(kAbl & 64) && g.nunits > 0 && i < g.out) ? g.w_off + static_cast<unsigned>((i * g.in + q4) * 4) : kOob;
+  };
+
+  // ---- the first unit's weights are requested before anything else
+  PipeGeo cur = geo(0);
+  f32x4 aq[4];
+  auto first_batch = [&](const PipeGeo& g) {
+    const unsigned base0 = a_base(g, unit_ob(g, 0));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) aq[u] = buf_load4(wr, u < g.KC ? base0 + static_cast<unsigned>(u) * 64u : kOob);
+  };
+  first_batch(cur);
+  bool have_aq = cur.nunits > 0;      // aq holds the first batch of this wave's first unit of the layer
+  int stamp = 0;
+  chain_fwd_prologue<G, W>(a, tile_a, tile_b, row0, lane, wave, stamp);
+
+  f32x4 acc[4], accP[4], b0[4], b1[4], an[4], ar[4], biasC, biasP;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = accP[g] = an[g] = ar[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  biasC = biasP = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  float* tin = tile_a;
+  float* tout = tile_b;
+  for (int L = 0; L < num_layers; ++L) {
+    const bool last = (L == num_layers - 1);
+    const PipeGeo nxt = geo(L + 1);
+    const int l_out = cur.out, l_act = pin_s(a.layer[L].act);
+    const unsigned b_off = static_cast<unsigned>(pin_s(static_cast<int>(a.b_off[L])));
+    float* l_h = pin_s(a.layer[L].h);
+    const long long l_ldh = pin_s(a.layer[L].ldh);
+    const bool h_on = l_h != nullptr;
+    const bool h_fast = pin_s(static_cast<int>(h_on && vec4_ok(l_h, l_ldh) && (l_out & 3) == 0)) != 0;
+    const bool bias_fast = pin_s(static_cast<int>(((reinterpret_cast<uintptr_t>(a.w_base) + b_off) & 15u) == 0 && (l_out & 3) == 0)) != 0;
+    const rsrc_t hr = make_rsrc(h_on ? l_h + row0 * l_ldh : nullptr, h_on ? tile_bytes(n_rows - row0, 16 * G, l_ldh) : 0u);
+    const unsigned h_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(l_ldh) + q4) * 4);
+    const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(l_ldh) * 4);       // bytes between row groups
+    const float* bp = tin + lane * 4;
+    const int KC = cur.KC;
+
+    auto load_bias = [&](int ob) -> f32x4 {
+      const int f = ob * 16 + q4;
+      if (bias_fast) return buf_load4(wr, f < l_out ? b_off + static_cast<unsigned>(f) * 4u : kOob);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = buf_load1(wr, f + e < l_out ? b_off + static_cast<unsigned>(f + e) * 4u : kOob);
+      return v;
+    };
+    // B fragments of chunk c: all G row groups, or the one group g1 of a remainder unit
+    auto load_b = [&](auto ng_tag, f32x4 (&bv)[4], int c, int g1) {
+      constexpr int NG = decltype(ng_tag)::value;
+      if (kAbl & 128) return;
+      if constexpr (NG == G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) bv[g] = *reinterpret_cast<const f32x4*>(bp + (c * G + g) * 256);
+      } else {
+        bv[0] = *reinterpret_cast<const f32x4*>(bp + (c * G + g1) * 256);
+      }
+    };
+    int pend_ng = 0, pend_ob = 0, pend_g = 0;
+    // epilogue piece U of the pending unit: fragment (pend_ob, row group U | pend_g)
+    auto piece = [&](auto u_tag) {
+      constexpr int U = decltype(u_tag)::value;
+      const int g = pend_ng == G ? U : pend_g;
+      const int f = pend_ob * 16 + q4;
+      if ((kAbl & 4) && n_rows >= 0) return;
+      const f32x4 v = (kAbl & 1) ? accP[U] : chain_act4<HACT>(accP[U] + biasP, l_act);
+      if (!last) *reinterpret_cast<f32x4*>(tout + ((pend_ob * G + g) * 64 + lane) * 4) = v;
+      if ((kAbl & 2) && !last) return;
+      if (h_on) {
+        const unsigned off = h_lane + static_cast<unsigned>(g) * h_group + static_cast<unsigned>(pend_ob) * 64u;
+        if (h_fast) {
+          buf_store4(hr, f < l_out ? off : kOob, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) buf_store1(hr, f + e < l_out ? off + 4u * e : kOob, v[e]);
+        }
+      }
+    };
+    // The MFMAs of chunk c of a unit with NG row groups, the B fragments of chunk c + 1 (double buffer b0 / b1 by
+    // chunk parity; past the reduction's end the read is a harmless one of LDS behind the tile) and the refill of
+    // A slot U with chunk c + 4 (zero beyond the reduction: an out-of-range load) - ONE scheduling region, in which
+    // sched_group_barrier deals the LDS / VMEM / VALU instructions out between the MFMAs: at one wave per SIMD a
+    // clump of more than ~6 other instructions between two MFMAs leaves the matrix core idle (tools/exp/mfma_probe).
+    auto chunk = [&](auto ng_tag, auto bank_tag, auto u_tag, int c, int g1, unsigned base_cur) {
+      constexpr int NG = decltype(ng_tag)::value;
+      constexpr int U = decltype(u_tag)::value;
+      constexpr int BANK = decltype(bank_tag)::value;
+      f32x4 (&bc)[4] = (U & 1) ? b1 : b0;
+      f32x4 (&bn)[4] = (U & 1) ? b0 : b1;
+      // A slots come in two banks that alternate by batch of four chunks: the refill for chunk c + 4 goes into the
+      // OTHER bank's slot U while this bank's slot is still being read - straight into its final register
+      const f32x4 av = (BANK == 0) ? aq[U] : ar[U];
+      load_b(ng_tag, bn, c + 1, g1);
+      ((BANK == 0) ? ar[U] : aq[U]) = buf_load4(wr, c + 4 < KC ? base_cur + static_cast<unsigned>(c + 4) * 64u : kOob);
+      if constexpr (NG == G) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bc[g][s], acc[g], 0, 0, 0);
+        }
+        // issue order: MFMA, LDS read, MFMA, LDS read, ... then the refill's address arithmetic and load
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * G - G - 2, 0);
+      } else {
+        // a second accumulator takes the odd steps (40-cycle dependent-issue latency vs 32-cycle issue)
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bc[0][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bc[0][1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bc[0][2], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bc[0][3], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      RLG_PIN();
+    };
+    // One unit: [request the next unit's first batch + this unit's bias] [first batch: chunks 0..3, each followed
+    // by a piece of the pending epilogue] [the remaining batches] [hand-over].
+    auto run_unit = [&](auto ng_tag, int ob, int g1, unsigned base_cur, unsigned base_nxt, int KC_nxt) {
+      constexpr int NG = decltype(ng_tag)::value;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) an[u] = buf_load4(wr, u < KC_nxt ? base_nxt + static_cast<unsigned>(u) * 64u : kOob);
+      biasC = load_bias(ob);
+      RLG_PIN();
+      {
+        constexpr std::integral_constant<int, 0> U0{};
+        constexpr std::integral_constant<int, 1> U1{};
+        constexpr std::integral_constant<int, 2> U2{};
+        constexpr std::integral_constant<int, 3> U3{};
+        constexpr std::integral_constant<int, 0> BA{};
+        constexpr std::integral_constant<int, 1> BB{};
+        chunk(ng_tag, BA, U0, 0, g1, base_cur);
+        if (pend_ng > 0) piece(U0);
+        RLG_PIN();
+        if (1 < KC) chunk(ng_tag, BA, U1, 1, g1, base_cur);
+        if (pend_ng > 1) piece(U1);
+        RLG_PIN();
+        if (2 < KC) chunk(ng_tag, BA, U2, 2, g1, base_cur);
+        if constexpr (G > 2) { if (pend_ng > 2) piece(U2); }
+        RLG_PIN();
+        if (3 < KC) chunk(ng_tag, BA, U3, 3, g1, base_cur);
+        if constexpr (G > 2) { if (pend_ng > 3) piece(U3); }
+        RLG_PIN();
+        // the body of the reduction: eight chunks per iteration, no branch between them (hipcc falls back to
+        // vmcnt(0) behind a conditional chunk, i.e. it would wait for the refill it has just issued)
+        int c0 = 4;
+        for (; c0 + 8 <= KC; c0 += 8) {
+          chunk(ng_tag, BB, U0, c0, g1, base_cur);
+          chunk(ng_tag, BB, U1, c0 + 1, g1, base_cur);
+          chunk(ng_tag, BB, U2, c0 + 2, g1, base_cur);
+          chunk(ng_tag, BB, U3, c0 + 3, g1, base_cur);
+          chunk(ng_tag, BA, U0, c0 + 4, g1, base_cur);
+          chunk(ng_tag, BA, U1, c0 + 5, g1, base_cur);
+          chunk(ng_tag, BA, U2, c0 + 6, g1, base_cur);
+          chunk(ng_tag, BA, U3, c0 + 7, g1, base_cur);
+        }
+        // its last 0 .. 7 chunks
+        if (c0 < KC) {
+          chunk(ng_tag, BB, U0, c0, g1, base_cur);
+          if (c0 + 1 < KC) chunk(ng_tag, BB, U1, c0 + 1, g1, base_cur);
+          if (c0 + 2 < KC) chunk(ng_tag, BB, U2, c0 + 2, g1, base_cur);
+          if (c0 + 3 < KC) chunk(ng_tag, BB, U3, c0 + 3, g1, base_cur);
+          if (c0 + 4 < KC) chunk(ng_tag, BA, U0, c0 + 4, g1, base_cur);
+          if (c0 + 5 < KC) chunk(ng_tag, BA, U1, c0 + 5, g1, base_cur);
+          if (c0 + 6 < KC) chunk(ng_tag, BA, U2, c0 + 6, g1, base_cur);
+        }
+      }
+      // ---- hand-over: the accumulators move aside (their epilogue rides along with the next unit's first
+      //      steps), the next unit's first weight fragments - requested a whole unit ago - become current
+      if constexpr (NG == G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) accP[g] = acc[g];
+      } else {
+        accP[0] = acc[0] + acc[1];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) aq[u] = an[u];
+      biasP = biasC;
+      pend_ng = NG;
+      pend_ob = ob;
+      pend_g = g1;
+    };
+
+    // a wave without a unit in the previous layer (few blocks, G < 4) has nothing prefetched
+    if (!have_aq && cur.nunits > 0) first_batch(cur);
+    // the layer's first B fragments (the input tile is complete: a barrier precedes every layer)
+    if (cur.full > 0) load_b(WholeTag{}, b0, 0, 0);
+    else if (cur.nrem > 0) load_b(OneTag{}, b0, 0, rem_group(0));
+    unsigned base_cur = a_base(cur, unit_ob(cur, 0));
+    // whole blocks: all G row groups
+    for (int idx = 0; idx < cur.full; ++idx) {
+      const bool more = idx + 1 < cur.nunits;
+      const unsigned base_nxt = more ? a_base(cur, unit_ob(cur, idx + 1)) : a_base(nxt, unit_ob(nxt, 0));
+      run_unit(WholeTag{}, unit_ob(cur, idx), 0, base_cur, base_nxt, more ? KC : nxt.KC);
+      if (idx + 1 < cur.full) load_b(WholeTag{}, b0, 0, 0);
+      else if (more) load_b(OneTag{}, b0, 0, rem_group(0));
+      base_cur = base_nxt;
+    }
+    // remainder blocks, one row group at a time: every wave the same number of MFMAs (+- one unit)
+    for (int r = 0; r < ((kAbl & 8) ? 0 : cur.nrem); ++r) {
+      const int idx = cur.full + r;
+      const bool more = r + 1 < cur.nrem;
+      const unsigned base_nxt = more ? a_base(cur, unit_ob(cur, idx + 1)) : a_base(nxt, unit_ob(nxt, 0));
+      run_unit(OneTag{}, unit_ob(cur, idx), rem_group(r), base_cur, base_nxt, more ? KC : nxt.KC);
+      if (more) load_b(OneTag{}, b0, 0, rem_group(r + 1));
+      base_cur = base_nxt;
+    }
+    have_aq = cur.nunits > 0 && nxt.nunits > 0;
+    // the layer's last epilogue has no successor to ride with
+    if (pend_ng > 0) piece(std::integral_constant<int, 0>{});
+    if (pend_ng > 1) {
+      piece(std::integral_constant<int, 1>{});
+      if constexpr (G > 2) {
+        piece(std::integral_constant<int, 2>{});
+        piece(std::integral_constant<int, 3>{});
+      }
+    }
+    if (!(kAbl & 16)) __syncthreads();
+    float* t = tin;
+    tin = tout;
+    tout = t;
+    cur = nxt;
   }
 }
 
@@ -865,14 +1200,23 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
   }
 }
 
+static bool chain_pipe_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_CHAIN_PIPE");       // tools: A/B against the unit-structured kernels
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+
 // Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
 // profiles/r2_mlp_chain_microbench_*.txt): forward - two 32-row workgroups per CU (G = 2, two waves
 // per SIMD) beat one 64-row workgroup (G = 4, one wave per SIMD): the second wave covers the epilogue
 // and unit-boundary stalls of the first; below 16,384 rows G = 1 keeps every CU busy.
 static int pick_groups(long long rows, int requested, int direction = 0) {
   if (requested == 1 || requested == 2 || requested == 4) return requested;
-  // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU
-  if (rows >= 16384) return direction == 1 ? 4 : 2;
+  // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU.
+  // forward: the pipelined kernel (round 3) is fastest with 64-row workgroups, the unit-structured one with 32
+  if (rows >= 16384) return (direction == 1 || chain_pipe_enabled()) ? 4 : 2;
   return 1;
 }
 
@@ -980,6 +1324,47 @@ static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st,
   RLG_RETURN_LAUNCH_STATUS();
 }
 
+// The pipelined kernels address every weight matrix and bias vector through ONE buffer resource: fills w_base /
+// w_bytes / w_off / b_off, false when the arrays are too far apart (separate allocations more than 1 GiB apart)
+// or not 16-byte aligned rows (in % 4 != 0) - the unit-structured kernels take those.
+static bool chain_pipe_fill(ChainArgs& args, bool with_bias) {
+  uintptr_t lo = ~static_cast<uintptr_t>(0), hi = 0;
+  for (int L = 0; L < args.num_layers; ++L) {
+    const ChainLayer& ly = args.layer[L];
+    const uintptr_t w = reinterpret_cast<uintptr_t>(ly.w);
+    if ((w & 15u) != 0 || (ly.in & 3) != 0) return false;
+    lo = w < lo ? w : lo;
+    hi = w + static_cast<uintptr_t>(ly.in) * ly.out * 4 > hi ? w + static_cast<uintptr_t>(ly.in) * ly.out * 4 : hi;
+    if (with_bias) {
+      const uintptr_t b = reinterpret_cast<uintptr_t>(ly.bias);
+      if (b == 0 || (b & 3u) != 0) return false;
+      lo = b < lo ? b : lo;
+      hi = b + static_cast<uintptr_t>(ly.out) * 4 > hi ? b + static_cast<uintptr_t>(ly.out) * 4 : hi;
+    }
+  }
+  lo &= ~static_cast<uintptr_t>(15);
+  if (hi - lo >= static_cast<uintptr_t>(kOob)) return false;
+  args.w_base = reinterpret_cast<const float*>(lo);
+  args.w_bytes = static_cast<unsigned>(hi - lo);
+  for (int L = 0; L < args.num_layers; ++L) {
+    args.w_off[L] = static_cast<unsigned>(reinterpret_cast<uintptr_t>(args.layer[L].w) - lo);
+    args.b_off[L] = with_bias ? static_cast<unsigned>(reinterpret_cast<uintptr_t>(args.layer[L].bias) - lo) : 0u;
+  }
+  return true;
+}
+template <int G, int HACT>
+static int chain_launch_fwd_pipe(const ChainArgs& args, int lds_bytes, hipStream_t st) {
+  const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+  hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+  g_chain_ev_start = g_chain_ev_stop = nullptr;
+  if (ev0 != nullptr)
+    hipExtLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT>), dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st,
+                          ev0, ev1, 0, args);
+  else
+    hipLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT>), dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, args);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
 // Waves per workgroup.  Small minibatches (one data-parallel rank's 4,096 rows: 256 workgroups of 16
 // rows, at most one or two per CU) are bound by the serial chain of a workgroup, not by MFMA
 // throughput: 8 waves halve each wave's share of every layer and put two waves on every SIMD.
@@ -1040,6 +1425,8 @@ int rlg_mlp_chain_prepare(void) {
       reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChElu, 4>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny, 4>),
       reinterpret_cast<const void*>(mlp_chain_fwd_kernel<2, kChAny, 4>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4, kChAny, 4>),
       reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny, 8>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<4, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<4, kChAny>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<2, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<2, kChAny>),
       reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2, 4>),
       reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 8>)};
   for (const void* k : kernels) {
@@ -1118,6 +1505,12 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
     args.no_ksplit = off;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (G >= 2 && chain_pipe_enabled() && args.dbg == nullptr && chain_pipe_fill(args, true)) {
+    bool elu_only = true;
+    for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);
+    if (G == 4) return elu_only ? chain_launch_fwd_pipe<4, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<4, kChAny>(args, lds_bytes, st);
+    return elu_only ? chain_launch_fwd_pipe<2, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<2, kChAny>(args, lds_bytes, st);
+  }
   if (G == 4) return chain_launch<4, false>(args, lds_bytes, st);
   if (G == 2) return chain_launch<2, false>(args, lds_bytes, st);
   return chain_launch<1, false>(args, lds_bytes, st);

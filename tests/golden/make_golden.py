@@ -385,8 +385,74 @@ def make_central_value():
     print('central_value.pt written', os.path.getsize(os.path.join(HERE, 'central_value.pt')) // 1024, 'KiB')
 
 
+def make_lstm_full():
+    """BASELINE.json config #5 AT ITS OWN SIZE - 4,096 envs x seq_len 16, obs 3, act 1, MLP [64,64] + LSTM 64,
+    minibatch 16,384, 4 mini-epochs = 16 optimiser steps - one train_epoch of the REAL reference agent
+    (play_steps_rnn, a2c_common.py:1071-1202; recurrent.py:26-83) on the synthetic env.  Stored: the rollout batch
+    with the rnn states, the model state it was played with, and the reference's per-minibatch results.
+    gzip-compressed (the initial rnn states are zeros): tests/golden/lstm_full.pt.gz."""
+    import copy
+    import gzip
+    import io
+    import ref_import
+    ref_import.enable()
+    from rl_games.torch_runner import Runner
+    from rl_games_amd import configs
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    params = configs.pendulum_lstm_4096(device='cpu', train_dir='/tmp/rlg_golden_runs', games_to_track=100)
+    N, O_, A = 4096, 3, 1
+    params['seed'] = 7
+    env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=1234)
+    params['config']['env_info'] = env.get_env_info()
+    stored_params = copy.deepcopy({k: v for k, v in params.items()})
+    stored_params['config'].pop('env_info')
+    runner = Runner()
+    runner.load({'params': copy.deepcopy(params)})
+    runner.params['config']['vec_env'] = env
+    runner.params['config']['env_info'] = env.get_env_info()
+    agent = runner.algo_factory.create(runner.algo_name, base_name='golden', params=runner.params)
+    torch.manual_seed(11)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    cap = {'lrs': []}
+    orig_play = agent.play_steps_rnn
+
+    def play():
+        b = orig_play()
+        cap['batch'] = _clone({k: v for k, v in b.items() if isinstance(v, torch.Tensor)})
+        cap['batch']['rnn_states'] = _clone(b['rnn_states'])
+        cap['state_after_rollout'] = _clone(agent.model.state_dict())
+        return b
+    agent.play_steps_rnn = play
+    orig_update_lr = agent.update_lr
+
+    def update_lr(lr):
+        cap['lrs'].append(float(lr))
+        return orig_update_lr(lr)
+    agent.update_lr = update_lr
+    agent.epoch_num = 1
+    res = agent.train_epoch()
+    (_, _, _, _, a_losses, c_losses, b_losses, entropies, kls, last_lr, lr_mul) = res
+    cap['a_losses'] = torch.stack([x.detach() for x in a_losses])
+    cap['c_losses'] = torch.stack([x.detach() for x in c_losses])
+    cap['b_losses'] = torch.stack([x.detach() for x in b_losses])
+    cap['entropies'] = torch.stack([x.detach() for x in entropies])
+    cap['mini_epoch_kls'] = torch.stack([x.detach() for x in kls])
+    cap['last_lr'] = float(last_lr)
+    cap['final_state'] = _clone(agent.model.state_dict())
+    cap['params'] = stored_params
+    cap['env'] = {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 1234}
+    buf = io.BytesIO()
+    torch.save(cap, buf)
+    path = os.path.join(HERE, 'lstm_full.pt.gz')
+    with gzip.open(path, 'wb', compresslevel=9) as f:
+        f.write(buf.getvalue())
+    print('lstm_full: minibatches', len(a_losses), 'lrs', cap['lrs'][:4], 'kl', cap['mini_epoch_kls'].tolist())
+    print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
+
+
 SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'checkpoint': make_checkpoint,
-            'central_value': make_central_value}
+            'central_value': make_central_value, 'lstm_full': make_lstm_full}
 
 if __name__ == '__main__':
     only = sys.argv[1:] or list(SECTIONS)

@@ -292,6 +292,43 @@ def test_lstm_update_matches_reference_epoch(golden, manual_lstm):
         assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
 
 
+def test_lstm_config5_at_its_own_size_matches_reference_epoch():
+    """BASELINE.json config #5 AT ITS OWN SIZE - 4,096 envs x seq_len 16, obs 3, act 1, MLP [64,64] + LSTM 64,
+    minibatch 16,384 x 4 mini-epochs = 16 optimiser steps - against one train_epoch of the REAL reference agent
+    (tests/golden/lstm_full.pt.gz, written by tests/golden/make_golden.py lstm_full from /root/reference:
+    play_steps_rnn a2c_common.py:1071-1202, LSTMWithDones recurrent.py:26-83) on the recorded rollout and rnn
+    states, through the sequence-persistent LSTM kernels of the manual engine."""
+    import gzip
+    import io
+    import os
+    from conftest import GOLDEN_DIR
+    with gzip.open(os.path.join(GOLDEN_DIR, 'lstm_full.pt.gz'), 'rb') as f:
+        cap = torch.load(io.BytesIO(f.read()), map_location='cpu', weights_only=False)
+    agent = _make_agent(cap, manual_lstm=True)
+    assert agent.is_rnn and agent._engine is not None and agent._engine.lstm is not None
+    assert (agent.num_actors, agent.horizon_length, agent.seq_length, agent.minibatch_size) == (4096, 16, 16, 16384)
+    agent.model.load_state_dict(cap['state_after_rollout'])
+    batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else [s.to(DEV) for s in v])
+             for k, v in cap['batch'].items()}
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    rows = []
+    for mini_ep in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            rows.append(torch.stack([a, c, e, kl, b]).clone())
+    rows = torch.stack(rows).cpu()
+    assert rows.shape[0] == 16
+    assert torch.allclose(rows[:, 0], cap['a_losses'], rtol=1e-5, atol=2e-6), (rows[:, 0] - cap['a_losses']).abs().max()
+    assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6), (rows[:, 1] - cap['c_losses']).abs().max()
+    assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rows[:, 4], cap['b_losses'], rtol=1e-5, atol=1e-7)
+    kls = rows[:, 3].reshape(agent.mini_epochs_num, len(agent.dataset)).mean(1)
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-3, atol=1e-7), (kls, cap['mini_epoch_kls'])
+    # the learning-rate trajectory of the 16 steps (update_lr calls of the reference), bit for bit
+    assert agent.optimizer.last_and_next_lr()[1] == cap['lrs'][-1]
+
+
 def test_lstm_engine_matches_autograd_gradients_and_rollout():
     """LSTM policy: (i) the engine's rollout step (fused head + persistent LSTM kernel, T = 1) leaves
     the same buffer contents as the torch model path given the same noise-free quantities, and

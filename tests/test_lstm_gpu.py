@@ -1,10 +1,10 @@
-"""GPU: the sequence-persistent LSTM kernels (csrc/lstm.hip) against torch.nn.LSTM run step by step
-with the reference's done-reset semantics (rl_games/common/layers/recurrent.py:26-58; host mirror
-policy.RnnWithDones), forward and - through autograd on the torch side - backward.
+"""GPU: the sequence-persistent LSTM kernels (csrc/lstm.hip) against a CPU evaluation in fp64 of torch.nn.LSTM run
+step by step with the reference's done-reset semantics (rl_games/common/layers/recurrent.py:26-58; host mirror
+policy.RnnWithDones), forward and - through autograd on the CPU side - backward.  (Round 2 compared with
+torch.nn.LSTM on the same GPU, i.e. with MIOpen; the reference here is independent of any GPU library.)
 
-Tolerance: both sides are fp32 with different summation orders (H-term dot products, sigmoid /
-tanh implementations): rtol 1e-5 north_star tolerance on O(1) activations plus an absolute term
-for values near zero; gradients are compared relative to the tensor scale."""
+Tolerance: the kernels are fp32, the reference exact to fp32 resolution: rtol 1e-5 north_star tolerance on O(1)
+activations plus an absolute term for values near zero; gradients are compared relative to the tensor scale."""
 import pytest
 import torch
 
@@ -35,18 +35,33 @@ def _reference(x, lstm, h0, c0, dones, T):
 def test_lstm_forward_backward_match_torch(S, T, I, H, with_dones):
     from rl_games_amd import ops
     g = torch.Generator().manual_seed(S * 7 + T)
-    lstm = torch.nn.LSTM(I, H, 1).to(DEV)
-    x = torch.randn(S * T, I, generator=g).to(DEV).requires_grad_(True)
+    lstm32 = torch.nn.LSTM(I, H, 1)
+    x32 = torch.randn(S * T, I, generator=g)
     h0 = (0.5 * torch.randn(S, H, generator=g)).to(DEV)
     c0 = (0.5 * torch.randn(S, H, generator=g)).to(DEV)
     dones = (torch.rand(S * T, generator=g) < 0.2).to(torch.uint8).to(DEV) if with_dones else None
     d_out = torch.randn(S * T, H, generator=g).to(DEV)
 
-    ref_out, (ref_h, ref_c) = _reference(x, lstm, h0, c0, dones, T)
-    ref_out.backward(d_out)
+    # the reference: CPU, fp64, the fp32 parameters and inputs upcast exactly
+    lstm = torch.nn.LSTM(I, H, 1).double()
+    lstm.load_state_dict({k: v.double() for k, v in lstm32.state_dict().items()})
+    x = x32.double().requires_grad_(True)
+    ref_out, (ref_h, ref_c) = _reference(x, lstm, h0.cpu().double(), c0.cpu().double(),
+                                         None if dones is None else dones.cpu(), T)
+    ref_out.backward(d_out.cpu().double())
+    ref_out, ref_h, ref_c = ref_out.float().to(DEV), ref_h.float().to(DEV), ref_c.float().to(DEV)
 
-    w_ih, w_hh = lstm.weight_ih_l0.detach(), lstm.weight_hh_l0.detach()
-    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach()
+    class _Grads:
+        pass
+    for name in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'):
+        t = _Grads()
+        t.grad = getattr(lstm, name).grad.float().to(DEV)
+        setattr(lstm, '_' + name, t)
+    x_grad = x.grad.float().to(DEV)
+    x = x32.to(DEV)
+
+    w_ih, w_hh = lstm32.weight_ih_l0.detach().to(DEV), lstm32.weight_hh_l0.detach().to(DEV)
+    bias = (lstm32.bias_ih_l0 + lstm32.bias_hh_l0).detach().to(DEV)
     gates = torch.addmm(bias, x.detach(), w_ih.t())
     out = torch.empty(S * T, H, device=DEV)
     c_all = torch.empty(S * T, H, device=DEV)
@@ -67,11 +82,11 @@ def test_lstm_forward_backward_match_torch(S, T, I, H, with_dones):
     def close(a, b, name):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-7, (name, (a - b).abs().max().item(), scale)
-    close(dx, x.grad, 'dx')
-    close(dw_ih, lstm.weight_ih_l0.grad, 'dw_ih')
-    close(dw_hh, lstm.weight_hh_l0.grad, 'dw_hh')
-    close(db, lstm.bias_ih_l0.grad, 'db_ih')
-    close(db, lstm.bias_hh_l0.grad, 'db_hh')
+    close(dx, x_grad, 'dx')
+    close(dw_ih, lstm._weight_ih_l0.grad, 'dw_ih')
+    close(dw_hh, lstm._weight_hh_l0.grad, 'dw_hh')
+    close(db, lstm._bias_ih_l0.grad, 'db_ih')
+    close(db, lstm._bias_hh_l0.grad, 'db_hh')
 
 
 def test_lstm_rejects_unsupported_hidden_and_cpu():

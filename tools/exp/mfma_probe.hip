@@ -12,7 +12,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ w, int w_floats, int ld, float* out, int iters) {
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ w, int w_floats, int ld, float* out, int iters,
+                                             unsigned long long* clk) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   __shared__ __attribute__((aligned(16))) float lds[16 * 1024];   // 64 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 16 * 1024; i += 256) lds[i] = 0.001f * (i & 255);
@@ -69,23 +71,31 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ w, int w_
   }
   f32x4 s = acc[0] + acc[1] + acc[2] + acc[3];
   out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = __builtin_amdgcn_s_memtime() - t0;
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
 }
 
 template <int MODE>
 void run(const char* name, const float* w, int w_floats, int ld, float* out, int blocks, int iters) {
+  static unsigned long long* clk = nullptr;
+  if (!clk) hipMalloc(&clk, 16);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, w, w_floats, ld, out, iters);
+  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, w, w_floats, ld, out, iters, clk);
   hipEventRecord(e0);
   const int reps = 5;
-  for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, w, w_floats, ld, out, iters);
+  for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, w, w_floats, ld, out, iters, clk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
   const double flops = 2.0 * 16 * 16 * 4 * 64.0 * iters * blocks * 4;
-  printf("%-58s blocks %4d  %9.1f us  %7.1f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", name, blocks, us, flops / us / 1e6,
-         us * 1e-6 * 2.4e9 / (64.0 * iters) / ((blocks + 255) / 256));
+  unsigned long long h[2];
+  hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  printf("%-58s blocks %4d  %9.1f us  %7.1f TFLOP/s  shader clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz)\n", name, blocks, us,
+         flops / us / 1e6, 100.0 * (double)h[0] / (double)h[1]);
 }
 
 int main() {
