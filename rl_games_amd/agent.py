@@ -775,6 +775,10 @@ class A2CAgent:
         if eng.chain is not None:
             # normaliser + every layer + heads in one launch; nothing but the heads is written
             heads = eng.forward_obs(obs, self._obs_rms(), self._obs_eps(), keep=False)
+        elif self.is_rnn and eng.chain_rnn is not None and obs.dtype == torch.float32:
+            # recurrent policy: normaliser + trunk + gate-input product in one launch, then the LSTM step + heads
+            heads = eng.forward(obs, keep=False, rnn_states=rnn_states, seq_length=1,
+                                raw_rms=self._obs_rms() or (), eps=self._obs_eps())
         else:
             if self.normalize_input:
                 m = self.model.running_mean_std
@@ -818,6 +822,9 @@ class A2CAgent:
             x = x.contiguous()
         if eng.chain is not None:
             heads = eng.forward_obs(x, self._obs_rms(), self._obs_eps(), keep=False)
+        elif self.is_rnn and eng.chain_rnn is not None and x.dtype == torch.float32:
+            heads = eng.forward(x, keep=False, rnn_states=self.rnn_states, seq_length=1,
+                                raw_rms=self._obs_rms() or (), eps=self._obs_eps())
         else:
             if self.normalize_input:
                 m = self.model.running_mean_std
@@ -1066,12 +1073,22 @@ class A2CAgent:
                             self.model.running_mean_std.update(obs_batch)
                     heads = eng.forward_obs(obs_batch, rms, self._obs_eps(), rms_fold=fold)
                     obs_n = None
+                elif self.is_rnn and eng.chain_rnn is not None and obs_batch.dtype == torch.float32:
+                    # recurrent policy on the fused trunk: the statistics update stays its own (two) launches, the
+                    # normalisation happens inside the trunk launch
+                    if not obs_batch.is_contiguous():
+                        obs_batch = obs_batch.contiguous()
+                    if self.normalize_input and self.model.running_mean_std.training:
+                        self.model.running_mean_std.update(obs_batch)
+                    heads = eng.forward(obs_batch, rnn_states=batch['rnn_states'], dones=batch.get('dones'),
+                                        seq_length=self.seq_length, raw_rms=self._obs_rms() or (), eps=self._obs_eps())
+                    obs_n = None
                 elif self.normalize_input:                              # updates the obs statistics
                     out = self._obs_norm_mb[:obs_batch.shape[0]] if self._obs_norm_mb is not None else None
                     obs_n = self.model.running_mean_std(obs_batch, out=out)
                 else:
                     obs_n = obs_batch
-                if eng.chain is not None:
+                if eng.chain is not None or obs_n is None:
                     pass
                 elif self.is_rnn:
                     heads = eng.forward(obs_n, rnn_states=batch['rnn_states'], dones=batch.get('dones'),

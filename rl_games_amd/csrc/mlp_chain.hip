@@ -799,7 +799,9 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
   first_batch(cur);
   bool have_aq = cur.nunits > 0;      // aq holds the first batch of this wave's first unit of the layer
   int stamp = 0;
-  chain_fwd_prologue<G, W>(a, tile_a, tile_b, row0, lane, wave, stamp);
+  chain_stamp(a.dbg, wave, stamp);                                   // tools/exp/pipe_phases.py: start
+  chain_fwd_prologue<G, W>(a, tile_a, tile_b, row0, lane, wave, stamp);    // tile in LDS (stamped inside)
+  chain_stamp(a.dbg, wave, stamp);                                   // behind the prologue's barrier
 
   f32x4 acc[4], accP[4], b0[4], b1[4], an[4], ar[4], biasC, biasP;
 #pragma unroll
@@ -996,6 +998,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
       else if (more) load_b(OneTag{}, b0, 0, rem_group(0));
       base_cur = base_nxt;
     }
+    chain_stamp(a.dbg, wave, stamp);                                 // per layer: whole units done
     // remainder blocks, one row group at a time: every wave the same number of MFMAs (+- one unit)
     for (int r = 0; r < ((kAbl & 8) ? 0 : cur.nrem); ++r) {
       const int idx = cur.full + r;
@@ -1006,6 +1009,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
       base_cur = base_nxt;
     }
     have_aq = cur.nunits > 0 && nxt.nunits > 0;
+    chain_stamp(a.dbg, wave, stamp);                                 // remainder units done
     // the layer's last epilogue has no successor to ride with
     if (pend_ng > 0) piece(std::integral_constant<int, 0>{});
     if (pend_ng > 1) {
@@ -1015,7 +1019,9 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
         piece(std::integral_constant<int, 3>{});
       }
     }
+    chain_stamp(a.dbg, wave, stamp);                                 // last epilogue flushed
     if (!(kAbl & 16)) __syncthreads();
+    chain_stamp(a.dbg, wave, stamp);                                 // behind the barrier
     float* t = tin;
     tin = tout;
     tout = t;
@@ -1214,9 +1220,17 @@ static bool chain_pipe_enabled() {
 // and unit-boundary stalls of the first; below 16,384 rows G = 1 keeps every CU busy.
 static int pick_groups(long long rows, int requested, int direction = 0) {
   if (requested == 1 || requested == 2 || requested == 4) return requested;
+  {
+    static const int forced_fwd = [] { const char* e = std::getenv("RLG_CHAIN_FWD_GROUPS"); return e ? std::atoi(e) : 0; }();
+    static const int forced_bwd = [] { const char* e = std::getenv("RLG_CHAIN_BWD_GROUPS"); return e ? std::atoi(e) : 0; }();
+    const int f = direction == 1 ? forced_bwd : forced_fwd;       // tools: A/B measurements inside bench.py
+    if (rows >= 16384 && (f == 1 || f == 2 || f == 4)) return f;
+  }
   // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU.
-  // forward: the pipelined kernel (round 3) is fastest with 64-row workgroups, the unit-structured one with 32
-  if (rows >= 16384) return (direction == 1 || chain_pipe_enabled()) ? 4 : 2;
+  // forward: two 32-row workgroups per CU (two waves per SIMD) - in the epoch that beats one 64-row workgroup for
+  // both forward kernels (bench.py roofline_fwd via tools/bench_ab.sh: 122.8 / 132.6 us pipelined, 125 / 130.4 us
+  // unit-structured), although a back-to-back microbenchmark says the opposite for the pipelined one
+  if (rows >= 16384) return direction == 1 ? 4 : 2;
   return 1;
 }
 
@@ -1505,7 +1519,7 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
     args.no_ksplit = off;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (G >= 2 && chain_pipe_enabled() && args.dbg == nullptr && chain_pipe_fill(args, true)) {
+  if (G >= 2 && chain_pipe_enabled() && chain_pipe_fill(args, true)) {
     bool elu_only = true;
     for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);
     if (G == 4) return elu_only ? chain_launch_fwd_pipe<4, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<4, kChAny>(args, lds_bytes, st);

@@ -91,6 +91,7 @@ class ManualMLP:
         self.nb = [ops.act_bwd_blocks(max_rows, w) for w in widths]
         self.chain = None
         self._pending_backward = False
+        self._fused_trunk = False
         if fused_chain and self.lstm is None:
             try:
                 layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
@@ -98,7 +99,19 @@ class ManualMLP:
                 self.chain = ops.MlpChain(layers, dev)
             except NotImplementedError:
                 self.chain = None
-        if self.chain is not None:
+        # Recurrent policies (round 3): the trunk IN FRONT of the LSTM - observation normaliser, hidden layers and
+        # the gate-input product W_ih x + (b_ih + b_hh) as the chain's last (linear) layer - is the same fused
+        # forward / backward launch pair; the sequence-persistent LSTM kernels and the head product follow.
+        self.chain_rnn = None
+        if fused_chain and self.lstm is not None:
+            try:
+                self.bias_sum = torch.empty(4 * self.Hr, device=dev)
+                layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
+                layers.append((self.lstm.weight_ih_l0, self.bias_sum, 'None'))
+                self.chain_rnn = ops.MlpChain(layers, dev)
+            except NotImplementedError:
+                self.chain_rnn = None
+        if self.chain is not None or self.chain_rnn is not None:
             self.nb = [(max_rows + 15) // 16 for _ in widths]      # one partial row per 16-row group at most
             self.xn = torch.empty(max_rows, self.linears[0].in_features, device=dev)
         self.partials = [torch.empty(nb * w, dtype=torch.float64, device=dev) for nb, w in zip(self.nb, widths)]
@@ -110,7 +123,8 @@ class ManualMLP:
             self.d_rnn_out = torch.empty(max_rows, Hr, device=dev)
             self.c_all = torch.empty(max_rows, Hr, device=dev)
             self.hprev = torch.empty(max_rows, Hr, device=dev)
-            self.bias_sum = torch.empty(4 * Hr, device=dev)
+            if self.chain_rnn is None:
+                self.bias_sum = torch.empty(4 * Hr, device=dev)
             self.gate_partials = torch.empty(ops.act_bwd_blocks(max_rows, 4 * Hr) * 4 * Hr,
                                              dtype=torch.float64, device=dev)
             # final states of the last forward, ping-pong so that a caller may feed them back in
@@ -135,12 +149,14 @@ class ManualMLP:
 
     # ------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, keep=True, rnn_states=None, dones=None, seq_length=1):
+    def forward(self, x, keep=True, rnn_states=None, dones=None, seq_length=1, raw_rms=None, eps=1e-5):
         """x: [rows, in] normalised observations.  Returns heads [rows, V+A] (col 0..V-1 value,
         then mu).  `keep` retains what backward() needs (activations, LSTM cell states).  LSTM policies: rows are
         ordered (sequence, t) with `seq_length` steps each, rnn_states = (h0, c0) of shape
         [1, rows/seq_length, H], dones [rows] u8 resets the state entering a step (or None);
-        the final states are left in `self.last_states`."""
+        the final states are left in `self.last_states`.
+        raw_rms (recurrent policies on the fused trunk, `chain_rnn`): x holds RAW observations and raw_rms =
+        (running_mean, running_var) or () for normalize_input off - the launch normalises on the way in."""
         rows = x.shape[0]
         if self._pending_backward and not keep:
             # in-place activations: an inference forward reuses the buffers backward() reads
@@ -148,7 +164,10 @@ class ManualMLP:
                                'backward() still needs')
         self._pending_backward = bool(keep)
         a = x
-        for l, lin in enumerate(self.linears):
+        fused_trunk = raw_rms is not None
+        if fused_trunk and (self.chain_rnn is None or self.lstm is None):
+            raise ValueError('raw_rms: the fused recurrent trunk is not available for this policy')
+        for l, lin in enumerate(() if fused_trunk else self.linears):
             z = self.Z[l][:rows]
             torch.addmm(lin.bias, a, lin.weight.t(), out=z)
             h = self.Hs[l][:rows]                      # same storage as z when inplace_act
@@ -171,7 +190,19 @@ class ManualMLP:
                 raise ValueError(f'rnn_states must be contiguous [1, {S}, {self.Hr}] tensors')
             torch.add(rnn.bias_ih_l0, rnn.bias_hh_l0, out=self.bias_sum)
             gates = self.gates[:rows]
-            torch.addmm(self.bias_sum, a, rnn.weight_ih_l0.t(), out=gates)
+            if fused_trunk:
+                rms = raw_rms if len(raw_rms) else None
+                if keep:
+                    acts = [h[:rows] for h in self.Hs]
+                    xn = self.xn[:rows] if rms is not None else None
+                    self.chain_rnn.forward(x, gates, act_out=acts, rms=rms, eps=eps, xn_out=xn)
+                    x = xn if rms is not None else x          # what the first layer's weight gradient reads
+                    a = acts[-1]
+                else:
+                    self.chain_rnn.forward(x, gates, rms=rms, eps=eps)
+                    a = None
+            else:
+                torch.addmm(self.bias_sum, a, rnn.weight_ih_l0.t(), out=gates)
             out = self.rnn_out[:rows]
             # Final states are produced for inference calls only (keep=False: rollout / get_values),
             # into whichever buffer pair the inputs do NOT live in.  A training forward must not touch
@@ -196,6 +227,7 @@ class ManualMLP:
         else:
             torch.addmm(self.head_b, a, self.head_w.t(), out=heads)
         self._x, self._rows, self._last = x, rows, a
+        self._fused_trunk = fused_trunk and keep
         return heads
 
     @torch.no_grad()
@@ -278,6 +310,19 @@ class ManualMLP:
             colsums.append((gpart, nbg, G, rnn.bias_hh_l0.grad))     # d b_hh = d b_ih
             jobs.append((dg, self.hprev[:rows], rnn.weight_hh_l0.grad))
             jobs.append((dg, self._rnn_in, rnn.weight_ih_l0.grad))
+            if self._fused_trunk:
+                # dX chain of the trunk in ONE launch, from d gates down: dZ of every hidden layer + the
+                # per-workgroup bias-gradient column sums (the chain's "head" layer is W_ih)
+                nblk = self.chain_rnn.num_blocks(rows, 1)
+                acts = [h[:rows] for h in self.Hs]
+                dzs = [t[:rows] for t in self.dA]
+                parts = [p[:nblk * w.out_features] for p, w in zip(self.partials, self.linears)]
+                self.chain_rnn.backward(dg, acts, dzs, parts)
+                for l in range(L - 1, -1, -1):
+                    lin = self.linears[l]
+                    jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
+                    colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
+                return self._weight_grads(jobs, rows, colsums, loss_finalize)
             d = self.dA[L - 1][:rows]
             torch.mm(dg, rnn.weight_ih_l0, out=d)
         else:

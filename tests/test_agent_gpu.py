@@ -904,11 +904,15 @@ def test_folded_launches_match_the_separate_ones(graphs):
     assert (a[3] - b[3]).abs().max().item() <= 2.1 * 24 * 1e-2       # 24 Adam steps at lr <= max_lr
 
 
-@pytest.mark.parametrize('kind', ['mlp', 'lstm', 'discrete', 'central_value'])
-def test_two_rank_training_keeps_ranks_in_sync(kind):
+@pytest.mark.parametrize('kind,collective', [('mlp', 'ipc'), ('lstm', 'ipc'), ('discrete', 'ipc'), ('central_value', 'ipc'),
+                                             ('mlp', 'fallback'), ('mlp', 'ipc-two-phase'), ('lstm', 'fallback')])
+def test_two_rank_training_keeps_ranks_in_sync(kind, collective):
     """2 ranks on this box's single GPU (RLG_TEST_SINGLE_GPU=1: gloo collectives), different data per
     rank, 4 epochs of multi_gpu training for each agent kind: parameters, normaliser statistics
-    (pooled merge) and learning rate end bit-identical on both ranks."""
+    (pooled merge: ONE collective for all normalisers) and learning rate end bit-identical on both ranks.
+    collective: the in-graph hipIpc all-reduce kernel (default), its reduce-scatter + all-gather variant, or the
+    forced torch.distributed fallback (`native_allreduce: False` - RCCL in production, its gloo stand-in here) through
+    the same agent code."""
     import os
     import socket
     import subprocess
@@ -917,13 +921,17 @@ def test_two_rank_training_keeps_ranks_in_sync(kind):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, RLG_TEST_SINGLE_GPU='1')
+    over = {'ipc': '{}', 'fallback': '{"native_allreduce": false}',
+            'ipc-two-phase': '{"native_allreduce_two_phase": true}'}[collective]
+    env = dict(os.environ, RLG_TEST_SINGLE_GPU='1', RLG_TWO_RANK_CONFIG=over)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(root, 'tools', 'two_rank_check.py'), kind]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert f'TWO_RANK_CHECK {kind} in_sync' in res.stdout
+    want = {'ipc': 'ipc one_shot', 'fallback': 'rccl one_shot', 'ipc-two-phase': 'ipc two_phase'}[collective]
+    assert f'TWO_RANK_ALLREDUCE {want}' in res.stdout, res.stdout[-600:]
 
 
 class _HostVecEnv:

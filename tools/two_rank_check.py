@@ -29,6 +29,11 @@ else:
     from rl_games_amd.agent import A2CAgent as Agent
     params = configs.tiny(num_actors=64, horizon=8, multi_gpu=True)
 params['config']['env_config']['seed'] = 10 + rank          # different data per rank
+# RLG_TWO_RANK_CONFIG='{"native_allreduce": false}': the torch.distributed fallback (RCCL in production, gloo in this
+# one-GPU test mode) through the same agent code; '{"native_allreduce_two_phase": true}': the reduce-scatter +
+# all-gather variant of the in-graph kernel
+import json
+params['config'].update(json.loads(os.environ.get('RLG_TWO_RANK_CONFIG', '{}')))
 agent = Agent('mr', params)
 agent.init_tensors()
 agent.obs = agent.env_reset()
@@ -48,6 +53,7 @@ dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 ok = bool(torch.equal(lo, hi)) and bool(torch.isfinite(p).all())
 if rank == 0:
+    print('TWO_RANK_ALLREDUCE', agent.last_allreduce, 'two_phase' if (agent._ipc_comm and agent._ipc_comm.two_phase) else 'one_shot', flush=True)
     print('TWO_RANK_CHECK', kind, 'in_sync' if ok else f'OUT_OF_SYNC {lo.tolist()} {hi.tolist()}', flush=True)
 dist.barrier()
 dist.destroy_process_group()
