@@ -504,6 +504,18 @@ int rlg_lstm_seq_backward(const float* gates, const float* c_all, const float* c
                           const unsigned char* dones_or_null, const float* w_hh, const float* d_out,
                           float* d_gates, int num_seqs, int seq_len, int hidden, void* stream);
 
+/* ---- products too narrow for the MFMA kernels (csrc/mlp_narrow.hip; BASELINE config #5: obs 3, act 1) ----------
+ * rlg_narrow_dx: dX [rows, in] = dZ [rows, out] W [out, in] for out <= 8 - autograd's grad_output.mm(weight) of the fused
+ *   (value | mu) head (rl_games/algos_torch/network_builder.py:295-311, :506-512).
+ * rlg_narrow_dw: grad [out, in] = dZ^T X for in <= 8, out <= 256 - grad_output.t().mm(input) of actor_mlp's first
+ *   nn.Linear over a few observations (network_builder.py:118-147); partials: rlg_narrow_dw_blocks(rows) * out * in
+ *   doubles of scratch (fp64 partial sums per workgroup, combined in a fixed order). */
+int rlg_narrow_dx(const float* dz, long long lddz, const float* w, float* dx, long long lddx, long long rows,
+                  int out_features, int in_features, void* stream);
+int rlg_narrow_dw_blocks(long long rows);
+int rlg_narrow_dw(const float* dz, long long lddz, const float* x, long long ldx, float* grad, double* partials,
+                  long long rows, int out_features, int in_features, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * In-graph gradient all-reduce over peer-mapped device memory (csrc/ipc_allreduce.hip)
  *   replaces dist.all_reduce(SUM) of the flattened gradients in A2CBase.trancate_gradients_and_step

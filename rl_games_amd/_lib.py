@@ -73,6 +73,9 @@ _PROTOTYPES = {
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_float, _P,
                           _P, _P],
+    'rlg_narrow_dx': [_P, _c_ll, _P, _P, _c_ll, _c_ll, _c_int, _c_int, _P],
+    'rlg_narrow_dw_blocks': [_c_ll],
+    'rlg_narrow_dw': [_P, _c_ll, _P, _c_ll, _P, _P, _c_ll, _c_int, _c_int, _P],
     # mlp_chain.hip
     'rlg_mlp_chain_prepare': [],
     'rlg_mlp_chain_groups': [_c_ll, _c_int, _c_int],

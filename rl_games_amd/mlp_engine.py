@@ -298,7 +298,10 @@ class ManualMLP:
         if self.lstm is not None:
             rnn = self.lstm
             d_out = self.d_rnn_out[:rows]
-            torch.mm(d_heads, self.head_w, out=d_out)
+            if self.V + self.A <= ops.NARROW_MAX:
+                ops.narrow_dx(d_heads, self.head_w, d_out)
+            else:
+                torch.mm(d_heads, self.head_w, out=d_out)
             gates, dg = self.gates[:rows], self.d_gates[:rows]
             ops.lstm_seq_backward(gates, self.c_all[:rows], self._c0, self._dones, rnn.weight_hh_l0, d_out, dg,
                                   self._T)
@@ -388,7 +391,12 @@ class ManualMLP:
         for part, nb, cols, out in colsums:
             ops.colsum_finalize(part, nb, cols, out)
         self.last_dw_path = 'mfma' if fast else 'library'
-        self.last_dw_library_jobs = len(slow)
+        self.last_dw_library_jobs = 0
         for dz, x, g in slow:
-            torch.mm(dz.t(), x, out=g)
+            if (g.shape[1] <= ops.NARROW_MAX and g.shape[0] <= 256 and dz.stride(1) == 1 and x.stride(1) == 1
+                    and g.is_contiguous()):
+                ops.narrow_dw(dz, x, g)            # a first layer over a few observations (config #5: obs 3)
+            else:
+                torch.mm(dz.t(), x, out=g)
+                self.last_dw_library_jobs += 1
         return norm_blocks

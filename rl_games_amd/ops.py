@@ -559,6 +559,38 @@ def mlp_linear_act_backward(dz, w, z_prev, dz_prev, act_kind=0):
         'rlg_mlp_linear_act_backward')
 
 
+NARROW_MAX = 8
+
+
+def narrow_dx(dz, w, dx):
+    """dx [rows, in] = dz [rows, out] @ w [out, in] for out <= 8 (csrc/mlp_narrow.hip)."""
+    rows, No = dz.shape
+    if w.shape[0] != No or dx.shape != (rows, w.shape[1]) or dz.stride(1) != 1 or dx.stride(1) != 1:
+        raise ValueError('narrow_dx: shape mismatch')
+    _lib.require_gpu(dz, 'dz')
+    _lib.check(_lib.load().rlg_narrow_dx(dz.data_ptr(), dz.stride(0), _need(w, F32, 'w'), dx.data_ptr(), dx.stride(0),
+                                         rows, No, w.shape[1], _stream(dz)), 'rlg_narrow_dx')
+
+
+_narrow_scratch = {}
+
+
+def narrow_dw(dz, x, grad):
+    """grad [out, in] = dz[rows, out].T @ x[rows, in] for in <= 8, out <= 256 (csrc/mlp_narrow.hip)."""
+    rows, No = dz.shape
+    Mi = x.shape[1]
+    if x.shape[0] != rows or tuple(grad.shape) != (No, Mi) or dz.stride(1) != 1 or x.stride(1) != 1:
+        raise ValueError('narrow_dw: shape mismatch')
+    _lib.require_gpu(dz, 'dz')
+    lib = _lib.load()
+    need = lib.rlg_narrow_dw_blocks(rows) * No * Mi
+    key = (str(dz.device), need)
+    if key not in _narrow_scratch:          # (fixed address per shape: the launches are replayed from HIP graphs)
+        _narrow_scratch[key] = torch.empty(need, dtype=F64, device=dz.device)
+    _lib.check(lib.rlg_narrow_dw(dz.data_ptr(), dz.stride(0), x.data_ptr(), x.stride(0), _need(grad, F32, 'grad'),
+                                 _narrow_scratch[key].data_ptr(), rows, No, Mi, _stream(dz)), 'rlg_narrow_dw')
+
+
 # ------------------------------------------------------------------ fused MLP chain (MFMA, LDS-resident)
 
 chain_timers = None     # bench.py: {'fwd': [...], 'bwd': [...]} of gae.HipEventPair, one per eager chain launch

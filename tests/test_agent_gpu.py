@@ -378,9 +378,9 @@ def test_lstm_engine_matches_autograd_gradients_and_rollout():
         res = ag.train_result
         grads[-1]['_scalars'] = torch.stack([res[0], res[1], res[2], res[3], res[8]])
     g1, g2 = grads
-    # heads, W_ih, W_hh and the second trunk layer through the MFMA launch; only the [64 x 3]
-    # first layer (3 observations: not a multiple of 4) on the library GEMM
-    assert a1._engine.last_dw_path == 'mfma' and a1._engine.last_dw_library_jobs == 1
+    # heads, W_ih, W_hh and the second trunk layer through the MFMA launch; the [64 x 3] first layer (3
+    # observations: not a multiple of 4) through the narrow weight-gradient kernel - no library GEMM left
+    assert a1._engine.last_dw_path == 'mfma' and a1._engine.last_dw_library_jobs == 0
     assert torch.allclose(g1.pop('_scalars'), g2.pop('_scalars'), rtol=1e-5, atol=1e-7)
     for n in g2:
         scale = g2[n].abs().max().item() + 1e-12

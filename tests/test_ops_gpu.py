@@ -630,3 +630,41 @@ def test_stats_sync_function_seams_and_clamp():
     assert m.count.item() == before[2] and torch.equal(m.running_mean, before[0]) and torch.equal(m.running_var, m.running_var)
     with pytest.raises(ValueError):
         rdist.StatsSync([])
+
+
+# ----------------------------------------------------------------------------- narrow products (config #5 shapes)
+
+@pytest.mark.parametrize('rows,No,Mi', [(16384, 2, 64), (4096, 2, 64), (37, 5, 13), (1, 1, 4), (1000, 8, 100)])
+def test_narrow_dx_matches_fp64(rows, No, Mi):
+    """rlg_narrow_dx (dX = dZ W for heads with <= 8 outputs: the (value | mu) head of a Pendulum-shaped policy)
+    against an fp64 evaluation; at most K fp32 roundings per element."""
+    from rl_games_amd import ops
+    gen = g(rows + No)
+    dz = torch.randn(rows, No, generator=gen)
+    w = torch.randn(No, Mi, generator=gen)
+    dx = torch.full((rows, Mi), float('nan'), device=DEV)
+    ops.narrow_dx(dz.to(DEV), w.to(DEV), dx)
+    ref = dz.double() @ w.double()
+    scale = (dz.abs().double() @ w.abs().double())
+    assert ((dx.cpu().double() - ref).abs() <= (No + 1) * 6e-8 * scale + 1e-30).all()
+    with pytest.raises(RuntimeError):
+        ops.narrow_dx(torch.zeros(4, 9, device=DEV), torch.zeros(9, 4, device=DEV), torch.zeros(4, 4, device=DEV))
+
+
+@pytest.mark.parametrize('rows,No,Mi', [(16384, 64, 3), (4096, 64, 3), (37, 20, 7), (1, 4, 1), (70000, 256, 8), (513, 100, 2)])
+def test_narrow_dw_matches_fp64_and_is_deterministic(rows, No, Mi):
+    """rlg_narrow_dw (grad = dZ^T X for a first layer over <= 8 observations) against fp64: fp32 products, fp32
+    sums over a thread's run of rows, fp64 across - far inside rtol 1e-5 of the |dZ|^T |X| scale; two launches agree
+    bit for bit (fixed combination order)."""
+    from rl_games_amd import ops
+    gen = g(rows + Mi)
+    dz = torch.randn(rows, No, generator=gen)
+    x = torch.randn(rows, Mi, generator=gen) * 2 + 0.3
+    g1 = torch.full((No, Mi), float('nan'), device=DEV)
+    g2 = torch.full((No, Mi), float('nan'), device=DEV)
+    ops.narrow_dw(dz.to(DEV), x.to(DEV), g1)
+    ops.narrow_dw(dz.to(DEV), x.to(DEV), g2)
+    assert torch.equal(g1, g2)
+    ref = dz.double().t() @ x.double()
+    scale = dz.abs().double().t() @ x.abs().double()
+    assert ((g1.cpu().double() - ref).abs() <= 1e-5 * scale + 1e-30).all()
