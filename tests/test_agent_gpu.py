@@ -529,16 +529,36 @@ def _run_two_ranks(script_args, timeout=600, nproc=2):
     return subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize('nproc', [2, 4])
-def test_ipc_allreduce_between_processes_on_one_gpu(nproc):
-    """The in-graph all-reduce kernel (hipIpc-mapped peer staging buffers, device-side flags) between
-    2 and 4 processes sharing this box's GPU: eager and HIP-graph-replayed launches, every rank
-    bit-identical to the rank-ordered fp32 sum."""
+@pytest.mark.parametrize('nproc,two_phase', [(2, False), (4, False), (2, True), (4, True), (3, True)])
+def test_ipc_allreduce_between_processes_on_one_gpu(nproc, two_phase):
+    """The in-graph all-reduce kernels (hipIpc-mapped peer staging buffers, device-side flags) between
+    2 - 4 processes sharing this box's GPU: eager and HIP-graph-replayed launches, every rank
+    bit-identical to the rank-ordered fp32 sum - the one-shot kernel and the reduce-scatter + all-gather one."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_ipc_check.py')], nproc=nproc)
+    os.environ['RLG_IPC_CHECK_TWO_PHASE'] = '1' if two_phase else '0'
+    try:
+        res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_ipc_check.py')], nproc=nproc)
+    finally:
+        os.environ.pop('RLG_IPC_CHECK_TWO_PHASE', None)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert 'IPC_ALLREDUCE_CHECK ok' in res.stdout
+    assert 'IPC_ALLREDUCE_CHECK ok' in res.stdout and f'two_phase {two_phase}' in res.stdout
+
+
+@pytest.mark.parametrize('two_phase', [False, True])
+def test_ipc_allreduce_is_fail_safe_when_a_peer_never_arrives(two_phase):
+    """A rank skips a collective (2 processes on one GPU, 2 s bound): the waiting rank's launch gives up, leaves ZEROS
+    in the gradients (not a sum of stale staging data), sets the sticky error word, the Adam launch behind it
+    skips its step - parameters, moments and learning rate untouched - and later launches fail fast."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ['RLG_IPC_CHECK_TWO_PHASE'] = '1' if two_phase else '0'
+    try:
+        res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_ipc_failsafe.py')], nproc=2, timeout=300)
+    finally:
+        os.environ.pop('RLG_IPC_CHECK_TWO_PHASE', None)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert 'IPC_FAILSAFE_CHECK ok' in res.stdout
 
 
 @pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss'])

@@ -13,7 +13,8 @@ torch.cuda.set_device(0)
 rdist.init_process_group(True)
 dev = 'cuda:0'
 N = 229_937                       # humanoid arena size class, not a multiple of 4
-comm = IpcAllReduce(N, dev)
+two_phase = os.environ.get('RLG_IPC_CHECK_TWO_PHASE', '0') != '0'      # the reduce-scatter + all-gather kernel
+comm = IpcAllReduce(N, dev, two_phase=two_phase)
 launches0, _ = comm.status()       # the communicator's known-answer self-test (2 launches)
 
 
@@ -71,7 +72,7 @@ flag = torch.tensor([1.0 if ok else 0.0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
     print('IPC_ALLREDUCE_CHECK', 'ok' if flag.item() == 1.0 else 'FAILED', f'world {world} launches {launches} '
-          f'timed_out {timed_out} fine_grained {comm.fine_grained}', flush=True)
+          f'timed_out {timed_out} fine_grained {comm.fine_grained} two_phase {comm.two_phase}', flush=True)
 comm.close()
 dist.barrier()
 dist.destroy_process_group()
