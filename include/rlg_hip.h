@@ -452,7 +452,7 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                            * rms_batch: normalise with the state as it is. */
                           const double* rms_batch_or_null, const long long* rms_count,
                           double* rms_mean_out, double* rms_var_out, long long* rms_count_out,
-                          long long rows, int groups, void* stream);
+                          long long rows, int groups, void* pack_backward_planes_or_null, void* stream);
 /* Arguments of the clipped-PPO loss (the parameter list of rlg_ppo_loss_fused as a struct): with a
  * non-NULL descriptor the BACKWARD launch evaluates the loss of its own row tile in front of its
  * prologue - no separate loss launch - i.e. it first writes d mu / d values (which must be views of the
@@ -485,7 +485,24 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
                            const int* out_features, const int* acts, const float* const* act_in,
                            const long long* act_ld, const float* d_out, long long ld_dout,
                            float* const* dz_out, const long long* dz_ld, double* const* bias_partials_or_null,
-                           const rlg_ppo_loss_desc* ppo_loss_or_null, long long rows, int groups, void* stream);
+                           const rlg_ppo_loss_desc* ppo_loss_or_null, long long rows, int groups,
+                           const void* weight_planes_or_null, void* stream);
+
+/* Split-bf16 form of the chain (csrc/mlp_chain_bx.hip): every fp32 product as six exact bf16 plane products on
+ * v_mfma_f32_16x16x32_bf16 (results within 3 * 2^-24 |x||w| per product of the exact-product kernels).  The weights
+ * are split ONCE per optimizer step into plane fragments; the launch that is given them (weight_planes_or_null of
+ * rlg_mlp_chain_backward, direction 1) uses the split kernel when rlg_mlp_chain_bx_supported says so and the
+ * activation arrays are 16-byte aligned, else the exact-product kernel.  Same autograd nodes as above
+ * (rl_games/algos_torch/network_builder.py:447-512).
+ * pack_backward_planes_or_null of rlg_mlp_chain_forward: the forward launch of a training step splits the weights
+ * for the backward launch that follows it (same weights) in extra workgroups at the end of its grid - no launch of its own.
+ *   rlg_mlp_chain_planes_bytes: size of the fragment buffer for one direction (0 forward products, 1 backward)
+ *   rlg_mlp_chain_pack_planes : weights [out, in] fp32 -> fragments (one launch, all layers) */
+long long rlg_mlp_chain_planes_bytes(int num_layers, const int* in_features, const int* out_features, int direction);
+int rlg_mlp_chain_pack_planes(int num_layers, const float* const* weights, const int* in_features,
+                              const int* out_features, int direction, void* planes, void* stream);
+int rlg_mlp_chain_bx_supported(int num_layers, const int* in_features, const int* out_features, long long rows,
+                               int groups, int direction);
 
 /* ---- recurrent policy (BASELINE config #5) -------------------------------------------------
  * Sequence-persistent LSTM layer: replaces the per-timestep torch.nn.LSTM calls + done-state

@@ -30,110 +30,10 @@
 // added after the sum like the library epilogue; ELU = x > 0 ? x : exp(x) - 1.
 // LDS tile of a layer with `nb` 16-feature blocks: [nb][G][64 lanes][4] floats (nb*G KiB).
 
-#include "rlg_device.hpp"
-#include "ppo_loss_tile.hpp"
-#include "rlg_hip.h"
-
-#include <hip/hip_ext.h>
-#include <cstdlib>
-#include <type_traits>
-#include <utility>
-
-// Timing-only ablations for tools/ablate_chain.sh (-DRLG_ABL=mask builds a library that computes WRONG results and
-// shows what a phase costs): 1 no bias/activation maths, 2 no global stores of the epilogues, 4 no epilogue at all,
-// 8 no remainder units, 16 no barriers between layers, 32 no prologue loads, 64 no weight traffic (A loads out of range),
-// 128 (pipelined kernels) no LDS reads of the B fragments
-#ifndef RLG_ABL
-#define RLG_ABL 0
-#endif
+#include "mlp_chain_common.hpp"
 
 namespace rlg {
 
-constexpr int kAbl = RLG_ABL;
-constexpr int kChainMaxLayers = 8;
-// K-split scratch of the forward (partial fragments of 256 floats): G = 1: up to 2 units x 3 parts (8 waves) or
-// 4 x 1; G = 2: up to 2 units x 1 part; G = 4: no split (a remainder block already has one unit per wave)
-static inline int chain_split_floats(int G) { return (G == 1 ? 6 : (G == 2 ? 2 : 0)) * 256; }
-constexpr int kChainWideBlocks = 384;   // up to this many 16-row workgroups run with 8 waves instead of 4
-constexpr unsigned kOob = 0x40000000u;     // byte offset far outside every weight buffer
-
-enum : int { kChIdentity = 0, kChElu = 1, kChRelu = 2, kChTanh = 3 };
-
-struct ChainLayer {
-  const float* w;        // [out, in] row-major
-  const float* bias;     // [out] (forward)
-  float* h;              // forward: activation output [rows, ldh] or nullptr;  backward: H of this layer (input)
-  float* dz;             // backward: dZ of this layer [rows, lddz] (output; nullptr for the last layer)
-  double* bias_partials; // backward: [gridDim.x, out] column sums of dZ, or nullptr
-  long long ldh, lddz;
-  int in, out;
-  int act;
-};
-
-struct ChainArgs {
-  ChainLayer layer[kChainMaxLayers];
-  int num_layers;
-  const float* x;              // forward: raw observations [rows, ldx]; backward: d(last layer output) [rows, ldx]
-  long long ldx;
-  const double* rms_mean;      // forward: RunningMeanStd state (fp64) or nullptr
-  const double* rms_var;
-  float rms_eps;
-  // forward, training: fold this minibatch's column moments {sum[in], sumsq[in], rows} into the state
-  // first (RunningMeanStd.forward in training mode updates, then normalises) - every block folds for
-  // itself, block 0 publishes the new state to the OTHER buffer set (the next launch reads that one)
-  const double* rms_batch;     // or nullptr: normalise with the state as it is
-  const long long* rms_count;
-  double* rms_mean_out;
-  double* rms_var_out;
-  long long* rms_count_out;
-  float* xn;                   // forward: normalised observations out [rows, in0] (dW of layer 0 reads them) or nullptr
-  long long rows;
-  int lds_b_floats;
-  int lds_split_floats;        // forward: offset of the K-split scratch (partial fragments of remainder units)
-  int no_ksplit;               // tools (RLG_CHAIN_KSPLIT=0): remainder units without the K-split            // start of the second LDS region, in floats
-  // pipelined kernels: ONE buffer resource over every weight matrix and bias vector (the flat parameter arena)
-  const float* w_base;
-  unsigned w_bytes;
-  unsigned w_off[kChainMaxLayers];     // byte offset of layer[L].w from w_base
-  unsigned b_off[kChainMaxLayers];     // byte offset of layer[L].bias from w_base (forward)
-  long long* dbg;
-  int with_loss;               // backward: evaluate the PPO loss of the tile first (LossArgs)              // tools only: [blocks][4 waves][32] shader-clock stamps per phase, or nullptr
-};
-
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-// phase stamps for tools/bench_mlp_chain.py --phases (one lane per wave; no effect when dbg is null)
-__device__ __forceinline__ void chain_stamp(long long* dbg, int wave, int& slot) {
-  if (dbg != nullptr) {
-    const long long t = __builtin_amdgcn_s_memtime();
-    if (lane_id() == 0 && slot < 32 && wave < 4) dbg[(static_cast<long long>(blockIdx.x) * 4 + wave) * 32 + slot] = t;
-    ++slot;
-  }
-}
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-
-__device__ __forceinline__ float chain_act(float v, int act) {
-  if (act == kChElu) return v > 0.0f ? v : __expf(v) - 1.0f;
-  if (act == kChRelu) return v > 0.0f ? v : 0.0f;
-  if (act == kChTanh) return tanhf(v);
-  return v;
-}
-// act' from the layer OUTPUT h (aten's *_backward with is_result = true)
-__device__ __forceinline__ float chain_act_grad(float h, int act) {
-  if (act == kChElu) return h > 0.0f ? 1.0f : h + 1.0f;
-  if (act == kChRelu) return h > 0.0f ? 1.0f : 0.0f;
-  if (act == kChTanh) return 1.0f - h * h;
-  return 1.0f;
-}
 
 // A wave's share of one layer: `nunits` output units, unit j = the NF consecutive 16-feature blocks
 // ob_of(j) .. ob_of(j)+NF-1 for the NG row groups g_of(j) .. g_of(j)+NG-1 (NF > 1 shares the B fragments
@@ -392,95 +292,6 @@ __device__ __forceinline__ void chain_units(rsrc_t wr, int I, int K, int ld, con
   }
 }
 
-// Kernel arguments that the epilogues use are copied into scalar registers ONCE per layer and made
-// opaque, otherwise hipcc re-materialises them as s_load from the kernarg segment at every use (a
-// scalar-cache round trip plus an lgkmcnt(0) per use - thousands of cycles per output block).
-__device__ __forceinline__ int pin_s(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ long long pin_s(long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned long long>(v) & 0xffffffffu));
-  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned long long>(v) >> 32));
-  return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
-}
-template <class T>
-__device__ __forceinline__ T* pin_s(T* ptr) {
-  return reinterpret_cast<T*>(pin_s(reinterpret_cast<long long>(ptr)));
-}
-
-// activation of a fragment: one wave-uniform switch per fragment, not per element.  HACT >= 0: the
-// launch knows that every layer is either HACT or identity (the usual network: one hidden activation,
-// linear heads) - the kernel then carries one activation body instead of all of them (48 inlined
-// tanhf bodies pushed the G = 4 forward past the 64 KiB instruction cache); HACT = kChAny: per layer.
-constexpr int kChAny = -1;
-template <int HACT>
-__device__ __forceinline__ f32x4 chain_act4(f32x4 v, int act) {
-  if constexpr (HACT != kChAny) {
-    if (act == kChIdentity) return v;
-    act = HACT;
-  }
-  if (act == kChElu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : __expf(v[e]) - 1.0f;
-  } else if (act == kChRelu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-  } else if (act == kChTanh) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-  }
-  return v;
-}
-// acc * act'(h), act' from the layer OUTPUT h (aten's *_backward with is_result = true)
-__device__ __forceinline__ f32x4 chain_act_grad4(f32x4 d, f32x4 h, int act) {
-  if (act == kChElu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = d[e] * (h[e] > 0.0f ? 1.0f : h[e] + 1.0f);
-  } else if (act == kChRelu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = d[e] * (h[e] > 0.0f ? 1.0f : 0.0f);
-  } else if (act == kChTanh) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = d[e] * (1.0f - h[e] * h[e]);
-  }
-  return d;
-}
-
-// Pointers that went through pin_s (an integer round trip) have lost their address space: hipcc then emits FLAT
-// loads / stores, which count on lgkmcnt as well and turn every later LDS wait into lgkmcnt(0).  All arrays
-// of these kernels are global memory: say so at the access.
-template <class T>
-using glob_t = T __attribute__((address_space(1)));
-template <class T>
-__device__ __forceinline__ glob_t<T>* as_global(T* p) { return (glob_t<T>*)p; }
-template <class T>
-__device__ __forceinline__ const glob_t<T>* as_global(const T* p) { return (const glob_t<T>*)p; }
-
-// 4 consecutive features [f, f+4) of row `row` of a row-major array, masked to `width`
-__device__ __forceinline__ void store_row4(float* base, long long ld, long long row, int f, int width,
-                                           const f32x4& v, bool vec_ok) {
-  glob_t<float>* p = as_global(base + row * ld + f);
-  if (vec_ok && f + 4 <= width) {
-    *(glob_t<f32x4>*)p = v;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (f + e < width) p[e] = v[e];
-    }
-  }
-}
-__device__ __forceinline__ f32x4 load_row4(const float* base, long long ld, long long row, int f, int width,
-                                           bool vec_ok) {
-  const glob_t<float>* p = as_global(base + row * ld + f);
-  if (vec_ok && f + 4 <= width) return *(const glob_t<f32x4>*)p;
-  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (f + e < width) v[e] = p[e];
-  }
-  return v;
-}
-__device__ __forceinline__ bool vec4_ok(const void* p, long long ld) {
-  return aligned16(p) && (ld & 3) == 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -575,6 +386,10 @@ __device__ __forceinline__ void chain_fwd_prologue(const ChainArgs& a, float* ti
 template <int G, int HACT, int W>
 __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: weight planes
+    for (int t = threadIdx.x; t < 256; t += 64 * W) chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, t);
+    return;
+  }
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
@@ -724,18 +539,6 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_kernel(ChainArgs a) {
 //     and the addresses are 32-bit lane offsets.
 // Same products in the same order as mlp_chain_fwd_kernel<4>: the results are bit-identical.
 // ------------------------------------------------------------------------------------------------
-using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(std::declval<rsrc_t>(), 0u, 0, 0));
-__device__ __forceinline__ void buf_store4(rsrc_t r, unsigned off, const f32x4& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, v), r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_store1(rsrc_t r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
-}
-// bound of a resource over the (at most) tile_rows rows of a [rows, ld] fp32 array that are left from its base on
-__device__ __forceinline__ unsigned tile_bytes(long long rows_left, long long tile_rows, long long ld) {
-  const long long r = rows_left < tile_rows ? rows_left : tile_rows;
-  return static_cast<unsigned>(r * ld * 4);
-}
 
 struct PipeGeo {
   int in, out, KC, full, nrem, rem_first, nunits;
@@ -748,6 +551,10 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
   using WholeTag = std::integral_constant<int, G>;
   using OneTag = std::integral_constant<int, 1>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: weight planes
+    chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
+    return;
+  }
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const int q4 = 4 * (lane >> 4);
@@ -787,7 +594,6 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
     const int i = ob * 16 + (lane & 15);
     return (!(kAbl & 64) && g.nunits > 0 && i < g.out) ? g.w_off + static_cast<unsigned>((i * g.in + q4) * 4) : kOob;
   };
-
   // ---- the first unit's weights are requested before anything else
   PipeGeo cur = geo(0);
   f32x4 aq[4];
@@ -1214,6 +1020,14 @@ static bool chain_pipe_enabled() {
   return on;
 }
 
+static bool chain_bx_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_CHAIN_BX");         // tools: A/B against the exact-f32-product kernels
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+
 // Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
 // profiles/r2_mlp_chain_microbench_*.txt): forward - two 32-row workgroups per CU (G = 2, two waves
 // per SIMD) beat one 64-row workgroup (G = 4, one wave per SIMD): the second wave covers the epilogue
@@ -1295,6 +1109,10 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
   args.num_layers = num_layers;
   args.dbg = nullptr;
   args.with_loss = 0;
+  args.fwd_blocks = 0;
+  args.pack.njobs = args.pack.total_pairs = 0;
+  args.pack.dst = nullptr;
+  args.planes = nullptr;
   return 0;
 }
 
@@ -1304,8 +1122,11 @@ static bool g_chain_prepared = false;     // rlg_mlp_chain_prepare raised the LD
 static hipEvent_t g_chain_ev_start = nullptr, g_chain_ev_stop = nullptr;
 
 template <int G, bool kBackward, int HACT, int W>
-static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss) {
-  const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+static int chain_launch_as(const ChainArgs& args_in, int lds_bytes, hipStream_t st, const LossArgs* loss) {
+  ChainArgs args = args_in;
+  int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+  args.fwd_blocks = grid;
+  if (!kBackward && args.pack.total_pairs > 0) grid += chain_bx_pack_blocks(args.pack);
   const void* kern;
   if constexpr (kBackward) kern = reinterpret_cast<const void*>(mlp_chain_bwd_kernel<G, W>);
   else kern = reinterpret_cast<const void*>(mlp_chain_fwd_kernel<G, HACT, W>);
@@ -1343,6 +1164,42 @@ static int chain_launch_as(const ChainArgs& args, int lds_bytes, hipStream_t st,
 // or not 16-byte aligned rows (in % 4 != 0) - the unit-structured kernels take those.
 static bool chain_pipe_fill(ChainArgs& args, bool with_bias) {
   uintptr_t lo = ~static_cast<uintptr_t>(0), hi = 0;
+  // A lane's 16 bytes of a row's last chunk reach past the row when `in` is not a multiple of 16: into the next row
+  // (finite values that meet zero activations) and, behind the LAST row, up to 48 bytes past the matrix.  Under one
+  // resource over all arrays that read is not bounds-checked per matrix, so it must land in another array of this
+  // network (the layout of the flat parameter arena: every weight matrix is followed by its bias) - not in whatever
+  // follows a separately allocated tensor, which may be NaN bits or an unmapped page.
+  {
+    uintptr_t begin[2 * kChainMaxLayers], end[2 * kChainMaxLayers];
+    int n = 0;
+    for (int L = 0; L < args.num_layers; ++L) {
+      const ChainLayer& ly = args.layer[L];
+      begin[n] = reinterpret_cast<uintptr_t>(ly.w);
+      end[n] = begin[n] + static_cast<uintptr_t>(ly.in) * ly.out * 4;
+      ++n;
+      if (with_bias && ly.bias) {
+        begin[n] = reinterpret_cast<uintptr_t>(ly.bias);
+        end[n] = begin[n] + static_cast<uintptr_t>(ly.out) * 4;
+        ++n;
+      }
+    }
+    for (int L = 0; L < args.num_layers; ++L) {
+      const ChainLayer& ly = args.layer[L];
+      if ((ly.in & 15) == 0) continue;
+      uintptr_t covered = reinterpret_cast<uintptr_t>(ly.w) + static_cast<uintptr_t>(ly.in) * ly.out * 4;
+      const uintptr_t need = covered + 48;
+      for (bool grew = true; grew && covered < need;) {
+        grew = false;
+        for (int k = 0; k < n; ++k) {
+          if (begin[k] <= covered + 16 && end[k] > covered) {     // (gaps of up to 16 bytes: the arena's alignment padding)
+            covered = end[k];
+            grew = true;
+          }
+        }
+      }
+      if (covered < need) return false;
+    }
+  }
   for (int L = 0; L < args.num_layers; ++L) {
     const ChainLayer& ly = args.layer[L];
     const uintptr_t w = reinterpret_cast<uintptr_t>(ly.w);
@@ -1367,8 +1224,11 @@ static bool chain_pipe_fill(ChainArgs& args, bool with_bias) {
   return true;
 }
 template <int G, int HACT>
-static int chain_launch_fwd_pipe(const ChainArgs& args, int lds_bytes, hipStream_t st) {
-  const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+static int chain_launch_fwd_pipe(const ChainArgs& args_in, int lds_bytes, hipStream_t st) {
+  ChainArgs args = args_in;
+  int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+  args.fwd_blocks = grid;
+  if (args.pack.total_pairs > 0) grid += chain_bx_pack_blocks(args.pack);
   hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
   g_chain_ev_start = g_chain_ev_stop = nullptr;
   if (ev0 != nullptr)
@@ -1447,8 +1307,27 @@ int rlg_mlp_chain_prepare(void) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return static_cast<int>(e);
   }
+  if (const int e = chain_bx_prepare()) return e;
   g_chain_prepared = true;
   return 0;
+}
+
+// 1: rlg_mlp_chain_backward (direction 1) runs the split-bf16 kernel for this network and minibatch when it is given
+// weight planes (and its arrays are 16-byte aligned); the caller packs planes only then.
+int rlg_mlp_chain_bx_supported(int num_layers, const int* in_features, const int* out_features, long long rows,
+                               int groups, int direction) {
+  using namespace rlg;
+  if (direction != 1 || num_layers < 2 || num_layers > kChainMaxLayers || !chain_bx_enabled()) return 0;
+  const int G = pick_groups(rows, groups, 1);
+  if (G != 4) return 0;
+  ChainArgs probe;
+  probe.num_layers = num_layers;
+  for (int L = 0; L < num_layers; ++L) {
+    probe.layer[L].in = in_features[L];
+    probe.layer[L].out = out_features[L];
+  }
+  if (chain_bx_plane_offsets(num_layers, in_features, out_features, 1, nullptr) >= static_cast<long long>(kOob)) return 0;
+  return chain_bx_bwd_lds(probe, G) >= 0 ? 1 : 0;
 }
 
 int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* out_features, int groups,
@@ -1479,11 +1358,15 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
                           const double* rms_batch, const long long* rms_count, double* rms_mean_out,
                           double* rms_var_out, long long* rms_count_out,
-                          long long rows, int groups, void* stream) {
+                          long long rows, int groups, void* pack_backward_planes_or_null, void* stream) {
   using namespace rlg;
   if (rows <= 0) return 0;
   ChainArgs args;
   if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
+  // the backward launch's weight planes ride along as extra workgroups (not with the tools' phase stamps: they index
+  // their buffer by workgroup)
+  if (pack_backward_planes_or_null != nullptr && g_chain_dbg == nullptr)
+    chain_bx_fill_pack(args.pack, num_layers, weights, in_features, out_features, 1, pack_backward_planes_or_null);
   for (int L = 0; L < num_layers; ++L) {
     args.layer[L].bias = biases[L];
     args.layer[L].h = act_out[L];
@@ -1534,7 +1417,8 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
                            const int* out_features, const int* acts, const float* const* act_in,
                            const long long* act_ld, const float* d_out, long long ld_dout,
                            float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
-                           const rlg_ppo_loss_desc* ppo_loss, long long rows, int groups, void* stream) {
+                           const rlg_ppo_loss_desc* ppo_loss, long long rows, int groups,
+                           const void* weight_planes_or_null, void* stream) {
   using namespace rlg;
   if (rows <= 0) return 0;
   if (num_layers < 2) return static_cast<int>(hipErrorInvalidValue);
@@ -1604,6 +1488,25 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const LossArgs* lp = ppo_loss ? &loss : nullptr;
+  // split-bf16 products on pre-split weight planes (mlp_chain_bx.hip): 64-row workgroups, aligned activations
+  args.planes = nullptr;
+  if (weight_planes_or_null != nullptr && G == 4 && chain_bx_enabled()) {
+    const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, 1, args.p_off);
+    ChainArgs bx = args;
+    bx.dbg = g_chain_dbg;
+    bx.planes = weight_planes_or_null;
+    bx.planes_bytes = static_cast<unsigned>(total);
+    int bx_lds = chain_bx_bwd_lds(bx, G);
+    if (bx_lds >= 0 && total < static_cast<long long>(kOob) && chain_bx_bwd_eligible(bx)) {
+      if (ppo_loss) {
+        const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, ppo_loss->actions_num, 512));
+        if (need > bx_lds) bx_lds = need;
+      }
+      hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+      g_chain_ev_start = g_chain_ev_stop = nullptr;
+      return chain_bx_launch_bwd(bx, G, bx_lds, st, lp, ev0, ev1);
+    }
+  }
   if (G == 4) return chain_launch<4, true>(args, lds_bytes, st, lp);
   if (G == 2) return chain_launch<2, true>(args, lds_bytes, st, lp);
   return chain_launch<1, true>(args, lds_bytes, st, lp);

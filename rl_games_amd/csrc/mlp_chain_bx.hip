@@ -1,0 +1,560 @@
+// The fused MLP chain on split-bf16 products (gfx950): the same vertical fusion as mlp_chain.hip - every layer of a
+// 64-row tile in ONE launch, activations resident in LDS, weights streamed from L2 - but every fp32 product is the
+// sum of six exact bf16 plane products on v_mfma_f32_16x16x32_bf16 (the scheme of mlp_dw.hip, split_bf16.hpp):
+// 6 x 16 cycles per 16x16x32 tile instead of 8 x 32 on the f32 MFMA.
+//
+// The f32 MFMA kernels are bound by everything that is NOT an MFMA (VALU and MFMA never co-execute on a CDNA4 SIMD,
+// profiles/r3_coexec_and_launch_probes.txt), so the split must not cost inner-loop VALU:
+//   * the WEIGHTS are split once per optimizer step by rlg_mlp_chain_pack_planes into fragment order: fragment
+//     (block ib, chunk c, plane p) = 64 lanes x 8 bf16 = 1 KiB, lane l holds A[16 ib + (l & 15)][k] for its 8 k slots
+//     of chunk c.  A wave's A operands of a chunk are three 16-byte buffer loads at SCALAR addresses (no address VALU),
+//     1 KiB contiguous each; out-of-range rows / k are zero in the fragments, so the kernels need no masks;
+//   * the ACTIVATIONS are split once, by the epilogue that produces them, and live in LDS as planes: fragment
+//     (chunk c, row group g, plane p) = 1 KiB, read back with one ds_read_b128 per lane.
+// k slots: a chunk is 32 input features = two 16-feature blocks; lane l (q = l >> 4) takes features 4q .. 4q+3 of
+// block 2c (elements 0..3) and of block 2c+1 (elements 4..7).  The MFMA output D[4q + r][row] of a 16-feature block
+// is exactly elements 4*(block & 1) .. +3 of the SAME lane's B fragment for the next layer: the epilogue writes 8
+// bytes per plane, no transposes (a sum does not care which k sits in which slot as long as A and B agree).
+// Numerics: products exact up to 3 * 2^-24 |x||w| (the three dropped plane products), fp32 accumulation; see
+// tests/test_mlp_chain_gpu.py for the bounds against fp64.
+//
+// Backward (this file, round 3):  d heads -> ((dZ W) * act'(H)) x L with the PPO loss tile in front, like
+// mlp_chain_bwd_kernel<4, 4>; replaces the autograd dX / activation-backward / bias-sum nodes behind
+// rl_games/algos_torch/network_builder.py:447-512.
+
+#include "mlp_chain_common.hpp"
+#include "split_bf16.hpp"
+
+namespace rlg {
+
+constexpr int kBxW = 4;                  // waves per workgroup: one per SIMD (the tiles fill the LDS: one workgroup per
+                                         // CU; eight waves on the same tile measured 1.7x SLOWER, 128 + 128 registers)
+constexpr int kBxFrag = 1024;            // bytes of one plane fragment: 64 lanes x 8 bf16
+constexpr int kBxChunk = 3 * kBxFrag;    // the three planes of one (block, chunk) / (chunk, row group)
+
+static inline int bx_kc(int K) { return (K + 31) >> 5; }
+static inline int bx_nb(int I) { return (I + 15) >> 4; }
+
+// direction 0: forward products of layer L (i = out, k = in); 1: backward (i = in, k = out; layer 0 needs no dX)
+long long chain_bx_plane_offsets(int num_layers, const int* in_features, const int* out_features, int direction,
+                                 unsigned* offsets) {
+  long long total = 0;
+  for (int L = 0; L < num_layers; ++L) {
+    if (offsets) offsets[L] = static_cast<unsigned>(total);
+    if (direction == 1 && L == 0) continue;
+    const int I = direction == 0 ? out_features[L] : in_features[L];
+    const int K = direction == 0 ? in_features[L] : out_features[L];
+    total += static_cast<long long>(bx_nb(I)) * bx_kc(K) * kBxChunk;
+  }
+  return total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights -> plane fragments
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chain_pack_planes_kernel(PackArgs a) {
+  chain_pack_planes_block(a, blockIdx.x, threadIdx.x);
+}
+
+int chain_bx_pack_blocks(const PackArgs& a) { return (a.total_pairs * 64 + 255) / 256; }
+
+bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weights, const int* in_features,
+                        const int* out_features, int direction, void* planes) {
+  args.njobs = 0;
+  args.total_pairs = 0;
+  args.dst = static_cast<unsigned char*>(planes);
+  if (num_layers < 1 || num_layers > kChainMaxLayers || (direction != 0 && direction != 1) || planes == nullptr) return false;
+  unsigned off[kChainMaxLayers];
+  const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, direction, off);
+  if (total >= static_cast<long long>(kOob)) return false;
+  for (int L = (direction == 1 ? 1 : 0); L < num_layers; ++L) {
+    PackJob& J = args.job[args.njobs++];
+    J.w = weights[L];
+    J.in = in_features[L];
+    J.I = direction == 0 ? out_features[L] : in_features[L];
+    J.K = direction == 0 ? in_features[L] : out_features[L];
+    J.KC = bx_kc(J.K);
+    J.transposed = direction;
+    J.pair_begin = args.total_pairs;
+    J.dst_off = off[L];
+    args.total_pairs += bx_nb(J.I) * J.KC;
+  }
+  return args.total_pairs > 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The unit engine.  A wave's share of one layer: `nunits` output units, unit j = the NF consecutive 16-feature blocks
+// ob_of(j) .. +NF-1 for NG row groups (all G, or the one group g_of(j) of a remainder unit):
+//   pre(j);  acc[f][g] = sum over the KC chunks of  A(ob + f, chunk) x B(chunk, group);  [request unit j+1's first
+//   chunk];  epi(j, acc)
+// Two register banks per operand: while the MFMAs of chunk c issue from one bank, chunk c+1 is loaded into the
+// other; the last chunk of a unit is followed by the loads of the NEXT unit's first chunk into bank 0, which the
+// epilogue's VALU work covers.  sched_group_barrier deals the loads out between the MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <int G, int NG, int NF, class ObOf, class GOf, class Pre, class Rot, class Epi>
+__device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, const char* tile_lane, int nunits,
+                                         ObOf ob_of, GOf g_of, Pre pre, Rot rot, Epi epi, bool primed,
+                                         long long* dbg = nullptr, int dbg_wave = 0, int* dbg_slot = nullptr) {
+  if (nunits <= 0) return;
+  const unsigned lane16 = static_cast<unsigned>(lane_id()) * 16u;
+  const int block_stride = KC * kBxChunk;            // bytes between the fragments of consecutive blocks
+  u32x4 a0[NF][3], a1[NF][3], b0[NG][3], b1[NG][3];
+  auto unit_off = [&](int j) -> int {
+    const int jj = j < nunits ? j : nunits - 1;
+    if (kAbl & 64) return static_cast<int>(layer_off);      // timing only: every A load from the same fragments
+    return __builtin_amdgcn_readfirstlane(static_cast<int>(layer_off) + ob_of(jj) * block_stride);
+  };
+  auto group_of = [&](int j) -> int {
+    if constexpr (NG == G) return 0;
+    const int jj = j < nunits ? j : nunits - 1;
+    return g_of(jj);
+  };
+  auto load_a = [&](u32x4 (&av)[NF][3], int soff) {
+    if ((kAbl & 256) && soff != static_cast<int>(layer_off)) return;       // timing only: no weight loads after the first
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        av[f][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, lane16 + static_cast<unsigned>(p * kBxFrag),
+                                                                                  (kAbl & 64) ? soff : soff + f * block_stride, 0));
+    }
+  };
+  auto load_b = [&](u32x4 (&bv)[NG][3], int c, int g0) {
+    if (kAbl & 128) return;                                  // timing only: no LDS reads
+    const char* p = tile_lane + (c * G + g0) * kBxChunk;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bv[g][pl] = *reinterpret_cast<const u32x4*>(p + (g * 3 + pl) * kBxFrag);
+    }
+  };
+
+  if (kAbl & 128) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        b0[g][pl] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        b1[g][pl] = b0[g][pl];
+        asm volatile("" : "+v"(b0[g][pl]), "+v"(b1[g][pl]));
+      }
+    }
+  }
+  int uoff = unit_off(0);
+  int g0 = group_of(0);
+  load_a(a0, uoff);
+  load_b(b0, 0, g0);
+  // pre(j) requests what unit j's epilogue will read from global memory (into a "next" register set), rot() makes
+  // that set current.  vmcnt retires in issue order on gfx9, so a load that goes to HBM stalls every LATER load's
+  // first use: the request for unit j+1 is issued in front of unit j's LAST chunk - behind all of unit j's weight
+  // loads, with unit j's epilogue to arrive in.
+  // pre(nunits) is the caller's hook for the unit that FOLLOWS this call (the next call's, the next layer's first
+  // unit); `primed`: the previous call has requested this call's first unit that way.
+  if (!primed) pre(0);
+  rot();
+
+  f32x4 acc[NF][NG];
+  // The six plane products of one accumulator are issued back to back, small ones first: a dependent chain runs at
+  // the full rate (16.3 cycles per MFMA: the accumulator is forwarded inside the matrix core), a rotation through
+  // many accumulators does not (21.7 cycles with 16 of them, profiles/r3_mfma_peak_probe.txt).
+  // (a unit's first chunk starts from the constant 0 as SrcC: no accumulator is zeroed by hand)
+  auto mfmas = [&](auto first_tag, const u32x4 (&av)[NF][3], const u32x4 (&bv)[NG][3]) {
+    constexpr bool kFirst = decltype(first_tag)::value;
+    constexpr int kPa[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int kPb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[f][kPa[t]]),
+                                                             __builtin_bit_cast(bf16x8, bv[g][kPb[t]]),
+                                                             (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g], 0, 0, 0);
+        if constexpr (kFirst) asm volatile("" : "+a"(acc[f][g]));      // accumulators live in AGPRs
+      }
+    }
+  };
+  // chunk c from bank kCur1; kPf: chunk c + 1 is requested into the other bank, its loads dealt out between the MFMAs
+  auto step = [&](auto cur_tag, auto pf_tag, int c, auto first_tag) {
+    constexpr bool kCur1 = decltype(cur_tag)::value;
+    constexpr bool kPf = decltype(pf_tag)::value;
+    if constexpr (kPf) {
+      load_a(kCur1 ? a0 : a1, (kAbl & 64) ? uoff : uoff + (c + 1) * kBxChunk);
+      load_b(kCur1 ? b0 : b1, c + 1, g0);
+    }
+    mfmas(first_tag, kCur1 ? a1 : a0, kCur1 ? b1 : b0);
+    if constexpr (kPf) {
+#pragma unroll
+      for (int i = 0; i < 3 * NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 3 * NG; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if constexpr (6 * NF * NG - 3 * NF - 3 * NG > 0) __builtin_amdgcn_sched_group_barrier(0x008, 6 * NF * NG - 3 * NF - 3 * NG, 0);
+    }
+    RLG_PIN();
+  };
+  constexpr std::true_type T{};
+  constexpr std::false_type F{};
+  // behind a unit's last chunk: the next unit's first chunk is requested into bank 0 (this unit's again behind the
+  // last one: harmless), then the epilogue, whose VALU work covers those loads
+  auto finish_unit = [&](int j, int jn) {
+    uoff = unit_off(jn);
+    g0 = group_of(jn);
+    load_a(a0, uoff);
+    load_b(b0, 0, g0);
+    RLG_PIN();
+    // wait states between the last MFMA and the first VALU read of an accumulator (tools/audit_mfma.py)
+    asm volatile("s_nop 7" : "+a"(acc[0][0]));
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (f + g > 0) asm volatile("" : "+a"(acc[f][g]));
+      }
+    }
+    epi(j, acc);
+    rot();
+    RLG_PIN();
+  };
+
+  if (KC == 1) {
+    for (int j = 0; j < nunits; ++j) {
+      const int jn = j + 1 < nunits ? j + 1 : j;
+      pre(j + 1);
+      RLG_PIN();
+      step(F, F, 0, T);
+      finish_unit(j, jn);
+    }
+    return;
+  }
+  // KC >= 2.  The unit loop is rotated - a pass = [chunks 1 .. KC-1 of unit j] [request unit j+1's first chunk]
+  // [epilogue j] [chunk 0 of unit j+1] - so that the first use of those requested fragments sits in the same
+  // straight-line code as the epilogue's stores: hipcc then waits with the exact vmcnt (the stores stay in flight);
+  // across a loop edge it falls back to vmcnt(0), i.e. it would wait for the stores to be acknowledged as well.
+  if (dbg) chain_stamp(dbg, dbg_wave, *dbg_slot);          // call start (first H claimed)
+  step(F, T, 0, T);
+  if (dbg) chain_stamp(dbg, dbg_wave, *dbg_slot);          // first chunk
+  for (int j = 0; j < nunits; ++j) {
+    const int jn = j + 1 < nunits ? j + 1 : j;
+    int c = 1;                                     // chunk c sits in bank 1
+    for (; c + 2 < KC; c += 2) {
+      step(T, T, c, F);
+      step(F, T, c + 1, F);
+    }
+    if (KC - c == 2) {
+      step(T, T, c, F);
+      pre(j + 1);
+      RLG_PIN();
+      step(F, F, c + 1, F);
+    } else {
+      pre(j + 1);
+      RLG_PIN();
+      step(T, F, c, F);
+    }
+    if (dbg) chain_stamp(dbg, dbg_wave, *dbg_slot);        // chunks done
+    finish_unit(j, jn);
+    if (dbg) chain_stamp(dbg, dbg_wave, *dbg_slot);        // epilogue + claim of the next H done
+    if (j + 1 < nunits) step(F, T, 0, T);
+    if (dbg) chain_stamp(dbg, dbg_wave, *dbg_slot);        // first chunk of the next unit
+  }
+}
+
+// sum over the 16 lanes of a row (lanes that share l >> 4), result in all of them: rotations within the row on the
+// DPP path (no LDS round trips), fixed order
+__device__ __forceinline__ float row16_sum(float t) {
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x122, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x121, 0xf, 0xf, false));
+  return t;
+}
+
+// PACT: the activation of every hidden layer when the launch knows it (the usual network), else kChAny: per layer
+template <int G, int PACT>
+__global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a, LossArgs loss) {
+  constexpr int W = kBxW;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const int q4 = 4 * (lane >> 4);
+  const long long row0 = static_cast<long long>(blockIdx.x) * (16 * G);
+  char* tile_a = ldsb;
+  char* tile_b = ldsb + static_cast<long long>(a.lds_b_floats) * 4;
+
+  int stamp = 0;
+  chain_stamp(a.dbg, wave, stamp);                                   // tools/exp/bx_phases.py: start
+  if (a.with_loss) {
+    ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x);
+    // the prologue reads d heads that OTHER waves of this workgroup have just stored (see mlp_chain_bwd_kernel)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  chain_stamp(a.dbg, wave, stamp);                                   // loss tile done
+  const rsrc_t pr = make_rsrc(a.planes, a.planes_bytes);
+  const int num_layers = pin_s(a.num_layers);
+  const long long n_rows = pin_s(a.rows);
+
+  // ---- prologue: d heads tile -> planes in LDS -----------------------------------------------------
+  {
+    const int w = a.layer[num_layers - 1].out;
+    const int KC0 = (w + 31) >> 5;
+    const bool xv = vec4_ok(a.x, a.ldx);
+    for (int u = wave; u < KC0 * G; u += W) {
+      const int c = u / G;
+      const int g = u - c * G;
+      const long long row = row0 + g * 16 + (lane & 15);
+      const int f = c * 32 + q4;
+      f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < n_rows) {
+        lo = load_row4(a.x, a.ldx, row, f, w, xv);
+        hi = load_row4(a.x, a.ldx, row, f + 16, w, xv);
+      }
+      const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      u32x4 plane[3];
+      dw_split8(x, plane);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(tile_a + (u * 3 + p) * kBxFrag + lane * 16) = plane[p];
+    }
+    __syncthreads();
+  }
+  chain_stamp(a.dbg, wave, stamp);                                   // prologue + barrier
+
+  // H fragments of the units: two register sets, "next" is requested one unit ahead (see bx_units) - also across the
+  // calls and the layers: H does not depend on the barrier between two layers
+  f32x4 hval[2][G], hnext[2][G];
+  auto wave_blocks = [&](int nob) -> int { return nob / W + (wave < nob % W ? 1 : 0); };
+  auto wave_first = [&](int nob) -> int { return wave * (nob / W) + (wave < nob % W ? wave : nob % W); };
+  // blocks ob .. ob + nf - 1 (nf <= 2) of H_{L-1}, the layer whose dZ step L produces; every global access is a
+  // buffer instruction with the tile's row range as the bound: ragged tiles need no masks, out of range reads 0
+  auto request_h = [&](int L, int ob, int nf) {
+    const float* ph = pin_s(a.layer[L - 1].h);
+    const long long ld = pin_s(a.layer[L - 1].ldh);
+    const int width = pin_s(a.layer[L].in);
+    const rsrc_t hr = make_rsrc(ph + row0 * ld, tile_bytes(n_rows - row0, 16 * G, ld));
+    const unsigned h_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(ld) + q4) * 4);
+    const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(ld) * 4);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const bool ok = !(kAbl & 4) && f < nf && (ob + f) * 16 + q4 < width;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        hnext[f][g] = buf_load4(hr, ok ? h_lane + static_cast<unsigned>(g) * h_group + static_cast<unsigned>(ob + f) * 64u : kOob);
+    }
+  };
+  {
+    const int nob = (pin_s(a.layer[num_layers - 1].in) + 15) >> 4;
+    request_h(num_layers - 1, wave_first(nob), wave_blocks(nob) >= 2 ? 2 : wave_blocks(nob));
+  }
+
+  char* tin = tile_a;
+  char* tout = tile_b;
+  for (int L = num_layers - 1; L >= 1; --L) {
+    const int l_in = pin_s(a.layer[L].in), l_out = pin_s(a.layer[L].out), p_act = pin_s(a.layer[L - 1].act);
+    float* p_dz = pin_s(a.layer[L - 1].dz);
+    const long long p_lddz = pin_s(a.layer[L - 1].lddz);
+    const unsigned l_off = static_cast<unsigned>(pin_s(static_cast<int>(a.p_off[L])));
+    const int width = l_in;                     // == layer[L-1].out
+    const int KC = (l_out + 31) >> 5;
+    const int NOB = (width + 15) >> 4;
+    const bool keep_tile = (L - 1 >= 1);        // dZ_0 feeds nothing further down
+    double* bpart = pin_s(a.layer[L - 1].bias_partials);
+    if (bpart != nullptr) bpart += static_cast<long long>(blockIdx.x) * width;
+    // every global access is a buffer instruction: the row range of the tile is the bound, ragged tiles need no masks
+    const rsrc_t dr = make_rsrc(p_dz + row0 * p_lddz, tile_bytes(n_rows - row0, 16 * G, p_lddz));
+    const unsigned d_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(p_lddz) + q4) * 4);
+    const unsigned d_group = static_cast<unsigned>(16 * static_cast<int>(p_lddz) * 4);
+
+    // dZ = acc * act'(h): fp32 to global, planes to the output tile; returns the lane's 4 feature values (rows past
+    // the end are exact zeros: their d heads are, and out-of-range H reads 0)
+    auto epilogue = [&](int ob, int g, const f32x4& accv, const f32x4& hval) -> f32x4 {
+      const int f = ob * 16 + q4;
+      f32x4 v;
+      if constexpr (PACT == kChElu) {
+        // h > 0 ? 1 : h + 1  ==  min(h, 0) + 1, the same bits with one VALU instruction less per element
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = accv[e] * (__builtin_fminf(hval[e], 0.0f) + 1.0f);
+      } else {
+        v = chain_act_grad4(accv, hval, p_act);
+      }
+      if (!(kAbl & 2)) buf_store4(dr, f < width ? d_lane + static_cast<unsigned>(g) * d_group + static_cast<unsigned>(ob) * 64u : kOob, v);
+      if (keep_tile) {
+        unsigned plane[3][2];
+        split4_planes(v, plane);
+        char* dst = tout + (((ob >> 1) * G + g) * 3) * kBxFrag + lane * 16 + (ob & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * kBxFrag) = make_uint2(plane[p][0], plane[p][1]);
+      }
+      return v;
+    };
+    // column sums over the workgroup's rows of one 16-feature block (fixed butterfly order: deterministic)
+    auto colsum_store = [&](int ob, f32x4 s) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = row16_sum(s[e]);
+      if (bpart != nullptr && (lane & 15) == 0) {
+        const int f = ob * 16 + q4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (f + e < width) as_global(bpart)[f + e] = static_cast<double>(s[e]);
+        }
+      }
+    };
+
+    // This wave's blocks of the layer: NOB / W each, the first NOB % W waves one more (a whole extra block on some
+    // waves costs less than the row-group-split remainder units of mlp_chain.hip: one 16-wide block has 6 x 4
+    // MFMAs per chunk here, a unit of one row group would expose every load's latency behind 6 of them).
+    // Two blocks per unit, then one.
+    const int nb_w = wave_blocks(NOB), first_ob = wave_first(NOB);
+    const int units2 = nb_w >> 1, left = nb_w & 1;
+    // what follows a call's last unit: the single-block unit of this layer, else the next layer's first unit
+    auto request_after = [&](bool after_pairs) {
+      if (after_pairs && left) {
+        request_h(L, first_ob + 2 * units2, 1);
+      } else if (L >= 2) {
+        const int nob_n = (pin_s(a.layer[L - 1].in) + 15) >> 4;
+        request_h(L - 1, wave_first(nob_n), wave_blocks(nob_n) >= 2 ? 2 : wave_blocks(nob_n));
+      }
+    };
+    auto whole = [&](auto nf_tag, int first, int nunits) {
+      constexpr int NF = decltype(nf_tag)::value;
+      bx_units<G, G, NF>(
+          pr, l_off, KC, tin + lane * 16, nunits, [&](int j) { return first + j * NF; }, [&](int) { return 0; },
+          [&](int j) {
+            if (j < nunits) request_h(L, first + j * NF, NF);
+            else request_after(NF == 2);
+          },
+          [&]() {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+              for (int g = 0; g < G; ++g) {
+                hval[f][g] = hnext[f][g];
+                asm volatile("" : "+v"(hval[f][g]));      // claimed here (one exact wait), not at its first use
+              }
+            }
+          },
+          [&](int j, const f32x4 (&acc)[NF][G]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              const int ob = first + j * NF + f;
+              f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+              for (int g = 0; g < G; ++g) s += epilogue(ob, g, acc[f][g], hval[f][g]);
+              colsum_store(ob, s);
+            }
+          },
+          true, (NF == 2 && L == 1) ? a.dbg : nullptr, wave, &stamp);
+    };
+    whole(std::integral_constant<int, 2>{}, first_ob, units2);
+    whole(std::integral_constant<int, 1>{}, first_ob + 2 * units2, left);
+    if (nb_w == 0) request_after(false);        // a wave without a block here still owes itself the next layer's first H
+    chain_stamp(a.dbg, wave, stamp);                                 // per layer: units done
+    // an odd number of blocks leaves half a chunk of the output tile unwritten: zero it (the weights there are zero,
+    // but 0 x stale bits may be NaN)
+    if (keep_tile && (NOB & 1)) {
+      for (int u = wave; u < G * 3; u += W)
+        *reinterpret_cast<uint2*>(tout + (((NOB >> 1) * G) * 3 + u) * kBxFrag + lane * 16 + 8) = make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    chain_stamp(a.dbg, wave, stamp);                                 // barrier
+    char* t = tin;
+    tin = tout;
+    tout = t;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+int chain_bx_bwd_lds(ChainArgs& args, int G) {
+  const int n = args.num_layers;
+  // tiles: d heads (region A), then dZ_{L-1} for L = n-1 .. 2 alternating, starting with B
+  long long a_chunks = bx_kc(args.layer[n - 1].out), b_chunks = 0;
+  int flip = 0;
+  for (int L = n - 1; L >= 2; --L, flip ^= 1) {
+    const long long kc = bx_kc(args.layer[L].in);
+    if (flip == 0) b_chunks = kc > b_chunks ? kc : b_chunks;
+    else a_chunks = kc > a_chunks ? kc : a_chunks;
+  }
+  const long long a_bytes = a_chunks * G * kBxChunk, b_bytes = b_chunks * G * kBxChunk;
+  const long long bytes = a_bytes + b_bytes;
+  args.lds_b_floats = static_cast<int>(a_bytes / 4);
+  args.lds_scratch_floats = static_cast<int>((a_bytes + b_bytes) / 4);
+  return bytes <= 160 * 1024 ? static_cast<int>(bytes) : -1;
+}
+
+bool chain_bx_bwd_eligible(const ChainArgs& args) {
+  if (args.planes == nullptr || args.num_layers < 2) return false;
+  for (int L = 0; L + 1 < args.num_layers; ++L) {
+    const ChainLayer& ly = args.layer[L];
+    if ((reinterpret_cast<uintptr_t>(ly.h) & 15u) || (reinterpret_cast<uintptr_t>(ly.dz) & 15u) || (ly.ldh & 3) || (ly.lddz & 3) || (ly.out & 3)) return false;
+    if (ly.ldh * 64 * 4 >= static_cast<long long>(kOob) || ly.lddz * 64 * 4 >= static_cast<long long>(kOob)) return false;
+  }
+  return true;
+}
+
+template <int G, int PACT>
+static int chain_bx_launch_bwd_as(const ChainArgs& args, int lds_bytes, hipStream_t st, const LossArgs* loss, hipEvent_t ev0,
+                                  hipEvent_t ev1) {
+  const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
+  LossArgs none = {};
+  if (ev0 != nullptr)
+    hipExtLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, ev0,
+                          ev1, 0, args, loss ? *loss : none);
+  else
+    hipLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, args,
+                       loss ? *loss : none);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+// raises the dynamic-LDS limit of the kernels once, outside any stream capture (rlg_mlp_chain_prepare)
+int chain_bx_prepare() {
+  static bool raised = false;
+  if (raised) return 0;
+  for (const void* k : {reinterpret_cast<const void*>(mlp_chain_bwd_bx_kernel<4, kChElu>),
+                        reinterpret_cast<const void*>(mlp_chain_bwd_bx_kernel<4, kChAny>)}) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  raised = true;
+  return 0;
+}
+int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t st, const LossArgs* loss, hipEvent_t ev0,
+                        hipEvent_t ev1) {
+  if (G != 4) return static_cast<int>(hipErrorInvalidValue);
+  if (const int e = chain_bx_prepare()) return e;
+  bool elu_only = true;       // every layer whose derivative is taken (all but the head)
+  for (int L = 0; L + 1 < args.num_layers; ++L) elu_only = elu_only && args.layer[L].act == kChElu;
+  return elu_only ? chain_bx_launch_bwd_as<4, kChElu>(args, lds_bytes, st, loss, ev0, ev1)
+                  : chain_bx_launch_bwd_as<4, kChAny>(args, lds_bytes, st, loss, ev0, ev1);
+}
+
+}  // namespace rlg
+
+// ---------------------------------------------------------------------------------
+// C ABI (declared in include/rlg_hip.h)
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+long long rlg_mlp_chain_planes_bytes(int num_layers, const int* in_features, const int* out_features, int direction) {
+  if (num_layers < 1 || num_layers > rlg::kChainMaxLayers || (direction != 0 && direction != 1)) return -1;
+  return rlg::chain_bx_plane_offsets(num_layers, in_features, out_features, direction, nullptr);
+}
+
+int rlg_mlp_chain_pack_planes(int num_layers, const float* const* weights, const int* in_features,
+                              const int* out_features, int direction, void* planes, void* stream) {
+  using namespace rlg;
+  if (num_layers < 1 || num_layers > kChainMaxLayers || (direction != 0 && direction != 1) || planes == nullptr)
+    return static_cast<int>(hipErrorInvalidValue);
+  PackArgs args;
+  if (!chain_bx_fill_pack(args, num_layers, weights, in_features, out_features, direction, planes)) {
+    return args.total_pairs == 0 && args.njobs >= 0 && num_layers == 1 && direction == 1 ? 0 : static_cast<int>(hipErrorInvalidValue);
+  }
+  hipLaunchKernelGGL(chain_pack_planes_kernel, dim3(chain_bx_pack_blocks(args)), dim3(256), 0, static_cast<hipStream_t>(stream), args);
+  RLG_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

@@ -33,6 +33,7 @@
 // the same class as the library kernels it replaces; only the summation order differs.
 
 #include "rlg_device.hpp"
+#include "split_bf16.hpp"
 #include "rlg_hip.h"
 
 namespace rlg {
@@ -104,29 +105,6 @@ template <int B> __device__ __forceinline__ typename DwVec<B>::type dw_zero() { 
 // fp32 rounding: against fp64 the launch is as accurate as with exact f32 products and ~10x more accurate
 // than the library's fp32 GEMM (tools/exp/split_bf16_numerics.py, tools/exp/dw_bf16_check.py,
 // profiles/r2_dw_bf16x6.txt).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// 8 floats (the lane's 8 k values of one 16-wide block) -> 3 planes of 8 packed bf16.  The conversion is
-// an asm statement so that hipcc keeps ONE v_cvt_pk_bf16_f32 (RNE) per pair (it otherwise converts the low
-// half a second time for the shift) and leaves the residuals as plain v_sub_f32 (no v_pk_add_f32 + moves).
-__device__ __forceinline__ void dw_split8(const float (&x)[8], u32x4 (&plane)[3]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float lo = x[2 * q], hi = x[2 * q + 1];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      unsigned w;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
-      plane[p][q] = w;
-      if (p < 2) {
-        lo -= __uint_as_float(w << 16);                  // exact: the residual has <= 16 (8) significant bits
-        hi -= __uint_as_float(w & 0xffff0000u);
-      }
-    }
-  }
-}
-
 // kSplit = false: exact f32 products (v_mfma_f32_16x16x4_f32).  kSplit = true: split-bf16 products, two
 // register sets of 32 rows.
 template <int BO, int BI, bool kSplit>

@@ -80,6 +80,44 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   const long long e0 = row0 * A;              // first element of the tile
   const int tile_elems = rows * A;
 
+  // The per-row inputs of phase 2 and the first kBatch element rounds of phase 1 are requested before anything else
+  // is computed: as written phase by phase, a tile is ~14 dependent memory round trips (the element loop cannot be
+  // pipelined by the compiler: old_mu / old_sigma are read AND written), which a backward workgroup that owns its CU
+  // alone (csrc/mlp_chain_bx.hip) pays in full.
+  float r_adv = 0.0f, r_onlp = 0.0f, r_v = 0.0f, r_vo = 0.0f, r_ret = 0.0f, r_mask = 1.0f;
+  if (tid < rows) {
+    const long long i = row0 + tid;
+    r_adv = p.advantages[i];
+    r_onlp = p.old_neglogp[i];
+    r_v = p.values[i * p.ld_val];
+    r_vo = p.old_values[i];
+    r_ret = p.returns[i];
+    if (p.mask) r_mask = p.mask[i];
+  }
+  constexpr int kBatch = 8;                   // element rounds held in registers (A <= 8 * kThreads / kRows)
+  float e_mu[kBatch], e_x[kBatch], e_omu[kBatch], e_osg[kBatch];
+  {
+    int r = tid / A, a = tid - r * A;
+    const int dr = kThreads / A, da = kThreads - dr * A;
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int e = tid + k * kThreads;
+      e_mu[k] = e_x[k] = e_omu[k] = 0.0f;
+      e_osg[k] = 1.0f;
+      if (e < tile_elems) {
+        e_mu[k] = p.mu[(row0 + r) * p.ld_mu + a];
+        e_x[k] = p.actions[e0 + e];
+        e_omu[k] = p.old_mu[e0 + e];
+        e_osg[k] = p.old_sigma[e0 + e];
+      }
+      a += da;
+      r += dr;
+      if (a >= A) {
+        a -= A;
+        r += 1;
+      }
+    }
+  }
   for (int a = tid; a < A; a += kThreads) {
     const float ls = p.logstd[a];
     col_logstd[a] = ls;
@@ -98,11 +136,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   {
     int r = tid / A, a = tid - r * A;
     const int dr = kThreads / A, da = kThreads - dr * A;
-    for (int e = tid; e < tile_elems; e += kThreads) {
-      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
-      const float x = p.actions[e0 + e];
-      const float omu = p.old_mu[e0 + e];
-      const float osg = p.old_sigma[e0 + e];
+    auto element = [&](int e, int r, int a, float mu, float x, float omu, float osg) {
       const float sg = col_sigma[a];
       const float z = (x - mu) / sg;                                          // models.py:362
       t_z2[r * AP + a] = z * z;
@@ -124,12 +158,24 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
         p.old_mu[e0 + e] = mu;
         p.old_sigma[e0 + e] = sg;
       }
+    };
+    auto advance = [&]() {
       a += da;
       r += dr;
       if (a >= A) {
         a -= A;
         r += 1;
       }
+    };
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int e = tid + k * kThreads;
+      if (e < tile_elems) element(e, r, a, e_mu[k], e_x[k], e_omu[k], e_osg[k]);
+      advance();
+    }
+    for (int e = tid + kBatch * kThreads; e < tile_elems; e += kThreads) {
+      element(e, r, a, p.mu[(row0 + r) * p.ld_mu + a], p.actions[e0 + e], p.old_mu[e0 + e], p.old_sigma[e0 + e]);
+      advance();
     }
   }
   __syncthreads();
@@ -148,8 +194,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     }
     // neglogp                                                                models.py:361-364
     const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
-    const float adv = p.advantages[i];
-    const float ratio = expf(p.old_neglogp[i] - nlp);                         // common_losses.py:75
+    const float adv = r_adv;
+    const float ratio = expf(r_onlp - nlp);                                   // common_losses.py:75
     const float surr1 = adv * ratio;
     float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
     if (p.smooth) {
@@ -177,7 +223,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
 
     // critic                                                                 common_losses.py:20-27
-    const float v = p.values[i * p.ld_val], vo = p.old_values[i], R = p.returns[i];
+    const float v = r_v, vo = r_vo, R = r_ret;
     float c_loss, g_v;
     if (p.clip_value) {
       const float delta = v - vo;
@@ -199,7 +245,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
       g_v = -2.0f * d;
     }
 
-    const float m = p.mask ? p.mask[i] : 1.0f;
+    const float m = r_mask;
     const float w = m / denom_count;          // d(mean)/d(element)
     row_g[tid] = g_nlp * w;
     row_w[tid] = w;
@@ -225,9 +271,7 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   {
     int r = tid / A, a = tid - r * A;
     const int dr = kThreads / A, da = kThreads - dr * A;
-    for (int e = tid; e < tile_elems; e += kThreads) {
-      const float mu = p.mu[(row0 + r) * p.ld_mu + a];
-      const float x = p.actions[e0 + e];
+    auto element = [&](int r, int a, float mu, float x) {
       const float sg = col_sigma[a];
       const float z = (x - mu) / sg;
       float db = 0.0f;
@@ -242,12 +286,23 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
       t_kl[r * AP + a] = dmu;                     // column sums -> bias gradient of the mu head
       // d nlp / d logstd = 1 - z^2
       t_z2[r * AP + a] = row_g[r] * (1.0f - z * z);
+    };
+    auto advance = [&]() {
       a += da;
       r += dr;
       if (a >= A) {
         a -= A;
         r += 1;
       }
+    };
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (tid + k * kThreads < tile_elems) element(r, a, e_mu[k], e_x[k]);     // (mu, x: still in registers)
+      advance();
+    }
+    for (int e = tid + kBatch * kThreads; e < tile_elems; e += kThreads) {
+      element(r, a, p.mu[(row0 + r) * p.ld_mu + a], p.actions[e0 + e]);
+      advance();
     }
   }
   __syncthreads();

@@ -635,6 +635,29 @@ class MlpChain:
             if best == 0 and (direction == 0 or n > 1):
                 raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
             self.max_groups[direction] = best
+        self._planes = {}          # direction -> bf16 plane fragments of the weights (csrc/mlp_chain_bx.hip)
+        self._planes_fresh_rows = None
+
+    def split_products(self, rows, direction, requested=0):
+        """True when the launch of this direction runs the split-bf16 kernel for `rows` rows."""
+        return bool(_lib.load().rlg_mlp_chain_bx_supported(self.n, self._in, self._out, int(rows),
+                                                           self.groups(rows, direction, requested), int(direction)))
+
+    def pack_planes(self, direction, stream_of):
+        """Weights -> bf16 plane fragments (one launch).  The planes must be re-packed after every change of the
+        weights; backward() does it itself, right in front of its launch."""
+        buf = self._plane_buffer(direction)
+        _lib.check(_lib.load().rlg_mlp_chain_pack_planes(self.n, self._w, self._in, self._out, int(direction),
+                                                         buf.data_ptr(), _stream(stream_of)), 'rlg_mlp_chain_pack_planes')
+        return buf
+
+    def _plane_buffer(self, direction):
+        if direction not in self._planes:
+            nbytes = _lib.load().rlg_mlp_chain_planes_bytes(self.n, self._in, self._out, int(direction))
+            if nbytes < 0:
+                raise ValueError('rlg_mlp_chain_planes_bytes: bad network')
+            self._planes[direction] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+        return self._planes[direction]
 
     def groups(self, rows, direction, requested=0):
         g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested), int(direction))
@@ -671,17 +694,26 @@ class MlpChain:
                 raise ValueError('rms_fold: moments row of 2*in0+1 doubles expected')
             fold = [_need(row, F64, 'moments row'), _need(cnt, torch.int64, 'count'), _need(mean_o, F64, 'mean out'),
                     _need(var_o, F64, 'var out'), _need(cnt_o, torch.int64, 'count out')]
+        # a training forward also splits the weights for the backward launch that follows it (extra workgroups of
+        # the same launch); backward() uses those planes once, any other caller packs for itself
+        planes = None
+        self._planes_fresh_rows = None
+        if act_out is not None and self.n > 1 and self.split_products(rows, 1):
+            planes = self._plane_buffer(1).data_ptr()
+            self._planes_fresh_rows = rows
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
-            self.groups(rows, 0, groups), _stream(x)), 'rlg_mlp_chain_forward')
+            self.groups(rows, 0, groups), planes, _stream(x)), 'rlg_mlp_chain_forward')
 
-    def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None):
+    def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None, split_products=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
         dZ_l output; bias_partials: per hidden layer fp64 [num_blocks(rows, 1), out_l] or None.
         ppo_loss = ops.ppo_loss_desc(...): the launch first evaluates the PPO loss of its row tiles, i.e.
-        it produces d_heads itself (and the loss partials, the mu/sigma write-back)."""
+        it produces d_heads itself (and the loss partials, the mu/sigma write-back).
+        split_products: None = the library's choice (split-bf16 products on 64-row tiles for minibatches of
+        >= 16,384 rows, csrc/mlp_chain_bx.hip), False = exact f32 products."""
         rows = d_heads.shape[0]
         n = self.n
         h = self._P(*([_need(t, F32, 'H', contiguous=False) for t in acts] + [None]))
@@ -692,11 +724,18 @@ class MlpChain:
         if bias_partials is not None:
             bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
         _lib.require_gpu(d_heads, 'd_heads')
+        planes = None
+        if split_products is not False and self.split_products(rows, 1, groups):
+            if self._planes_fresh_rows is not None:
+                planes = self._plane_buffer(1).data_ptr()       # packed by the forward launch of this step
+            else:
+                planes = self.pack_planes(1, d_heads).data_ptr()
+        self._planes_fresh_rows = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
             n, self._w, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl,
             bp, None if ppo_loss is None else ctypes.addressof(ppo_loss), rows, self.groups(rows, 1, groups),
-            _stream(d_heads)), 'rlg_mlp_chain_backward')
+            planes, _stream(d_heads)), 'rlg_mlp_chain_backward')
 
 
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)

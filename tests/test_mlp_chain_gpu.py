@@ -16,14 +16,30 @@ DEV = 'cuda:0'
 ACT = {'elu': torch.nn.functional.elu, 'relu': torch.relu, 'tanh': torch.tanh, 'None': lambda t: t}
 
 
-def _net(in_dim, units, out_dim, act, seed):
+def _net(in_dim, units, out_dim, act, seed, packed=True):
+    """packed: the parameters are views into ONE flat tensor, every weight matrix followed by its bias - the layout of
+    the optimizer's arena (rl_games_amd/flat_optim.py), which the pipelined forward relies on (a row's last chunk may
+    read up to 48 bytes past a matrix whose width is not a multiple of 16: chain_pipe_fill in csrc/mlp_chain.hip
+    checks that this lands in another array of the network).  packed=False: separately allocated tensors - the
+    launch must then fall back to the unit-structured kernels for such widths instead of reading foreign memory."""
     g = torch.Generator().manual_seed(seed)
-    layers, last = [], in_dim
+    shapes, last = [], in_dim
     for u in list(units) + [out_dim]:
-        w = (torch.randn(u, last, generator=g) / last ** 0.5).to(DEV)
-        b = (0.1 * torch.randn(u, generator=g)).to(DEV)
-        layers.append([w, b, act])
+        shapes.append((u, last))
         last = u
+    flat = torch.empty(sum(u * i + u for u, i in shapes), device=DEV) if packed else None
+    layers, off = [], 0
+    for u, i in shapes:
+        w = torch.randn(u, i, generator=g) / i ** 0.5
+        b = 0.1 * torch.randn(u, generator=g)
+        if packed:
+            wv, bv = flat[off:off + u * i].view(u, i), flat[off + u * i:off + u * i + u]
+            wv.copy_(w)
+            bv.copy_(b)
+            off += u * i + u
+            layers.append([wv, bv, act])
+        else:
+            layers.append([w.to(DEV), b.to(DEV), act])
     layers[-1][2] = 'None'
     return [tuple(l) for l in layers], g
 
@@ -57,10 +73,11 @@ SHAPES = [
 
 
 @pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
-@pytest.mark.parametrize('rows,groups', [(1, 0), (63, 1), (64, 2), (1000, 4), (4113, 0), (16384, 4)])
-def test_chain_forward_matches_fp64(in_dim, units, out_dim, act, rows, groups):
+@pytest.mark.parametrize('rows,groups,packed', [(1, 0, True), (63, 1, True), (64, 2, True), (1000, 4, True), (4113, 0, True),
+                                                (16384, 4, True), (64, 2, False), (16384, 0, False), (20000, 4, False)])
+def test_chain_forward_matches_fp64(in_dim, units, out_dim, act, rows, groups, packed):
     from rl_games_amd import ops
-    layers, g = _net(in_dim, units, out_dim, act, seed=rows + in_dim)
+    layers, g = _net(in_dim, units, out_dim, act, seed=rows + in_dim, packed=packed)
     chain = ops.MlpChain(layers, DEV)
     x = (3 * torch.randn(rows, in_dim, generator=g) + 1).to(DEV)
     mean = torch.randn(in_dim, generator=g, dtype=torch.float64).to(DEV)
@@ -447,3 +464,84 @@ def test_dw_exact_f32_product_form_passes_the_same_tests():
                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
     assert ' passed' in res.stdout and 'failed' not in res.stdout, res.stdout[-500:]
+
+
+# ------------------------------------------------------------------ split-bf16 chain (csrc/mlp_chain_bx.hip)
+
+def _bf16_bits_to_f64(u16):
+    return (u16.to(torch.int32) << 16).view(torch.float32).double()
+
+
+@pytest.mark.parametrize('direction', [0, 1])
+@pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
+def test_weight_planes_are_an_exact_split_in_fragment_order(in_dim, units, out_dim, act, direction):
+    """rlg_mlp_chain_pack_planes: fragment (block, chunk, plane) = 64 lanes x 8 bf16; lane l, element e holds
+    A[16 block + (l & 15)][32 chunk + (e < 4 ? 4 (l >> 4) + e : 16 + 4 (l >> 4) + e - 4)], A = W (forward) or W^T
+    (backward), zero outside the matrix; the three planes add up to the fp32 weight EXACTLY."""
+    from rl_games_amd import ops
+    layers, _ = _net(in_dim, units, out_dim, act, seed=5 + in_dim)
+    chain = ops.MlpChain(layers, DEV)
+    planes = chain.pack_planes(direction, layers[0][0])
+    torch.cuda.synchronize()
+    raw = planes.cpu().view(torch.int16)
+    off = 0
+    lane = torch.arange(64)
+    e = torch.arange(8)
+    for L, (w, _, _) in enumerate(layers):
+        if direction == 1 and L == 0:
+            continue
+        A = w.cpu() if direction == 0 else w.cpu().t()
+        I, K = A.shape
+        nb, kc = (I + 15) // 16, (K + 31) // 32
+        frag = raw[off // 2: off // 2 + nb * kc * 3 * 512].view(nb, kc, 3, 64, 8)
+        off += nb * kc * 3 * 1024
+        total = sum(_bf16_bits_to_f64(frag[:, :, p]) for p in range(3))          # [nb, kc, 64, 8]
+        i = (torch.arange(nb)[:, None, None, None] * 16 + (lane & 15)[None, None, :, None]).expand(nb, kc, 64, 8)
+        q4 = 4 * (lane >> 4)[None, None, :, None]
+        k = torch.arange(kc)[None, :, None, None] * 32 + torch.where(e < 4, q4 + e, 16 + q4 + e - 4)
+        k = k.expand(nb, kc, 64, 8)
+        inside = (i < I) & (k < K)
+        want = torch.zeros(nb, kc, 64, 8, dtype=torch.float64)
+        want[inside] = A.double()[i[inside], k[inside]]
+        assert torch.equal(total, want)
+    assert off == planes.numel() or (off == 0 and planes.numel() == 16)
+
+
+@pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
+@pytest.mark.parametrize('rows', [64, 1000, 16384, 32768 + 17])
+def test_split_bf16_backward_agrees_with_the_exact_product_kernel(in_dim, units, out_dim, act, rows):
+    """The split-bf16 backward (64-row tiles, weight planes) against the exact-f32-product kernel on the same inputs:
+    not the same bits (that would mean the split kernel did not run), but within 1e-6 of the tensor scale - each
+    product differs by at most 3 * 2^-24 of its magnitude - and the bias-gradient partial sums add up to the same
+    column sums.  Tolerance of the chain against fp64: test_chain_backward_matches_autograd_fp64 (same bound as the
+    exact kernel)."""
+    from rl_games_amd import ops
+    layers, g = _net(in_dim, units, out_dim, act, seed=3 * rows + in_dim)
+    chain = ops.MlpChain(layers, DEV)
+    assert chain.split_products(rows, 1, 4)
+    x = torch.randn(rows, in_dim, generator=g).to(DEV)
+    heads = torch.empty(rows, out_dim, device=DEV)
+    acts = [torch.empty(rows, u, device=DEV) for u in units]
+    chain.forward(x, heads, act_out=acts)
+    d_heads = torch.randn(rows, out_dim, generator=g).to(DEV)
+    nblk = chain.num_blocks(rows, 1, 4)
+    out = {}
+    for split in (False, None):
+        dzs = [torch.full((rows, u), float('nan'), device=DEV) for u in units]
+        parts = [torch.full((nblk * u,), float('nan'), dtype=torch.float64, device=DEV) for u in units]
+        chain.backward(d_heads, acts, dzs, parts, groups=4, split_products=split)
+        out[split] = (dzs, parts)
+    differs = False
+    for l, u in enumerate(units):
+        exact, got = out[False][0][l], out[None][0][l]
+        assert torch.isfinite(got).all()
+        scale = exact.abs().max().item()
+        assert (got - exact).abs().max().item() <= 1e-6 * scale
+        differs = differs or not torch.equal(got, exact)
+        cs_exact = out[False][1][l].view(nblk, u).sum(0)
+        cs_got = out[None][1][l].view(nblk, u).sum(0)
+        # (sums over the rows of per-element differences of <= 1e-6 of the scale)
+        assert torch.allclose(cs_got, cs_exact, rtol=1e-5, atol=1e-6 * scale * rows ** 0.5 + 1e-6)
+        want = got.double().sum(0)
+        assert torch.allclose(cs_got, want, rtol=1e-5, atol=1e-5 * max(1.0, want.abs().max().item()))
+    assert differs or len(units) == 1 and act == 'None'

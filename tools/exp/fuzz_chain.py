@@ -1,5 +1,5 @@
 """Random-shape fuzz of the fused MLP kernels against fp64 torch (forward, backward with and without the
-loss tile, weight gradients).  python tools/exp/fuzz_chain.py [cases] [seed]"""
+loss tile, weight gradients).  python tools/exp/fuzz_chain.py [cases] [seed] [only this case]"""
 import os, sys, random, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rl_games_amd import ops
@@ -7,6 +7,7 @@ DEV = 'cuda:0'
 ACT = {'elu': torch.nn.functional.elu, 'relu': torch.relu, 'tanh': torch.tanh, 'None': lambda t: t}
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1       # run this case alone
 bad = 0
 for case in range(cases):
     in_dim = rng.choice([1, 3, 7, 12, 16, 33, 60, 108, 130])
@@ -16,6 +17,8 @@ for case in range(cases):
     act = rng.choice(['elu', 'relu', 'tanh', 'None'])
     rows = rng.choice([1, 5, 16, 17, 100, 512, 1000, 4096, 4100, 16384, 20000])
     groups = rng.choice([0, 0, 1, 2, 4])
+    if only >= 0 and case != only:
+        continue
     g = torch.Generator().manual_seed(case)
     layers, last = [], in_dim
     for u in units + [V + A]:
