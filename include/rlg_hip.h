@@ -452,7 +452,8 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                            * rms_batch: normalise with the state as it is. */
                           const double* rms_batch_or_null, const long long* rms_count,
                           double* rms_mean_out, double* rms_var_out, long long* rms_count_out,
-                          long long rows, int groups, void* pack_backward_planes_or_null, void* stream);
+                          long long rows, int groups, void* pack_backward_planes_or_null,
+                          const void* weight_planes_or_null, void* stream);
 /* Arguments of the clipped-PPO loss (the parameter list of rlg_ppo_loss_fused as a struct): with a
  * non-NULL descriptor the BACKWARD launch evaluates the loss of its own row tile in front of its
  * prologue - no separate loss launch - i.e. it first writes d mu / d values (which must be views of the

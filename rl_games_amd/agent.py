@@ -23,6 +23,7 @@ What runs where (per epoch):
   minibatch : obs normaliser 3 launches, fused loss fwd+bwd+KL 2 launches, clip+Adam+adaptive-lr
               2 launches, one all-reduce; learning rate and KL stay on the device.
 """
+import gc
 import os
 import time
 from datetime import datetime
@@ -1284,12 +1285,19 @@ class A2CAgent:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
         count0 = self.optimizer.step_count
+        # No automatic garbage collection while the stream is capturing: a cycle that owns device objects of an
+        # earlier graph (torch.cuda.graph collects once on entry, but the body allocates hundreds of Python objects)
+        # would be finalised in the middle of the capture, and releasing device resources there aborts the process.
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
                 body()
         except Exception as e:
             raise GraphCaptureError('HIP graph capture failed') from e
         finally:
+            if gc_was_enabled:
+                gc.enable()
             self.optimizer.step_count = count0
         return g
 

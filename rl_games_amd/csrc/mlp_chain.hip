@@ -350,28 +350,7 @@ __device__ __forceinline__ void chain_fwd_prologue(const ChainArgs& a, float* ti
     };
     load_frags(wave);
     if (norm) {
-      // mean32 / denom exactly like rms_apply_kernel mode 0 (running_mean_std.py:112-113)
-      for (int f = threadIdx.x; f < in0; f += (64 * W)) {
-        double mean = a.rms_mean[f], var = a.rms_var[f];
-        if (a.rms_batch) {
-          // rms_update_kernel mode 0: population moments of the minibatch, rounded to fp32 like the
-          // reference's input.mean / input.var, Chan merge in fp64 (running_mean_std.py:55-67,:74-83)
-          const double n = fmax(a.rms_batch[2 * in0], 1.0);
-          double bm = a.rms_batch[f] / n;
-          double bv = fmax(a.rms_batch[in0 + f] / n - bm * bm, 0.0);
-          bm = static_cast<double>(static_cast<float>(bm));
-          bv = static_cast<double>(static_cast<float>(bv));
-          const long long old_count = *a.rms_count;
-          chan_merge(mean, var, static_cast<double>(old_count), bm, bv, static_cast<double>(a.rows));
-          if (blockIdx.x == 0) {
-            a.rms_mean_out[f] = mean;
-            a.rms_var_out[f] = var;
-            if (f == 0) *a.rms_count_out = old_count + a.rows;
-          }
-        }
-        tile_b[f] = static_cast<float>(mean);
-        tile_b[in0p + f] = sqrt_rn(static_cast<float>(var) + a.rms_eps);
-      }
+      chain_norm_stats<W>(a, tile_b, in0, in0p);
       __syncthreads();
     }
     put_frags(wave);
@@ -1028,6 +1007,15 @@ static bool chain_bx_enabled() {
   return on;
 }
 
+static bool chain_bx_fwd_wanted(long long rows, int groups) {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_CHAIN_BX_FWD");     // tools: A/B against the exact-product forward kernels
+    return !(e && std::atoi(e) == 0);
+  }();
+  // (2: what pick_groups resolves the automatic choice to at these sizes - the callers pass the resolved value)
+  return on && chain_bx_enabled() && rows >= 16384 && (groups == 0 || groups == 2 || groups == 4);
+}
+
 // Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
 // profiles/r2_mlp_chain_microbench_*.txt): forward - two 32-row workgroups per CU (G = 2, two waves
 // per SIMD) beat one 64-row workgroup (G = 4, one wave per SIMD): the second wave covers the epilogue
@@ -1308,6 +1296,7 @@ int rlg_mlp_chain_prepare(void) {
     if (e != hipSuccess) return static_cast<int>(e);
   }
   if (const int e = chain_bx_prepare()) return e;
+  if (const int e = chain_bx_fwd_prepare()) return e;
   g_chain_prepared = true;
   return 0;
 }
@@ -1317,15 +1306,21 @@ int rlg_mlp_chain_prepare(void) {
 int rlg_mlp_chain_bx_supported(int num_layers, const int* in_features, const int* out_features, long long rows,
                                int groups, int direction) {
   using namespace rlg;
-  if (direction != 1 || num_layers < 2 || num_layers > kChainMaxLayers || !chain_bx_enabled()) return 0;
-  const int G = pick_groups(rows, groups, 1);
-  if (G != 4) return 0;
+  if (num_layers < 1 || num_layers > kChainMaxLayers || !chain_bx_enabled()) return 0;
   ChainArgs probe;
   probe.num_layers = num_layers;
   for (int L = 0; L < num_layers; ++L) {
     probe.layer[L].in = in_features[L];
     probe.layer[L].out = out_features[L];
   }
+  if (direction == 0) {
+    if (!chain_bx_fwd_wanted(rows, groups)) return 0;
+    if (chain_bx_plane_offsets(num_layers, in_features, out_features, 0, nullptr) >= static_cast<long long>(kOob)) return 0;
+    return chain_bx_fwd_plan(probe) >= 0 ? 1 : 0;
+  }
+  if (direction != 1 || num_layers < 2) return 0;
+  const int G = pick_groups(rows, groups, 1);
+  if (G != 4) return 0;
   if (chain_bx_plane_offsets(num_layers, in_features, out_features, 1, nullptr) >= static_cast<long long>(kOob)) return 0;
   return chain_bx_bwd_lds(probe, G) >= 0 ? 1 : 0;
 }
@@ -1358,15 +1353,20 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
                           const double* rms_batch, const long long* rms_count, double* rms_mean_out,
                           double* rms_var_out, long long* rms_count_out,
-                          long long rows, int groups, void* pack_backward_planes_or_null, void* stream) {
+                          long long rows, int groups, void* pack_backward_planes_or_null,
+                          const void* weight_planes_or_null, void* stream) {
   using namespace rlg;
   if (rows <= 0) return 0;
   ChainArgs args;
   if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
-  // the backward launch's weight planes ride along as extra workgroups (not with the tools' phase stamps: they index
-  // their buffer by workgroup)
-  if (pack_backward_planes_or_null != nullptr && g_chain_dbg == nullptr)
-    chain_bx_fill_pack(args.pack, num_layers, weights, in_features, out_features, 1, pack_backward_planes_or_null);
+  // the backward launch's weight planes ride along as extra workgroups (with the tools' phase stamps, which index
+  // their buffer by workgroup, as a launch of their own)
+  if (pack_backward_planes_or_null != nullptr &&
+      chain_bx_fill_pack(args.pack, num_layers, weights, in_features, out_features, 1, pack_backward_planes_or_null) &&
+      g_chain_dbg != nullptr) {
+    if (const int e = chain_bx_pack_launch(args.pack, static_cast<hipStream_t>(stream))) return e;
+    args.pack.total_pairs = 0;
+  }
   for (int L = 0; L < num_layers; ++L) {
     args.layer[L].bias = biases[L];
     args.layer[L].h = act_out[L];
@@ -1402,6 +1402,19 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
     args.no_ksplit = off;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // split-bf16 products on pre-split weight planes (mlp_chain_bx_fwd.hip): 64-row workgroups
+  if (weight_planes_or_null != nullptr && chain_bx_fwd_wanted(rows, groups)) {
+    ChainArgs bx = args;
+    const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, 0, bx.p_off);
+    bx.planes = weight_planes_or_null;
+    bx.planes_bytes = static_cast<unsigned>(total);
+    const int bx_lds = chain_bx_fwd_plan(bx);
+    if (bx_lds >= 0 && total < static_cast<long long>(kOob) && chain_bx_fwd_eligible(bx)) {
+      hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+      g_chain_ev_start = g_chain_ev_stop = nullptr;
+      return chain_bx_launch_fwd(bx, bx_lds, st, ev0, ev1);
+    }
+  }
   if (G >= 2 && chain_pipe_enabled() && chain_pipe_fill(args, true)) {
     bool elu_only = true;
     for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);

@@ -89,6 +89,11 @@ struct ChainArgs {
   unsigned planes_bytes;
   unsigned p_off[kChainMaxLayers];     // byte offset of layer L's fragments
   int lds_scratch_floats;              // backward: offset of the remainder blocks' column-sum scratch
+  // split-bf16 forward: byte offset of tile L (the input of layer L) in LDS, of the normaliser scratch; the tile of
+  // layer bx_pass_layer (-1: none) does not fit and is produced / consumed in windows of bx_pass_chunks chunks
+  int bx_tile_off[kChainMaxLayers + 1];
+  int bx_stats_off;
+  int bx_pass_layer, bx_pass_chunks;
   // forward: workgroups fwd_blocks .. gridDim.x-1 pack weight planes (pack.total_pairs > 0) instead of a row tile
   int fwd_blocks;
   PackArgs pack;
@@ -235,6 +240,34 @@ __device__ __forceinline__ unsigned tile_bytes(long long rows_left, long long ti
   return static_cast<unsigned>(r * ld * 4);
 }
 
+// mean32 / denominator of the observation normaliser into scratch[0 .. in0) / scratch[in0p .. in0p + in0), exactly
+// like rms_apply_kernel mode 0 (running_mean_std.py:112-113); with a.rms_batch the minibatch's moments are folded into
+// the state first (training-mode RunningMeanStd.forward) and workgroup 0 publishes the new state.  No barrier inside.
+template <int W>
+__device__ __forceinline__ void chain_norm_stats(const ChainArgs& a, float* scratch, int in0, int in0p) {
+  for (int f = threadIdx.x; f < in0; f += (64 * W)) {
+    double mean = a.rms_mean[f], var = a.rms_var[f];
+    if (a.rms_batch) {
+      // rms_update_kernel mode 0: population moments of the minibatch, rounded to fp32 like the
+      // reference's input.mean / input.var, Chan merge in fp64 (running_mean_std.py:55-67,:74-83)
+      const double n = fmax(a.rms_batch[2 * in0], 1.0);
+      double bm = a.rms_batch[f] / n;
+      double bv = fmax(a.rms_batch[in0 + f] / n - bm * bm, 0.0);
+      bm = static_cast<double>(static_cast<float>(bm));
+      bv = static_cast<double>(static_cast<float>(bv));
+      const long long old_count = *a.rms_count;
+      chan_merge(mean, var, static_cast<double>(old_count), bm, bv, static_cast<double>(a.rows));
+      if (blockIdx.x == 0) {
+        a.rms_mean_out[f] = mean;
+        a.rms_var_out[f] = var;
+        if (f == 0) *a.rms_count_out = old_count + a.rows;
+      }
+    }
+    scratch[f] = static_cast<float>(mean);
+    scratch[in0p + f] = sqrt_rn(static_cast<float>(var) + a.rms_eps);
+  }
+}
+
 // workgroup `block` (256 threads) of a pack job: one thread per lane of a (block, chunk) fragment pair.  Fragment
 // (block ib, chunk c, plane p) = 64 lanes x 8 bf16 = 1 KiB at ((ib * KC + c) * 3 + p) KiB; lane l, element e holds
 // A[16 ib + (l & 15)][32 c + (e < 4 ? 4 (l >> 4) + e : 16 + 4 (l >> 4) + e - 4)], zero outside the matrix.
@@ -263,6 +296,7 @@ __device__ __forceinline__ void chain_pack_planes_block(const PackArgs& a, int b
   for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 1024) = plane[p];
 }
 int chain_bx_pack_blocks(const PackArgs& a);
+int chain_bx_pack_launch(const PackArgs& a, hipStream_t st);
 // fills the pack job of one direction; false: nothing to pack / bad arguments
 bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weights, const int* in_features,
                         const int* out_features, int direction, void* planes);
@@ -275,6 +309,11 @@ long long chain_bx_plane_offsets(int num_layers, const int* in_features, const i
                                  unsigned* offsets);
 bool chain_bx_bwd_eligible(const ChainArgs& args);
 int chain_bx_prepare();
+// forward: LDS plan (fills bx_tile_off / bx_stats_off / bx_pass_*), bytes or -1; eligibility; launch
+int chain_bx_fwd_plan(ChainArgs& args);
+bool chain_bx_fwd_eligible(const ChainArgs& args);
+int chain_bx_launch_fwd(const ChainArgs& args, int lds_bytes, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int chain_bx_fwd_prepare();
 int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t st, const LossArgs* loss, hipEvent_t ev0,
                         hipEvent_t ev1);
 

@@ -701,11 +701,14 @@ class MlpChain:
         if act_out is not None and self.n > 1 and self.split_products(rows, 1):
             planes = self._plane_buffer(1).data_ptr()
             self._planes_fresh_rows = rows
+        fwd_planes = None
+        if self.split_products(rows, 0, groups):
+            fwd_planes = self.pack_planes(0, x).data_ptr()
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
-            self.groups(rows, 0, groups), planes, _stream(x)), 'rlg_mlp_chain_forward')
+            self.groups(rows, 0, groups), planes, fwd_planes, _stream(x)), 'rlg_mlp_chain_forward')
 
     def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None, split_products=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
