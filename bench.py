@@ -336,6 +336,20 @@ def main():
                 'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
                           'timed region (= rocprofv3 --kernel-trace begin/end); exact fp32 products on '
                           'v_mfma_f32_16x16x4_f32, useful flops 2*rows*sum(in*out), tile padding not counted'}
+            if key in ('roofline_fwd', 'roofline_fwd_infer') and eng.chain.split_products(rows, 0):
+                pad = sum(-(-o // 16) * 16 * -(-i // 32) * 32 for i, o in zip(ins, outs))
+                issued = 6 * 2.0 * rows * pad / us / 1e6
+                chain_roof[key].update({
+                    'kernel': 'rlg::mlp_chain_fwd_bx_kernel (' + ('training forward: statistics fold + normalise + every layer '
+                              '+ heads, activations written' if key == 'roofline_fwd' else 'rollout inference forward') +
+                              '; split-bf16 products on pre-split weight planes)',
+                    'issued_tflops_bf16': issued, 'issued_frac_of_bf16_peak': issued / BF16_MFMA_PEAK_TFLOPS,
+                    'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
+                              'timed region (= rocprofv3 --kernel-trace begin/end; the plane-pack launch in front of it '
+                              'is not included); six exact bf16 plane products per fp32 product on '
+                              'v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx_fwd.hip); achieved / frac = useful fp32 flops '
+                              '2*rows*sum(in*out) against the fp32 MFMA peak, issued_* = 6 x the padded-tile flops '
+                              'against the dense bf16 peak'})
             if key == 'roofline_bwd' and eng.chain.split_products(rows, 1):
                 # the split-bf16 kernel: fp32-equivalent flops against the fp32 peak (comparable with the other rows)
                 # and what it ISSUES - six bf16 plane products per product over 16 x 32 padded tiles - on the bf16 peak

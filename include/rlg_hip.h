@@ -497,9 +497,13 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
  * (rl_games/algos_torch/network_builder.py:447-512).
  * pack_backward_planes_or_null of rlg_mlp_chain_forward: the forward launch of a training step splits the weights
  * for the backward launch that follows it (same weights) in extra workgroups at the end of its grid - no launch of its own.
- *   rlg_mlp_chain_planes_bytes: size of the fragment buffer for one direction (0 forward products, 1 backward)
- *   rlg_mlp_chain_pack_planes : weights [out, in] fp32 -> fragments (one launch, all layers) */
+ *   rlg_mlp_chain_planes_bytes : size of the fragment buffer for one direction (0 forward products, 1 backward) or,
+ *                                direction 2, of ONE buffer with both (the backward fragments at
+ *                                rlg_mlp_chain_planes_offset(..., 1))
+ *   rlg_mlp_chain_pack_planes  : weights [out, in] fp32 -> fragments (one launch, all layers; direction 2: both
+ *                                directions into the combined buffer - networks of up to 4 layers) */
 long long rlg_mlp_chain_planes_bytes(int num_layers, const int* in_features, const int* out_features, int direction);
+long long rlg_mlp_chain_planes_offset(int num_layers, const int* in_features, const int* out_features, int direction);
 int rlg_mlp_chain_pack_planes(int num_layers, const float* const* weights, const int* in_features,
                               const int* out_features, int direction, void* planes, void* stream);
 int rlg_mlp_chain_bx_supported(int num_layers, const int* in_features, const int* out_features, long long rows,

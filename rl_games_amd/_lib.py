@@ -88,6 +88,7 @@ _PROTOTYPES = {
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P, _P],
     # mlp_chain_bx.hip
     'rlg_mlp_chain_planes_bytes': [_c_int, _P, _P, _c_int],
+    'rlg_mlp_chain_planes_offset': [_c_int, _P, _P, _c_int],
     'rlg_mlp_chain_pack_planes': [_c_int, _P, _P, _P, _c_int, _P, _P],
     'rlg_mlp_chain_bx_supported': [_c_int, _P, _P, _c_ll, _c_int, _c_int],
     'rlg_lstm_supported': [_c_int],
@@ -135,7 +136,7 @@ def exported_prototypes():
     return dict(_PROTOTYPES)
 
 
-_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan', 'rlg_stats_sync_flat_size', 'rlg_mlp_chain_planes_bytes'}
+_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan', 'rlg_stats_sync_flat_size', 'rlg_mlp_chain_planes_bytes', 'rlg_mlp_chain_planes_offset'}
 
 
 def load():

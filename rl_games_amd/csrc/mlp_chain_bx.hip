@@ -54,26 +54,38 @@ int chain_bx_pack_launch(const PackArgs& a, hipStream_t st) {
   RLG_RETURN_LAUNCH_STATUS();
 }
 
+// direction 2: both directions into one buffer - the forward fragments at 0, the backward ones at
+// chain_bx_both_offset (one launch splits the weights for the forward AND the backward launch of a training step)
+long long chain_bx_both_offset(int num_layers, const int* in_features, const int* out_features) {
+  const long long fwd = chain_bx_plane_offsets(num_layers, in_features, out_features, 0, nullptr);
+  return (fwd + 255) & ~255LL;
+}
+
 bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weights, const int* in_features,
                         const int* out_features, int direction, void* planes) {
   args.njobs = 0;
   args.total_pairs = 0;
   args.dst = static_cast<unsigned char*>(planes);
-  if (num_layers < 1 || num_layers > kChainMaxLayers || (direction != 0 && direction != 1) || planes == nullptr) return false;
-  unsigned off[kChainMaxLayers];
-  const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, direction, off);
-  if (total >= static_cast<long long>(kOob)) return false;
-  for (int L = (direction == 1 ? 1 : 0); L < num_layers; ++L) {
-    PackJob& J = args.job[args.njobs++];
-    J.w = weights[L];
-    J.in = in_features[L];
-    J.I = direction == 0 ? out_features[L] : in_features[L];
-    J.K = direction == 0 ? in_features[L] : out_features[L];
-    J.KC = bx_kc(J.K);
-    J.transposed = direction;
-    J.pair_begin = args.total_pairs;
-    J.dst_off = off[L];
-    args.total_pairs += bx_nb(J.I) * J.KC;
+  if (num_layers < 1 || num_layers > kChainMaxLayers || direction < 0 || direction > 2 || planes == nullptr) return false;
+  for (int dir = 0; dir < 2; ++dir) {
+    if (direction != 2 && direction != dir) continue;
+    unsigned off[kChainMaxLayers];
+    const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, dir, off);
+    const long long base = (direction == 2 && dir == 1) ? chain_bx_both_offset(num_layers, in_features, out_features) : 0;
+    if (base + total >= static_cast<long long>(kOob)) return false;
+    for (int L = (dir == 1 ? 1 : 0); L < num_layers; ++L) {
+      if (args.njobs >= kChainMaxLayers) return false;          // (deep networks: one launch per direction)
+      PackJob& J = args.job[args.njobs++];
+      J.w = weights[L];
+      J.in = in_features[L];
+      J.I = dir == 0 ? out_features[L] : in_features[L];
+      J.K = dir == 0 ? in_features[L] : out_features[L];
+      J.KC = bx_kc(J.K);
+      J.transposed = dir;
+      J.pair_begin = args.total_pairs;
+      J.dst_off = static_cast<unsigned>(base + off[L]);
+      args.total_pairs += bx_nb(J.I) * J.KC;
+    }
   }
   return args.total_pairs > 0;
 }
@@ -343,14 +355,22 @@ int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t
 extern "C" {
 
 long long rlg_mlp_chain_planes_bytes(int num_layers, const int* in_features, const int* out_features, int direction) {
-  if (num_layers < 1 || num_layers > rlg::kChainMaxLayers || (direction != 0 && direction != 1)) return -1;
+  if (num_layers < 1 || num_layers > rlg::kChainMaxLayers || direction < 0 || direction > 2) return -1;
+  if (direction == 2)
+    return rlg::chain_bx_both_offset(num_layers, in_features, out_features) +
+           rlg::chain_bx_plane_offsets(num_layers, in_features, out_features, 1, nullptr);
   return rlg::chain_bx_plane_offsets(num_layers, in_features, out_features, direction, nullptr);
+}
+
+long long rlg_mlp_chain_planes_offset(int num_layers, const int* in_features, const int* out_features, int direction) {
+  if (num_layers < 1 || num_layers > rlg::kChainMaxLayers || (direction != 0 && direction != 1)) return -1;
+  return direction == 0 ? 0 : rlg::chain_bx_both_offset(num_layers, in_features, out_features);
 }
 
 int rlg_mlp_chain_pack_planes(int num_layers, const float* const* weights, const int* in_features,
                               const int* out_features, int direction, void* planes, void* stream) {
   using namespace rlg;
-  if (num_layers < 1 || num_layers > kChainMaxLayers || (direction != 0 && direction != 1) || planes == nullptr)
+  if (num_layers < 1 || num_layers > kChainMaxLayers || direction < 0 || direction > 2 || planes == nullptr)
     return static_cast<int>(hipErrorInvalidValue);
   PackArgs args;
   if (!chain_bx_fill_pack(args, num_layers, weights, in_features, out_features, direction, planes)) {

@@ -297,7 +297,7 @@ __device__ __forceinline__ void chain_pack_planes_block(const PackArgs& a, int b
 }
 int chain_bx_pack_blocks(const PackArgs& a);
 int chain_bx_pack_launch(const PackArgs& a, hipStream_t st);
-// fills the pack job of one direction; false: nothing to pack / bad arguments
+// fills the pack job of one direction (2: both, into one buffer); false: nothing to pack / bad arguments / too many jobs
 bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weights, const int* in_features,
                         const int* out_features, int direction, void* planes);
 

@@ -635,7 +635,8 @@ class MlpChain:
             if best == 0 and (direction == 0 or n > 1):
                 raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
             self.max_groups[direction] = best
-        self._planes = {}          # direction -> bf16 plane fragments of the weights (csrc/mlp_chain_bx.hip)
+        self._planes = None        # bf16 plane fragments of the weights, both directions (csrc/mlp_chain_bx.hip)
+        self._bwd_offset = 0
         self._planes_fresh_rows = None
 
     def split_products(self, rows, direction, requested=0):
@@ -644,20 +645,37 @@ class MlpChain:
                                                            self.groups(rows, direction, requested), int(direction)))
 
     def pack_planes(self, direction, stream_of):
-        """Weights -> bf16 plane fragments (one launch).  The planes must be re-packed after every change of the
-        weights; backward() does it itself, right in front of its launch."""
-        buf = self._plane_buffer(direction)
-        _lib.check(_lib.load().rlg_mlp_chain_pack_planes(self.n, self._w, self._in, self._out, int(direction),
-                                                         buf.data_ptr(), _stream(stream_of)), 'rlg_mlp_chain_pack_planes')
-        return buf
+        """Weights -> bf16 plane fragments (one launch; direction 0 forward operand, 1 backward, 2 both).  Returns the
+        view of that direction's fragments (direction 2: the whole buffer).  The planes must be re-packed after
+        every change of the weights: forward() / backward() do it themselves, right in front of their launch."""
+        buf = self._plane_buffer()
+        lib = _lib.load()
+        if direction == 2 and 2 * self.n - 1 > 8:                 # more jobs than one launch carries
+            self.pack_planes(0, stream_of)
+            self.pack_planes(1, stream_of)
+            return buf
+        view = (buf[:self._fwd_bytes], buf[self._bwd_offset:self._bwd_offset + self._bwd_bytes], buf)[direction]
+        if view.numel() > 0:
+            _lib.check(lib.rlg_mlp_chain_pack_planes(self.n, self._w, self._in, self._out, int(direction),
+                                                     view.data_ptr(), _stream(stream_of)), 'rlg_mlp_chain_pack_planes')
+        return view
 
-    def _plane_buffer(self, direction):
-        if direction not in self._planes:
-            nbytes = _lib.load().rlg_mlp_chain_planes_bytes(self.n, self._in, self._out, int(direction))
-            if nbytes < 0:
+    def _plane_buffer(self):
+        """ONE buffer for both directions: forward fragments at 0, backward fragments at _bwd_offset."""
+        if self._planes is None:
+            lib = _lib.load()
+            nbytes = lib.rlg_mlp_chain_planes_bytes(self.n, self._in, self._out, 2)
+            off = lib.rlg_mlp_chain_planes_offset(self.n, self._in, self._out, 1)
+            if nbytes < 0 or off < 0:
                 raise ValueError('rlg_mlp_chain_planes_bytes: bad network')
-            self._planes[direction] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
-        return self._planes[direction]
+            self._planes = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+            self._bwd_offset = int(off)
+            self._fwd_bytes = int(lib.rlg_mlp_chain_planes_bytes(self.n, self._in, self._out, 0))
+            self._bwd_bytes = int(lib.rlg_mlp_chain_planes_bytes(self.n, self._in, self._out, 1))
+        return self._planes
+
+    def _planes_ptr(self, direction):
+        return self._plane_buffer().data_ptr() + (self._bwd_offset if direction == 1 else 0)
 
     def groups(self, rows, direction, requested=0):
         g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested), int(direction))
@@ -666,13 +684,16 @@ class MlpChain:
     def num_blocks(self, rows, direction, requested=0):
         return _lib.load().rlg_mlp_chain_num_blocks(int(rows), self.groups(rows, direction, requested))
 
-    def forward(self, x, heads, act_out=None, rms=None, eps=1e-5, xn_out=None, groups=0, rms_fold=None):
+    def forward(self, x, heads, act_out=None, rms=None, eps=1e-5, xn_out=None, groups=0, rms_fold=None,
+                split_products=None):
         """x [rows, in0] (row stride free), heads [rows, out_last] out.  act_out: per hidden layer a
         [rows, out_l] tensor or None.  rms = (running_mean, running_var) fp64 -> the observations are
         normalised on the way in (xn_out [rows, in0] optionally receives them).  rms_fold =
         (moments_row [2*in0+1] fp64, count int64, mean_out, var_out, count_out): training-mode
         RunningMeanStd - the minibatch's moments are folded into the state first, the new state is
-        written to the *_out tensors (a second buffer set)."""
+        written to the *_out tensors (a second buffer set).
+        split_products: None = the library's choice (split-bf16 products on 64-row tiles for minibatches of
+        >= 16,384 rows, csrc/mlp_chain_bx_fwd.hip), False = exact f32 products."""
         rows = x.shape[0]
         n = self.n
         outs = list(act_out) if act_out is not None else [None] * (n - 1)
@@ -694,16 +715,20 @@ class MlpChain:
                 raise ValueError('rms_fold: moments row of 2*in0+1 doubles expected')
             fold = [_need(row, F64, 'moments row'), _need(cnt, torch.int64, 'count'), _need(mean_o, F64, 'mean out'),
                     _need(var_o, F64, 'var out'), _need(cnt_o, torch.int64, 'count out')]
-        # a training forward also splits the weights for the backward launch that follows it (extra workgroups of
-        # the same launch); backward() uses those planes once, any other caller packs for itself
-        planes = None
+        # A training forward also has the weights split for the backward launch that follows it: by the forward's own
+        # pack launch when the forward runs on planes as well (one launch, both directions), else in extra workgroups
+        # of the exact-product forward launch.  backward() uses those planes once; any other caller packs for itself.
+        train = act_out is not None and self.n > 1
+        bwd_split = train and self.split_products(rows, 1)
+        planes = fwd_planes = None
         self._planes_fresh_rows = None
-        if act_out is not None and self.n > 1 and self.split_products(rows, 1):
-            planes = self._plane_buffer(1).data_ptr()
+        if split_products is not False and self.split_products(rows, 0, groups):
+            self.pack_planes(2 if bwd_split else 0, x)
+            fwd_planes = self._planes_ptr(0)
+        elif bwd_split:
+            planes = self._planes_ptr(1)
+        if bwd_split:
             self._planes_fresh_rows = rows
-        fwd_planes = None
-        if self.split_products(rows, 0, groups):
-            fwd_planes = self.pack_planes(0, x).data_ptr()
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
@@ -729,10 +754,9 @@ class MlpChain:
         _lib.require_gpu(d_heads, 'd_heads')
         planes = None
         if split_products is not False and self.split_products(rows, 1, groups):
-            if self._planes_fresh_rows is not None:
-                planes = self._plane_buffer(1).data_ptr()       # packed by the forward launch of this step
-            else:
-                planes = self.pack_planes(1, d_heads).data_ptr()
+            if self._planes_fresh_rows is None:
+                self.pack_planes(1, d_heads)                    # (else: packed with the forward launch of this step)
+            planes = self._planes_ptr(1)
         self._planes_fresh_rows = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
