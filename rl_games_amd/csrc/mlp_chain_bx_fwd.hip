@@ -369,31 +369,43 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-// Tiles: T_L = the input of layer L (T_0: the observations), alternately in region A (even L) and B (odd L); at most
-// one tile (T_p, p >= 1) is windowed when the chain does not fit otherwise.
+// Tiles: T_L = the input of layer L (T_0: the observations).  T_L is written during layer L-1 and read during layer L,
+// so only CONSECUTIVE tiles are alive together: even tiles sit at the bottom of the LDS, odd tiles at the top, and a pair
+// fits when the two sizes add up to the budget at most.  At most one tile (T_p, p >= 1) is windowed when a pair does not
+// fit: the window gets what T_{p-1} leaves free (T_{p+1}, written behind the last pass, may overlap both).
 int chain_bx_fwd_plan(ChainArgs& args) {
   const int n = args.num_layers;
   long long kc[kChainMaxLayers];
   for (int L = 0; L < n; ++L) kc[L] = bx_kc(args.layer[L].in);
   const long long chunk = kFwG * kBxChunk;
-  const long long stats = ((2LL * ((args.layer[0].in + 3) & ~3) * 4) + 15) & ~15LL;
-  const long long budget = 160 * 1024 - stats;
-  auto layout = [&](int p, long long window) -> long long {       // region sizes with T_p windowed (p < 0: none)
-    long long ra = 0, rb = 0;
+  const long long stats = ((2LL * ((args.layer[0].in + 3) & ~3) * 4) + 15) & ~15LL;     // prologue only: shares the top
+  // the smallest LDS that holds every consecutive pair (small networks then run several workgroups per CU), else all of it
+  long long need = kc[0] * chunk + stats;
+  for (int L = 0; L < n; ++L) {
+    const long long pair = (kc[L] + (L + 1 < n ? kc[L + 1] : 0)) * chunk;
+    need = pair > need ? pair : need;
+  }
+  const long long budget = need <= 160 * 1024 ? need : 160 * 1024;
+  auto place = [&](int p, long long window) -> bool {
     for (int L = 0; L < n; ++L) {
       const long long c = (L == p) ? window : kc[L];
-      if (L & 1) rb = c > rb ? c : rb;
-      else ra = c > ra ? c : ra;
+      if (c * chunk > budget) return false;
+      args.bx_tile_off[L] = static_cast<int>((L & 1) ? budget - c * chunk : 0);
     }
-    for (int L = 0; L < n; ++L) args.bx_tile_off[L] = static_cast<int>((L & 1) ? ra * chunk : 0);
     args.bx_tile_off[n] = 0;
-    args.bx_stats_off = static_cast<int>((ra + rb) * chunk);
-    return (ra + rb) * chunk;
+    for (int L = 0; L + 1 < n; ++L) {
+      if (L == p) continue;        // T_{p+1} is written behind the last pass, when the window is dead: they may overlap
+      const long long c0 = kc[L], c1 = (L + 1 == p) ? window : kc[L + 1];
+      if ((c0 + c1) * chunk > budget) return false;
+    }
+    // the normaliser scratch lives during the prologue, next to T_0 only
+    if (kc[0] * chunk + stats > budget) return false;
+    args.bx_stats_off = static_cast<int>(budget - stats);
+    return true;
   };
   args.bx_pass_layer = -1;
   args.bx_pass_chunks = 0;
-  long long bytes = layout(-1, 0);
-  if (bytes <= budget) return static_cast<int>(bytes + stats);
+  if (place(-1, 0)) return static_cast<int>(budget);
   // window the largest tile
   int p = -1;
   for (int L = 1; L < n; ++L) {
@@ -403,11 +415,10 @@ int chain_bx_fwd_plan(ChainArgs& args) {
   if (bx_nb(args.layer[p].out) > kFwMaxPersist * kBxW) return -1;     // the consumer's accumulators stay in registers
   for (long long passes = 2; passes <= kc[p]; ++passes) {
     const long long window = (kc[p] + passes - 1) / passes;
-    bytes = layout(p, window);
-    if (bytes <= budget) {
+    if (place(p, window)) {
       args.bx_pass_layer = p;
       args.bx_pass_chunks = static_cast<int>(window);
-      return static_cast<int>(bytes + stats);
+      return static_cast<int>(budget);
     }
   }
   return -1;
