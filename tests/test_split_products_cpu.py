@@ -62,3 +62,43 @@ def test_six_plane_products_are_as_accurate_as_an_fp32_product(rows, No, Mi):
     (pa, _), (pb, _) = _planes(dz.t().contiguous()), _planes(x)
     three = pa[0] @ pb[0] + pa[0] @ pb[1] + pa[1] @ pb[0]
     assert ((three.double() - ref).abs() / scale).pow(2).mean().sqrt() > 5 * err_split.pow(2).mean().sqrt()
+
+
+# ------------------------------------------------------------------ host side of the split-bf16 chain (no GPU needed)
+
+def _arr(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def test_chain_plane_buffer_sizes_and_envelope_of_the_split_kernels():
+    """rlg_mlp_chain_planes_bytes / _offset / _bx_supported are host logic of the C ABI: fragment counts (16-row blocks
+    x 32-column chunks x 3 planes of 1 KiB; the backward needs none for layer 0), the combined buffer of both
+    directions, and the envelope - minibatches of >= 16,384 rows; the forward's LDS plan must fit (a windowed
+    400- or 512-wide tile is fine, a windowed tile whose consumer has more than 256 outputs is not)."""
+    from rl_games_amd import _lib
+    lib = _lib.load()
+    ins, outs = [108, 400, 200, 100], [400, 200, 100, 22]
+    n = len(ins)
+    blocks = lambda v: -(-v // 16)
+    chunks = lambda v: -(-v // 32)
+    fwd = sum(blocks(o) * chunks(i) * 3072 for i, o in zip(ins, outs))
+    bwd = sum(blocks(i) * chunks(o) * 3072 for i, o in list(zip(ins, outs))[1:])
+    assert lib.rlg_mlp_chain_planes_bytes(n, _arr(ins), _arr(outs), 0) == fwd
+    assert lib.rlg_mlp_chain_planes_bytes(n, _arr(ins), _arr(outs), 1) == bwd
+    off = lib.rlg_mlp_chain_planes_offset(n, _arr(ins), _arr(outs), 1)
+    assert off >= fwd and off % 256 == 0 and lib.rlg_mlp_chain_planes_offset(n, _arr(ins), _arr(outs), 0) == 0
+    assert lib.rlg_mlp_chain_planes_bytes(n, _arr(ins), _arr(outs), 2) == off + bwd
+    assert lib.rlg_mlp_chain_planes_bytes(n, _arr(ins), _arr(outs), 3) == -1
+
+    def supported(i, o, rows, direction, groups=0):
+        return lib.rlg_mlp_chain_bx_supported(len(i), _arr(i), _arr(o), rows, groups, direction)
+    for direction in (0, 1):
+        assert supported(ins, outs, 32768, direction) == 1            # the benchmarked update shape
+        assert supported(ins, outs, 16384, direction) == 1
+        assert supported(ins, outs, 4096, direction) == 0             # a data-parallel rank's minibatch: exact products
+        assert supported([60, 256, 128, 64], [256, 128, 64, 9], 32768, direction) == 1
+    assert supported(ins, outs, 65536, 0) == 1                        # the rollout forward
+    assert supported([33, 512, 64], [512, 64, 8], 16384, 0) == 1      # windowed 512-wide tile, 4 consumer blocks
+    assert supported([33, 1024, 512], [1024, 512, 8], 16384, 0) == 0  # its consumer would need 32 blocks in registers
+    assert supported([108], [22], 32768, 1) == 0                      # a single layer has no dX chain
