@@ -150,6 +150,13 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     char* t0 = ldsb + a.bx_tile_off[0];
     constexpr int kProBatch = 4;        // fragments per wave at a time: every load is issued before the first is used
     f32x4 xlo[kProBatch], xhi[kProBatch];
+    // fast path (rows of 4-float groups at 16-byte aligned addresses - every BASELINE shape): buffer loads over the
+    // tile with 32-bit lane offsets (rows past the end and columns past the width read zero), the normaliser's
+    // mean / denominator as two 16-byte LDS reads per half fragment
+    const bool fast = pin_s(static_cast<int>(xv && (in0 & 3) == 0 && a.ldx * 64 * 4 < static_cast<long long>(kOob))) != 0;
+    const rsrc_t xr = make_rsrc(a.x + row0 * a.ldx, fast ? tile_bytes(n_rows - row0, 16 * G, a.ldx) : 0u);
+    const unsigned x_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(a.ldx) + q4) * 4);
+    const unsigned x_group = static_cast<unsigned>(16 * static_cast<int>(a.ldx) * 4);
     auto load_frags = [&](int u0) {
 #pragma unroll
       for (int k = 0; k < kProBatch; ++k) {
@@ -157,7 +164,11 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         const int c = u / G, g = u - c * G;
         const long long row = row0 + g * 16 + (lane & 15);
         xlo[k] = xhi[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (u < nfrag && row < n_rows) {
+        if (fast) {
+          const unsigned off = x_lane + static_cast<unsigned>(g) * x_group + static_cast<unsigned>(c) * 128u;
+          xlo[k] = buf_load4(xr, (u < nfrag && c * 32 + q4 < in0) ? off : kOob);
+          xhi[k] = buf_load4(xr, (u < nfrag && c * 32 + 16 + q4 < in0) ? off + 64u : kOob);
+        } else if (u < nfrag && row < n_rows) {
           xlo[k] = load_row4(a.x, a.ldx, row, c * 32 + q4, in0, xv);
           xhi[k] = load_row4(a.x, a.ldx, row, c * 32 + 16 + q4, in0, xv);
         }
@@ -174,7 +185,16 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int f = c * 32 + 16 * h + q4;
-            if (row < n_rows) {
+            if (fast) {
+              if (norm && f < in0) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(stats + f);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + in0p + f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[h][e] = fminf(fmaxf((v[h][e] - m4[e]) / d4[e], -5.0f), 5.0f);
+                if (row >= n_rows) v[h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};       // (rows past the end stay zero)
+              }
+              if (a.xn && f < in0 && row < n_rows) store_row4(a.xn, in0, row, f, in0, v[h], xnv);
+            } else if (row < n_rows) {
               if (norm) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
