@@ -45,5 +45,20 @@ planes = chain.pack_planes(1, d_heads)
 t_pack = timeit(lambda: chain.pack_planes(1, d_heads))
 t_exact = timeit(lambda: chain.backward(d_heads, acts, dzs, parts, groups=G, split_products=False))
 t_bx = timeit(lambda: chain.backward(d_heads, acts, dzs, parts, groups=G))
+# with the PPO loss tile in front (what the epoch runs)
+A = 21
+gg = torch.Generator().manual_seed(1)
+logstd = (0.1 * torch.randn(A, generator=gg) - 0.3).to(dev)
+dd = {'actions': torch.randn(rows, A, generator=gg), 'old_neglogp': 1.4 * A + torch.randn(rows, generator=gg),
+      'adv': torch.randn(rows, generator=gg), 'old_values': torch.randn(rows, generator=gg), 'returns': torch.randn(rows, generator=gg),
+      'old_mu': 0.3 * torch.randn(rows, A, generator=gg), 'old_sigma': 0.5 + torch.rand(rows, A, generator=gg)}
+dd = {k: v.to(dev) for k, v in dd.items()}
+partials = torch.empty(nblk, ops.ppo_loss_partials_per_block(A), dtype=torch.float64, device=dev)
+largs = (heads[:, 1:], logstd, heads[:, 0], dd['actions'], dd['old_neglogp'], dd['adv'], dd['old_values'], dd['returns'],
+         dd['old_mu'], dd['old_sigma'], d_heads[:, 1:], d_heads[:, 0], partials, 0.2, 2.0, 1e-4)
+desc = ops.ppo_loss_desc(*largs)
+t_loss_exact = timeit(lambda: chain.backward(d_heads, acts, dzs, parts, groups=G, ppo_loss=desc, split_products=False))
+t_loss_bx = timeit(lambda: chain.backward(d_heads, acts, dzs, parts, groups=G, ppo_loss=desc))
+print(f'rows {rows}: with the loss tile: exact-product {t_loss_exact:.1f} us | split-bf16 incl. pack {t_loss_bx:.1f} us')
 print(f'rows {rows}: pack {t_pack:.1f} us | exact-product backward {t_exact:.1f} us ({flops / t_exact * 1e-6:.1f} TFLOP/s) | '
       f'split-bf16 backward incl. pack {t_bx:.1f} us ({flops / t_bx * 1e-6:.1f} TFLOP/s fp32-equivalent)')
