@@ -84,9 +84,14 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   // is computed: as written phase by phase, a tile is ~14 dependent memory round trips (the element loop cannot be
   // pipelined by the compiler: old_mu / old_sigma are read AND written), which a backward workgroup that owns its CU
   // alone (csrc/mlp_chain_bx.hip) pays in full.
+  // phase 2 works on a row with kPart threads (a quad: three of them take one of the row's three sums over the
+  // actions each, in the order a = 0 .. A-1 of a single thread, the fourth the two sums of column constants) when the
+  // workgroup has four threads per row, else with one
+  constexpr int kPart = (kThreads >= 4 * kRows) ? 4 : 1;
+  const int prow = tid / kPart, ppart = tid % kPart;
   float r_adv = 0.0f, r_onlp = 0.0f, r_v = 0.0f, r_vo = 0.0f, r_ret = 0.0f, r_mask = 1.0f;
-  if (tid < rows) {
-    const long long i = row0 + tid;
+  if (prow < rows) {
+    const long long i = row0 + prow;
     r_adv = p.advantages[i];
     r_onlp = p.old_neglogp[i];
     r_v = p.values[i * p.ld_val];
@@ -95,16 +100,17 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     if (p.mask) r_mask = p.mask[i];
   }
   constexpr int kBatch = 8;                   // element rounds held in registers (A <= 8 * kThreads / kRows)
-  float e_mu[kBatch], e_x[kBatch], e_omu[kBatch], e_osg[kBatch];
+  float e_mu[kBatch], e_x[kBatch], e_omu[kBatch], e_osg[kBatch], e_ls[kBatch];
   {
     int r = tid / A, a = tid - r * A;
     const int dr = kThreads / A, da = kThreads - dr * A;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int e = tid + k * kThreads;
-      e_mu[k] = e_x[k] = e_omu[k] = 0.0f;
+      e_mu[k] = e_x[k] = e_omu[k] = e_ls[k] = 0.0f;
       e_osg[k] = 1.0f;
       if (e < tile_elems) {
+        e_ls[k] = p.logstd[a];
         e_mu[k] = p.mu[(row0 + r) * p.ld_mu + a];
         e_x[k] = p.actions[e0 + e];
         e_omu[k] = p.old_mu[e0 + e];
@@ -126,7 +132,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
     // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale) - once per column, not once per row and column
     col_ent[a] = 1.4189385332046727f + logf(sg);
   }
-  __syncthreads();
+  // (no barrier here: phase 1 forms sigma = expf(logstd[a]) per element - the same bits; the column arrays are read
+  //  behind the barrier that ends phase 1)
 
   const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
   float denom_count = static_cast<float>(p.mb);
@@ -136,8 +143,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   {
     int r = tid / A, a = tid - r * A;
     const int dr = kThreads / A, da = kThreads - dr * A;
-    auto element = [&](int e, int r, int a, float mu, float x, float omu, float osg) {
-      const float sg = col_sigma[a];
+    auto element = [&](int e, int r, int a, float mu, float x, float omu, float osg, float ls) {
+      const float sg = expf(ls);                                              // models.py:296
       const float z = (x - mu) / sg;                                          // models.py:362
       t_z2[r * AP + a] = z * z;
       // policy_kl(p0 = new, p1 = old)                                        torch_ext.py:28-31
@@ -170,11 +177,11 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int e = tid + k * kThreads;
-      if (e < tile_elems) element(e, r, a, e_mu[k], e_x[k], e_omu[k], e_osg[k]);
+      if (e < tile_elems) element(e, r, a, e_mu[k], e_x[k], e_omu[k], e_osg[k], e_ls[k]);
       advance();
     }
     for (int e = tid + kBatch * kThreads; e < tile_elems; e += kThreads) {
-      element(e, r, a, p.mu[(row0 + r) * p.ld_mu + a], p.actions[e0 + e], p.old_mu[e0 + e], p.old_sigma[e0 + e]);
+      element(e, r, a, p.mu[(row0 + r) * p.ld_mu + a], p.actions[e0 + e], p.old_mu[e0 + e], p.old_sigma[e0 + e], p.logstd[a]);
       advance();
     }
   }
@@ -182,16 +189,38 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 
   // ------------------------------ phase 2: one thread per row ------------------------
   double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (tid < rows) {
-    const long long i = row0 + tid;
-    float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+  float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+  if constexpr (kPart == 4) {
+    // every sum by ONE thread in the order a = 0 .. A-1 (the bits of the one-thread-per-row form), the five of a row
+    // by the four threads of its quad at the same time; then each thread of the quad collects all five
+    const int rr = prow < rows ? prow : 0;
+    float mine = 0.0f, mine2 = 0.0f;
+    if (ppart == 3) {
+      for (int a = 0; a < A; ++a) {
+        mine += col_logstd[a];
+        mine2 += col_ent[a];
+      }
+    } else {
+      const float* tile = ppart == 0 ? t_z2 : (ppart == 1 ? t_kl : t_b);
+      for (int a = 0; a < A; ++a) mine += tile[rr * AP + a];
+    }
+    const int quad = static_cast<int>(threadIdx.x & 63) & ~3;
+    s_z2 = __shfl(mine, quad + 0, kWave);
+    s_kl = __shfl(mine, quad + 1, kWave);
+    s_b = __shfl(mine, quad + 2, kWave);
+    s_ls = __shfl(mine, quad + 3, kWave);
+    s_ent = __shfl(mine2, quad + 3, kWave);
+  } else if (prow < rows) {
     for (int a = 0; a < A; ++a) {
-      s_z2 += t_z2[tid * AP + a];
-      s_kl += t_kl[tid * AP + a];
-      s_b += t_b[tid * AP + a];
+      s_z2 += t_z2[prow * AP + a];
+      s_kl += t_kl[prow * AP + a];
+      s_b += t_b[prow * AP + a];
       s_ls += col_logstd[a];
       s_ent += col_ent[a];
     }
+  }
+  if (prow < rows && ppart == 0) {
+    const long long i = row0 + prow;
     // neglogp                                                                models.py:361-364
     const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
     const float adv = r_adv;
@@ -247,8 +276,8 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 
     const float m = r_mask;
     const float w = m / denom_count;          // d(mean)/d(element)
-    row_g[tid] = g_nlp * w;
-    row_w[tid] = w;
+    row_g[prow] = g_nlp * w;
+    row_w[prow] = w;
     const float dv = (0.5f * p.critic_coef) * g_v * w;                        // a2c_continuous.py:133
     p.d_values[i * p.ld_dval] = dv;
     acc[6] = static_cast<double>(dv);
@@ -308,23 +337,26 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   __syncthreads();
 
   // ------------------------------ phase 4: column sums over the block's rows ----------
-  // two column sets (d logstd terms in t_z2, d mu in t_kl); 8 row groups x A columns each, then
-  // A threads fold the 8 partials (fixed order).
-  for (int set = 0; set < 2; ++set) {
-    const float* tile = set == 0 ? t_z2 : t_kl;
-    const int groups = 8;
+  // two column sets (d logstd terms in t_z2, d mu in t_kl); 8 row groups x A columns each - both sets in one sweep - then
+  // 2 A threads fold the 8 partials of their column (fixed order).
+  {
+    constexpr int groups = 8;
     const int per = (rows + groups - 1) / groups;
-    for (int j = tid; j < groups * A; j += kThreads) {
-      const int g = j / A, a = j - g * A;
+    for (int j = tid; j < 2 * groups * A; j += kThreads) {
+      const int set = j / (groups * A);
+      const int jj = j - set * groups * A;
+      const int g = jj / A, a = jj - g * A;
+      const float* tile = set == 0 ? t_z2 : t_kl;
       double s = 0.0;
       const int r_end = min(rows, (g + 1) * per);
       for (int r = g * per; r < r_end; ++r) s += static_cast<double>(tile[r * AP + a]);
       red[j] = s;
     }
     __syncthreads();
-    for (int a = tid; a < A; a += kThreads) {
+    for (int j = tid; j < 2 * A; j += kThreads) {
+      const int set = j / A, a = j - set * A;
       double s = 0.0;
-      for (int g = 0; g < groups; ++g) s += red[g * A + a];
+      for (int g = 0; g < groups; ++g) s += red[set * groups * A + g * A + a];
       out[kLossScalars + set * A + a] = s;
     }
     __syncthreads();
@@ -333,13 +365,13 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 
 
 // LDS bytes of one ppo_loss_tile<rows>: 3 tiles [rows][A|1] + 2 row vectors + 3 column vectors (floats),
-// then the fp64 reduction scratch.
+// then the fp64 reduction scratch (2 column sets x 8 row groups x A, or the block sums' per-wave values).
 inline size_t ppo_loss_lds_bytes(int rows, int A, int threads = kLossThreads) {
   const int AP = A | 1;
   size_t shm = (static_cast<size_t>(3) * rows * AP + 2 * rows + 3 * A + 4) * sizeof(float);
   shm = (shm + 7) & ~static_cast<size_t>(7);
-  const size_t red_doubles = static_cast<size_t>(8) * A > static_cast<size_t>(kLossScalars) * (threads / kWave)
-                                 ? static_cast<size_t>(8) * A
+  const size_t red_doubles = static_cast<size_t>(16) * A > static_cast<size_t>(kLossScalars) * (threads / kWave)
+                                 ? static_cast<size_t>(16) * A
                                  : static_cast<size_t>(kLossScalars) * (threads / kWave);
   return shm + red_doubles * sizeof(double);
 }
