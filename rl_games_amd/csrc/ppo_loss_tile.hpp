@@ -55,11 +55,86 @@ __device__ __forceinline__ float smooth_clamp_grad(float x, float mi, float mx) 
   return (4.0f * e) * (s * s);
 }
 
+// The row-level part of the loss: from a row's five sums over the actions (z^2, KL terms, bound terms, log sigma, entropy
+// terms) and its scalars to  g = d loss / d neglogp x weight,  w = mask / count,  dv = d loss / d value,  and the row's
+// seven contributions to the tile's partial sums.  One definition for both tile forms below.
+struct LossRow {
+  float g, w, dv;
+};
+__device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float s_z2, float s_kl, float s_b, float s_ls, float s_ent,
+                                                float r_adv, float r_onlp, float r_v, float r_vo, float r_ret, float r_mask, float lo,
+                                                float hi, float denom_count, double (&acc)[kLossScalars]) {
+  // neglogp                                                                models.py:361-364
+  const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
+  const float adv = r_adv;
+  const float ratio = expf(r_onlp - nlp);                                   // common_losses.py:75
+  const float surr1 = adv * ratio;
+  float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
+  if (p.smooth) {
+    l2 = adv * smooth_clamp_f(ratio, lo, hi);
+    dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
+  } else {
+    l2 = adv * fminf(fmaxf(ratio, lo), hi);
+    dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+  }
+  const float n1 = -surr1, n2 = -l2;
+  const float a_loss = fmaxf(n1, n2);                                       // :78
+  // torch.max backward: the larger branch takes the gradient, equal branches split it
+  float w1, w2;
+  if (n1 > n2) {
+    w1 = 1.0f;
+    w2 = 0.0f;
+  } else if (n2 > n1) {
+    w1 = 0.0f;
+    w2 = 1.0f;
+  } else {
+    w1 = 0.5f;
+    w2 = 0.5f;
+  }
+  // d a_loss / d ratio = -adv*(w1 + w2*dl2) ; d ratio / d nlp = -ratio
+  const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
+
+  // critic                                                                 common_losses.py:20-27
+  const float v = r_v, vo = r_vo, R = r_ret;
+  float c_loss, g_v;
+  if (p.clip_value) {
+    const float delta = v - vo;
+    const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+    const float d1 = v - R, d2 = vclip - R;
+    const float c1 = d1 * d1, c2 = d2 * d2;
+    c_loss = fmaxf(c1, c2);
+    const float in = (delta >= -p.e_clip && delta <= p.e_clip) ? 1.0f : 0.0f;
+    if (c1 > c2) {
+      g_v = 2.0f * d1;
+    } else if (c2 > c1) {
+      g_v = 2.0f * d2 * in;
+    } else {
+      g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
+    }
+  } else {
+    const float d = R - v;
+    c_loss = d * d;
+    g_v = -2.0f * d;
+  }
+
+  const float m = r_mask;
+  const float w = m / denom_count;          // d(mean)/d(element)
+  const float dv = (0.5f * p.critic_coef) * g_v * w;                        // a2c_continuous.py:133
+  acc[6] = static_cast<double>(dv);
+  acc[0] = static_cast<double>(a_loss) * m;
+  acc[1] = static_cast<double>(c_loss) * m;
+  acc[2] = static_cast<double>(s_ent) * m;
+  acc[3] = static_cast<double>(s_b) * m;
+  acc[4] = static_cast<double>(s_kl) * m;
+  acc[5] = m;
+  return LossRow{g_nlp * w, w, dv};
+}
+
 // One tile of kRows rows (the tile_index-th of the minibatch) by the kThreads threads of a workgroup; `lds`:
 // ppo_loss_lds_bytes(kRows, A) bytes, 16-byte aligned.  Called by ppo_loss_kernel and by the fused backward
 // kernel in front of its own prologue (csrc/mlp_chain.hip: d heads of the tile are then already there).
 template <int kRows, int kThreads = kLossThreads>
-__device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int tile_index) {
+__device__ __forceinline__ void ppo_loss_tile_rows(const LossArgs& p, float* lds, int tile_index) {
   static_assert(kRows <= kThreads, "one thread per row in phase 2");
   const int A = p.A;
   const int AP = A | 1;                       // odd row stride: conflict-free row walks
@@ -221,72 +296,10 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
   }
   if (prow < rows && ppart == 0) {
     const long long i = row0 + prow;
-    // neglogp                                                                models.py:361-364
-    const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * A)) + s_ls;
-    const float adv = r_adv;
-    const float ratio = expf(r_onlp - nlp);                                   // common_losses.py:75
-    const float surr1 = adv * ratio;
-    float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
-    if (p.smooth) {
-      l2 = adv * smooth_clamp_f(ratio, lo, hi);
-      dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
-    } else {
-      l2 = adv * fminf(fmaxf(ratio, lo), hi);
-      dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
-    }
-    const float n1 = -surr1, n2 = -l2;
-    const float a_loss = fmaxf(n1, n2);                                       // :78
-    // torch.max backward: the larger branch takes the gradient, equal branches split it
-    float w1, w2;
-    if (n1 > n2) {
-      w1 = 1.0f;
-      w2 = 0.0f;
-    } else if (n2 > n1) {
-      w1 = 0.0f;
-      w2 = 1.0f;
-    } else {
-      w1 = 0.5f;
-      w2 = 0.5f;
-    }
-    // d a_loss / d ratio = -adv*(w1 + w2*dl2) ; d ratio / d nlp = -ratio
-    const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
-
-    // critic                                                                 common_losses.py:20-27
-    const float v = r_v, vo = r_vo, R = r_ret;
-    float c_loss, g_v;
-    if (p.clip_value) {
-      const float delta = v - vo;
-      const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
-      const float d1 = v - R, d2 = vclip - R;
-      const float c1 = d1 * d1, c2 = d2 * d2;
-      c_loss = fmaxf(c1, c2);
-      const float in = (delta >= -p.e_clip && delta <= p.e_clip) ? 1.0f : 0.0f;
-      if (c1 > c2) {
-        g_v = 2.0f * d1;
-      } else if (c2 > c1) {
-        g_v = 2.0f * d2 * in;
-      } else {
-        g_v = 0.5f * (2.0f * d1) + 0.5f * (2.0f * d2 * in);
-      }
-    } else {
-      const float d = R - v;
-      c_loss = d * d;
-      g_v = -2.0f * d;
-    }
-
-    const float m = r_mask;
-    const float w = m / denom_count;          // d(mean)/d(element)
-    row_g[prow] = g_nlp * w;
-    row_w[prow] = w;
-    const float dv = (0.5f * p.critic_coef) * g_v * w;                        // a2c_continuous.py:133
-    p.d_values[i * p.ld_dval] = dv;
-    acc[6] = static_cast<double>(dv);
-    acc[0] = static_cast<double>(a_loss) * m;
-    acc[1] = static_cast<double>(c_loss) * m;
-    acc[2] = static_cast<double>(s_ent) * m;
-    acc[3] = static_cast<double>(s_b) * m;
-    acc[4] = static_cast<double>(s_kl) * m;
-    acc[5] = m;
+    const LossRow R = ppo_loss_row(p, A, s_z2, s_kl, s_b, s_ls, s_ent, r_adv, r_onlp, r_v, r_vo, r_ret, r_mask, lo, hi, denom_count, acc);
+    row_g[prow] = R.g;
+    row_w[prow] = R.w;
+    p.d_values[i * p.ld_dval] = R.dv;
   }
   block_sum<kLossScalars, kThreads>(acc, red);
   double* out = p.partials + static_cast<long long>(tile_index) * (kLossScalars + 2 * A);
@@ -364,6 +377,181 @@ __device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Quad form (A <= 4 * kQuadK, four threads per row available - every shape the agent runs): thread (row r = tid >> 2,
+// q = tid & 3) owns the actions a = q, q + 4, ... of its row IN REGISTERS from the loads to the stores.  The tile form
+// above walks the tile four times through LDS behind seven barriers - ~14 dependent memory round trips and 21 k cycles
+// for 64 rows when nothing else runs on the CU (the split-bf16 backward, csrc/mlp_chain_bx.hip).  Here: every load up
+// front, the row's five sums by two butterfly steps inside the quad, the row-level maths redundantly in its four
+// threads, d mu / write-back straight from the registers, the column sums over the rows by butterflies over the
+// lanes that share q (fp64) and one exchange between the waves: two barriers.
+// Same formulas (ppo_loss_row, the element expressions); the fp32 sums over a row's actions associate differently
+// ((q-partial sums) + butterfly instead of a = 0 .. A-1), so results differ from the tile form in the last bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQuadK = 8;
+
+template <int kRows, int kThreads>
+__device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds, int tile_index) {
+  static_assert(kThreads >= 4 * kRows, "four threads per row");
+  constexpr int kWaves = kThreads / kWave;
+  const int A = p.A;
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, q = tid & 3;
+  const long long row0 = static_cast<long long>(tile_index) * kRows;
+  const int rows = static_cast<int>(min(static_cast<long long>(kRows), p.mb - row0));
+  const bool row_ok = r < rows;                       // (threads >= 4 * kRows and rows past the end: no row)
+  const long long i = row0 + (row_ok ? r : 0);
+  double* red = reinterpret_cast<double*>(lds);       // [kWaves][2][A] column partials, then the block sums' scratch
+  double* red_cols = red;
+  double* red_scal = red + kWaves * 2 * A;
+
+  // ---- every load of the tile, up front
+  float r_adv = 0.0f, r_onlp = 0.0f, r_v = 0.0f, r_vo = 0.0f, r_ret = 0.0f, r_mask = 1.0f;
+  float e_mu[kQuadK], e_x[kQuadK], e_omu[kQuadK], e_osg[kQuadK], e_ls[kQuadK];
+  if (row_ok) {
+    r_adv = p.advantages[i];
+    r_onlp = p.old_neglogp[i];
+    r_v = p.values[i * p.ld_val];
+    r_vo = p.old_values[i];
+    r_ret = p.returns[i];
+    if (p.mask) r_mask = p.mask[i];
+  }
+#pragma unroll
+  for (int k = 0; k < kQuadK; ++k) {
+    const int a = q + 4 * k;
+    e_mu[k] = e_x[k] = e_omu[k] = e_ls[k] = 0.0f;
+    e_osg[k] = 1.0f;
+    if (row_ok && a < A) {
+      e_ls[k] = p.logstd[a];
+      e_mu[k] = p.mu[i * p.ld_mu + a];
+      e_x[k] = p.actions[i * A + a];
+      e_omu[k] = p.old_mu[i * A + a];
+      e_osg[k] = p.old_sigma[i * A + a];
+    }
+  }
+  const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
+  float denom_count = static_cast<float>(p.mb);
+  if (p.mask) denom_count = fmaxf(*p.mask_sum, 1.0f);                         // torch_ext.py:165
+
+  // ---- element-wise: the terms of the row's five sums
+  float e_z[kQuadK], e_sg[kQuadK];
+  float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kQuadK; ++k) {
+    const int a = q + 4 * k;
+    e_z[k] = 0.0f;
+    e_sg[k] = 1.0f;
+    if (a < A) {                                       // (also for threads without a row: keeps s_ls / s_ent uniform)
+      const float ls = row_ok ? e_ls[k] : p.logstd[a];
+      const float sg = expf(ls);                                              // models.py:296
+      e_sg[k] = sg;
+      s_ls += ls;
+      s_ent += 1.4189385332046727f + logf(sg);        // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale)
+      if (row_ok) {
+        const float mu = e_mu[k], x = e_x[k], omu = e_omu[k], osg = e_osg[k];
+        const float z = (x - mu) / sg;                                        // models.py:362
+        e_z[k] = z;
+        s_z2 += z * z;
+        // policy_kl(p0 = new, p1 = old)                                      torch_ext.py:28-31
+        const float c1 = logf(osg / sg + 1e-5f);
+        const float dm = omu - mu;
+        const float c2 = (sg * sg + dm * dm) / (2.0f * (osg * osg + 1e-5f));
+        s_kl += (c1 + c2) + (-0.5f);
+        if (p.bound_kind == 1) {                                              // a2c_continuous.py:248-253
+          const float hi_t = fmaxf(mu - 1.1f, 0.0f);
+          const float lo_t = fminf(mu + 1.1f, 0.0f);
+          s_b += lo_t * lo_t + hi_t * hi_t;
+        } else if (p.bound_kind == 2) {                                       // :241-246
+          s_b += mu * mu;
+        }
+        if (p.write_back) {                                                   // datasets.py:42-43
+          p.old_mu[i * A + a] = mu;
+          p.old_sigma[i * A + a] = sg;
+        }
+      }
+    }
+  }
+  // the quad's four partial sums -> the row's sums, the same bits in all four threads: (s0 + s1) + (s2 + s3)
+  auto quad_sum = [&](float v) -> float {
+    v += __shfl_xor(v, 1, kWave);
+    v += __shfl_xor(v, 2, kWave);
+    return v;
+  };
+  s_z2 = quad_sum(s_z2);
+  s_kl = quad_sum(s_kl);
+  s_b = quad_sum(s_b);
+  s_ls = quad_sum(s_ls);
+  s_ent = quad_sum(s_ent);
+
+  // ---- the row
+  double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double none[kLossScalars];
+  const LossRow R = ppo_loss_row(p, A, s_z2, s_kl, s_b, s_ls, s_ent, r_adv, r_onlp, r_v, r_vo, r_ret, r_mask, lo, hi, denom_count,
+                                 (row_ok && q == 0) ? acc : none);
+  if (row_ok && q == 0) p.d_values[i * p.ld_dval] = R.dv;
+
+  // ---- d mu and the d logstd terms of the thread's elements; their sums over the rows of this wave (fp64 butterflies
+  //      over the lanes that share q: xor 4 .. 32), lanes 0..3 of every wave leave them in LDS
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < kQuadK; ++k) {
+    const int a = q + 4 * k;
+    double c_dls = 0.0, c_dmu = 0.0;
+    if (row_ok && a < A) {
+      const float mu = e_mu[k], z = e_z[k], sg = e_sg[k];
+      float db = 0.0f;
+      if (p.bound_kind == 1) {
+        db = 2.0f * fminf(mu + 1.1f, 0.0f) + 2.0f * fmaxf(mu - 1.1f, 0.0f);
+      } else if (p.bound_kind == 2) {
+        db = 2.0f * mu;
+      }
+      // d nlp / d mu = -z / sigma
+      const float dmu = R.g * (-(z / sg)) + (R.w * p.bounds_coef) * db;
+      p.d_mu[i * p.ld_dmu + a] = dmu;
+      c_dmu = static_cast<double>(dmu);                // column sums -> bias gradient of the mu head
+      c_dls = static_cast<double>(R.g * (1.0f - z * z));     // d nlp / d logstd = 1 - z^2
+    }
+    if (4 * k < A) {                                   // (uniform: some thread of the tile owns column q + 4 k)
+#pragma unroll
+      for (int o = 4; o < kWave; o <<= 1) {
+        c_dls += __shfl_xor(c_dls, o, kWave);
+        c_dmu += __shfl_xor(c_dmu, o, kWave);
+      }
+      if (lane < 4 && a < A) {
+        red_cols[(wave * 2 + 0) * A + a] = c_dls;
+        red_cols[(wave * 2 + 1) * A + a] = c_dmu;
+      }
+    }
+  }
+  block_sum<kLossScalars, kThreads>(acc, red_scal);      // (its barrier also publishes red_cols)
+  double* out = p.partials + static_cast<long long>(tile_index) * (kLossScalars + 2 * A);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < kLossScalars; ++k) out[k] = acc[k];
+  }
+  if constexpr (kWaves == 1) __syncthreads();            // (block_sum of a single wave has no barrier)
+  for (int j = tid; j < 2 * A; j += kThreads) {
+    const int set = j / A, a = j - set * A;
+    double s2 = 0.0;
+    for (int w = 0; w < kWaves; ++w) s2 += red_cols[(w * 2 + set) * A + a];
+    out[kLossScalars + set * A + a] = s2;
+  }
+  __syncthreads();                                       // the LDS is the caller's again
+}
+
+// The tile by whichever form fits.
+template <int kRows, int kThreads = kLossThreads>
+__device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int tile_index) {
+  if constexpr (kThreads >= 4 * kRows) {
+    if (p.A <= 4 * kQuadK) {
+      ppo_loss_tile_quad<kRows, kThreads>(p, lds, tile_index);
+      return;
+    }
+  }
+  ppo_loss_tile_rows<kRows, kThreads>(p, lds, tile_index);
+}
+
+
 // LDS bytes of one ppo_loss_tile<rows>: 3 tiles [rows][A|1] + 2 row vectors + 3 column vectors (floats),
 // then the fp64 reduction scratch (2 column sets x 8 row groups x A, or the block sums' per-wave values).
 inline size_t ppo_loss_lds_bytes(int rows, int A, int threads = kLossThreads) {
@@ -373,7 +561,10 @@ inline size_t ppo_loss_lds_bytes(int rows, int A, int threads = kLossThreads) {
   const size_t red_doubles = static_cast<size_t>(16) * A > static_cast<size_t>(kLossScalars) * (threads / kWave)
                                  ? static_cast<size_t>(16) * A
                                  : static_cast<size_t>(kLossScalars) * (threads / kWave);
-  return shm + red_doubles * sizeof(double);
+  const size_t tile_form = shm + red_doubles * sizeof(double);
+  // quad form: [waves][2][A] column partials + the block sums' per-wave values, all fp64
+  const size_t quad_form = (static_cast<size_t>(threads / kWave) * (2 * A + kLossScalars)) * sizeof(double);
+  return tile_form > quad_form ? tile_form : quad_form;
 }
 
 }  // namespace rlg
