@@ -1511,9 +1511,23 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
     bx.planes_bytes = static_cast<unsigned>(total);
     int bx_lds = chain_bx_bwd_lds(bx, G);
     if (bx_lds >= 0 && total < static_cast<long long>(kOob) && chain_bx_bwd_eligible(bx)) {
+      bx.bx_handoff_off = -1;
+      bx.bx_handoff_ld = 0;
       if (ppo_loss) {
         const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, ppo_loss->actions_num, 512));
         if (need > bx_lds) bx_lds = need;
+        // the loss tile writes exactly the d heads array this launch reads (column 0: d value, 1 .. A: d mu): hand
+        // them over in LDS, behind everything else
+        const rlg_ppo_loss_desc& d = *ppo_loss;
+        const int w = out_features[num_layers - 1];
+        const int hld = (w + 1) | 1;
+        const int hbytes = 16 * G * hld * 4;
+        if (w == 1 + d.actions_num && d.d_values == d_out && d.d_mu == d_out + 1 && d.ld_d_values == ld_dout &&
+            d.ld_d_mu == ld_dout && d.actions_num <= 32 && bx_lds + hbytes <= 160 * 1024) {
+          bx.bx_handoff_off = (bx_lds + 15) & ~15;
+          bx.bx_handoff_ld = hld;
+          bx_lds = bx.bx_handoff_off + hbytes;
+        }
       }
       hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
       g_chain_ev_start = g_chain_ev_stop = nullptr;

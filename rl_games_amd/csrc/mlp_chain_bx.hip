@@ -105,11 +105,17 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
 
   int stamp = 0;
   chain_stamp(a.dbg, wave, stamp);                                   // tools/exp/bx_phases.py: start
+  bool via_lds = false;        // d heads handed over by the loss tile in LDS
   if (a.with_loss) {
-    ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x);
-    // the prologue reads d heads that OTHER waves of this workgroup have just stored (see mlp_chain_bwd_kernel)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    float* handoff = a.bx_handoff_off >= 0 ? reinterpret_cast<float*>(ldsb + a.bx_handoff_off) : nullptr;
+    via_lds = ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x, handoff, a.bx_handoff_ld);
+    if (!via_lds) {
+      // the prologue reads d heads that OTHER waves of this workgroup have just stored (see mlp_chain_bwd_kernel)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // (via LDS: the tile ends with a barrier behind its last LDS write - nothing to wait for; the stores of d mu /
+    //  d values to global memory - the weight-gradient launch reads them - complete with the kernel)
   }
   chain_stamp(a.dbg, wave, stamp);                                   // loss tile done
   const rsrc_t pr = make_rsrc(a.planes, a.planes_bytes);
@@ -128,8 +134,17 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
       const int f = c * 32 + q4;
       f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row < n_rows) {
-        lo = load_row4(a.x, a.ldx, row, f, w, xv);
-        hi = load_row4(a.x, a.ldx, row, f + 16, w, xv);
+        if (via_lds) {
+          const float* d = reinterpret_cast<const float*>(ldsb + a.bx_handoff_off) + (g * 16 + (lane & 15)) * a.bx_handoff_ld;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (f + e < w) lo[e] = d[f + e];
+            if (f + 16 + e < w) hi[e] = d[f + 16 + e];
+          }
+        } else {
+          lo = load_row4(a.x, a.ldx, row, f, w, xv);
+          hi = load_row4(a.x, a.ldx, row, f + 16, w, xv);
+        }
       }
       const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       u32x4 plane[3];

@@ -89,6 +89,8 @@ struct ChainArgs {
   unsigned planes_bytes;
   unsigned p_off[kChainMaxLayers];     // byte offset of layer L's fragments
   int lds_scratch_floats;              // backward: offset of the remainder blocks' column-sum scratch
+  int bx_handoff_off;                  // split-bf16 backward: byte offset in LDS of the loss tile's d heads, or -1
+  int bx_handoff_ld;                   //   (the loss writes exactly the array the chain reads: no fence + re-load)
   // split-bf16 forward: byte offset of tile L (the input of layer L) in LDS, of the normaliser scratch; the tile of
   // layer bx_pass_layer (-1: none) does not fit and is produced / consumed in windows of bx_pass_chunks chunks
   int bx_tile_off[kChainMaxLayers + 1];

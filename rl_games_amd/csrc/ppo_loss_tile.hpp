@@ -390,8 +390,11 @@ __device__ __forceinline__ void ppo_loss_tile_rows(const LossArgs& p, float* lds
 // ------------------------------------------------------------------------------------------------
 constexpr int kQuadK = 8;
 
+// handoff (optional, LDS, [kRows][handoff_ld] floats): the tile's d heads - column 0 d value, columns 1 .. A d mu - for a
+// caller that consumes them in the same workgroup (the fused backward: no store fence + re-load from global memory).
 template <int kRows, int kThreads>
-__device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds, int tile_index) {
+__device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds, int tile_index, float* handoff = nullptr,
+                                                   int handoff_ld = 0) {
   static_assert(kThreads >= 4 * kRows, "four threads per row");
   constexpr int kWaves = kThreads / kWave;
   const int A = p.A;
@@ -488,7 +491,10 @@ __device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds
   double none[kLossScalars];
   const LossRow R = ppo_loss_row(p, A, s_z2, s_kl, s_b, s_ls, s_ent, r_adv, r_onlp, r_v, r_vo, r_ret, r_mask, lo, hi, denom_count,
                                  (row_ok && q == 0) ? acc : none);
-  if (row_ok && q == 0) p.d_values[i * p.ld_dval] = R.dv;
+  if (row_ok && q == 0) {
+    p.d_values[i * p.ld_dval] = R.dv;
+    if (handoff != nullptr) handoff[r * handoff_ld] = R.dv;
+  }
 
   // ---- d mu and the d logstd terms of the thread's elements; their sums over the rows of this wave (fp64 butterflies
   //      over the lanes that share q: xor 4 .. 32), lanes 0..3 of every wave leave them in LDS
@@ -508,6 +514,7 @@ __device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds
       // d nlp / d mu = -z / sigma
       const float dmu = R.g * (-(z / sg)) + (R.w * p.bounds_coef) * db;
       p.d_mu[i * p.ld_dmu + a] = dmu;
+      if (handoff != nullptr) handoff[r * handoff_ld + 1 + a] = dmu;
       c_dmu = static_cast<double>(dmu);                // column sums -> bias gradient of the mu head
       c_dls = static_cast<double>(R.g * (1.0f - z * z));     // d nlp / d logstd = 1 - z^2
     }
@@ -539,16 +546,18 @@ __device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds
   __syncthreads();                                       // the LDS is the caller's again
 }
 
-// The tile by whichever form fits.
+// The tile by whichever form fits.  Returns true when the d heads were left in `handoff` (quad form only).
 template <int kRows, int kThreads = kLossThreads>
-__device__ __forceinline__ void ppo_loss_tile(const LossArgs& p, float* lds, int tile_index) {
+__device__ __forceinline__ bool ppo_loss_tile(const LossArgs& p, float* lds, int tile_index, float* handoff = nullptr,
+                                              int handoff_ld = 0) {
   if constexpr (kThreads >= 4 * kRows) {
     if (p.A <= 4 * kQuadK) {
-      ppo_loss_tile_quad<kRows, kThreads>(p, lds, tile_index);
-      return;
+      ppo_loss_tile_quad<kRows, kThreads>(p, lds, tile_index, handoff, handoff_ld);
+      return handoff != nullptr;
     }
   }
   ppo_loss_tile_rows<kRows, kThreads>(p, lds, tile_index);
+  return false;
 }
 
 
