@@ -829,19 +829,15 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
 
   // ---- the PPO loss of this row tile first (training steps): d heads = d loss / d (value, mu) of the rows,
   //      the mu / sigma write-back and the tile's partial sums; the tile regions are still free
-  bool via_lds = false;        // d heads handed over by the loss tile in LDS (quad form, the agent's array layout)
   if (a.with_loss) {
-    float* handoff = a.bx_handoff_off >= 0 ? lds + a.bx_handoff_off / 4 : nullptr;
-    via_lds = ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x, handoff, a.bx_handoff_ld);
-    if (!via_lds) {
-      // The prologue below reads d heads that OTHER waves of this workgroup have just stored.  A workgroup
-      // barrier alone does not wait for global stores on gfx950 (hipcc emits no vmcnt(0) in front of
-      // s_barrier at workgroup scope) and the loads did overtake them (wrong dZ with 8 waves): every wave
-      // waits for its stores to be acknowledged by the L2 first.  (An agent-scope fence here - L2
-      // write-back + invalidate in every workgroup - cost 15 ms per epoch.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    ppo_loss_tile<16 * G, 64 * W>(loss, lds, blockIdx.x);
+    // The prologue below reads d heads that OTHER waves of this workgroup have just stored.  A workgroup
+    // barrier alone does not wait for global stores on gfx950 (hipcc emits no vmcnt(0) in front of
+    // s_barrier at workgroup scope) and the loads did overtake them (wrong dZ with 8 waves): every wave
+    // waits for its stores to be acknowledged by the L2 first.  (An agent-scope fence here - L2
+    // write-back + invalidate in every workgroup - cost 15 ms per epoch.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
   // ---- prologue: d heads tile -> LDS -----------------------------------------------------------
@@ -855,17 +851,7 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
       const long long row = row0 + g * 16 + (lane & 15);
       const int f = c * 16 + 4 * (lane >> 4);
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row < a.rows) {
-        if (via_lds) {
-          const float* d = lds + a.bx_handoff_off / 4 + (g * 16 + (lane & 15)) * a.bx_handoff_ld;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (f + e < w) v[e] = d[f + e];
-          }
-        } else {
-          v = load_row4(a.x, a.ldx, row, f, w, xv);
-        }
-      }
+      if (row < a.rows) v = load_row4(a.x, a.ldx, row, f, w, xv);
       *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
     }
     __syncthreads();
@@ -1112,8 +1098,6 @@ static int chain_fill(ChainArgs& args, int num_layers, const float* const* weigh
   args.dbg = nullptr;
   args.with_loss = 0;
   args.fwd_blocks = 0;
-  args.bx_handoff_off = -1;
-  args.bx_handoff_ld = 0;
   args.pack.njobs = args.pack.total_pairs = 0;
   args.pack.dst = nullptr;
   args.planes = nullptr;
@@ -1514,18 +1498,6 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
     const int need = static_cast<int>(ppo_loss_lds_bytes(16 * G, d.actions_num, 512));
     if (need > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
     if (need > lds_bytes) lds_bytes = need;
-    // the loss tile writes exactly the d heads array this launch reads (column 0: d value, 1 .. A: d mu): it hands
-    // them to the prologue in LDS, behind everything else (no store fence, no re-load from global memory)
-    const int w = out_features[num_layers - 1];
-    const int hld = (w + 1) | 1;
-    const int hbytes = 16 * G * hld * 4;
-    const int hoff = (lds_bytes + 15) & ~15;
-    if (w == 1 + d.actions_num && d.d_values == d_out && d.d_mu == d_out + 1 && d.ld_d_values == ld_dout &&
-        d.ld_d_mu == ld_dout && d.actions_num <= 32 && hoff + hbytes <= 160 * 1024) {
-      args.bx_handoff_off = hoff;
-      args.bx_handoff_ld = hld;
-      lds_bytes = hoff + hbytes;
-    }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const LossArgs* lp = ppo_loss ? &loss : nullptr;
