@@ -584,3 +584,28 @@ def test_split_bf16_forward_agrees_with_the_exact_product_kernel(in_dim, units, 
     heads2 = torch.full((rows, out_dim), float('nan'), device=DEV)
     chain.forward(x, heads2, rms=(mean, var), eps=1e-5)
     assert torch.equal(heads2, out[None][0][-1])
+
+
+def test_split_bf16_forward_is_invariant_under_power_of_two_rescaling():
+    """The plane split works on the significand: observations times 2^40 with first-layer weights times 2^-40 (and the same
+    with 2^-60 / 2^60) give the same products plane by plane, so every output is the SAME BITS - no hidden dependence on
+    the magnitude of the operands (bf16 has fp32's exponent range).  Documented limit: a +-Inf operand becomes NaN in
+    the split (Inf - Inf in the residual), where an exact product would propagate the infinity."""
+    from rl_games_amd import ops
+    rows = 16384
+    base, g = _net(60, [256, 128], 9, 'elu', seed=77)
+    x = (2 * torch.randn(rows, 60, generator=g)).to(DEV)
+
+    def run(scale_x, scale_w):
+        layers = [(w.clone(), b.clone(), a) for w, b, a in base]
+        layers[0][0].mul_(scale_w)
+        chain = ops.MlpChain(layers, DEV)
+        assert chain.split_products(rows, 0)
+        heads = torch.empty(rows, 9, device=DEV)
+        acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+        chain.forward(x * scale_x, heads, act_out=acts)
+        return acts + [heads]
+    ref = run(1.0, 1.0)
+    for e in (40, -60):
+        got = run(2.0 ** e, 2.0 ** -e)
+        assert all(torch.equal(p, q) for p, q in zip(got, ref)), e
