@@ -88,7 +88,6 @@ struct ChainArgs {
   const void* planes;
   unsigned planes_bytes;
   unsigned p_off[kChainMaxLayers];     // byte offset of layer L's fragments
-  int lds_scratch_floats;              // backward: offset of the remainder blocks' column-sum scratch
   int bx_handoff_off;                  // split-bf16 backward: byte offset in LDS of the loss tile's d heads, or -1
   int bx_handoff_ld;                   //   (the loss writes exactly the array the chain reads: no fence + re-load)
   // split-bf16 forward: byte offset of tile L (the input of layer L) in LDS, of the normaliser scratch; the tile of
@@ -304,7 +303,7 @@ bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weig
                         const int* out_features, int direction, void* planes);
 
 // ---- mlp_chain_bx.hip ----------------------------------------------------------------------------------------------
-// LDS bytes of the split-bf16 backward at 16 G rows per workgroup (G = 4: one workgroup per CU, 2: two) (fills lds_b_floats / lds_scratch_floats), -1: does not fit
+// LDS bytes of the split-bf16 backward at 16 G rows per workgroup (fills lds_b_floats), -1: does not fit
 int chain_bx_bwd_lds(ChainArgs& args, int G);
 // byte offsets of every layer's plane fragments (direction 0: forward products, 1: backward), returns the total
 long long chain_bx_plane_offsets(int num_layers, const int* in_features, const int* out_features, int direction,
