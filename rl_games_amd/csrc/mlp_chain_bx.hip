@@ -386,10 +386,10 @@ int rlg_mlp_chain_pack_planes(int num_layers, const float* const* weights, const
   using namespace rlg;
   if (num_layers < 1 || num_layers > kChainMaxLayers || direction < 0 || direction > 2 || planes == nullptr)
     return static_cast<int>(hipErrorInvalidValue);
+  if (direction == 1 && num_layers == 1) return 0;        // a single layer has no dX chain: nothing to pack
   PackArgs args;
-  if (!chain_bx_fill_pack(args, num_layers, weights, in_features, out_features, direction, planes)) {
-    return args.total_pairs == 0 && args.njobs >= 0 && num_layers == 1 && direction == 1 ? 0 : static_cast<int>(hipErrorInvalidValue);
-  }
+  if (!chain_bx_fill_pack(args, num_layers, weights, in_features, out_features, direction, planes))
+    return static_cast<int>(hipErrorInvalidValue);         // (too large for 32-bit offsets / too many matrices for one launch)
   return chain_bx_pack_launch(args, static_cast<hipStream_t>(stream));
 }
 
