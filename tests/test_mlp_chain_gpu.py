@@ -205,7 +205,8 @@ def test_dw_finalize_bias_column_sums(nblocks):
         assert torch.allclose(o.double(), want, rtol=1e-6, atol=1e-6 * max(1.0, want.abs().max().item()))
 
 
-@pytest.mark.parametrize('in_dim,mb_rows,nmb', [(108, 4096, 3), (60, 1000, 4), (13, 37, 5)])
+@pytest.mark.parametrize('in_dim,mb_rows,nmb', [(108, 4096, 3), (60, 1000, 4), (13, 37, 5),
+                                                (108, 16384, 2), (13, 20000, 2)])      # (the last two: the split-bf16 forward)
 def test_forward_folds_minibatch_moments_like_running_mean_std(in_dim, mb_rows, nmb):
     """Training-mode RunningMeanStd.forward = update, then normalise (running_mean_std.py:69-84).  The
     fused forward folds the epoch's precomputed minibatch moments in its prologue; the state and the
