@@ -122,6 +122,34 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
   const int num_layers = pin_s(a.num_layers);
   const long long n_rows = pin_s(a.rows);
 
+  // H fragments of the units: two register sets, "next" is requested one unit ahead (see bx_units) - also across the
+  // calls and the layers: H does not depend on the barrier between two layers
+  f32x4 hval[2][G], hnext[2][G];
+  auto wave_blocks = [&](int nob) -> int { return nob / W + (wave < nob % W ? 1 : 0); };
+  auto wave_first = [&](int nob) -> int { return wave * (nob / W) + (wave < nob % W ? wave : nob % W); };
+  // blocks ob .. ob + nf - 1 (nf <= 2) of H_{L-1}, the layer whose dZ step L produces; every global access is a
+  // buffer instruction with the tile's row range as the bound: ragged tiles need no masks, out of range reads 0
+  auto request_h = [&](int L, int ob, int nf) {
+    const float* ph = pin_s(a.layer[L - 1].h);
+    const long long ld = pin_s(a.layer[L - 1].ldh);
+    const int width = pin_s(a.layer[L].in);
+    const rsrc_t hr = make_rsrc(ph + row0 * ld, tile_bytes(n_rows - row0, 16 * G, ld));
+    const unsigned h_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(ld) + q4) * 4);
+    const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(ld) * 4);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const bool ok = !(kAbl & 4) && f < nf && (ob + f) * 16 + q4 < width;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        hnext[f][g] = buf_load4(hr, ok ? h_lane + static_cast<unsigned>(g) * h_group + static_cast<unsigned>(ob + f) * 64u : kOob);
+    }
+  };
+  // (the first request goes out in front of the prologue, which covers part of its round trip)
+  {
+    const int nob = (pin_s(a.layer[num_layers - 1].in) + 15) >> 4;
+    request_h(num_layers - 1, wave_first(nob), wave_blocks(nob) >= 2 ? 2 : wave_blocks(nob));
+  }
+
   // ---- prologue: d heads tile -> planes in LDS -----------------------------------------------------
   {
     const int w = a.layer[num_layers - 1].out;
@@ -155,33 +183,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     __syncthreads();
   }
   chain_stamp(a.dbg, wave, stamp);                                   // prologue + barrier
-
-  // H fragments of the units: two register sets, "next" is requested one unit ahead (see bx_units) - also across the
-  // calls and the layers: H does not depend on the barrier between two layers
-  f32x4 hval[2][G], hnext[2][G];
-  auto wave_blocks = [&](int nob) -> int { return nob / W + (wave < nob % W ? 1 : 0); };
-  auto wave_first = [&](int nob) -> int { return wave * (nob / W) + (wave < nob % W ? wave : nob % W); };
-  // blocks ob .. ob + nf - 1 (nf <= 2) of H_{L-1}, the layer whose dZ step L produces; every global access is a
-  // buffer instruction with the tile's row range as the bound: ragged tiles need no masks, out of range reads 0
-  auto request_h = [&](int L, int ob, int nf) {
-    const float* ph = pin_s(a.layer[L - 1].h);
-    const long long ld = pin_s(a.layer[L - 1].ldh);
-    const int width = pin_s(a.layer[L].in);
-    const rsrc_t hr = make_rsrc(ph + row0 * ld, tile_bytes(n_rows - row0, 16 * G, ld));
-    const unsigned h_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(ld) + q4) * 4);
-    const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(ld) * 4);
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const bool ok = !(kAbl & 4) && f < nf && (ob + f) * 16 + q4 < width;
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-        hnext[f][g] = buf_load4(hr, ok ? h_lane + static_cast<unsigned>(g) * h_group + static_cast<unsigned>(ob + f) * 64u : kOob);
-    }
-  };
-  {
-    const int nob = (pin_s(a.layer[num_layers - 1].in) + 15) >> 4;
-    request_h(num_layers - 1, wave_first(nob), wave_blocks(nob) >= 2 ? 2 : wave_blocks(nob));
-  }
 
   char* tin = tile_a;
   char* tout = tile_b;
