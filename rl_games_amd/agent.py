@@ -393,12 +393,14 @@ class A2CAgent:
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_epoch = None
         self._graph_norm_state = None
+        self._graph_step_inside = False   # the per-minibatch graphs end with the optimiser step (fused_step_tail)
         self.last_allreduce = None    # 'ipc' | 'rccl' once a multi-GPU step has run (bench.py reports it)
         self._graph_failed = False
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
         self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
         self._fin_norm_partials = None
         self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
+        self._step_in_backward = False  # the finalise launch of the current minibatch performed the optimiser step itself
         self._roll_env_actions = None
         self._ar_norm_partials = None
         self._fold_index = None
@@ -1143,11 +1145,18 @@ class A2CAgent:
                 # the loss partials are folded by the weight-gradient finalise launch (one launch less),
                 # and - single GPU, every gradient of the arena written by that launch - the sums of
                 # squares for clip_grad_norm_ with them (another one)
-                norm = None
+                norm = step = None
                 if self._norm_in_finalize():
                     norm = (self._fin_norm_partials, 1.0, opt.step_counter)
-                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo)
-                self._norm_ready = (self._fin_norm_partials, nb) if nb else None
+                    if self.config.get('fused_step_tail', True):
+                        # ... and then the whole optimiser step as well: finalise + norm + clip + Adam + lr rule are
+                        # ONE launch (csrc/mlp_dw.hip, mlp_dw_finalize_adam_kernel); _optimizer_kernels then only
+                        # advances the host mirrors
+                        step = opt.step_desc(**self._step_arguments())
+                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo,
+                                  step=step)
+                self._step_in_backward = nb == 'step'
+                self._norm_ready = (self._fin_norm_partials, nb) if (nb and nb != 'step') else None
             else:
                 ops.ppo_loss_finalize(*fin)
                 if eng is not None:
@@ -1218,17 +1227,26 @@ class A2CAgent:
             self._fin_norm_ok = ok
         return ok
 
-    def _optimizer_kernels(self):
-        opt = self.optimizer
+    def _step_arguments(self):
         scale = 1.0 / self.world_size if self.multi_gpu else 1.0
         schedule = None
         if self.is_adaptive_lr and self.schedule_type == 'per_minibatch':
             schedule = self.scheduler.device_rule()
+        return dict(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
+                    schedule=schedule, kl_scale=scale)
+
+    def _optimizer_kernels(self):
+        opt = self.optimizer
+        if self._step_in_backward:
+            # the weight-gradient finalise launch of this minibatch performed the step (fused_step_tail)
+            self._step_in_backward = False
+            self._norm_ready = None
+            opt.step_done()
+            return
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
-        opt.step(grad_scale=scale, max_norm=self.grad_norm if self.truncate_grads else None,
-                 schedule=schedule, kl_scale=scale, norm_ready=self._norm_ready, skip_flag=skip)
+        opt.step(norm_ready=self._norm_ready, skip_flag=skip, **self._step_arguments())
         self._norm_ready = None
 
     # ------------------------------------------------------------------ HIP graphs
@@ -1294,6 +1312,7 @@ class A2CAgent:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
                 body()
         except Exception as e:
+            self._step_in_backward = False
             raise GraphCaptureError('HIP graph capture failed') from e
         finally:
             if gc_was_enabled:
@@ -1316,6 +1335,14 @@ class A2CAgent:
             g = self._graphs[i] = self._capture(lambda: self._with_fold(i, self._forward_loss_backward, item,
                                                                        self._graph_rows[i]))
             self._graph_norm_state = self._norm_ready      # what the captured launches will have produced
+            self._graph_step_inside = self._step_in_backward
+            self._step_in_backward = False
+        if self._graph_step_inside:
+            # (fused_step_tail: the optimiser step is the last launch of graph g itself)
+            g.replay()
+            self._norm_ready = None
+            self.optimizer.step_done()
+            return
         if self._graph_opt is None:
             # Captured BEFORE anything of this minibatch runs (a failed capture then leaves minibatch i untouched
             # for the eager path), knowing which launch in front of it produces the gradient norm - the
@@ -1330,7 +1357,7 @@ class A2CAgent:
             self._all_reduce_grads()
         self._norm_ready = None
         self._graph_opt.replay()
-        self.optimizer.step_count += 1
+        self.optimizer.step_done()
 
     def _graph_mini_epoch(self, nmb):
         """Single-GPU runs with nothing to do on the host between minibatches (device-side or
@@ -1354,6 +1381,7 @@ class A2CAgent:
             self._graph_epoch = self._capture(body)
         self._graph_epoch.replay()
         self.optimizer.step_count += nmb
+        self.optimizer.weights_version += nmb
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,
@@ -1555,6 +1583,7 @@ class A2CAgent:
     def set_weights(self, weights):
         model_state = {k.replace('_orig_mod.', ''): v for k, v in weights['model'].items()}
         self.model.load_state_dict(model_state)      # copy_ into the arena views: params stay flat
+        self.optimizer.weights_changed()
         self.set_stats_weights(weights)
         self._seed_stats_sync_snapshots()
 
@@ -1642,6 +1671,7 @@ class A2CAgent:
             return
         import torch.distributed as dist
         dist.broadcast(self.optimizer.flat_params, 0)
+        self.optimizer.weights_changed()
         if self.has_central_value:
             dist.broadcast(self.central_value_net.optimizer.flat_params, 0)
         sync = self._stats_sync()

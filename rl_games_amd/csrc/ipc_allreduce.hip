@@ -45,6 +45,8 @@ struct IpcPeers {
   unsigned* flags[kIpcMaxWorld];        // [rank] -> that rank's flag array (unsigned[kIpcMaxWorld])
   float* res[2][kIpcMaxWorld];          // two-phase variant: [parity][rank] reduced-chunk buffers
   unsigned* flags2[kIpcMaxWorld];       // two-phase variant: second flag array (chunk of rank q is reduced)
+  unsigned* abort_word[kIpcMaxWorld];   // [rank] -> that rank's abort word (fine-grained, mapped): a rank that gives up
+                                        // writes its launch ordinal into EVERY rank's word, so that the peers fail fast too
   unsigned* state;                      // local, device memory: [0] launch ordinal, [1] arrival ticket, [2] done ticket, [3] error (sticky),
                                         // [4] two-phase: chunk ticket
   unsigned long long timeout_ticks;     // of s_memrealtime; 0 = wait for ever
@@ -62,15 +64,30 @@ struct IpcNorm {
 };
 
 // Bounded wait of one lane for flags[q] >= e, q = 0 .. world-1 (see the protocol notes above); true = gave up.
+// A rank that gives up tells every peer (abort words): a peer that is still waiting - or starts a later launch - fails
+// at once instead of summing staging buffers the failed rank keeps overwriting.  Between the failure and the moment a
+// peer sees the word the ranks can still differ by the steps the peer completed in between; the host's end-of-epoch
+// check raises on every rank either way.
 __device__ __forceinline__ bool ipc_wait_all(const IpcPeers& p, const unsigned* my, unsigned e) {
+  const unsigned* my_abort = p.abort_word[p.rank];
   bool failed = __hip_atomic_load(p.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // sticky
+  if (!failed && __hip_atomic_load(my_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+    __hip_atomic_store(p.state + 3, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    failed = true;
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned spins = 0;
   for (int q = 0; q < p.world && !failed; ++q) {
     while (static_cast<int>(__hip_atomic_load(my + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if ((++spins & 1023u) == 0u && p.timeout_ticks != 0ull && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+      if ((++spins & 1023u) != 0u) continue;
+      const bool peer_gave_up = __hip_atomic_load(my_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+      if (peer_gave_up || (p.timeout_ticks != 0ull && __builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks)) {
         __hip_atomic_store(p.state + 3, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!peer_gave_up) {
+          for (int r = 0; r < p.world; ++r)
+            __hip_atomic_store(p.abort_word[r], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         failed = true;
         break;
       }
@@ -301,6 +318,7 @@ struct IpcComm {
   int fine_grained;
   int connected;
   int two_phase;               // rlg_ipc_comm_set_variant
+  double timeout_s;            // effective bound (<= 0: none)
 };
 
 }  // namespace rlg
@@ -316,7 +334,7 @@ int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_o
   IpcComm* c = new IpcComm();
   c->capacity = max_floats;
   c->stage_bytes = (static_cast<size_t>(max_floats) * sizeof(float) + 255) & ~static_cast<size_t>(255);
-  const size_t total = 4 * c->stage_bytes + 256;      // stage0 | stage1 | res0 | res1 | flags, flags2
+  const size_t total = 4 * c->stage_bytes + 256;      // stage0 | stage1 | res0 | res1 | flags [0,64) flags2 [128,192) abort word [192,196)
   // Fine-grained (system-scope coherent) memory or nothing: the protocol needs the peers' stores and flags to
   // become visible MID-KERNEL; coarse-grained memory is only coherent at kernel boundaries, and a self-test on
   // it can pass by timing luck.  Without it the caller uses RCCL.
@@ -336,8 +354,16 @@ int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_o
   c->peers.rank = rank;
   c->peers.world = world;
   {
+    // RLG_IPC_TIMEOUT_S: a positive number of seconds; "0" (or a negative number) = wait for ever; anything that
+    // does not parse as a number is ignored (atof's 0 for garbage would have meant "for ever")
     double seconds = kIpcDefaultTimeoutS;
-    if (const char* env = std::getenv("RLG_IPC_TIMEOUT_S")) seconds = std::atof(env);
+    if (const char* env = std::getenv("RLG_IPC_TIMEOUT_S")) {
+      char* end = nullptr;
+      const double v = std::strtod(env, &end);
+      while (end && (*end == ' ' || *end == '\t' || *end == '\n')) ++end;
+      if (end != env && end && *end == '\0') seconds = v;
+    }
+    c->timeout_s = seconds;
     c->peers.timeout_ticks = seconds > 0.0 ? static_cast<unsigned long long>(seconds * static_cast<double>(kIpcRealtimeHz)) : 0ull;
   }
   for (int q = 0; q < kIpcMaxWorld; ++q) {
@@ -346,6 +372,7 @@ int rlg_ipc_comm_create(int rank, int world, long long max_floats, void** comm_o
     c->peers.flags[q] = nullptr;
     c->peers.res[0][q] = c->peers.res[1][q] = nullptr;
     c->peers.flags2[q] = nullptr;
+    c->peers.abort_word[q] = nullptr;
   }
   c->connected = 0;
   c->two_phase = 0;
@@ -378,6 +405,7 @@ int rlg_ipc_comm_connect(void* comm, const void* all_handles) {
     c->peers.res[1][q] = reinterpret_cast<float*>(base + 3 * c->stage_bytes);
     c->peers.flags[q] = reinterpret_cast<unsigned*>(base + 4 * c->stage_bytes);
     c->peers.flags2[q] = reinterpret_cast<unsigned*>(base + 4 * c->stage_bytes + 128);
+    c->peers.abort_word[q] = reinterpret_cast<unsigned*>(base + 4 * c->stage_bytes + 192);
   }
   c->connected = 1;
   return 0;
@@ -389,8 +417,17 @@ int rlg_ipc_comm_fine_grained(void* comm) { return static_cast<rlg::IpcComm*>(co
 // RLG_IPC_TIMEOUT_S.  Takes effect for launches (and graph captures) issued afterwards.
 int rlg_ipc_comm_set_timeout(void* comm, double seconds) {
   using namespace rlg;
+  static_cast<IpcComm*>(comm)->timeout_s = seconds;
   static_cast<IpcComm*>(comm)->peers.timeout_ticks =
       seconds > 0.0 ? static_cast<unsigned long long>(seconds * static_cast<double>(kIpcRealtimeHz)) : 0ull;
+  return 0;
+}
+
+// The settings in effect (environment defaults included): what the host compares across ranks before the first launch.
+int rlg_ipc_comm_get_config(void* comm, int* two_phase_out, double* timeout_s_out) {
+  const rlg::IpcComm* c = static_cast<const rlg::IpcComm*>(comm);
+  if (two_phase_out) *two_phase_out = c->two_phase;
+  if (timeout_s_out) *timeout_s_out = c->timeout_s > 0.0 ? c->timeout_s : 0.0;
   return 0;
 }
 

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
       const f32x4 av = (BANK == 0) ? aq[U] : ar[U];
       load_b(ng_tag, bn, c + 1, g1);
       ((BANK == 0) ? ar[U] : aq[U]) = buf_load4(wr, c + 4 < KC ? base_cur + static_cast<unsigned>(c + 4) * 64u : kOob);
-      if constexpr (NG == G) {
+      if constexpr (NG == G && G > 1) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
       }
       // ---- hand-over: the accumulators move aside (their epilogue rides along with the next unit's first
       //      steps), the next unit's first weight fragments - requested a whole unit ago - become current
-      if constexpr (NG == G) {
+      if constexpr (NG == G && G > 1) {
 #pragma unroll
         for (int g = 0; g < G; ++g) accP[g] = acc[g];
       } else {
@@ -991,9 +991,287 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined backward for small minibatches (round 4): 16-row workgroups, 4 waves = one per SIMD.
+//
+// A data-parallel rank's minibatch (4,096 - 8,192 rows) is 256 - 512 workgroups of 16 rows, i.e. one or two per
+// CU: the launch time is the serial chain of ONE workgroup, and mlp_chain_bwd_kernel<1, W> pays a cold weight fetch
+// at the head of each of its chain_units calls there (two per layer step) with a handful of MFMAs behind it.
+// This kernel is the backward counterpart of mlp_chain_fwd_pipe_kernel<1>: per wave and layer step ONE stream of
+// chunk steps over the wave's output blocks (a unit = one 16-feature block of dZ_{L-1}, two accumulators taking
+// the even / odd MFMA steps), the A operand (W_L transposed: four 4-byte loads per chunk and lane) refilled four
+// chunks ahead into two register banks - across units and across LAYERS (weights and H do not depend on the
+// barrier) -, the H fragment of the next unit requested a unit ahead, a finished unit's epilogue (act', LDS
+// write, dZ store, bias column sums over the row group on the DPP path) riding behind the next unit's first chunk.
+// Same products as mlp_chain_bwd_kernel<1, W> in the same k order per accumulator pair: bit-identical dZ.
+// Requirements (host-checked, else the unit-structured kernel runs): H / dZ rows 16-byte aligned, widths % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+struct BwdPipeGeo {
+  int K, I, ld, KC, full, nunits, rem_first;
+  const float* w;
+};
+
+__global__ __launch_bounds__(256) void mlp_chain_bwd_pipe_kernel(ChainArgs a, LossArgs loss) {
+  constexpr int W = 4;
+  constexpr std::integral_constant<int, 0> U0{};
+  constexpr std::integral_constant<int, 1> U1{};
+  constexpr std::integral_constant<int, 2> U2{};
+  constexpr std::integral_constant<int, 3> U3{};
+  constexpr std::integral_constant<int, 0> BA{};
+  constexpr std::integral_constant<int, 1> BB{};
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const int q4 = 4 * (lane >> 4), r16 = lane & 15;
+  const long long row0 = static_cast<long long>(blockIdx.x) * 16;
+  float* tile_a = lds;
+  float* tile_b = lds + a.lds_b_floats;
+  const int num_layers = pin_s(a.num_layers);
+  const long long n_rows = pin_s(a.rows);
+
+  // geometry of the step that consumes layer L's weights (L >= 1) and produces dZ_{L-1}
+  auto geo = [&](int L) -> BwdPipeGeo {
+    BwdPipeGeo g;
+    if (L < 1) {
+      g.K = g.I = g.ld = g.KC = g.full = g.nunits = g.rem_first = 0;
+      g.w = nullptr;
+      return g;
+    }
+    g.K = pin_s(a.layer[L].out);
+    g.I = pin_s(a.layer[L].in);
+    g.ld = g.I;
+    g.w = pin_s(a.layer[L].w);
+    g.KC = (g.K + 15) >> 4;
+    const int NOB = (g.I + 15) >> 4;
+    g.full = NOB / W;
+    g.rem_first = g.full * W;
+    g.nunits = g.full + ((NOB - g.rem_first > wave) ? 1 : 0);
+    return g;
+  };
+  auto unit_ob = [&](const BwdPipeGeo& g, int idx) -> int { return idx < g.full ? wave * g.full + idx : g.rem_first + wave; };
+  // per-lane byte offset of (k = 4 q, i) in W_L [K][I]; out-of-range columns read zero
+  auto a_base = [&](const BwdPipeGeo& g, int ob) -> unsigned {
+    const int i = ob * 16 + r16;
+    return (g.nunits > 0 && i < g.I) ? static_cast<unsigned>((q4 * g.ld + i) * 4) : kOob;
+  };
+  // chunk c of a block: k = 16 c + 4 q + s, s = 0 .. 3 (rows of W past K lie behind the resource: zero)
+  auto load_a = [&](rsrc_t wr, unsigned base, int c, int KC, int ld) -> f32x4 {
+    const unsigned step = static_cast<unsigned>(ld) * 4u;
+    const unsigned off = (c < KC) ? base + static_cast<unsigned>(c) * 16u * step : kOob;
+    f32x4 v;
+    v[0] = buf_load1(wr, off);
+    v[1] = buf_load1(wr, off + step);
+    v[2] = buf_load1(wr, off + 2u * step);
+    v[3] = buf_load1(wr, off + 3u * step);
+    return v;
+  };
+
+  // ---- the first unit's weights are requested before anything else (they arrive during the loss tile)
+  BwdPipeGeo cur = geo(num_layers - 1);
+  rsrc_t wr_cur = make_rsrc(cur.w, static_cast<unsigned>(cur.K) * cur.I * 4u);
+  f32x4 aq[4], ar[4], an[4];
+  {
+    const unsigned base0 = a_base(cur, unit_ob(cur, 0));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) aq[u] = load_a(wr_cur, base0, u, cur.KC, cur.ld);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) ar[u] = an[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // ---- the PPO loss of this row tile (training steps), as in mlp_chain_bwd_kernel
+  if (a.with_loss) {
+    ppo_loss_tile<16, 64 * W>(loss, lds, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- prologue: d heads tile -> LDS (fragment layout)
+  {
+    const int w = a.layer[num_layers - 1].out;
+    const int KC0 = (w + 15) >> 4;
+    const bool xv = vec4_ok(a.x, a.ldx);
+    for (int u = wave; u < KC0; u += W) {
+      const long long row = row0 + r16;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < n_rows) v = load_row4(a.x, a.ldx, row, u * 16 + q4, w, xv);
+      *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
+    }
+    __syncthreads();
+  }
+
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f}, accP = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 hC = {0.0f, 0.0f, 0.0f, 0.0f}, hN = {0.0f, 0.0f, 0.0f, 0.0f}, hP = {0.0f, 0.0f, 0.0f, 0.0f};
+  float* tin = tile_a;
+  float* tout = tile_b;
+
+  // H fragment of block ob of the layer whose dZ a step produces; rows past the end read zero
+  auto h_rsrc = [&](int L) -> rsrc_t {
+    if (L < 1) return make_rsrc(nullptr, 0u);
+    const float* p_h = pin_s(a.layer[L - 1].h);
+    const long long p_ldh = pin_s(a.layer[L - 1].ldh);
+    return make_rsrc(p_h + row0 * p_ldh, tile_bytes(n_rows - row0, 16, p_ldh));
+  };
+  auto load_h = [&](rsrc_t hr, long long ldh, int width, int ob) -> f32x4 {
+    const int f = ob * 16 + q4;
+    return buf_load4(hr, f < width ? static_cast<unsigned>((r16 * static_cast<int>(ldh) + f) * 4) : kOob);
+  };
+  rsrc_t hr_cur = h_rsrc(num_layers - 1);
+  if (cur.nunits > 0) hC = load_h(hr_cur, pin_s(a.layer[num_layers - 2].ldh), cur.I, unit_ob(cur, 0));
+
+  for (int L = num_layers - 1; L >= 1; --L) {
+    const BwdPipeGeo nxt = geo(L - 1);
+    const rsrc_t wr_nxt = make_rsrc(nxt.w, static_cast<unsigned>(nxt.K) * nxt.I * 4u);
+    const rsrc_t hr_nxt = h_rsrc(L - 1);
+    const long long ldh_nxt = (L - 1 >= 1) ? pin_s(a.layer[L - 2].ldh) : 0;
+    const int p_act = pin_s(a.layer[L - 1].act);
+    float* p_dz = pin_s(a.layer[L - 1].dz);
+    const long long p_ldh = pin_s(a.layer[L - 1].ldh), p_lddz = pin_s(a.layer[L - 1].lddz);
+    const int width = cur.I;
+    const bool keep_tile = (L - 1 >= 1);
+    double* bpart = pin_s(a.layer[L - 1].bias_partials);
+    if (bpart != nullptr) bpart += static_cast<long long>(blockIdx.x) * width;
+    const rsrc_t dzr = make_rsrc(p_dz + row0 * p_lddz, tile_bytes(n_rows - row0, 16, p_lddz));
+    const unsigned dz_lane = static_cast<unsigned>((r16 * static_cast<int>(p_lddz) + q4) * 4);
+    const float* bp = tin + lane * 4;
+    const int KC = cur.KC;
+    const int ld = cur.ld;
+    const bool row_ok = row0 + r16 < n_rows;
+    int pend = -1;                                  // block whose epilogue is pending, or -1
+
+    auto piece = [&]() {
+      const int ob = pend;
+      const int f = ob * 16 + q4;
+      f32x4 v = chain_act_grad4(accP, hP, p_act);
+      if (!row_ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (keep_tile) *reinterpret_cast<f32x4*>(tout + (ob * 64 + lane) * 4) = v;
+      buf_store4(dzr, f < width ? dz_lane + static_cast<unsigned>(ob) * 64u : kOob, v);
+      if (bpart != nullptr) {
+        f32x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = row16_sum(v[e]);
+        if (r16 == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (f + e < width) as_global(bpart)[f + e] = static_cast<double>(s[e]);
+          }
+        }
+      }
+    };
+    // the MFMAs of chunk c (slot U of bank BANK), the B fragment of chunk c + 1 and the refill of the OTHER bank's
+    // slot U with chunk c + 4 of this unit - one scheduling region
+    auto chunk = [&](auto bank_tag, auto u_tag, int c, unsigned base_cur) {
+      constexpr int U = decltype(u_tag)::value;
+      constexpr int BANK = decltype(bank_tag)::value;
+      f32x4& bc = (U & 1) ? b1 : b0;
+      f32x4& bn = (U & 1) ? b0 : b1;
+      const f32x4 av = (BANK == 0) ? aq[U] : ar[U];
+      bn = *reinterpret_cast<const f32x4*>(bp + (c + 1) * 256);
+      ((BANK == 0) ? ar[U] : aq[U]) = load_a(wr_cur, base_cur, c + 4, KC, ld);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bc[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bc[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bc[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bc[3], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      RLG_PIN();
+    };
+    // One unit: [request the next unit's first batch + its H] [chunk 0, the pending epilogue] [the other chunks] [hand-over]
+    auto run_unit = [&](int ob, unsigned base_cur, rsrc_t wr_n, unsigned base_nxt, int KC_nxt, int ld_nxt, rsrc_t hr_n,
+                        long long ldh_n, int width_n, int ob_nxt, bool has_nxt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) an[u] = load_a(wr_n, base_nxt, u, KC_nxt, ld_nxt);
+      hN = has_nxt ? load_h(hr_n, ldh_n, width_n, ob_nxt) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      RLG_PIN();
+      chunk(BA, U0, 0, base_cur);
+      if (pend >= 0) piece();
+      RLG_PIN();
+      if (1 < KC) chunk(BA, U1, 1, base_cur);
+      if (2 < KC) chunk(BA, U2, 2, base_cur);
+      if (3 < KC) chunk(BA, U3, 3, base_cur);
+      int c0 = 4;
+      for (; c0 + 8 <= KC; c0 += 8) {
+        chunk(BB, U0, c0, base_cur);
+        chunk(BB, U1, c0 + 1, base_cur);
+        chunk(BB, U2, c0 + 2, base_cur);
+        chunk(BB, U3, c0 + 3, base_cur);
+        chunk(BA, U0, c0 + 4, base_cur);
+        chunk(BA, U1, c0 + 5, base_cur);
+        chunk(BA, U2, c0 + 6, base_cur);
+        chunk(BA, U3, c0 + 7, base_cur);
+      }
+      if (c0 < KC) {
+        chunk(BB, U0, c0, base_cur);
+        if (c0 + 1 < KC) chunk(BB, U1, c0 + 1, base_cur);
+        if (c0 + 2 < KC) chunk(BB, U2, c0 + 2, base_cur);
+        if (c0 + 3 < KC) chunk(BB, U3, c0 + 3, base_cur);
+        if (c0 + 4 < KC) chunk(BA, U0, c0 + 4, base_cur);
+        if (c0 + 5 < KC) chunk(BA, U1, c0 + 5, base_cur);
+        if (c0 + 6 < KC) chunk(BA, U2, c0 + 6, base_cur);
+      }
+      // hand-over (the s_nop: 10 wait states between the last MFMA and the first VALU read of its result on every
+      // path into this point, tools/audit_mfma.py)
+      asm volatile("s_nop 7\n\ts_nop 1" : "+a"(acc0), "+a"(acc1));
+      accP = acc0 + acc1;
+      acc0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) aq[u] = an[u];
+      hP = hC;
+      hC = hN;
+      pend = ob;
+    };
+
+    if (cur.nunits > 0) b0 = *reinterpret_cast<const f32x4*>(bp);
+    unsigned base_cur = a_base(cur, unit_ob(cur, 0));
+    for (int idx = 0; idx < cur.nunits; ++idx) {
+      const bool more = idx + 1 < cur.nunits;
+      const int ob_nxt = more ? unit_ob(cur, idx + 1) : unit_ob(nxt, 0);
+      const unsigned base_nxt = more ? a_base(cur, ob_nxt) : a_base(nxt, ob_nxt);
+      if (more) run_unit(unit_ob(cur, idx), base_cur, wr_cur, base_nxt, KC, ld, hr_cur, p_ldh, width, ob_nxt, true);
+      else run_unit(unit_ob(cur, idx), base_cur, wr_nxt, base_nxt, nxt.KC, nxt.ld, hr_nxt, ldh_nxt, nxt.I, ob_nxt, nxt.nunits > 0);
+      if (more) b0 = *reinterpret_cast<const f32x4*>(bp);
+      base_cur = base_nxt;
+    }
+    if (pend >= 0) piece();                         // the layer's last epilogue has no successor to ride with
+    __syncthreads();
+    float* t = tin;
+    tin = tout;
+    tout = t;
+    // a wave without a unit in this step has nothing prefetched for the next one
+    if (cur.nunits == 0 && nxt.nunits > 0) {
+      const unsigned base0 = a_base(nxt, unit_ob(nxt, 0));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) aq[u] = load_a(wr_nxt, base0, u, nxt.KC, nxt.ld);
+      hC = load_h(hr_nxt, ldh_nxt, nxt.I, unit_ob(nxt, 0));
+    }
+    cur = nxt;
+    wr_cur = wr_nxt;
+    hr_cur = hr_nxt;
+  }
+}
+
+static bool vec4_ok_host(const void* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0; }
+
 static bool chain_pipe_enabled() {
   static const bool on = [] {
     const char* e = std::getenv("RLG_CHAIN_PIPE");       // tools: A/B against the unit-structured kernels
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+
+// round 4: the pipelined forward for 16-row workgroups as well (minibatches < 16,384 rows: a data-parallel rank's
+// shapes) - the unit-structured kernel pays a cold weight fetch at the head of each of its 8 chain_units calls there
+// (profiles/r4_rank_chain_phases.txt: 58k cycles per tile for 21k of MFMA issue)
+static bool chain_pipe1_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_CHAIN_PIPE1");      // tools: A/B against the unit-structured 16-row kernels
     return !(e && std::atoi(e) == 0);
   }();
   return on;
@@ -1289,8 +1567,10 @@ int rlg_mlp_chain_prepare(void) {
       reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_fwd_kernel<1, kChAny, 8>),
       reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<4, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<4, kChAny>),
       reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<2, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<2, kChAny>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny>),
       reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2, 4>),
-      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 8>)};
+      reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 8>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel)};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return static_cast<int>(e);
@@ -1415,9 +1695,10 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
       return chain_bx_launch_fwd(bx, bx_lds, st, ev0, ev1);
     }
   }
-  if (G >= 2 && chain_pipe_enabled() && chain_pipe_fill(args, true)) {
+  if ((G >= 2 || chain_pipe1_enabled()) && chain_pipe_enabled() && chain_pipe_fill(args, true)) {
     bool elu_only = true;
     for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);
+    if (G == 1) return elu_only ? chain_launch_fwd_pipe<1, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<1, kChAny>(args, lds_bytes, st);
     if (G == 4) return elu_only ? chain_launch_fwd_pipe<4, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<4, kChAny>(args, lds_bytes, st);
     return elu_only ? chain_launch_fwd_pipe<2, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<2, kChAny>(args, lds_bytes, st);
   }
@@ -1536,6 +1817,27 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
   }
   if (G == 4) return chain_launch<4, true>(args, lds_bytes, st, lp);
   if (G == 2) return chain_launch<2, true>(args, lds_bytes, st, lp);
+  // 16-row workgroups: the pipelined kernel when every H / dZ array takes 16-byte row accesses
+  if (chain_pipe1_enabled() && chain_pipe_enabled()) {
+    bool ok = g_chain_dbg == nullptr;
+    for (int L = 0; L + 1 < num_layers && ok; ++L) {
+      const ChainLayer& ly = args.layer[L];
+      ok = vec4_ok_host(ly.h, ly.ldh) && vec4_ok_host(ly.dz, ly.lddz) && (ly.out & 3) == 0 && ly.ldh < (1 << 20) && ly.lddz < (1 << 20);
+    }
+    if (ok) {
+      const int grid = static_cast<int>((rows + 15) / 16);
+      hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+      g_chain_ev_start = g_chain_ev_stop = nullptr;
+      LossArgs none = {};
+      if (ev0 != nullptr)
+        hipExtLaunchKernelGGL(mlp_chain_bwd_pipe_kernel, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0,
+                              args, lp ? *lp : none);
+      else
+        hipLaunchKernelGGL(mlp_chain_bwd_pipe_kernel, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, args,
+                           lp ? *lp : none);
+      RLG_RETURN_LAUNCH_STATUS();
+    }
+  }
   return chain_launch<1, true>(args, lds_bytes, st, lp);
 }
 

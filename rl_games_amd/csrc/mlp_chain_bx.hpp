@@ -198,14 +198,4 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
   }
 }
 
-// sum over the 16 lanes of a row (lanes that share l >> 4), result in all of them: rotations within the row on the
-// DPP path (no LDS round trips), fixed order
-__device__ __forceinline__ float row16_sum(float t) {
-  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xf, 0xf, false));
-  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124, 0xf, 0xf, false));
-  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x122, 0xf, 0xf, false));
-  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x121, 0xf, 0xf, false));
-  return t;
-}
-
 }  // namespace rlg

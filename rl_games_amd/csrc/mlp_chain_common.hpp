@@ -241,6 +241,16 @@ __device__ __forceinline__ unsigned tile_bytes(long long rows_left, long long ti
   return static_cast<unsigned>(r * ld * 4);
 }
 
+// sum over the 16 lanes of a row (lanes that share l >> 4), result in all of them: rotations within the row on the
+// DPP path (no LDS round trips), fixed order
+__device__ __forceinline__ float row16_sum(float t) {
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x122, 0xf, 0xf, false));
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x121, 0xf, 0xf, false));
+  return t;
+}
+
 // mean32 / denominator of the observation normaliser into scratch[0 .. in0) / scratch[in0p .. in0p + in0), exactly
 // like rms_apply_kernel mode 0 (running_mean_std.py:112-113); with a.rms_batch the minibatch's moments are folded into
 // the state first (training-mode RunningMeanStd.forward) and workgroup 0 publishes the new state.  No barrier inside.

@@ -16,7 +16,7 @@
 // Every block recomputes the (tiny) global-norm reduction from the per-block partial sums, so
 // no grid barrier or atomic is needed and results are bit-reproducible.
 
-#include "rlg_device.hpp"
+#include "optim_common.hpp"
 
 namespace rlg {
 
@@ -41,29 +41,6 @@ __global__ __launch_bounds__(kOptBlock) void grad_sumsq_kernel(const float* __re
   block_sum<1, kOptBlock>(s, scratch);
   if (threadIdx.x == 0) partials[blockIdx.x] = s[0];
 }
-
-struct AdamArgs {
-  float* params;
-  float* grads;            // overwritten with the scaled/clipped gradient (like clip_grad_norm_)
-  float* exp_avg;
-  float* exp_avg_sq;
-  long long n;
-  const double* norm_partials;  // [norm_blocks] from grad_sumsq_kernel, or nullptr (no truncation)
-  int norm_blocks;
-  float grad_scale;        // 1/world_size (multi-GPU average), 1 otherwise
-  float max_norm;          // grad_norm
-  double* lr_slots;        // [2] fp64; slot (step-1)&1 is read, the other receives the next lr
-  const long long* step_counter;  // device: Adam step count AFTER this update (1-based)
-  double beta1, beta2, eps, weight_decay;
-  // adaptive schedule (schedule_kind 1) driven by the KL of THIS minibatch
-  int schedule_kind;       // 0 keep lr, 1 adaptive on *kl
-  const float* kl;         // device scalar (already averaged over ranks)
-  float kl_scale;          // 1/world_size when kl holds a cross-rank SUM
-  double kl_threshold, min_lr, max_lr, lr_multiplier;
-  float* stats_out;        // [4]: total_norm, clip_coef, lr used, lr next
-  const unsigned* skip_flag;  // device word or nullptr; non-zero: the gradients are invalid (a failed in-graph
-                              // all-reduce) - nothing is updated, the learning rate is carried over unchanged
-};
 
 __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   __shared__ float sh_clip;
@@ -90,8 +67,7 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
     if (a.norm_partials) {
       const double s = sq[0];
       total_norm = static_cast<float>(sqrt(s));
-      // clip_coef = max_norm / (total_norm + 1e-6); clamp(max=1.0)       torch clip_grad_norm_
-      coef = fminf(a.max_norm / (total_norm + 1e-6f), 1.0f);
+      coef = adam_clip_coef(a.max_norm, total_norm);
     }
     sh_clip = coef;
     sh_norm = total_norm;
@@ -102,51 +78,13 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   const long long step = *a.step_counter;
   const int cur = static_cast<int>((step - 1) & 1);
   const double lr = a.lr_slots[cur];
-
-  // torch.optim.Adam (single-tensor path) scalar prologue, evaluated in double like Python
-  const double bc1 = 1.0 - pow(a.beta1, static_cast<double>(step));
-  const double bc2 = 1.0 - pow(a.beta2, static_cast<double>(step));
-  const float step_size = static_cast<float>(lr / bc1);
-  const float bc2_sqrt = static_cast<float>(sqrt(bc2));
-  const float w1 = static_cast<float>(1.0 - a.beta1);
-  const float b2 = static_cast<float>(a.beta2);
-  const float w2 = static_cast<float>(1.0 - a.beta2);
-  const float eps = static_cast<float>(a.eps);
-  const float wd = static_cast<float>(a.weight_decay);
+  const AdamScalars k = adam_scalars(a, step, lr);
 
   for (long long i = static_cast<long long>(blockIdx.x) * kOptBlock + threadIdx.x; i < a.n && !skip;
-       i += static_cast<long long>(gridDim.x) * kOptBlock) {
-    float g = (a.grads[i] * a.grad_scale) * clip;
-    a.grads[i] = g;
-    float p = a.params[i];
-    if (wd != 0.0f) g = g + wd * p;                              // grad.add(param, alpha=wd)
-    float m = a.exp_avg[i];
-    m = m + w1 * (g - m);                                        // exp_avg.lerp_(grad, 1-beta1)
-    float v = a.exp_avg_sq[i];
-    v = v * b2 + (w2 * g) * g;                                   // mul_(beta2).addcmul_(g, g, 1-beta2)
-    const float denom = sqrt_rn(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);                             // addcdiv_(exp_avg, denom, -step_size)
-    a.exp_avg[i] = m;
-    a.exp_avg_sq[i] = v;
-    a.params[i] = p;
-  }
+       i += static_cast<long long>(gridDim.x) * kOptBlock)
+    adam_update(a, k, i, clip);
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double next = lr;
-    if (a.schedule_kind == 1 && !skip) {
-      // AdaptiveScheduler.update, python-float arithmetic                 schedulers.py:27-33
-      const double kl = static_cast<double>(*a.kl * a.kl_scale);
-      if (kl > 2.0 * a.kl_threshold) next = fmax(lr / a.lr_multiplier, a.min_lr);
-      if (kl < 0.5 * a.kl_threshold) next = fmin(lr * a.lr_multiplier, a.max_lr);
-    }
-    a.lr_slots[cur ^ 1] = next;
-    if (a.stats_out) {
-      a.stats_out[0] = sh_norm;
-      a.stats_out[1] = clip;
-      a.stats_out[2] = static_cast<float>(lr);
-      a.stats_out[3] = static_cast<float>(next);
-    }
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) adam_finish(a, cur, lr, skip, sh_norm, clip);
 }
 
 }  // namespace rlg

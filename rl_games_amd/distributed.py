@@ -99,8 +99,13 @@ class StatsSync:
         self.has_snapshot = [False] * len(self.modules)
 
     def covers(self, modules):
+        """Same normalisers AND still the same state tensors: the kernels hold raw device pointers, and a module's
+        buffers can be rebound behind its identity (load_state_dict(assign=True), .to(), a manual swap)."""
         modules = list(modules)
-        return len(modules) == len(self.modules) and all(a is b for a, b in zip(modules, self.modules))
+        if len(modules) != len(self.modules) or not all(a is b for a, b in zip(modules, self.modules)):
+            return False
+        bound = getattr(self.kernels, 'bound_to', None)
+        return True if bound is None else bound(modules)
 
     def seed(self):
         """The current state is shared history (a checkpoint was loaded on every rank)."""

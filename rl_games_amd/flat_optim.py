@@ -31,6 +31,9 @@ class FlatArena:
         self.params = [p for p in params]
         if not self.params:
             raise ValueError('no parameters')
+        # bumped by everything in this package that changes parameter VALUES (optimiser steps, restores, broadcasts):
+        # derived copies of the weights (ops.MlpChain's bf16 planes) are valid for one value of it
+        self.weights_version = 0
         physical = list(layout) if layout is not None else self.params
         if sorted(id(p) for p in physical) != sorted(id(p) for p in self.params):
             raise ValueError('layout must be a permutation of params')
@@ -53,6 +56,10 @@ class FlatArena:
 
     def zero_grad(self, set_to_none=False):
         self.flat_grads.zero_()
+
+    def weights_changed(self):
+        """Call after writing parameter values by any other way than FlatAdam.step."""
+        self.weights_version += 1
 
     def span(self, first, last):
         """(params view, grads view) of the contiguous arena range covering parameters `first`
@@ -80,6 +87,7 @@ class FlatAdam(FlatArena):
         self.lr_slots = torch.tensor([float(lr), float(lr)], dtype=torch.float64, device=dev)
         self.norm_partials = torch.zeros(ops.grad_norm_blocks(self.numel), dtype=torch.float64, device=dev)
         self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._tail_sync = None
         self.param_groups = [{'params': self.params, 'lr': float(lr), 'betas': betas, 'eps': eps,
                               'weight_decay': weight_decay}]
 
@@ -119,6 +127,7 @@ class FlatAdam(FlatArena):
         address of the in-graph all-reduce's error word (IpcAllReduce.error_word): a step behind a failed
         collective leaves parameters, moments and learning rate untouched."""
         self.step_count += 1
+        self.weights_version += 1
         if norm_ready is None:
             # it also advances the device step counter the Adam kernel reads
             ops.grad_sumsq(self.grads, grad_scale, self.norm_partials, self.step_counter)
@@ -137,6 +146,30 @@ class FlatAdam(FlatArena):
                       weight_decay=self.weight_decay, schedule_kind=kind,
                       kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats,
                       skip_flag=skip_flag, **kw)
+
+    def step_desc(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
+        """The arguments of step() as (rlg_adam_desc, sync_state, sync_partials) for a launch that performs the step
+        behind its own work (ops.MlpDwPlan.launch(step=...)); the caller reports it with step_done()."""
+        from . import _lib
+        if self._tail_sync is None:
+            dev = self.flat_params.device
+            self._tail_sync = (torch.zeros(2, dtype=torch.int32, device=dev),
+                               torch.zeros(ops.step_tail_max_blocks(), dtype=torch.float64, device=dev))
+        kw = schedule or {}
+        desc = _lib.AdamDesc(
+            self.flat_params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.numel, float(grad_scale), 0.0 if max_norm is None else float(max_norm), 0 if max_norm is None else 1,
+            1 if schedule is not None else 0, self.lr_slots.data_ptr(), self.step_counter.data_ptr(),
+            float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+            self.kl_slot.data_ptr() if schedule is not None else None, float(kl_scale),
+            float(kw.get('kl_threshold', 0.0)), float(kw.get('min_lr', 0.0)), float(kw.get('max_lr', 0.0)),
+            float(kw.get('lr_multiplier', 1.0)), self.stats.data_ptr())
+        return desc, self._tail_sync[0], self._tail_sync[1]
+
+    def step_done(self):
+        """Host mirrors after a launch that performed the step itself (step_desc)."""
+        self.step_count += 1
+        self.weights_version += 1
 
     # ------------------------------------------------------------------ checkpoint format
     def state_dict(self):

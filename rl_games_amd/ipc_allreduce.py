@@ -50,9 +50,19 @@ class IpcAllReduce:
         self.fine_grained = bool(lib.rlg_ipc_comm_fine_grained(self._comm))     # (creation fails without it)
         if timeout_s is not None:
             lib.rlg_ipc_comm_set_timeout(self._comm, float(timeout_s))
-        self.two_phase = bool(two_phase) if two_phase is not None else False
         if two_phase is not None:
             lib.rlg_ipc_comm_set_variant(self._comm, int(bool(two_phase)))
+        # what the library will actually run (RLG_IPC_TWO_PHASE / RLG_IPC_TIMEOUT_S are per-process defaults): the
+        # variant is a collective choice, and ranks with different bounds would give up at different times
+        variant, bound = ctypes.c_int(), ctypes.c_double()
+        lib.rlg_ipc_comm_get_config(self._comm, ctypes.byref(variant), ctypes.byref(bound))
+        self.two_phase = bool(variant.value)
+        self.timeout_s = float(bound.value)
+        settings = [None] * self.world
+        dist.all_gather_object(settings, (self.two_phase, self.timeout_s), group=group)
+        if any(s != settings[0] for s in settings):
+            self.close()
+            raise _lib.HipLibraryError(f'in-graph all-reduce: ranks disagree on (two_phase, timeout_s): {settings}')
         word = ctypes.c_void_p()
         lib.rlg_ipc_comm_error_word(self._comm, ctypes.byref(word))
         self.error_word = int(word.value)      # device address: FlatAdam.step(skip_flag=...)

@@ -14,9 +14,8 @@ _CONFIG_ERRORS = (('minibatch_size', 'Batch size must be divisible by minibatch 
 
 
 class PPODataset:
-    special_names = ['rnn_states']
-
     def __init__(self, batch_size, minibatch_size, is_discrete, is_rnn, device, seq_length, permute=False):
+        self.special_names = ['rnn_states']        # per instance, like the reference (callers may append)
         sizes = {'minibatch_size': minibatch_size, 'seq_length': seq_length}
         for key, message in _CONFIG_ERRORS:
             if batch_size % sizes[key]:

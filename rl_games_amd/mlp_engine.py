@@ -96,7 +96,7 @@ class ManualMLP:
             try:
                 layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
                 layers.append((self.head_w, self.head_b, 'None'))
-                self.chain = ops.MlpChain(layers, dev)
+                self.chain = ops.MlpChain(layers, dev, weights_version=lambda: arena.weights_version)
             except NotImplementedError:
                 self.chain = None
         # Recurrent policies (round 3): the trunk IN FRONT of the LSTM - observation normaliser, hidden layers and
@@ -108,7 +108,7 @@ class ManualMLP:
                 self.bias_sum = torch.empty(4 * self.Hr, device=dev)
                 layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
                 layers.append((self.lstm.weight_ih_l0, self.bias_sum, 'None'))
-                self.chain_rnn = ops.MlpChain(layers, dev)
+                self.chain_rnn = ops.MlpChain(layers, dev, weights_version=lambda: arena.weights_version)
             except NotImplementedError:
                 self.chain_rnn = None
         if self.chain is not None or self.chain_rnn is not None:
@@ -264,7 +264,7 @@ class ManualMLP:
         return heads[:, self.V:]
 
     @torch.no_grad()
-    def backward(self, d_heads, loss_finalize=None, norm=None, ppo_loss=None):
+    def backward(self, d_heads, loss_finalize=None, norm=None, ppo_loss=None, step=None):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
         finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
@@ -275,7 +275,8 @@ class ManualMLP:
         ops.MlpDwPlan.launch; returns the number of valid norm partials, or None when the gradient norm
         was not produced (a gradient of this step did not come out of that launch).  ppo_loss
         (ops.ppo_loss_desc, fused chain only): the backward launch evaluates the PPO loss first and so
-        produces d_heads itself."""
+        produces d_heads itself.  step = FlatAdam.step_desc(...) (fused chain, single GPU): the finalise launch also
+        performs the optimiser step; returns 'step' when it did (the caller then only advances its host mirrors)."""
         rows = self._rows
         L = len(self.linears)
         self._pending_backward = False
@@ -292,7 +293,7 @@ class ManualMLP:
                 lin = self.linears[l]
                 jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm)
+            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm, step)
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
@@ -346,7 +347,7 @@ class ManualMLP:
                 d = d_prev
         return self._weight_grads(jobs, rows, colsums, loss_finalize)
 
-    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None):
+    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None, step=None):
         """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
@@ -377,9 +378,13 @@ class ManualMLP:
                 #  launch takes over instead of an error in the middle of an epoch)
                 whole = (norm is not None and not slow and loss_finalize is not None
                          and norm[0].numel() >= plan.finalize_blocks(colsums, loss_finalize))
-                norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
-                if not whole:
-                    norm_blocks = None
+                if whole and step is not None:
+                    plan.launch(fast, colsums, loss_finalize, step=step)
+                    norm_blocks = 'step'
+                else:
+                    norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
+                    if not whole:
+                        norm_blocks = None
                 colsums = ()
                 loss_finalize = None
                 self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run

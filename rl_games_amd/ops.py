@@ -218,9 +218,14 @@ class StatsSyncKernels:
     PACK_DELTAS, PACK_SEED, PACK_STATE = 0, 1, 2
     APPLY_MERGE, APPLY_STATE = 0, 2
 
+    MAX_SEGMENTS = 8      # kStatsMaxSegments of csrc/running_stats.hip
+
     def __init__(self, modules):
         import ctypes
         n = len(modules)
+        if n > self.MAX_SEGMENTS:
+            raise ValueError(f'StatsSyncKernels: {n} normalisers, one launch carries at most {self.MAX_SEGMENTS} '
+                             '(build one StatsSync per group of normalisers)')
         self.device = modules[0].running_mean.device
         self._keep = [(m.running_mean, m.running_var, m.count) for m in modules]
         self.dims = [int(m.running_mean.numel()) for m in modules]
@@ -231,6 +236,13 @@ class StatsSyncKernels:
         self._n = n
         self._ctypes = ctypes
         self.flat_size = int(_lib.load().rlg_stats_sync_flat_size(n, ctypes.cast(self._dims, ctypes.c_void_p)))
+        self._ptrs = [(m.running_mean.data_ptr(), m.running_var.data_ptr(), m.count.data_ptr()) for m in modules]
+
+    def bound_to(self, modules):
+        """True while the pointer tables still address these modules' state tensors."""
+        return len(modules) == self._n and all(
+            (m.running_mean.data_ptr(), m.running_var.data_ptr(), m.count.data_ptr()) == p
+            for m, p in zip(modules, self._ptrs))
 
     def _tables(self, has_snapshot):
         c = self._ctypes
@@ -611,11 +623,14 @@ class MlpChain:
     name) - tensors are referenced, not copied, so optimiser updates are seen.  Raises
     NotImplementedError if the network does not fit the LDS even with one 16-row group."""
 
-    def __init__(self, layers, device):
+    def __init__(self, layers, device, weights_version=None):
         import ctypes
         self.n = n = len(layers)
         self.layers = layers
         self.device = device
+        # callable -> a number that changes whenever the referenced weights change (FlatArena.weights_version):
+        # planes packed by a training forward are re-used by backward() only for the SAME weights
+        self._weights_version = weights_version
         self.ins = [int(w.shape[1]) for w, _, _ in layers]
         self.outs = [int(w.shape[0]) for w, _, _ in layers]
         P, I, L = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
@@ -637,7 +652,14 @@ class MlpChain:
             self.max_groups[direction] = best
         self._planes = None        # bf16 plane fragments of the weights, both directions (csrc/mlp_chain_bx.hip)
         self._bwd_offset = 0
-        self._planes_fresh_rows = None
+        self._planes_fresh = None  # (rows, weights version) of the training forward that packed the backward planes
+
+    def invalidate_planes(self):
+        """The weights changed behind this object's back: backward() re-packs its planes."""
+        self._planes_fresh = None
+
+    def _version(self):
+        return None if self._weights_version is None else self._weights_version()
 
     def split_products(self, rows, direction, requested=0):
         """True when the launch of this direction runs the split-bf16 kernel for `rows` rows."""
@@ -721,19 +743,20 @@ class MlpChain:
         train = act_out is not None and self.n > 1
         bwd_split = train and self.split_products(rows, 1)
         planes = fwd_planes = None
-        self._planes_fresh_rows = None
+        self._planes_fresh = None
         if split_products is not False and self.split_products(rows, 0, groups):
             self.pack_planes(2 if bwd_split else 0, x)
             fwd_planes = self._planes_ptr(0)
         elif bwd_split:
             planes = self._planes_ptr(1)
-        if bwd_split:
-            self._planes_fresh_rows = rows
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
             self.groups(rows, 0, groups), planes, fwd_planes, _stream(x)), 'rlg_mlp_chain_forward')
+        if bwd_split:
+            # only behind a launch that succeeded, and only for the weights as they are now
+            self._planes_fresh = (rows, self._version())
 
     def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None, split_products=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
@@ -754,10 +777,10 @@ class MlpChain:
         _lib.require_gpu(d_heads, 'd_heads')
         planes = None
         if split_products is not False and self.split_products(rows, 1, groups):
-            if self._planes_fresh_rows is None:
+            if self._planes_fresh is None or self._planes_fresh != (rows, self._version()):
                 self.pack_planes(1, d_heads)                    # (else: packed with the forward launch of this step)
             planes = self._planes_ptr(1)
-        self._planes_fresh_rows = None
+        self._planes_fresh = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
             n, self._w, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl,
@@ -766,6 +789,10 @@ class MlpChain:
 
 
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)
+
+def step_tail_max_blocks():
+    return int(_lib.load().rlg_mlp_dw_step_tail_max_blocks())
+
 
 class MlpDwPlan:
     """All weight-gradient GEMMs of one MLP backward as one launch (csrc/mlp_dw.hip).
@@ -810,13 +837,17 @@ class MlpDwPlan:
             n += 1 + (2 * loss_finalize.actions_num + 7) // 8
         return n
 
-    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None):
+    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None, step=None):
         """jobs: (dz, x, grad) per planned layer.  colsums: optional (partials fp64 [blocks*cols],
         blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch.
         loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well.
         norm = (partials fp64 [>= finalise blocks], grad_scale, step_counter int64 [1]): the finalise
         launch also leaves per-block sums of (g * grad_scale)^2 and advances the Adam step counter (what
         grad_sumsq does) - only meaningful when this launch writes every gradient of the arena.
+        step = (adam_desc, sync_state uint32 [2], sync_partials fp64 [step_tail_max_blocks()]) - FlatAdam.step_desc:
+        the finalise launch also performs the WHOLE optimiser step (norm, clip, Adam, lr rule; csrc/mlp_dw.hip,
+        mlp_dw_finalize_adam_kernel) - single GPU, every gradient of the arena written by this launch, loss_finalize
+        given; `norm` is ignored then.
         Returns the number of finalise blocks (= valid entries of the norm partials)."""
         import ctypes
         if len(jobs) != self.n:
@@ -844,6 +875,19 @@ class MlpDwPlan:
             self._dz[k] = _need(dz, F32, 'dz')
             self._x[k] = _need(x, F32, 'x')
             self._grad[k] = _need(grad, F32, 'grad')
+        if step is not None:
+            if loss_finalize is None:
+                raise ValueError('MlpDwPlan.launch(step=...) needs loss_finalize')
+            desc, sync_state, sync_partials = step
+            if sync_state.dtype != torch.int32 or sync_state.numel() < 2 or sync_partials.dtype != F64 or \
+                    sync_partials.numel() < step_tail_max_blocks():
+                raise ValueError('step: sync_state int32 [2] and sync_partials fp64 [step_tail_max_blocks()] expected')
+            _lib.check(_lib.load().rlg_mlp_dw_launch_step(
+                self.n, self._dz, self._x, self._ws, self._grad, self._no, self._mi, self._plans, self.rows, nc, cs_part,
+                cs_blocks, cs_cols, cs_out, ctypes.addressof(loss_finalize), ctypes.addressof(desc),
+                _need(sync_state, torch.int32, 'sync_state'), _need(sync_partials, F64, 'sync_partials'),
+                _lib.stream_handle(self._device)), 'rlg_mlp_dw_launch_step')
+            return self.finalize_blocks(colsums, loss_finalize)
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
                                                  cs_cols, cs_out,
