@@ -49,6 +49,7 @@ import json
 import os
 import signal
 import statistics
+import subprocess
 import sys
 import time
 
@@ -88,60 +89,143 @@ def make_params(workload, num_actors, minibatch, device, multi_gpu=False):
 
 
 def cpu_baseline(workload, sample_envs):
-    """The oracle epoch (CPU port of the reference path) on `sample_envs` envs, at the reference's
-    default threading (torch_threads = min(4, cores), torch_runner.py:217-226) and on many cores
-    (min(cores, 16): with all 256 threads of a GPU-box host the same epoch is ~400x SLOWER than with 4 -
-    measured 187 vs 86,511 env-steps/s - so "all cores" is neither a sensible baseline nor bounded)."""
+    """the UNTOUCHED reference agent (rl_games a2c_continuous.A2CAgent.train_epoch, device cpu,
+    RLG_NO_TRITON=1) timed on THIS box's host cores in this run, on `sample_envs` envs of the same workload - at the
+    reference's default threading (torch_threads = min(4, cores), torch_runner.py:217-226) and on many cores
+    (min(cores, 16): with all 256 threads of a GPU-box host the same epoch is ~400x SLOWER than with 4 - measured
+    187 vs 86,511 env-steps/s - so "all cores" is neither a sensible baseline nor bounded).  The reference is the
+    archive oracle/stage_reference.py staged from /root/reference (git-ignored, travels with the snapshot); where
+    it is absent the oracle's port of the same path is timed instead (kind "port").  The port's default-thread row
+    is kept next to the reference's as a cross-check of the two.  Bounded: every row is 1 warm-up epoch + at most
+    2 timed ones (one, if the warm-up took more than 15 s)."""
     from oracle.ppo_epoch_oracle import OracleAgent
+    from oracle import reference_baseline as RB
     from rl_games_amd.synthetic_env import SyntheticTensorEnv
     w = WORKLOADS[workload]
     cores = os.cpu_count() or 1
     prev = torch.get_num_threads()
-    rows = {}
-    try:
-        for label, threads in (('default_threads', max(1, min(4, cores))), ('all_cores', min(cores, 16))):
-            if label == 'all_cores' and threads == rows['default_threads']['threads']:
-                rows[label] = dict(rows['default_threads'])
-                continue
-            torch.set_num_threads(threads)
-            params = make_params(workload, sample_envs, min(w['minibatch'], sample_envs * w['horizon']), 'cpu')
-            env = SyntheticTensorEnv(sample_envs, w['obs'], w['act'], device='cpu', seed=1234)
+    steps = sample_envs * w['horizon']
+    plan = (('default_threads', max(1, min(4, cores))), ('all_cores', min(cores, 16)))
+
+    def run(kind, threads):
+        torch.set_num_threads(threads)
+        params = make_params(workload, sample_envs, min(w['minibatch'], sample_envs * w['horizon']), 'cpu')
+        params['config']['train_dir'] = '/tmp/rlg_cpu_baseline_runs'
+        env = SyntheticTensorEnv(sample_envs, w['obs'], w['act'], device='cpu', seed=1234)
+        source = None
+        if kind == 'reference':
+            params['seed'] = 7
+            agent, source = RB.reference_agent(params, env)
+        else:
             agent = OracleAgent(params, env, seed=0)
-            warm = agent.train_epoch()['total_time']          # warm-up epoch
-            # bounded: a row never takes more than ~3 epochs of <= 15 s
-            times = [agent.train_epoch()['total_time'] for _ in range(2)] if warm < 15.0 else [warm]
-            per_epoch = sum(times) / len(times)
-            rows[label] = {'threads': threads, 'value': sample_envs * w['horizon'] / per_epoch,
-                           'seconds_per_epoch': per_epoch}
+        t0 = time.perf_counter()
+        warm, times = RB.time_epochs(agent, 2, kind == 'reference', budget_s=15.0)
+        if not times:
+            times = [warm]
+        per_epoch = sum(times) / len(times)
+        return {'threads': threads, 'value': steps / per_epoch, 'seconds_per_epoch': per_epoch,
+                'timed_epochs': len(times), 'row_seconds': time.perf_counter() - t0, 'reference_source': source}
+
+    rows, port_rows, kind, why = {}, {}, 'port', None
+    import contextlib
+    stdout_guard = contextlib.redirect_stdout(sys.stderr)      # the reference prints while it builds its agent: stdout
+    stdout_guard.__enter__()                                   # carries exactly ONE JSON line
+    try:
+        if RB.available():
+            try:
+                for label, threads in plan:
+                    if label == 'all_cores' and threads == rows['default_threads']['threads']:
+                        rows[label] = dict(rows['default_threads'])
+                    else:
+                        rows[label] = run('reference', threads)
+                kind = 'reference'
+            except Exception as e:          # an import the stubs do not cover, a changed reference: say so, time the port
+                why = f'{type(e).__name__}: {e}'
+                rows = {}
+        else:
+            why = 'no reference on this box (neither /root/reference nor oracle/_ref/rl_games_ref.zip)'
+        port_plan = plan[:1] if kind == 'reference' else plan
+        for label, threads in port_plan:
+            if label == 'all_cores' and threads == port_rows['default_threads']['threads']:
+                port_rows[label] = dict(port_rows['default_threads'])
+            else:
+                port_rows[label] = run('port', threads)
     finally:
+        stdout_guard.__exit__(None, None, None)
         torch.set_num_threads(prev)
-    calibration = None
-    try:   # untouched reference vs this port, measured where /root/reference exists
-        with open(os.path.join(ROOT, 'profiles', 'cpu_baseline_calibration.json')) as f:
-            cal = json.load(f)
-        calibration = {
-            'source': 'profiles/cpu_baseline_calibration.json (tools/cpu_reference_baseline.py, build container: '
-                      'untouched rl_games a2c_continuous.A2CAgent.train_epoch vs this port, same config/env/host)',
-            'host_cores': cal.get('host_cores'),
-            'ref_over_port': {k: r['ref_over_port'] for k, r in cal['rows'].items()},
-            'reference_env_steps_per_s_build_container': {k: r['reference_env_steps_per_s'] for k, r in cal['rows'].items()},
-            'reference_leaf_seconds_build_container': {k: r.get('leaf_s') for k, r in cal['rows'].items()},
-        }
-    except Exception:
-        calibration = None
+    if kind == 'port':
+        rows = port_rows
     d = rows['default_threads']
     out = {
-        'value': d['value'], 'unit': 'env-steps/s', 'cores': d['threads'], 'kind': 'port',
+        'value': d['value'], 'unit': 'env-steps/s', 'cores': d['threads'], 'kind': kind,
+        'what': ('untouched rl_games a2c_continuous.A2CAgent.train_epoch (device cpu, RLG_NO_TRITON=1) built by the '
+                 "reference's own torch_runner.Runner on the synthetic tensor env" if kind == 'reference' else
+                 'oracle/ppo_epoch_oracle.OracleAgent - the CPU port of the reference path (reference unavailable: '
+                 + str(why) + ')'),
         'sample': f'{sample_envs} envs x {w["horizon"]} (1/{max(1, w["envs"] // sample_envs)} of the workload), same '
-                  f'model / minibatch / mini-epochs, 1 warm-up + 2 timed epochs per row, host cores {cores}',
-        'seconds_per_epoch': d['seconds_per_epoch'], 'rows': rows, 'calibration': calibration,
-        'host_cores': cores, 'host_cores_note': 'cores of THIS box; calibration.host_cores = the build container the '
-                                                'port -> reference factor was measured on',
+                  f'model / minibatch / mini-epochs, 1 warm-up + <= 2 timed epochs per row, host cores {cores}',
+        'seconds_per_epoch': d['seconds_per_epoch'], 'rows': rows, 'host_cores': cores,
+        'torch_threads_default_rule': 'min(4, cores) (torch_runner.py:217-226)',
         'rows_note': "'all_cores' uses min(host cores, 16) torch threads (more threads run this workload slower)",
     }
-    if calibration is not None:
-        out['calibrated_to_reference'] = {k: rows[k]['value'] * calibration['ref_over_port'][k]
-                                          for k in rows if k in calibration['ref_over_port']}
+    if kind == 'reference':
+        out['reference_source'] = d.get('reference_source')
+        out['port_cross_check'] = {
+            'rows': port_rows,
+            'reference_over_port': d['value'] / port_rows['default_threads']['value'],
+            'note': "the oracle's port of the same epoch at the default thread count, same box, same run"}
+    return out
+
+
+def collective_preflight(agent, device, world):
+    """Before anything is timed (multi-GPU runs): the latency of ONE gradient all-reduce of this model's flat arena
+    by each transport the agent can use - RCCL through torch.distributed, the in-graph hipIpc kernel (one-shot) and
+    its reduce-scatter + all-gather variant - each with its own known-answer check, so that a single run of
+    `bench.py --gpus N` says which collective the hardware prefers and whether the hand-written one works across
+    real xGMI links at all (a2c_common.py:493-509 is what all three replace).  Collective: every rank runs it."""
+    import torch.distributed as dist
+    from rl_games_amd.ipc_allreduce import IpcAllReduce
+    n = agent.optimizer.flat_grads.numel()
+    out = {'floats': n, 'world': world}
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    t = torch.ones(n, dtype=torch.float32, device=device)
+    try:
+        chk = torch.full((n,), float(dist.get_rank() + 1), device=device)
+        dist.all_reduce(chk)
+        ok = bool((chk == world * (world + 1) / 2).all().item())
+        out['rccl'] = {'us_per_allreduce': timed(lambda: dist.all_reduce(t)), 'known_answer': ok,
+                       'backend': dist.get_backend()}
+    except Exception as e:
+        out['rccl'] = {'error': f'{type(e).__name__}: {e}'}
+    for name, two_phase in (('ipc', False), ('ipc_two_phase', True)):
+        comm = None
+        try:
+            comm = IpcAllReduce(n, device, timeout_s=30.0, two_phase=two_phase)     # (runs its own self-test)
+            t.fill_(1.0)
+            us = timed(lambda: comm.all_reduce_sum(t))
+            _, gave_up = comm.status()
+            out[name] = {'us_per_allreduce': us, 'self_test': 'passed', 'timed_out_launch': gave_up,
+                         'note': 'eager launches incl. the host launch cost; inside the mini-epoch graph only the kernel remains'}
+        except Exception as e:
+            out[name] = {'error': f'{type(e).__name__}: {e}'}
+        finally:
+            if comm is not None:
+                comm.close()
+        oks = [None] * world
+        dist.all_gather_object(oks, 'error' not in out[name])
+        if not all(oks):
+            out[name].setdefault('error', 'failed on another rank')
     return out
 
 
@@ -152,6 +236,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='humanoid')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact-row', action='store_true', help='skip the exact-fp32-product comparison run (a child '
+                    'process with RLG_CHAIN_BX=0 RLG_DW_BF16=0 after the timed region; humanoid, 1 GPU only)')
     ap.add_argument('--cpu-sample-envs', type=int, default=0, help='0: 4096 (humanoid) / 1024 (ant, lstm)')
     ap.add_argument('--max-seconds', type=int, default=1500, help='watchdog: the process exits non-zero with a '
                     'message instead of hanging (a peer rank that died, a collective that never completes)')
@@ -223,6 +309,8 @@ def main():
         if multi:
             dist.barrier()
             torch.cuda.synchronize()
+
+    preflight = collective_preflight(agent, device, world) if multi else None
 
     for _ in range(args.warmup):
         agent.update_epoch()
@@ -365,6 +453,22 @@ def main():
                               'flops 2*rows*sum(in*out) against the fp32 MFMA peak, issued_* = 6 x the padded-tile flops '
                               'against the dense bf16 peak'})
 
+    # what arithmetic the forward / backward chain launches of the timed region ran on
+    chain_products = None
+    if eng is not None and getattr(eng, 'chain', None) is not None:
+        mbr = global_mb // world
+        form = {True: 'split-bf16 (6 exact bf16 plane products per fp32 product on v_mfma_f32_16x16x32_bf16, fp32 '
+                      'accumulation; dropped terms <= 3*2^-24 |x||w|)', False: 'exact fp32 (v_mfma_f32_16x16x4_f32)'}
+        chain_products = {'training_forward': form[bool(eng.chain.split_products(mbr, 0))],
+                          'backward': form[bool(eng.chain.split_products(mbr, 1))],
+                          'rollout_forward': form[bool(eng.chain.split_products(envs, 0))]}
+    for key in ('roofline_fwd', 'roofline_fwd_infer', 'roofline_bwd'):
+        r = chain_roof.get(key)
+        if r is not None and 'issued_tflops_bf16' in r:
+            # the scheme's own ceiling: six bf16 products per useful fp32 product
+            r['split_ceiling_tflops'] = BF16_MFMA_PEAK_TFLOPS / 6.0
+            r['split_ceiling_frac'] = r['achieved'] / (BF16_MFMA_PEAK_TFLOPS / 6.0)
+
     traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
     try:
         with open(os.path.join(ROOT, 'profiles', 'gae_pmc_traffic.json')) as f:
@@ -394,6 +498,7 @@ def main():
                 'lr_schedule': 'adaptive (device side)', 'mixed_precision': False,
                 'mlp': 'fused chain kernels' if (eng is not None and getattr(eng, 'chain', None) is not None)
                        else 'per-layer engine',
+                'chain_products': chain_products,
                 'weight_gradient_products': ('split-bf16 (six exact bf16 plane products per fp32 product, fp32 '
                                              'accumulation; as accurate against fp64 as exact fp32 products)'
                                              if os.environ.get('RLG_DW_BF16', '1') != '0' else 'exact fp32'),
@@ -425,6 +530,27 @@ def main():
                                               ('not requested' if params['config'].get('native_allreduce', True) is False
                                                else 'failed'))
             out['config']['hsa_enable_ipc_mode_legacy'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
+        if preflight is not None:
+            out['config']['collective_preflight'] = preflight
+        if (world == 1 and args.workload == 'humanoid' and not args.no_exact_row and not overrides
+                and os.environ.get('RLG_BENCH_CHILD') != '1' and os.environ.get('RLG_CHAIN_BX', '1') != '0'):
+            # the same job on exact fp32 products in all three MFMA launches, measured the same way right after the
+            # timed region (a child process: the product form is a process-wide setting of the library)
+            try:
+                child = subprocess.run(
+                    [sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '2', '--no-cpu-baseline',
+                     '--no-exact-row'], env=dict(os.environ, RLG_CHAIN_BX='0', RLG_DW_BF16='0', RLG_BENCH_CHILD='1'),
+                    capture_output=True, text=True, timeout=600)
+                line = [l for l in child.stdout.splitlines() if l.startswith('{')][-1]
+                row = json.loads(line)
+                out['exact_products_ms_per_step'] = row['ms_per_step']
+                out['exact_products_env_steps_per_s'] = row['value']
+                out['exact_products_note'] = ('same workload with RLG_CHAIN_BX=0 RLG_DW_BF16=0 (every MFMA launch on exact '
+                                              'fp32 products, v_mfma_f32_16x16x4_f32), 2 warm-up + 3 timed epochs in a child '
+                                              'process after the timed region')
+            except Exception as e:
+                out['exact_products_ms_per_step'] = None
+                out['exact_products_note'] = f'child run failed: {type(e).__name__}: {e}'
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample_envs or (4096 if args.workload == 'humanoid' else 1024)
             signal.alarm(0)          # the CPU baseline is bounded by construction

@@ -103,8 +103,8 @@ int rlg_rollout_store_streaming(int enable);
 
 int rlg_rollout_post_step_num_blocks(int num_envs);
 
-/* After vec_env.step: DefaultRewardsShaper (rl_games/common/tr_helpers.py:33-42, log_val
- * unsupported), time-out bootstrap (a2c_common.py:1021-1023), update_data('rewards') (:1025),
+/* After vec_env.step: DefaultRewardsShaper (rl_games/common/tr_helpers.py:33-42; clamp_rewards bit 0 =
+ * clamp to [rmin, rmax], bit 1 = log_val: log of the shaped reward behind the clamp), time-out bootstrap (a2c_common.py:1021-1023), update_data('rewards') (:1025),
  * current_rewards/current_shaped_rewards/current_lengths accumulate + zero-on-done
  * (:1027-1051).  Finished-episode sums go to ep_partials[step][block][2V+2] (fp64) and are
  * folded into the meters by rlg_episode_meters_update.  time_outs_kind: 0 none, 1 u8/bool,
@@ -325,6 +325,21 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
                   const float* kl_or_null, float kl_scale, double kl_threshold, double min_lr,
                   double max_lr, double lr_multiplier, float* stats_out_or_null,
                   const unsigned* skip_flag_or_null, void* stream);
+
+/* rlg_adam_step that also leaves the fused chain's weight planes (both directions, the layout and buffer of
+ * rlg_mlp_chain_pack_planes direction 2) for the NEW weights: the thread that updates a 4 x 4 block of a weight
+ * matrix writes its rows as forward fragments and its columns as backward fragments (csrc/mlp_chain_bx.hip,
+ * adam_pack_kernel) - one launch instead of rlg_adam_step + rlg_mlp_chain_pack_planes per optimiser step, and no pack
+ * launch in front of the rollout forwards.  Same Adam arithmetic, same plane bytes.  hipErrorInvalidValue (use the
+ * two launches) unless every weights[l] lies inside [params, params + n) at a multiple of 4 floats with
+ * in_features[l] % 4 == 0; `planes` must have been packed in full once (the zero padding of the fragments). */
+int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                       const double* norm_partials_or_null, int norm_blocks, float grad_scale, float max_norm,
+                       double* lr_slots, const long long* step_counter, double beta1, double beta2, double eps,
+                       double weight_decay, int schedule_kind, const float* kl_or_null, float kl_scale,
+                       double kl_threshold, double min_lr, double max_lr, double lr_multiplier, float* stats_out_or_null,
+                       const unsigned* skip_flag_or_null, int num_layers, const float* const* weights,
+                       const int* in_features, const int* out_features, void* planes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Manual MLP backward helpers

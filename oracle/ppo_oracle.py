@@ -534,11 +534,14 @@ class StatsSyncOracle:
 # --------------------------------------------------------------------------------------
 
 
-def shape_rewards(rewards, scale=1.0, shift=0.0, min_val=-math.inf, max_val=math.inf):
-    """rl_games/common/tr_helpers.py:33-42 (DefaultRewardsShaper.__call__, log_val False)."""
+def shape_rewards(rewards, scale=1.0, shift=0.0, min_val=-math.inf, max_val=math.inf, log_val=False):
+    """rl_games/common/tr_helpers.py:33-42 (DefaultRewardsShaper.__call__)."""
     r = rewards + shift
     r = r * scale
-    return torch.clamp(r, min_val, max_val)
+    r = torch.clamp(r, min_val, max_val)
+    if log_val:
+        r = torch.log(r)
+    return r
 
 
 def bootstrap_timeouts(shaped, values, time_outs, gamma):

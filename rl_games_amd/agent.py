@@ -394,6 +394,7 @@ class A2CAgent:
         self._graph_epoch = None
         self._graph_norm_state = None
         self._graph_step_inside = False   # the per-minibatch graphs end with the optimiser step (fused_step_tail)
+        self._fused_tail_in_graph = False
         self.last_allreduce = None    # 'ipc' | 'rccl' once a multi-GPU step has run (bench.py reports it)
         self._graph_failed = False
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
@@ -401,6 +402,7 @@ class A2CAgent:
         self._fin_norm_partials = None
         self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
         self._step_in_backward = False  # the finalise launch of the current minibatch performed the optimiser step itself
+        self._adam_pack = None        # decided on first use (_adam_pack_chain)
         self._roll_env_actions = None
         self._ar_norm_partials = None
         self._fold_index = None
@@ -458,10 +460,8 @@ class A2CAgent:
     def _shaper_params(self):
         s = self.rewards_shaper
         get = (lambda k, d: s.get(k, d)) if isinstance(s, dict) else (lambda k, d: getattr(s, k, d))
-        if get('log_val', False):
-            raise NotImplementedError('reward_shaper log_val is not implemented in the post-step kernel')
         return (float(get('shift_value', 0)), float(get('scale_value', 1)),
-                float(get('min_val', -np.inf)), float(get('max_val', np.inf)))
+                float(get('min_val', -np.inf)), float(get('max_val', np.inf)), bool(get('log_val', False)))
 
     def _uses_observer_infos(self):
         fn = getattr(type(self.algo_observer), 'process_infos', None)
@@ -1148,10 +1148,12 @@ class A2CAgent:
                 norm = step = None
                 if self._norm_in_finalize():
                     norm = (self._fin_norm_partials, 1.0, opt.step_counter)
-                    if self.config.get('fused_step_tail', True):
-                        # ... and then the whole optimiser step as well: finalise + norm + clip + Adam + lr rule are
+                    if self.config.get('fused_step_tail', False):
+                        # ... and then the whole optimiser step as well: finalise + norm + clip + Adam + lr rule as
                         # ONE launch (csrc/mlp_dw.hip, mlp_dw_finalize_adam_kernel); _optimizer_kernels then only
-                        # advances the host mirrors
+                        # advances the host mirrors.  Opt-in: bit-identical to the launch pair, but measured SLOWER
+                        # (profiles/r4_step_tail.txt: a persistent grid walks its finalise blocks one after the other
+                        # where the pair has all 2,300 of them in flight: +25 us per step at 32,768 rows)
                         step = opt.step_desc(**self._step_arguments())
                 nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo,
                                   step=step)
@@ -1246,8 +1248,31 @@ class A2CAgent:
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
-        opt.step(norm_ready=self._norm_ready, skip_flag=skip, **self._step_arguments())
+        opt.step(norm_ready=self._norm_ready, skip_flag=skip, pack=self._adam_pack_chain(), **self._step_arguments())
         self._norm_ready = None
+
+    def _adam_pack_chain(self):
+        """The fused chain whose bf16 weight planes the Adam launch writes itself (csrc/mlp_chain_bx.hip,
+        adam_pack_kernel: one launch instead of Adam + pack per optimiser step, no pack in front of the rollout
+        forwards), or None: no fused chain, or none of this agent's launch sizes runs on planes."""
+        c = self._adam_pack
+        if c is None:
+            c = False
+            eng = self._engine
+            chain = getattr(eng, 'chain', None) if eng is not None else None
+            if chain is not None and self.config.get('adam_writes_planes', True):
+                rows = (self.minibatch_size, self.num_actors * self.num_agents)
+                if any(chain.split_products(r, d) for r in rows for d in (0, 1)):
+                    c = chain
+            self._adam_pack = c
+        return c or None
+
+    def _planes_before_replay(self):
+        """A captured graph of this mode contains no pack launch: the planes must belong to the weights as they are
+        (they do behind the previous step's Adam launch; not behind a restore / broadcast / set_weights)."""
+        chain = self._adam_pack_chain()
+        if chain is not None:
+            chain.ensure_planes(self.optimizer.flat_params)
 
     # ------------------------------------------------------------------ HIP graphs
     def _with_fold(self, mb_index, fn, *args):
@@ -1337,6 +1362,7 @@ class A2CAgent:
             self._graph_norm_state = self._norm_ready      # what the captured launches will have produced
             self._graph_step_inside = self._step_in_backward
             self._step_in_backward = False
+        self._planes_before_replay()
         if self._graph_step_inside:
             # (fused_step_tail: the optimiser step is the last launch of graph g itself)
             g.replay()
@@ -1358,6 +1384,8 @@ class A2CAgent:
         self._norm_ready = None
         self._graph_opt.replay()
         self.optimizer.step_done()
+        if self._adam_pack_chain() is not None and not self._graph_step_inside:
+            self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
 
     def _graph_mini_epoch(self, nmb):
         """Single-GPU runs with nothing to do on the host between minibatches (device-side or
@@ -1379,9 +1407,13 @@ class A2CAgent:
                 if self._fold_ready:
                     self.model.running_mean_std.fold_sync(nmb)
             self._graph_epoch = self._capture(body)
+            self._fused_tail_in_graph = bool(self.config.get('fused_step_tail', False)) and bool(self._fin_norm_ok)
+        self._planes_before_replay()
         self._graph_epoch.replay()
         self.optimizer.step_count += nmb
         self.optimizer.weights_version += nmb
+        if self._adam_pack_chain() is not None and not self._fused_tail_in_graph:
+            self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,

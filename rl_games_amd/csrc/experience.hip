@@ -101,7 +101,7 @@ struct PostStepArgs {
   float* cur_lengths;          // [N]
   double* ep_partials;         // [H][nblocks][2V+2]: sum rew[V], sum shaped[V], sum len, count
   float shift, scale, rmin, rmax;
-  int clamp_rewards;           // 0: min/max are -inf/+inf (skip clamp, bit-identical anyway)
+  int clamp_rewards;           // bit 0: clamp to [rmin, rmax] (0: the bounds are -inf/+inf); bit 1: log_val (log of the shaped reward)
   int bootstrap;               // value_bootstrap and 'time_outs' in infos
   float gamma;
   int N, H, V, step;
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kPostBlock) void rollout_post_step_kernel(PostStepA
         const float rew = a.rewards[env * V + k];
         // DefaultRewardsShaper.__call__: (r + shift) * scale, clamp           tr_helpers.py:35-39
         float shaped = (rew + a.shift) * a.scale;
-        if (a.clamp_rewards) shaped = fminf(fmaxf(shaped, a.rmin), a.rmax);
+        if (a.clamp_rewards & 1) shaped = clamp_nan(shaped, a.rmin, a.rmax);
+        if (a.clamp_rewards & 2) shaped = logf(shaped);                      // log_val       tr_helpers.py:40-41
         // shaped += gamma * values * time_outs                               a2c_common.py:1022-1023
         if (a.bootstrap) shaped = shaped + (a.gamma * a.values[env * V + k]) * to;
         a.rewards_buf[(static_cast<long long>(env) * a.H + a.step) * V + k] = shaped;   // :1025
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void rollout_policy_head_kernel(PolicyHeadArgs
     if (p.v_mean) {
       const float m = static_cast<float>(p.v_mean[0]);
       const float d = sqrt_rn(static_cast<float>(p.v_var[0]) + p.eps);
-      v = d * fminf(fmaxf(v, -5.0f), 5.0f) + m;
+      v = d * clamp_nan(v, -5.0f, 5.0f) + m;
     }
     p.values_out[env] = v;
     p.buf_values[slot] = v;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void rollout_policy_head_kernel(PolicyHeadArgs
       // reference's separate torch kernels
       const float lo = p.act_low[a], hi = p.act_high[a];
       const float d = (hi - lo) / 2.0f, m = (hi + lo) / 2.0f;
-      p.env_actions_out[e * p.A + a] = fminf(fmaxf(act, -1.0f), 1.0f) * d + m;
+      p.env_actions_out[e * p.A + a] = clamp_nan(act, -1.0f, 1.0f) * d + m;
     }
     p.buf_actions[o] = act;
     p.buf_mus[o] = mu;

@@ -339,7 +339,7 @@ __device__ __forceinline__ void chain_fwd_prologue(const ChainArgs& a, float* ti
             if (norm) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                if (f + e < in0) v[e] = fminf(fmaxf((v[e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f), 5.0f);
+                if (f + e < in0) v[e] = clamp_nan((v[e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f, 5.0f);
               }
             }
             if (a.xn) store_row4(a.xn, in0, row, f, in0, v, xnv);
@@ -524,14 +524,13 @@ struct PipeGeo {
   unsigned w_off;
 };
 
-template <int G, int HACT>
-__global__ __launch_bounds__(256) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
-  constexpr int W = 4;
+template <int G, int HACT, int W = 4>
+__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
   using WholeTag = std::integral_constant<int, G>;
   using OneTag = std::integral_constant<int, 1>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: weight planes
-    chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
+    if (threadIdx.x < 256) chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
     return;
   }
   const int lane = lane_id();
@@ -1003,7 +1002,8 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_kernel(ChainArgs a, Loss
 // chunks ahead into two register banks - across units and across LAYERS (weights and H do not depend on the
 // barrier) -, the H fragment of the next unit requested a unit ahead, a finished unit's epilogue (act', LDS
 // write, dZ store, bias column sums over the row group on the DPP path) riding behind the next unit's first chunk.
-// Same products as mlp_chain_bwd_kernel<1, W> in the same k order per accumulator pair: bit-identical dZ.
+// Same exact fp32 products as mlp_chain_bwd_kernel<1, W>; every block accumulates its even k-steps and its odd
+// k-steps in two accumulators that are added at the end (that kernel does so only for its single-block units).
 // Requirements (host-checked, else the unit-structured kernel runs): H / dZ rows 16-byte aligned, widths % 4 == 0.
 // ------------------------------------------------------------------------------------------------
 struct BwdPipeGeo {
@@ -1011,8 +1011,8 @@ struct BwdPipeGeo {
   const float* w;
 };
 
-__global__ __launch_bounds__(256) void mlp_chain_bwd_pipe_kernel(ChainArgs a, LossArgs loss) {
-  constexpr int W = 4;
+template <int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_pipe_kernel(ChainArgs a, LossArgs loss) {
   constexpr std::integral_constant<int, 0> U0{};
   constexpr std::integral_constant<int, 1> U1{};
   constexpr std::integral_constant<int, 2> U2{};
@@ -1489,7 +1489,7 @@ static bool chain_pipe_fill(ChainArgs& args, bool with_bias) {
   }
   return true;
 }
-template <int G, int HACT>
+template <int G, int HACT, int W = 4>
 static int chain_launch_fwd_pipe(const ChainArgs& args_in, int lds_bytes, hipStream_t st) {
   ChainArgs args = args_in;
   int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
@@ -1498,11 +1498,19 @@ static int chain_launch_fwd_pipe(const ChainArgs& args_in, int lds_bytes, hipStr
   hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
   g_chain_ev_start = g_chain_ev_stop = nullptr;
   if (ev0 != nullptr)
-    hipExtLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT>), dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st,
+    hipExtLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st,
                           ev0, ev1, 0, args);
   else
-    hipLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT>), dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, args);
+    hipLaunchKernelGGL((mlp_chain_fwd_pipe_kernel<G, HACT, W>), dim3(grid), dim3(64 * W), static_cast<size_t>(lds_bytes), st, args);
   RLG_RETURN_LAUNCH_STATUS();
+}
+// 16-row pipelined kernels: waves per workgroup (tools: RLG_PIPE1_WAVES=4|8)
+static int chain_pipe1_waves() {
+  // default 8: two waves per SIMD - at one wave the four-chunk look-ahead of the weight stream (512 MFMA cycles at one
+  // 16-row group) is shorter than the loaded L2 latency (~900 cycles) and every chunk waits; 16 waves were slower
+  // again (profiles/r4_rank_chain_probe.txt: 4,096 rows forward 30.6 / 26.5 / 26.0 us, backward 28.6 / 22.8 / 27.6 us)
+  static const int w = [] { const char* e = std::getenv("RLG_PIPE1_WAVES"); const int v = e ? std::atoi(e) : 0; return (v == 4 || v == 16) ? v : 8; }();
+  return w;
 }
 
 // Waves per workgroup.  Small minibatches (one data-parallel rank's 4,096 rows: 256 workgroups of 16
@@ -1570,7 +1578,10 @@ int rlg_mlp_chain_prepare(void) {
       reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny>),
       reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<2, 4>),
       reinterpret_cast<const void*>(mlp_chain_bwd_kernel<4, 4>), reinterpret_cast<const void*>(mlp_chain_bwd_kernel<1, 8>),
-      reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel)};
+      reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<4>), reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<8>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny, 8>),
+      reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<16>),
+      reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu, 16>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny, 16>)};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return static_cast<int>(e);
@@ -1698,6 +1709,10 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   if ((G >= 2 || chain_pipe1_enabled()) && chain_pipe_enabled() && chain_pipe_fill(args, true)) {
     bool elu_only = true;
     for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);
+    if (G == 1 && chain_pipe1_waves() == 8)
+      return elu_only ? chain_launch_fwd_pipe<1, kChElu, 8>(args, lds_bytes, st) : chain_launch_fwd_pipe<1, kChAny, 8>(args, lds_bytes, st);
+    if (G == 1 && chain_pipe1_waves() == 16)
+      return elu_only ? chain_launch_fwd_pipe<1, kChElu, 16>(args, lds_bytes, st) : chain_launch_fwd_pipe<1, kChAny, 16>(args, lds_bytes, st);
     if (G == 1) return elu_only ? chain_launch_fwd_pipe<1, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<1, kChAny>(args, lds_bytes, st);
     if (G == 4) return elu_only ? chain_launch_fwd_pipe<4, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<4, kChAny>(args, lds_bytes, st);
     return elu_only ? chain_launch_fwd_pipe<2, kChElu>(args, lds_bytes, st) : chain_launch_fwd_pipe<2, kChAny>(args, lds_bytes, st);
@@ -1829,12 +1844,28 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
       hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
       g_chain_ev_start = g_chain_ev_stop = nullptr;
       LossArgs none = {};
-      if (ev0 != nullptr)
-        hipExtLaunchKernelGGL(mlp_chain_bwd_pipe_kernel, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0,
-                              args, lp ? *lp : none);
-      else
-        hipLaunchKernelGGL(mlp_chain_bwd_pipe_kernel, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, args,
-                           lp ? *lp : none);
+      if (chain_pipe1_waves() == 16) {
+        if (ev0 != nullptr)
+          hipExtLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<16>, dim3(grid), dim3(1024), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0,
+                                args, lp ? *lp : none);
+        else
+          hipLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<16>, dim3(grid), dim3(1024), static_cast<size_t>(lds_bytes), st, args,
+                             lp ? *lp : none);
+      } else if (chain_pipe1_waves() == 8) {
+        if (ev0 != nullptr)
+          hipExtLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<8>, dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0,
+                                args, lp ? *lp : none);
+        else
+          hipLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<8>, dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, args,
+                             lp ? *lp : none);
+      } else {
+        if (ev0 != nullptr)
+          hipExtLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<4>, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0,
+                                args, lp ? *lp : none);
+        else
+          hipLaunchKernelGGL(mlp_chain_bwd_pipe_kernel<4>, dim3(grid), dim3(256), static_cast<size_t>(lds_bytes), st, args,
+                             lp ? *lp : none);
+      }
       RLG_RETURN_LAUNCH_STATUS();
     }
   }

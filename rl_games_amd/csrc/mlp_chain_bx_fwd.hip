@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
                 const f32x4 m4 = *reinterpret_cast<const f32x4*>(stats + f);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + in0p + f);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[h][e] = fminf(fmaxf((v[h][e] - m4[e]) / d4[e], -5.0f), 5.0f);
+                for (int e = 0; e < 4; ++e) v[h][e] = clamp_nan((v[h][e] - m4[e]) / d4[e], -5.0f, 5.0f);
                 if (row >= n_rows) v[h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};       // (rows past the end stay zero)
               }
               if (a.xn && f < in0 && row < n_rows) store_row4(a.xn, in0, row, f, in0, v[h], xnv);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
               if (norm) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  if (f + e < in0) v[h][e] = fminf(fmaxf((v[h][e] - stats[f + e]) / stats[in0p + f + e], -5.0f), 5.0f);
+                  if (f + e < in0) v[h][e] = clamp_nan((v[h][e] - stats[f + e]) / stats[in0p + f + e], -5.0f, 5.0f);
                 }
               }
               if (a.xn && f < in0) store_row4(a.xn, in0, row, f, in0, v[h], xnv);

@@ -126,7 +126,7 @@ __device__ __forceinline__ float buf_load1(rsrc_t r, unsigned off) {
 
 __device__ __forceinline__ float chain_act(float v, int act) {
   if (act == kChElu) return v > 0.0f ? v : __expf(v) - 1.0f;
-  if (act == kChRelu) return v > 0.0f ? v : 0.0f;
+  if (act == kChRelu) return v > 0.0f ? v : (v != v ? v : 0.0f);      // torch.relu(NaN) = NaN
   if (act == kChTanh) return tanhf(v);
   return v;
 }
@@ -168,7 +168,7 @@ __device__ __forceinline__ f32x4 chain_act4(f32x4 v, int act) {
     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : __expf(v[e]) - 1.0f;
   } else if (act == kChRelu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : (v[e] != v[e] ? v[e] : 0.0f);
   } else if (act == kChTanh) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);

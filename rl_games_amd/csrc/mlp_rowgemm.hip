@@ -36,7 +36,7 @@ enum { kRgNone = 0, kRgElu = 1, kRgRelu = 2, kRgTanh = 3 };
 template <int ACT>
 __device__ __forceinline__ float rg_act(float z) {
   if (ACT == kRgElu) return z > 0.0f ? z : expm1f(z);
-  if (ACT == kRgRelu) return fmaxf(z, 0.0f);
+  if (ACT == kRgRelu) return z != z ? z : fmaxf(z, 0.0f);       // torch.relu(NaN) = NaN
   if (ACT == kRgTanh) return tanhf(z);
   return z;
 }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
       l2 = adv * smooth_clamp_f(ratio, lo, hi);
       dl2 = smooth_clamp_grad(ratio, lo, hi);
     } else {
-      l2 = adv * fminf(fmaxf(ratio, lo), hi);
+      l2 = adv * clamp_nan(ratio, lo, hi);
       dl2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
     }
     const float n1 = -(adv * ratio), n2 = -l2;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
     float c_loss, g_v;
     if (p.clip_value) {
       const float delta = v - vo;
-      const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+      const float vclip = vo + clamp_nan(delta, -p.e_clip, p.e_clip);
       const float d1 = v - R, d2 = vclip - R;
       const float c1 = d1 * d1, c2 = d2 * d2;
       c_loss = fmaxf(c1, c2);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(
     float c_loss, g_v;
     if (clip_value) {
       const float delta = v - vo;
-      const float vclip = vo + fminf(fmaxf(delta, -e_clip), e_clip);
+      const float vclip = vo + clamp_nan(delta, -e_clip, e_clip);
       const float d1 = v - R, d2 = vclip - R;
       const float c1 = d1 * d1, c2 = d2 * d2;
       c_loss = fmaxf(c1, c2);

@@ -74,7 +74,7 @@ __device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float 
     l2 = adv * smooth_clamp_f(ratio, lo, hi);
     dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
   } else {
-    l2 = adv * fminf(fmaxf(ratio, lo), hi);
+    l2 = adv * clamp_nan(ratio, lo, hi);
     dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
   }
   const float n1 = -surr1, n2 = -l2;
@@ -99,7 +99,7 @@ __device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float 
   float c_loss, g_v;
   if (p.clip_value) {
     const float delta = v - vo;
-    const float vclip = vo + fminf(fmaxf(delta, -p.e_clip), p.e_clip);
+    const float vclip = vo + clamp_nan(delta, -p.e_clip, p.e_clip);
     const float d1 = v - R, d2 = vclip - R;
     const float c1 = d1 * d1, c2 = d2 * d2;
     c_loss = fmaxf(c1, c2);

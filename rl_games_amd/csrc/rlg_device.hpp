@@ -67,6 +67,14 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   return static_cast<float>(sqrt(static_cast<double>(x)));
 }
 
+// torch.clamp(x, lo, hi): min(max(x, lo), hi) that PROPAGATES NaN.  fmaxf / fminf (v_max_f32 / v_min_f32) return the
+// non-NaN operand, i.e. a NaN observation / reward / ratio would silently become a bound of the clamp - a finite wrong
+// value where the reference's op chain yields NaN (and a visibly broken run).
+__device__ __forceinline__ float clamp_nan(float x, float lo, float hi) {
+  const float c = fminf(fmaxf(x, lo), hi);
+  return x != x ? x : c;
+}
+
 __device__ __forceinline__ bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }

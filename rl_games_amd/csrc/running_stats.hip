@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void rms_apply_kernel(const float* __restrict_
     for (int u = 0; u < UNIT; ++u) {
       const float m = mean32[c0 + u], d = denom[c0 + u];
       if (mode == 0) {
-        o[u] = fminf(fmaxf((v[u] - m) / d, -5.0f), 5.0f);
+        o[u] = clamp_nan((v[u] - m) / d, -5.0f, 5.0f);
       } else if (mode == 1) {
-        o[u] = d * fminf(fmaxf(v[u], -5.0f), 5.0f) + m;
+        o[u] = d * clamp_nan(v[u], -5.0f, 5.0f) + m;
       } else {
         o[u] = v[u] / d;
       }
@@ -428,12 +428,12 @@ __global__ __launch_bounds__(256) void prepare_apply_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (nv) {
-        v[u] = fminf(fmaxf((v[u] - st.v_mean) / st.v_denom, -5.0f), 5.0f);
-        r[u] = fminf(fmaxf((r[u] - st.r_mean) / st.r_denom, -5.0f), 5.0f);
+        v[u] = clamp_nan((v[u] - st.v_mean) / st.v_denom, -5.0f, 5.0f);
+        r[u] = clamp_nan((r[u] - st.r_mean) / st.r_denom, -5.0f, 5.0f);
       }
       if (na) {
         a[u] = (a[u] - st.a_mean) / st.a_denom;
-        if (ema) a[u] = fminf(fmaxf(a[u], -5.0f), 5.0f);
+        if (ema) a[u] = clamp_nan(a[u], -5.0f, 5.0f);
       }
     }
     reinterpret_cast<f32x4*>(values_out)[i] = v;
@@ -445,12 +445,12 @@ __global__ __launch_bounds__(256) void prepare_apply_kernel(
   if (i < B) {
     float v = values[i], r = returns[i], a = advantages[i];
     if (nv) {
-      v = fminf(fmaxf((v - st.v_mean) / st.v_denom, -5.0f), 5.0f);
-      r = fminf(fmaxf((r - st.r_mean) / st.r_denom, -5.0f), 5.0f);
+      v = clamp_nan((v - st.v_mean) / st.v_denom, -5.0f, 5.0f);
+      r = clamp_nan((r - st.r_mean) / st.r_denom, -5.0f, 5.0f);
     }
     if (na) {
       a = (a - st.a_mean) / st.a_denom;
-      if (ema) a = fminf(fmaxf(a, -5.0f), 5.0f);
+      if (ema) a = clamp_nan(a, -5.0f, 5.0f);
     }
     values_out[i] = v;
     returns_out[i] = r;

@@ -118,14 +118,17 @@ class FlatAdam(FlatArena):
         return used, nxt
 
     # ------------------------------------------------------------------ step
-    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None, skip_flag=None):
+    def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None, skip_flag=None,
+             pack=None):
         """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
         driven by the KL in `kl_slot` (times kl_scale).  norm_ready = (partials fp64, count): the
         launch that wrote the gradients already left the per-block sums of (g * grad_scale)^2 AND advanced
         the device step counter (ops.MlpDwPlan.launch(norm=...)) - no grad_sumsq launch.  skip_flag: device
         address of the in-graph all-reduce's error word (IpcAllReduce.error_word): a step behind a failed
-        collective leaves parameters, moments and learning rate untouched."""
+        collective leaves parameters, moments and learning rate untouched.  pack: an ops.MlpChain whose weights live
+        in this arena - the launch also writes the chain's bf16 weight planes for the new weights (one launch instead of
+        Adam + pack; csrc/mlp_chain_bx.hip adam_pack_kernel)."""
         self.step_count += 1
         self.weights_version += 1
         if norm_ready is None:
@@ -145,7 +148,9 @@ class FlatAdam(FlatArena):
                       self.step_counter, betas=self.betas, eps=self.eps,
                       weight_decay=self.weight_decay, schedule_kind=kind,
                       kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats,
-                      skip_flag=skip_flag, **kw)
+                      skip_flag=skip_flag, pack=None if pack is None else pack.adam_pack_target(), **kw)
+        if pack is not None:
+            pack.mark_planes(self.weights_version)
 
     def step_desc(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
         """The arguments of step() as (rlg_adam_desc, sync_state, sync_partials) for a launch that performs the step

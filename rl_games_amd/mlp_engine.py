@@ -145,6 +145,11 @@ class ManualMLP:
         rest = [p for p in net.parameters() if id(p) not in skip]
         mats = [p for p in rest if p.dim() >= 2]
         vecs = [p for p in rest if p.dim() < 2]
+        # the layers' bias vectors directly behind the last matrix: the pipelined forward kernels read up to 48 bytes
+        # past a matrix whose width is no multiple of 16 and accept that only when the bytes belong to another array
+        # of the SAME network (csrc/mlp_chain.hip, chain_pipe_fill) - sigma and the like come after them
+        linear_biases = {id(m.bias) for m in net.modules() if isinstance(m, torch.nn.Linear) and m.bias is not None}
+        vecs.sort(key=lambda p: id(p) not in linear_biases)
         return mats + head_w + vecs + head_b
 
     # ------------------------------------------------------------------

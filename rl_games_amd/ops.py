@@ -68,11 +68,13 @@ def post_step_num_blocks(num_envs):
 def rollout_post_step(rewards, dones, time_outs, values, live_rows, rewards_buf, cur_rewards,
                       cur_shaped, cur_lengths, ep_partials, shaper, bootstrap, gamma, horizon, step,
                       num_agents=1):
-    """shaper = (shift, scale, min_val, max_val)."""
+    """shaper = (shift, scale, min_val, max_val[, log_val])."""
     lib = _lib.load()
     N, V = rewards.shape
-    shift, scale, rmin, rmax = shaper
+    shift, scale, rmin, rmax = shaper[:4]
     clamp = 0 if (rmin == -np.inf and rmax == np.inf) else 1
+    if len(shaper) > 4 and shaper[4]:
+        clamp |= 2
     kind, to_ptr = 0, None
     if time_outs is not None:
         if time_outs.dtype == F32:
@@ -518,10 +520,12 @@ def grad_sumsq(grads, grad_scale, partials, step_counter=None):
 def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max_norm, lr_slots,
               step_counter, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
               kl=None, kl_scale=1.0, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2,
-              lr_multiplier=1.5, stats_out=None, skip_flag=None):
-    """skip_flag: device address (int) of the in-graph all-reduce's error word, or None."""
+              lr_multiplier=1.5, stats_out=None, skip_flag=None, pack=None):
+    """skip_flag: device address (int) of the in-graph all-reduce's error word, or None.
+    pack = MlpChain.adam_pack_target() (n, weights, in, out, planes address): the launch also leaves the chain's
+    weight planes for the new weights (rlg_adam_step_pack, csrc/mlp_chain_bx.hip)."""
     lib = _lib.load()
-    _lib.check(lib.rlg_adam_step(
+    args = (
         _need(params, F32, 'params'), _need(grads, F32, 'grads'), _need(exp_avg, F32, 'exp_avg'),
         _need(exp_avg_sq, F32, 'exp_avg_sq'), params.numel(), _opt(norm_partials, F64, 'norm_partials'),
         0 if norm_partials is None else norm_partials.numel(), float(np.float32(grad_scale)),
@@ -529,8 +533,12 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
         _need(step_counter, torch.int64, 'step_counter'),
         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), schedule_kind,
         _opt(kl, F32, 'kl'), float(np.float32(kl_scale)), float(kl_threshold), float(min_lr),
-        float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), skip_flag, _stream(params)),
-        'rlg_adam_step')
+        float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), skip_flag)
+    if pack is not None:
+        n, w, ins, outs, planes = pack
+        _lib.check(lib.rlg_adam_step_pack(*args, n, w, ins, outs, planes, _stream(params)), 'rlg_adam_step_pack')
+    else:
+        _lib.check(lib.rlg_adam_step(*args, _stream(params)), 'rlg_adam_step')
 
 
 # ------------------------------------------------------------------ MLP forward / dX (MFMA, fused epilogues)
@@ -653,10 +661,40 @@ class MlpChain:
         self._planes = None        # bf16 plane fragments of the weights, both directions (csrc/mlp_chain_bx.hip)
         self._bwd_offset = 0
         self._planes_fresh = None  # (rows, weights version) of the training forward that packed the backward planes
+        self._planes_for = None    # weights version for which BOTH directions' planes are valid (optimiser-written or packed)
+        self._planes_packed_once = False
 
     def invalidate_planes(self):
         """The weights changed behind this object's back: backward() re-packs its planes."""
         self._planes_fresh = None
+        self._planes_for = None
+
+    def planes_current(self):
+        """Both directions' planes belong to the weights as they are now (needs a weights-version source)."""
+        v = self._version()
+        return v is not None and self._planes_for == v
+
+    def mark_planes(self, version):
+        """The planes of both directions now hold the weights of `version` (FlatAdam.step(pack=...), or after a
+        graph replay whose last launch was that step)."""
+        self._planes_for = version
+
+    def ensure_planes(self, stream_of):
+        """Eager full pack unless the planes are current (in front of a graph replay that contains no pack launch)."""
+        if not self.planes_current():
+            self.pack_planes(2, stream_of)
+            self._planes_for = self._version()
+
+    def adam_pack_target(self):
+        """(n, weights, in, out, planes address) for ops.adam_step(pack=...), or None when this network has no use for
+        planes / no version source.  The first call packs the whole buffer once (the fragments' zero padding)."""
+        if self._weights_version is None or self.n < 1:
+            return None
+        if not self._planes_packed_once:
+            self.pack_planes(2, self.layers[0][0])
+            self._planes_packed_once = True
+            self._planes_for = self._version()
+        return self.n, self._w, self._in, self._out, self._plane_buffer().data_ptr()
 
     def _version(self):
         return None if self._weights_version is None else self._weights_version()
@@ -744,10 +782,13 @@ class MlpChain:
         bwd_split = train and self.split_products(rows, 1)
         planes = fwd_planes = None
         self._planes_fresh = None
+        packed_both = False
         if split_products is not False and self.split_products(rows, 0, groups):
-            self.pack_planes(2 if bwd_split else 0, x)
+            if not self.planes_current():
+                self.pack_planes(2 if bwd_split else 0, x)
+                packed_both = bwd_split
             fwd_planes = self._planes_ptr(0)
-        elif bwd_split:
+        elif bwd_split and not self.planes_current():
             planes = self._planes_ptr(1)
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
@@ -757,6 +798,8 @@ class MlpChain:
         if bwd_split:
             # only behind a launch that succeeded, and only for the weights as they are now
             self._planes_fresh = (rows, self._version())
+        if packed_both and self._weights_version is not None:
+            self._planes_for = self._version()
 
     def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None, split_products=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
@@ -777,7 +820,7 @@ class MlpChain:
         _lib.require_gpu(d_heads, 'd_heads')
         planes = None
         if split_products is not False and self.split_products(rows, 1, groups):
-            if self._planes_fresh is None or self._planes_fresh != (rows, self._version()):
+            if not self.planes_current() and (self._planes_fresh is None or self._planes_fresh != (rows, self._version())):
                 self.pack_planes(1, d_heads)                    # (else: packed with the forward launch of this step)
             planes = self._planes_ptr(1)
         self._planes_fresh = None

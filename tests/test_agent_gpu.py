@@ -284,7 +284,9 @@ def test_lstm_update_matches_reference_epoch(golden, manual_lstm):
     assert torch.allclose(rows[:, 1], cap['c_losses'], rtol=1e-5, atol=2e-6)
     assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
     kls = rows[:, 3].reshape(agent.mini_epochs_num, len(agent.dataset)).mean(1)
-    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-3, atol=1e-7)
+    # KL at 1e-4 like the MLP configurations (tests/test_headline_gpu.py::test_kl_conditioning_fp64_demonstration
+    # shows why no pair of fp32 implementations can be held to 1e-5 on this quantity)
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-4, atol=2e-7), (kls, cap['mini_epoch_kls'])
     assert agent.optimizer.last_and_next_lr()[1] == cap['lrs'][-1]
     final = agent.model.state_dict()
     for k, v in cap['final_state'].items():
@@ -324,7 +326,7 @@ def test_lstm_config5_at_its_own_size_matches_reference_epoch():
     assert torch.allclose(rows[:, 2], cap['entropies'], rtol=1e-5, atol=2e-6)
     assert torch.allclose(rows[:, 4], cap['b_losses'], rtol=1e-5, atol=1e-7)
     kls = rows[:, 3].reshape(agent.mini_epochs_num, len(agent.dataset)).mean(1)
-    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-3, atol=1e-7), (kls, cap['mini_epoch_kls'])
+    assert torch.allclose(kls, cap['mini_epoch_kls'], rtol=1e-4, atol=2e-7), (kls, cap['mini_epoch_kls'])
     # the learning-rate trajectory of the 16 steps (update_lr calls of the reference), bit for bit
     assert agent.optimizer.last_and_next_lr()[1] == cap['lrs'][-1]
 
@@ -922,6 +924,73 @@ def test_folded_launches_match_the_separate_ones(graphs):
     bad = ~torch.isclose(a[3], b[3], rtol=1e-3, atol=1e-6)
     assert bad.float().mean().item() <= 0.01
     assert (a[3] - b[3]).abs().max().item() <= 2.1 * 24 * 1e-2       # 24 Adam steps at lr <= max_lr
+
+
+@pytest.mark.parametrize('graphs', [True, False])
+def test_adam_written_planes_match_the_pack_launch(graphs):
+    """Round 4: the Adam launch writes the split-bf16 chain's weight planes itself (adam_pack_kernel) - against the same
+    agent with a pack launch in front of every forward: BASELINE configs[1] (32,768-row minibatches: forward and
+    backward on planes, rollout forward at 4,096 rows on exact products), 2 epochs, eager and as mini-epoch graphs;
+    then a restore (set_weights) in between - the planes must follow the weights.  Bit for bit."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for fused in (True, False):
+        params = configs.ant_4096(hip_graphs=graphs, adam_writes_planes=fused)
+        torch.manual_seed(3)
+        agent = A2CAgent('p', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(2):
+            agent.update_epoch()
+            agent.train_epoch()
+        assert (agent._adam_pack_chain() is not None) == fused
+        saved = copy.deepcopy(agent.get_weights())
+        for _ in range(1):
+            agent.update_epoch()
+            agent.train_epoch()
+        agent.set_weights(saved)                       # the weights change behind the chain's back
+        agent.update_epoch()
+        agent.train_epoch()
+        opt = agent.optimizer
+        res.append((opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.last_and_next_lr()))
+    a, b = res
+    assert a[3] == b[3]
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('graphs', [True, False])
+def test_fused_step_tail_matches_the_launch_pair(graphs):
+    """Round 4: finalise + gradient norm + clip + Adam + lr rule as ONE launch (csrc/mlp_dw.hip,
+    mlp_dw_finalize_adam_kernel: persistent grid, one grid barrier, every thread updates the parameters whose
+    gradients it wrote) against the launch pair finalise -> adam_step on the same agent.  Identical gradients; the
+    gradient norm is summed over per-workgroup instead of per-finalise-block partials, so the clip coefficient may
+    differ in its last bit.  (The fused form is opt-in: correct - this test - but slower than the pair, see
+    profiles/r4_step_tail.txt.)"""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for fused in (True, False):
+        params = configs.tiny(num_actors=96, horizon=8, hip_graphs=graphs, fused_step_tail=fused)
+        params['config']['minibatch_size'] = 256                      # 768 rows -> 3 minibatches
+        torch.manual_seed(11)
+        agent = A2CAgent('t', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(3):
+            agent.update_epoch()
+            agent.train_epoch()
+        opt = agent.optimizer
+        steps = 3 * agent.mini_epochs_num * 3
+        assert opt.step_count == steps and int(opt.step_counter.item()) == steps
+        assert bool(agent._fin_norm_ok)
+        res.append((opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.grads.clone(),
+                    opt.stats.clone(), opt.last_and_next_lr()))
+    a, b = res
+    assert a[5] == b[5]                                               # same learning-rate trajectory
+    for x, y, name in zip(a[:5], b[:5], ('params', 'exp_avg', 'exp_avg_sq', 'grads', 'stats')):
+        assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (name, (x - y).abs().max().item())
 
 
 @pytest.mark.parametrize('kind,collective', [('mlp', 'ipc'), ('lstm', 'ipc'), ('discrete', 'ipc'), ('central_value', 'ipc'),

@@ -612,3 +612,160 @@ def test_split_bf16_forward_is_invariant_under_power_of_two_rescaling():
     for e in (40, -60):
         got = run(2.0 ** e, 2.0 ** -e)
         assert all(torch.equal(p, q) for p, q in zip(got, ref)), e
+
+
+# ----------------------------------------------------------------------------- non-finite inputs (round 4)
+
+@pytest.mark.parametrize('rows', [16384, 4096])
+def test_non_finite_inputs_stay_non_finite_and_stay_in_their_rows(rows):
+    """+-Inf / NaN in an observation row (no normaliser in front: RunningMeanStd would clamp +-Inf to +-5 like the
+    reference does) must come out of the forward as NON-FINITE heads of THAT row - never as a finite wrong value - and
+    must not touch any other row; the same for d heads -> dZ in the backward, and for the weight gradients (the columns
+    / rows a non-finite operand element feeds).  rows = 16,384 runs the split-bf16 kernels (an Inf operand becomes NaN
+    in the plane split: Inf - Inf in the residual - documented), 4,096 the exact-product 16-row kernels."""
+    from rl_games_amd import ops
+    layers, g = _net(60, [256, 128], 9, 'elu', seed=5)
+    chain = ops.MlpChain(layers, DEV)
+    x = torch.randn(rows, 60, generator=g).to(DEV)
+    bad_rows = {7: float('inf'), 100: float('-inf'), rows - 3: float('nan')}
+
+    def fwd(xin):
+        heads = torch.empty(rows, 9, device=DEV)
+        acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+        chain.forward(xin, heads, act_out=acts)
+        return acts, heads
+    acts0, heads0 = fwd(x)
+    assert torch.isfinite(heads0).all()
+    xb = x.clone()
+    for r, v in bad_rows.items():
+        xb[r, 11] = v
+    acts1, heads1 = fwd(xb)
+    clean = torch.ones(rows, dtype=torch.bool, device=DEV)
+    for r in bad_rows:
+        clean[r] = False
+        assert not torch.isfinite(heads1[r]).any(), (r, heads1[r])
+        # (the first hidden layer: elu(-Inf) = -1 is finite and correct with exact products; at least the units with a
+        #  positive weight on the bad observation are not)
+        assert not torch.isfinite(acts1[0][r]).all()
+    assert torch.equal(heads1[clean], heads0[clean])
+    for a1, a0 in zip(acts1, acts0):
+        assert torch.equal(a1[clean], a0[clean])
+
+    # backward: non-finite d heads of a row -> non-finite dZ of that row only
+    d_heads = torch.randn(rows, 9, generator=g).to(DEV)
+    nblk = chain.num_blocks(rows, 1)
+
+    def bwd(dh):
+        dzs = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+        parts = [torch.empty(nblk * u, dtype=torch.float64, device=DEV) for u in (256, 128)]
+        chain.backward(dh, acts0, dzs, parts)
+        return dzs
+    dz0 = bwd(d_heads)
+    dhb = d_heads.clone()
+    for r, v in bad_rows.items():
+        dhb[r, 3] = v
+    dz1 = bwd(dhb)
+    for r in bad_rows:
+        for d in dz1:
+            assert not torch.isfinite(d[r]).any(), r
+    for d1, d0 in zip(dz1, dz0):
+        assert torch.equal(d1[clean], d0[clean])
+
+    # weight gradients: dW[o, :] of the column o that a non-finite dZ element feeds, dW[:, i] for a non-finite X element
+    dz = torch.randn(rows, 128, generator=g).to(DEV)
+    xx = torch.randn(rows, 256, generator=g).to(DEV)
+    plan = ops.MlpDwPlan([(128, 256)], rows, DEV)
+    grad0 = torch.empty(128, 256, device=DEV)
+    plan.launch([(dz, xx, grad0)])
+    dzb, xxb = dz.clone(), xx.clone()
+    dzb[5, 17] = float('inf')
+    xxb[rows - 1, 200] = float('nan')
+    grad1 = torch.empty(128, 256, device=DEV)
+    plan.launch([(dzb, xxb, grad1)])
+    assert not torch.isfinite(grad1[17]).any() and not torch.isfinite(grad1[:, 200]).any()
+    keep = torch.ones(128, 256, dtype=torch.bool, device=DEV)
+    keep[17] = False
+    keep[:, 200] = False
+    assert torch.equal(grad1[keep], grad0[keep])
+
+
+def test_nan_observation_survives_the_normaliser_clamp():
+    """torch.clamp propagates NaN (running_mean_std.py:112-113: clamp((x - mean) / sqrt(var + eps), -5, 5)); v_max_f32 /
+    v_min_f32 return the non-NaN operand, so a clamp written as fminf(fmaxf(.)) would turn a NaN observation into -5.0 -
+    a finite wrong value.  All clamps of this library go through clamp_nan (csrc/rlg_device.hpp).  +-Inf clamps to
+    +-5 like the reference."""
+    from rl_games_amd import ops
+    for rows in (4096, 16384):
+        layers, g = _net(60, [256, 128], 9, 'elu', seed=6)
+        chain = ops.MlpChain(layers, DEV)
+        x = torch.randn(rows, 60, generator=g).to(DEV)
+        x[3, 5], x[9, 7], x[11, 0] = float('nan'), float('inf'), float('-inf')
+        mean = torch.zeros(60, dtype=torch.float64, device=DEV)
+        var = torch.ones(60, dtype=torch.float64, device=DEV)
+        heads = torch.empty(rows, 9, device=DEV)
+        xn = torch.empty(rows, 60, device=DEV)
+        acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+        chain.forward(x, heads, act_out=acts, rms=(mean, var), eps=1e-5, xn_out=xn)
+        want = torch.clamp((x - mean.float()) / torch.sqrt(var.float() + 1e-5), -5.0, 5.0)
+        assert torch.isnan(xn[3, 5]) and torch.isnan(want[3, 5])
+        assert xn[9, 7].item() == 5.0 and xn[11, 0].item() == -5.0
+        assert not torch.isfinite(heads[3]).any()
+        assert torch.isfinite(heads[9]).all() and torch.isfinite(heads[11]).all()
+        # the stand-alone normaliser kernel
+        out = ops.rms_apply(x, mean, var, 1e-5)
+        assert torch.isnan(out[3, 5]) and out[9, 7].item() == 5.0 and out[11, 0].item() == -5.0
+
+
+# ----------------------------------------------------------------------------- optimiser-written weight planes (round 4)
+
+@pytest.mark.parametrize('in_dim,units,out_dim', [(108, [400, 200, 100], 22), (60, [256, 128, 64], 9), (12, [100, 52], 22)])
+def test_adam_step_pack_equals_adam_then_pack(in_dim, units, out_dim):
+    """rlg_adam_step_pack (csrc/mlp_chain_bx.hip, adam_pack_kernel): the optimiser step that writes the chain's bf16
+    weight planes itself - every thread updates a 4 x 4 block of a weight matrix and stores its rows as forward and its
+    columns as backward fragments - against rlg_adam_step followed by rlg_mlp_chain_pack_planes: the same parameters,
+    moments and clipped gradients bit for bit, and the same plane bytes (zero padding included), also for a head whose
+    22 outputs end inside a group of four and with the skip flag set (nothing changes)."""
+    from rl_games_amd import ops
+    layers, g = _net(in_dim, units, out_dim, 'elu', seed=7)
+    flat = layers[0][0].untyped_storage()
+    n = sum(w.numel() + b.numel() for w, b, _ in layers)
+    params = torch.empty(0, device=DEV, dtype=torch.float32).set_(flat, 0, (n,))
+    assert params.data_ptr() == layers[0][0].data_ptr()
+    init = params.clone()
+    grads = (0.1 * torch.randn(n, generator=g)).to(DEV)
+    m0 = (0.01 * torch.randn(n, generator=g)).to(DEV)
+    v0 = (0.001 * torch.rand(n, generator=g)).to(DEV)
+    version = [0]
+    chain = ops.MlpChain(layers, DEV, weights_version=lambda: version[0])
+    res = {}
+    for mode in ('pair', 'fused', 'fused_skipped'):
+        params.copy_(init)
+        g_, m_, v_ = grads.clone(), m0.clone(), v0.clone()
+        lr_slots = torch.tensor([3e-4, 3e-4], dtype=torch.float64, device=DEV)
+        counter = torch.tensor([3], dtype=torch.int64, device=DEV)
+        norm = torch.zeros(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
+        ops.grad_sumsq(g_, 1.0, norm, None)
+        kl = torch.tensor([0.001], device=DEV)
+        stats = torch.zeros(4, device=DEV)
+        skip = torch.tensor([1 if mode == 'fused_skipped' else 0], dtype=torch.int32, device=DEV)
+        kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=1, kl=kl, kl_scale=1.0, kl_threshold=0.008,
+                  min_lr=1e-6, max_lr=1e-2, lr_multiplier=1.5, stats_out=stats, skip_flag=skip.data_ptr())
+        target = chain.adam_pack_target()                 # (first call: packs the buffer in full once)
+        if mode == 'pair':
+            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, **kw)
+            chain._plane_buffer().fill_(0x5a)
+            chain.pack_planes(2, params)
+        else:
+            # poison the in-matrix part only through a full pack of the OLD weights (what the agent's state is)
+            chain.pack_planes(2, params)
+            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, pack=target, **kw)
+        torch.cuda.synchronize()
+        res[mode] = (params.clone(), g_, m_, v_, lr_slots.clone(), stats.clone(), chain._plane_buffer().clone())
+    for a, b in zip(res['pair'], res['fused']):
+        assert torch.equal(a, b)
+    assert not torch.equal(res['pair'][0], init)
+    # skipped step: parameters, moments untouched, planes = those of the old weights
+    assert torch.equal(res['fused_skipped'][0], init) and torch.equal(res['fused_skipped'][2], m0)
+    params.copy_(init)
+    chain.pack_planes(2, params)
+    assert torch.equal(res['fused_skipped'][6], chain._plane_buffer())

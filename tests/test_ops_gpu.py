@@ -100,6 +100,29 @@ def test_post_step_matches_oracle(V, masked, to_dtype, agents):
         assert torch.allclose(dev_t.cpu(), ref_t.reshape(-1), rtol=RTOL, atol=1e-6)
 
 
+def test_post_step_log_val_shaper():
+    """reward_shaper log_val (tr_helpers.py:40-41): log of the shifted, scaled, clamped reward - inside the post-step
+    kernel (round 4; NotImplementedError before).  logf against torch.log: 1e-6 relative; a clamp floor > 0 keeps the
+    argument positive like every configuration that uses the option."""
+    from rl_games_amd import ops
+    N, H, V = 500, 3, 1
+    gen = g(4)
+    shaper = (2.0, 0.5, 0.05, 10.0, True)
+    nb = ops.post_step_num_blocks(N)
+    rewards_buf = torch.zeros(N, H, V, device=DEV)
+    cur = [torch.zeros(N, V, device=DEV), torch.zeros(N, V, device=DEV), torch.zeros(N, device=DEV)]
+    ep_partials = torch.zeros(H, nb, 2 * V + 2, dtype=torch.float64, device=DEV)
+    for step in range(H):
+        rewards = torch.randn(N, V, generator=gen) * 3
+        dones = (torch.rand(N, generator=gen) < 0.2).to(torch.uint8)
+        want = O.shape_rewards(rewards, scale=shaper[1], shift=shaper[0], min_val=shaper[2], max_val=shaper[3], log_val=True)
+        ops.rollout_post_step(rewards.to(DEV), dones.to(DEV), None, torch.zeros(N, V, device=DEV), None, rewards_buf,
+                              cur[0], cur[1], cur[2], ep_partials, shaper, False, 0.99, H, step)
+        got = rewards_buf[:, step].cpu()
+        assert torch.isfinite(got).all()
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
 # ----------------------------------------------------------------------------- RunningMeanStd
 
 @pytest.mark.parametrize('rows,C', [(4096, 108), (1000, 60), (777, 3), (5000, 1), (300, 260), (64, 7)])

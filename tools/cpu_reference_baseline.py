@@ -25,33 +25,15 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 import torch  # noqa: E402
 
 
+from oracle.reference_baseline import reference_agent as _reference_agent, time_epochs as _time_epochs  # noqa: E402
+
+
 def reference_agent(params, env):
-    import ref_import
-    ref_import.enable()
-    from rl_games.torch_runner import Runner
-    runner = Runner()
-    p = copy.deepcopy(params)
-    p['config']['env_info'] = env.get_env_info()
-    runner.load({'params': p})
-    runner.params['config']['vec_env'] = env
-    runner.params['config']['env_info'] = env.get_env_info()
-    agent = runner.algo_factory.create(runner.algo_name, base_name='cpu_baseline', params=runner.params)
-    agent.init_tensors()
-    agent.obs = agent.env_reset()
-    return agent
+    return _reference_agent(params, env)[0]
 
 
 def time_epochs(agent, epochs, is_reference):
-    times = []
-    for e in range(epochs + 1):                       # first epoch = warm-up
-        if is_reference:
-            agent.epoch_num += 1
-        t0 = time.perf_counter()
-        agent.train_epoch()
-        dt = time.perf_counter() - t0
-        if e > 0:
-            times.append(dt)
-    return times
+    return _time_epochs(agent, epochs, is_reference)[1]
 
 
 def leaf_timings(threads, H=32, N=65536, mb=32768, O_=108, A=21):
