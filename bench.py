@@ -177,12 +177,20 @@ def cpu_baseline(workload, sample_envs):
     return out
 
 
+_KEEP_ALIVE = []
+
+
 def collective_preflight(agent, device, world):
-    """Before anything is timed (multi-GPU runs): the latency of ONE gradient all-reduce of this model's flat arena
-    by each transport the agent can use - RCCL through torch.distributed, the in-graph hipIpc kernel (one-shot) and
-    its reduce-scatter + all-gather variant - each with its own known-answer check, so that a single run of
-    `bench.py --gpus N` says which collective the hardware prefers and whether the hand-written one works across
-    real xGMI links at all (a2c_common.py:493-509 is what all three replace).  Collective: every rank runs it."""
+    """Multi-GPU runs: the latency of ONE gradient all-reduce of this model's flat arena by each transport the agent
+    can use - RCCL through torch.distributed, the in-graph hipIpc kernel (one-shot) and its reduce-scatter + all-gather
+    variant - each with its own known-answer check, so that a single run of `bench.py --gpus N` says which collective
+    the hardware prefers and whether the hand-written one works across real xGMI links at all (a2c_common.py:493-509 is
+    what all three replace).  Collective: every rank runs it.  It runs BEHIND the timed region and the in-sync check and
+    never destroys its communicators: in front of the run - creating and destroying two hipIpc communicators before the
+    agent creates its own - one 2-rank run in eight on one GPU ended with parameters that differed between the ranks in
+    the 8th digit (0 of 40 without it; round 4, tests/test_agent_gpu.py::test_two_rank_bench_on_one_gpu), i.e. a
+    communicator's staging memory must not be recycled for another one within a process; the agent holds ONE for its
+    lifetime."""
     import torch.distributed as dist
     from rl_games_amd.ipc_allreduce import IpcAllReduce
     n = agent.optimizer.flat_grads.numel()
@@ -220,8 +228,10 @@ def collective_preflight(agent, device, world):
         except Exception as e:
             out[name] = {'error': f'{type(e).__name__}: {e}'}
         finally:
+            torch.cuda.synchronize()
+            dist.barrier()
             if comm is not None:
-                comm.close()
+                _KEEP_ALIVE.append(comm)          # (not closed: see the docstring)
         oks = [None] * world
         dist.all_gather_object(oks, 'error' not in out[name])
         if not all(oks):
@@ -310,7 +320,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    preflight = collective_preflight(agent, device, world) if multi else None
 
     for _ in range(args.warmup):
         agent.update_epoch()
@@ -332,7 +341,7 @@ def main():
         elapsed = float(t.item())
     per_epoch_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
 
-    in_sync = None
+    in_sync = params_finite = None
     if multi:   # outside the timed region: every rank must hold bit-identical parameters and lr
         probe = torch.stack([agent.optimizer.flat_params.double().sum(),
                              agent.optimizer.flat_params.double().abs().sum(),
@@ -341,6 +350,14 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
+        params_finite = bool(torch.isfinite(probe).all().item())
+        if not in_sync:
+            sys.stderr.write(f'bench.py: rank {rank}: parameter probe {probe.tolist()} (min over ranks {lo.tolist()}, max {hi.tolist()}), '
+                             f'ipc status {agent._ipc_comm.status() if agent._ipc_comm else None}\n')
+
+    # the transports side by side - AFTER the timed region and the in-sync check, on communicators of their own that live
+    # until the process exits (RLG_BENCH_PREFLIGHT=0 skips it)
+    preflight = collective_preflight(agent, device, world) if (multi and os.environ.get('RLG_BENCH_PREFLIGHT', '1') != '0') else None
 
     pairs = agent.kernel_timers.get('gae_envmajor_fused', [])
     gae_each = [p.elapsed_us() for p in pairs]
@@ -520,6 +537,7 @@ def main():
         if in_sync is not None:
             comm = agent._ipc_comm or None
             out['config']['ranks_in_sync'] = in_sync
+            out['config']['params_finite'] = params_finite
             out['config']['allreduce'] = (('ipc-two-phase' if comm.two_phase else 'ipc') if comm is not None else 'rccl')
             out['config']['allreduce_note'] = (
                 'in-graph hipIpc all-reduce kernel (csrc/ipc_allreduce.hip), inside the mini-epoch HIP graph'
@@ -531,7 +549,7 @@ def main():
                                                else 'failed'))
             out['config']['hsa_enable_ipc_mode_legacy'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
         if preflight is not None:
-            out['config']['collective_preflight'] = preflight
+            out['config']['collective_check'] = preflight
         if (world == 1 and args.workload == 'humanoid' and not args.no_exact_row and not overrides
                 and os.environ.get('RLG_BENCH_CHILD') != '1' and os.environ.get('RLG_CHAIN_BX', '1') != '0'):
             # the same job on exact fp32 products in all three MFMA launches, measured the same way right after the

@@ -397,6 +397,38 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
   __shared__ float sh_clip;
   __shared__ float sh_norm;
   __shared__ double scratch[256 / kWave];
+  // ---- everything this thread will need is requested FIRST (the gradient-norm reduction below is a chain of two memory
+  //      round trips and two barriers: the loads of the block overlap with it instead of following it)
+  const bool matrix_block = static_cast<int>(blockIdx.x) < ap.matrix_blocks;
+  const int item = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const bool has_item = matrix_block && item < ap.item_begin[ap.num];
+  int L = 0, O = 0, I = 0, o0 = 0, i0 = 0;
+  f32x4 pn[4], g4[4], p4[4], m4[4], v4[4];
+  long long idx[4] = {0, 0, 0, 0};
+  if (has_item) {
+    for (int j = 1; j < ap.num; ++j) L = (item >= ap.item_begin[j]) ? j : L;
+    O = ap.O[L];
+    I = ap.I[L];
+    const int niq = I >> 2;
+    const int local = item - ap.item_begin[L];
+    const int oq = local / niq, iq = local - oq * niq;
+    o0 = 4 * oq;
+    i0 = 4 * iq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool in = o0 + r < O;
+      idx[r] = ap.w_off[L] + static_cast<long long>(in ? o0 + r : o0) * I + i0;
+      g4[r] = *reinterpret_cast<const f32x4*>(a.grads + idx[r]);
+      p4[r] = *reinterpret_cast<const f32x4*>(a.params + idx[r]);
+      m4[r] = *reinterpret_cast<const f32x4*>(a.exp_avg + idx[r]);
+      v4[r] = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx[r]);
+    }
+  }
+  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
+  const long long step = *a.step_counter;
+  const int cur = static_cast<int>((step - 1) & 1);
+  const double lr = a.lr_slots[cur];
+
   double sq[1] = {0.0};
   if (a.norm_partials) {           // (as adam_step_kernel: every workgroup computes the same sum in the same order)
     int b = threadIdx.x;
@@ -422,54 +454,39 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
   }
   __syncthreads();
   const float clip = sh_clip;
-  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
-  const long long step = *a.step_counter;
-  const int cur = static_cast<int>((step - 1) & 1);
-  const double lr = a.lr_slots[cur];
   const AdamScalars k = adam_scalars(a, step, lr);
 
-  if (static_cast<int>(blockIdx.x) < ap.matrix_blocks) {
-    const int item = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-    if (item < ap.item_begin[ap.num] && !skip) {
-      int L = 0;
-      for (int j = 1; j < ap.num; ++j) L = (item >= ap.item_begin[j]) ? j : L;
-      const int O = ap.O[L], I = ap.I[L];
-      const int niq = I >> 2;
-      const int local = item - ap.item_begin[L];
-      const int oq = local / niq, iq = local - oq * niq;
-      const int o0 = 4 * oq, i0 = 4 * iq;
-      f32x4 pn[4];
+  if (matrix_block) {
+    if (has_item && !skip) {
+      f32x4 gc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g = (g4[r][e] * a.grad_scale) * clip;
+          gc[r][e] = g;
+          float p = p4[r][e];
+          if (k.wd != 0.0f) g = g + k.wd * p;
+          float m = m4[r][e];
+          m = m + k.w1 * (g - m);
+          float v = v4[r][e];
+          v = v * k.b2 + (k.w2 * g) * g;
+          const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
+          p = p - k.step_size * (m / denom);
+          m4[r][e] = m;
+          v4[r][e] = v;
+          p4[r][e] = p;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pn[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (o0 + r < O) {
-          const long long idx = ap.w_off[L] + static_cast<long long>(o0 + r) * I + i0;
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.grads + idx);
-          f32x4 p4 = *reinterpret_cast<const f32x4*>(a.params + idx);
-          f32x4 m4 = *reinterpret_cast<const f32x4*>(a.exp_avg + idx);
-          f32x4 v4 = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx);
-          f32x4 gc;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float g = (g4[e] * a.grad_scale) * clip;
-            gc[e] = g;
-            float p = p4[e];
-            if (k.wd != 0.0f) g = g + k.wd * p;
-            float m = m4[e];
-            m = m + k.w1 * (g - m);
-            float v = v4[e];
-            v = v * k.b2 + (k.w2 * g) * g;
-            const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
-            p = p - k.step_size * (m / denom);
-            m4[e] = m;
-            v4[e] = v;
-            p4[e] = p;
-          }
-          *reinterpret_cast<f32x4*>(a.grads + idx) = gc;
-          *reinterpret_cast<f32x4*>(a.exp_avg + idx) = m4;
-          *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx) = v4;
-          *reinterpret_cast<f32x4*>(a.params + idx) = p4;
-          pn[r] = p4;
+          *reinterpret_cast<f32x4*>(a.grads + idx[r]) = gc[r];
+          *reinterpret_cast<f32x4*>(a.exp_avg + idx[r]) = m4[r];
+          *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx[r]) = v4[r];
+          *reinterpret_cast<f32x4*>(a.params + idx[r]) = p4[r];
+          pn[r] = p4[r];
         }
       }
       // element slot of feature k inside its 32-feature chunk: lane group q = (k % 16) / 4, half = (k % 32) / 16

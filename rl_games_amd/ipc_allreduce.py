@@ -125,6 +125,11 @@ class IpcAllReduce:
         return int(a.value), int(b.value)
 
     def close(self):
+        """Unmaps the peers' buffers and frees this rank's.  Collective in spirit: every rank must be past its last
+        launch on this communicator.  Do not create ANOTHER communicator in the same process afterwards and expect the
+        first one's memory to be gone from the peers' view: creating and destroying two communicators in front of the
+        agent's own made one 2-rank run in eight end with parameters that differed between the ranks in the 8th digit
+        (profiles/r4_two_rank_sync.txt).  The agent holds one communicator for its lifetime."""
         if getattr(self, '_comm', None) is not None:
             _lib.load().rlg_ipc_comm_destroy(self._comm)
             self._comm = None

@@ -272,20 +272,46 @@ def _kl_fp64(mu, sigma, old_mu, old_sigma):
     return (c1 + c2 - 0.5).sum(dim=-1).mean()
 
 
-def test_benchmarked_job_65536x32_first_mini_epoch_matches_oracle():
-    """BASELINE.json configs[2] EXACTLY as bench.py times it: 65,536 envs x horizon 32, obs 108, act 21, MLP
-    [400,200,100], minibatch 32,768 (64 minibatches), 5 mini-epochs, every optimiser step a node of the
-    replayed mini-epoch HIP graph.  The 64 per-minibatch (a_loss, c_loss, entropy, b_loss, kl) of the FIRST
-    mini-epoch and the learning-rate trajectory against the oracle (OracleAgent = CPU restatement of
-    a2c_continuous.py:136-234 / a2c_common.py:1517-1584, pinned to the real reference) on the captured rollout;
-    the remaining four mini-epochs are checked through the device-side learning-rate rule."""
+def _observations_moved_by_one_ulp(batch, seed=1):
+    """The same rollout with every observation moved to its upper or lower fp32 neighbour at random: what ANY two fp32
+    implementations of the forward differ by from the first layer on.  The reference algorithm run on it is the
+    yardstick for how far a correct implementation can be from the oracle after n optimiser steps."""
+    out = dict(batch)
+    x = batch['obses']
+    up = torch.rand(x.shape, generator=torch.Generator().manual_seed(seed)) < 0.5
+    out['obses'] = torch.where(up, torch.nextafter(x, torch.full_like(x, float('inf'))),
+                               torch.nextafter(x, torch.full_like(x, float('-inf'))))
+    return out
+
+
+@pytest.mark.parametrize('N,MB', [(8192, 4096), (65536, 32768)], ids=['rank_8192x32_mb4096', 'benchmarked_65536x32_mb32768'])
+def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
+    """ALL 320 optimiser steps of one epoch against the oracle (OracleAgent = CPU restatement of
+    a2c_continuous.py:136-234 / a2c_common.py:1517-1584, pinned to the real reference), every step a node of the
+    replayed mini-epoch HIP graph:
+      * 65,536 envs x 32, minibatch 32,768 - BASELINE.json configs[2] EXACTLY as bench.py times it (split-bf16 chain
+        kernels, weight planes written by the Adam launch);
+      * 8,192 envs x 32, minibatch 4,096 - what ONE of 8 data-parallel ranks runs for configs[3] (the pipelined 16-row
+        exact-product chain kernels).
+    First mini-epoch: the 64 per-minibatch (a_loss, c_loss, entropy, b_loss) at rtol 1e-5 (+ the stated floors), KL at
+    1e-4 (test_kl_conditioning_fp64_demonstration), the learning-rate trajectory step for step.
+    Mini-epochs 2 - 5: two fp32 evaluations of the SAME algorithm drift apart from step to step (an Adam step is
+    lr * m / sqrt(v): rounding noise in a small gradient moves a parameter by a sizeable fraction of lr, and the next
+    forward sees it), so the bound is demonstrated, not assumed: the oracle is run a second time on the same rollout
+    with every observation moved by ONE ULP at random - the reference algorithm on inputs that differ in the last bit.
+    The agent must stay within max(stated schedule, 5 x the distance between the two oracle runs) of the first one,
+    per mini-epoch; measured in round 4 (profiles/r4_parity_drift.txt): a_loss 7e-8 / 1e-7 / 3e-6 / 2e-5 / 3e-5 absolute
+    over the five mini-epochs at the rank shape, 3e-8 ... 7e-6 at the benchmarked one - a factor of ~6 per mini-epoch.
+    The learning rates of all 320 steps must agree unless a KL of the oracle lies within 1e-3 of a threshold of the
+    rule.  End of epoch: every parameter tensor within max(1e-4 of its scale, 3 x the two oracle runs' distance, 2e-5
+    absolute = lr / 15) on average."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
-    N, H, NMB = 65536, 32, 64
-    params = configs.humanoid_65536(hip_graphs=True)
+    H, NMB, ME = 32, 64, 5
+    params = configs.humanoid_65536(num_actors=N, minibatch_size=MB, hip_graphs=True)
     torch.manual_seed(5)
-    agent = A2CAgent('benchmarked', copy.deepcopy(params))
-    assert (agent.num_actors, agent.horizon_length, agent.minibatch_size, agent.mini_epochs_num) == (N, H, 32768, 5)
+    agent = A2CAgent('epoch', copy.deepcopy(params))
+    assert (agent.num_actors, agent.horizon_length, agent.minibatch_size, agent.mini_epochs_num) == (N, H, MB, ME)
     assert agent._engine is not None and agent._engine.chain is not None
     agent.init_tensors()
     agent.obs = agent.env_reset()
@@ -295,43 +321,75 @@ def test_benchmarked_job_65536x32_first_mini_epoch_matches_oracle():
     res = agent.train_epoch()
     assert agent._graph_epoch is not None and not agent._graph_failed
     assert agent._engine.last_dw_path == 'mfma' and agent._engine.last_dw_library_jobs == 0
-    rows = agent._mb_scalars[:5 * NMB].cpu()          # [a_loss, c_loss, entropy, b_loss, kl, ...] per optimiser step
-    assert len(res[4]) == 5 * NMB
+    rows = agent._mb_scalars[:ME * NMB].cpu()          # [a_loss, c_loss, entropy, b_loss, kl, ...] per optimiser step
+    assert len(res[4]) == ME * NMB
 
     prev = torch.get_num_threads()
     torch.set_num_threads(_oracle_threads())
     try:
         oracle = _oracle_for(params, caps[0], N, 108, 21)
         batch = caps[0]['batch']
-        old_mu = batch['mus'][:32768].clone()
-        oracle.prepare_dataset(batch)
+        ref = oracle.update(batch)
         vd = agent.dataset.values_dict
         for key in ('old_values', 'returns', 'advantages'):
             assert torch.allclose(vd[key].cpu().reshape(-1), oracle.dataset[key].reshape(-1), rtol=RTOL, atol=2e-6), key
-        ref = [oracle.minibatch_step(i) for i in range(NMB)]
-        new_mu_oracle = oracle.dataset['mu'][:32768].clone()
+        twin = _oracle_for(params, caps[0], N, 108, 21)
+        ref2 = twin.update(_observations_moved_by_one_ulp(batch))
     finally:
         torch.set_num_threads(prev)
-    for col, key in enumerate(('a_loss', 'c_loss', 'entropy', 'b_loss')):
-        want = torch.stack([r[key].reshape(()) for r in ref])
-        got = rows[:NMB, col]
+    cols = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
+    stack = lambda rs, key, sl: torch.stack([r[key].reshape(()).float() for r in rs[sl]])
+    # ---- first mini-epoch: the strict bounds
+    first = slice(0, NMB)
+    for key in ('a_loss', 'c_loss', 'entropy', 'b_loss'):
+        want, got = stack(ref, key, first), rows[first, cols[key]]
         assert torch.allclose(got, want, rtol=RTOL, atol=ATOL[key]), (key, (got - want).abs().max().item(), got[:3], want[:3])
-    # KL per minibatch.  policy_kl subtracts 1/2 from terms of size 1/2: its fp32 value is conditioned ~1e-4
-    # relative on the fp32 roundings of mu (shown below in fp64), so 1e-5 is not a meaningful bar for ANY pair of
-    # fp32 implementations; both sides are held to 1e-4 of each other, and the first minibatch to its own fp64 value.
-    want_kl = torch.stack([r['kl'].reshape(()) for r in ref])
-    assert torch.allclose(rows[:NMB, 4], want_kl, rtol=1e-4, atol=ATOL['kl']), (rows[:4, 4], want_kl[:4])
-    # learning rate: the device-side rule over the agent's own 320 KL values == python-float AdaptiveScheduler
+    want_kl = stack(ref, 'kl', first)
+    assert torch.allclose(rows[first, 4], want_kl, rtol=1e-4, atol=ATOL['kl']), (rows[:4, 4], want_kl[:4])
+    # ---- learning rates: the device-side rule over the agent's own 320 KL values == python-float AdaptiveScheduler ...
     cfg = params['config']
     lr, traj = float(cfg['learning_rate']), []
-    for k in range(5 * NMB):
+    for k in range(ME * NMB):
         traj.append(lr)
         lr = O.adaptive_lr(lr, float(rows[k, 4]), cfg['kl_threshold'], cfg.get('min_lr', 1e-6), cfg.get('max_lr', 1e-2),
                            cfg.get('lr_multiplier', 1.5))
     assert agent.optimizer.last_and_next_lr() == (traj[-1], lr)
-    # ... and over the first mini-epoch it is the oracle's trajectory, step for step
-    assert traj[:NMB] == [r['lr'] for r in ref]
     assert res[9] == traj[-1]                        # train_epoch's last_lr (a2c_common.py:1584)
+    # ... and the oracle's trajectory, step for step, as far as its decisions are well-posed
+    margin_ok = NMB * ME
+    thr = cfg['kl_threshold']
+    for k, r in enumerate(ref):
+        kl = float(r['kl'])
+        if min(abs(kl / (2.0 * thr) - 1.0), abs(kl / (0.5 * thr) - 1.0)) < 1e-3:
+            margin_ok = k + 1            # the decision after step k is inside fp32 noise of its threshold
+            break
+    assert margin_ok >= NMB, 'a learning-rate decision of the FIRST mini-epoch lies within 1e-3 of its threshold: pick another seed'
+    assert traj[:margin_ok] == [r['lr'] for r in ref[:margin_ok]]
+    # ---- mini-epochs 2 .. 5: stated schedule, or 5 x what two runs of the reference algorithm differ by
+    schedule = {'a_loss': (2e-6, 2e-5, 1e-4, 2e-4), 'c_loss': (1e-5, 1e-5, 1e-4, 2e-4), 'entropy': (1e-4, 1e-4, 1e-4, 1e-4),
+                'b_loss': (1e-7, 1e-7, 1e-7, 1e-7), 'kl': (2e-6, 3e-6, 1e-5, 2e-5)}
+    report = []
+    for m in range(1, ME):
+        if m * NMB >= margin_ok:
+            break                        # (the two sides may legitimately run on different learning rates from here on)
+        sl = slice(m * NMB, (m + 1) * NMB)
+        for key, col in cols.items():
+            want, got, other = stack(ref, key, sl), rows[sl, col], stack(ref2, key, sl)
+            dev = (got - want).abs().max().item()
+            twin_dev = (other - want).abs().max().item()
+            bound = max(schedule[key][m - 1], 5.0 * twin_dev) + RTOL * want.abs().max().item()
+            report.append((m + 1, key, dev, twin_dev, bound))
+            assert dev <= bound, report
+    # ---- end of the epoch: parameters
+    if margin_ok == NMB * ME:
+        final, want, other = agent.model.state_dict(), oracle.model.full_state_dict(), twin.model.full_state_dict()
+        for name, v in want.items():
+            if not v.is_floating_point() or v.numel() < 16:
+                continue
+            scale = v.abs().mean().clamp_min(1e-12)
+            rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / scale).item()
+            twin_rel = ((other[name] - v).abs().mean() / scale).item()
+            assert rel <= max(1e-4, 3.0 * twin_rel, 2e-5 / scale.item()), (name, rel, twin_rel)
 
 
 def test_kl_conditioning_fp64_demonstration():
@@ -414,12 +472,19 @@ def test_gradients_after_first_step_match_oracle_autograd():
         assert step_gpu.abs().max().item() <= 3e-4 * (1 + 1e-5)
 
 
-def _lr_rule_margin(ref, cfg):
-    """Smallest relative distance of the oracle's per-step KL to a threshold of the adaptive rule (2 x and 0.5 x
-    kl_threshold, schedulers.py:27-33) over the steps in `ref`."""
-    thr = cfg['kl_threshold']
-    kls = torch.tensor([float(r['kl']) for r in ref], dtype=torch.float64)
-    return float(torch.minimum((kls / (2.0 * thr) - 1.0).abs(), (kls / (0.5 * thr) - 1.0).abs()).min())
+def _first_lr_split(agent_kls, ref, lr0, cfg):
+    """The adaptive rule (schedulers.py:27-33) over the agent's own per-step KLs, next to the oracle's recorded learning
+    rates: (index of the first step the two sides take with different learning rates or None, relative distance of the
+    oracle's deciding KL to the nearest threshold of the rule, the agent's learning rate after the last step)."""
+    lr = lr0
+    for k, r in enumerate(ref):
+        if lr != r['lr']:
+            thr = cfg['kl_threshold']
+            kl = float(ref[k - 1]['kl'])
+            return k, min(abs(kl / (2.0 * thr) - 1.0), abs(kl / (0.5 * thr) - 1.0)), lr
+        lr = O.adaptive_lr(lr, float(agent_kls[k]), cfg['kl_threshold'], cfg.get('min_lr', 1e-6), cfg.get('max_lr', 1e-2),
+                           cfg.get('lr_multiplier', 1.5))
+    return None, None, lr
 
 
 def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
@@ -427,19 +492,23 @@ def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
     THREE consecutive epochs on the same env stream.  The agent plays; the oracle is fed each epoch's rollout and
     continues from ITS OWN parameters, normaliser statistics, Adam moments and learning rate, so every difference
     accumulates.  Losses stay within rtol 1e-5 (+ floors) in the first epoch and within 2e-4 after three; the
-    learning rates are identical after every epoch; the parameters stay within 1e-4 of the parameter scale on average.
+    learning rates are identical STEP BY STEP; the parameters stay within 1e-4 of the parameter scale on average.
 
-    The adaptive learning-rate rule is a threshold on a KL that two fp32 implementations agree on to ~1e-4
-    (test_kl_conditioning_fp64_demonstration): a run in which some step's KL lies within 1e-3 of a threshold is not a
-    well-posed comparison - one side may take that step with lr x 1.5 and the other one step later, which moves every
-    parameter by a fraction of lr (seen in round 4: seed 9 drifted 6e-4 with one rollout kernel and 1e-7 with another,
-    both kernels equally close to fp64).  Such a seed is skipped and the next one taken; at least one must be clean."""
+    The adaptive learning-rate rule is a threshold on a KL that two fp32 implementations agree on to ~1e-4 at first
+    (test_kl_conditioning_fp64_demonstration) and ~1e-3 after a few dozen steps: when a KL of the run falls that close to
+    a threshold, one side takes the next step with lr x 1.5 and the other one step later - every parameter then differs
+    by a fraction of lr, although both sides are correct (round 4: seed 9 drifted 6e-4 with one rollout kernel and 1e-7
+    with another, both kernels equally close to fp64, profiles/r4_parity_drift.txt).  Such a seed is not a well-posed
+    comparison: it is recognised by the learning rates themselves (the two sides split at a step whose deciding KL lies
+    within 1e-2 of a threshold - anything else FAILS) and the next seed is taken; at least one seed must run clean."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     N = 4096
     clean = 0
+    skipped = []
     for seed in (9, 10, 11, 12, 13):
         params = configs.ant_4096(hip_graphs=True)
+        cfg = params['config']
         torch.manual_seed(seed)
         agent = A2CAgent('drift', copy.deepcopy(params))
         agent.init_tensors()
@@ -447,19 +516,29 @@ def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
         caps = _capture_rollout(agent)
         oracle = None
         results, refs = [], []
+        lr0, split = float(cfg['learning_rate']), None
         for epoch in range(3):
             agent.update_epoch()
             res = agent.train_epoch()
+            steps = len(res[4])
             # (the per-minibatch scalars are views of a ring the next epoch overwrites: snapshot them now)
             results.append({'a_loss': torch.stack(res[4]).cpu(), 'c_loss': torch.stack(res[5]).cpu(),
                             'entropy': torch.stack(res[7]).cpu(), 'b_loss': torch.stack(res[6]).cpu()})
+            kls = agent._mb_scalars[:steps, 4].cpu()
             if oracle is None:
                 oracle = _oracle_for(params, caps[0], N, 60, 8)
             refs.append(oracle.update(caps[epoch]['batch']))
-            assert agent.optimizer.last_and_next_lr()[1] == oracle.lr, (seed, epoch)
-        margin = min(_lr_rule_margin(ref, params['config']) for ref in refs)
-        if margin < 1e-3:
-            continue                       # a learning-rate decision inside fp32 noise of its threshold: next seed
+            k, margin, lr_end = _first_lr_split(kls, refs[-1], lr0, cfg)
+            if k is not None:
+                split = (epoch, k, margin)
+                break
+            assert agent.optimizer.last_and_next_lr()[1] == lr_end == oracle.lr, (seed, epoch)
+            lr0 = lr_end
+        if split is not None:
+            assert split[2] < 1e-2, ('the two sides took a step with different learning rates although the deciding KL '
+                                     'is nowhere near a threshold of the rule', seed, split)
+            skipped.append((seed, split))
+            continue
         clean += 1
         for epoch, (got, ref) in enumerate(zip(results, refs)):
             rtol = RTOL if epoch == 0 else 2e-4
@@ -473,6 +552,6 @@ def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
                 continue
             got = final[name].cpu().to(v.dtype)
             rel = ((got - v).abs().mean() / v.abs().mean().clamp_min(1e-12)).item()
-            assert rel <= 1e-4, (seed, name, rel, margin)
+            assert rel <= 1e-4, (seed, name, rel, skipped)
         break
-    assert clean >= 1, 'every seed had a learning-rate decision within 1e-3 of its threshold'
+    assert clean >= 1, ('every seed split its learning rates at a near-tie', skipped)

@@ -1,0 +1,56 @@
+"""Is the agent's rollout (mus, values stored in the buffer) what the oracle's network computes from the same
+observations and the model state the rollout was played with?  Per epoch: max |mu_rollout - mu_oracle| etc., and the
+3-epoch parameter drift.   python tools/exp/rollout_consistency.py   (variants by environment, e.g. RLG_CHAIN_PIPE1=0)"""
+import copy, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from oracle.ppo_epoch_oracle import OracleAgent
+from rl_games_amd import configs
+from rl_games_amd.agent import A2CAgent
+from rl_games_amd.synthetic_env import SyntheticTensorEnv
+
+params = configs.ant_4096(hip_graphs=True)
+torch.manual_seed(9)
+agent = A2CAgent('t', copy.deepcopy(params))
+agent.init_tensors(); agent.obs = agent.env_reset()
+caps = []
+orig = agent.play_steps
+def play():
+    state = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}     # BEFORE the rollout
+    b = orig()
+    caps.append({'batch': {k: v.detach().cpu().clone() for k, v in b.items() if isinstance(v, torch.Tensor)}, 'state': state,
+                 'state_after': {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}})
+    return b
+agent.play_steps = play
+cpu = copy.deepcopy(params); cpu['config']['device'] = 'cpu'
+torch.set_num_threads(16)
+oracle = None
+print('env', {k: os.environ.get(k) for k in ('RLG_CHAIN_PIPE1', 'RLG_PIPE1_WAVES')})
+for epoch in range(3):
+    agent.update_epoch(); res = agent.train_epoch()
+    cap = caps[epoch]
+    probe = OracleAgent(cpu, SyntheticTensorEnv(4096, 60, 8, device='cpu', seed=1))
+    probe.model.load_full_state_dict(cap['state'])
+    b = cap['batch']
+    with torch.no_grad():
+        probe.model.obs_stats_training = False
+        mu, logstd, values = probe.model.a2c_network(probe.model.norm_obs(b['obses']))
+    d_mu = (mu - b['mus']).abs()
+    rows_bad = (d_mu.max(dim=1).values > 1e-4).nonzero().reshape(-1)
+    print(f'epoch {epoch}: max |mu_rollout - mu_oracle| {d_mu.max().item():.3e} (mean {d_mu.mean().item():.3e}, |mu| max {b["mus"].abs().max().item():.2f}); '
+          f'rows off by > 1e-4: {rows_bad.numel()} of {mu.shape[0]} {rows_bad[:8].tolist()}')
+    same_state = all(torch.equal(cap['state'][k], cap['state_after'][k]) for k in cap['state'])
+    print(f'         model state unchanged by the rollout: {same_state}')
+    if oracle is None:
+        oracle = OracleAgent(cpu, SyntheticTensorEnv(4096, 60, 8, device='cpu', seed=1))
+        oracle.model.load_full_state_dict(cap['state_after'])
+    ref = oracle.update(b)
+    steps = len(res[4])
+    rows = agent._mb_scalars[:steps].cpu()
+    for k, r in enumerate(ref):
+        print(f'   step {k}: a_loss {rows[k,0].item():+.6e} vs {float(r["a_loss"]):+.6e}  kl {rows[k,4].item():.6e} vs {float(r["kl"]):.6e}  lr(oracle) {r["lr"]:.3e}')
+    final, want = agent.model.state_dict(), oracle.model.full_state_dict()
+    name = 'a2c_network.actor_mlp.0.weight'
+    rel = ((final[name].cpu() - want[name]).abs().mean() / want[name].abs().mean()).item()
+    print(f'   after epoch {epoch}: {name} mean|d|/mean|x| {rel:.2e}; lr agent {agent.optimizer.last_and_next_lr()[1]} oracle {oracle.lr}')
