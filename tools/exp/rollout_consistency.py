@@ -45,11 +45,34 @@ for epoch in range(3):
     if oracle is None:
         oracle = OracleAgent(cpu, SyntheticTensorEnv(4096, 60, 8, device='cpu', seed=1))
         oracle.model.load_full_state_dict(cap['state_after'])
-    ref = oracle.update(b)
+    # the oracle's update step by step, with a look at how close rows sit to the kinks of the objective before each step:
+    # the ratio clip (1 +- e_clip, common_losses.py:64-82), the value clip (|v - v_old| = e_clip, :16-29), the max() ties
+    from oracle import ppo_oracle as O
+    oracle.prepare_dataset(b)
+    ref, nmb = [], oracle.B // oracle.mb
+    e_clip = oracle.hp['e_clip']
+    for me in range(oracle.mini_epochs):
+        for i in range(nmb):
+            ds = oracle.dataset
+            lo, hi = i * oracle.mb, (i + 1) * oracle.mb
+            with torch.no_grad():
+                saved_stats = copy.deepcopy(oracle.model.obs_stats)       # (training-mode normalisation, as the step itself sees it)
+                oracle.model.obs_stats_training = True
+                mu_, logstd_, v_ = oracle.model.a2c_network(oracle.model.norm_obs(ds['obs'][lo:hi]))
+                oracle.model.obs_stats = saved_stats
+                sig_ = torch.exp(logstd_)
+                nlp_ = torch.squeeze(O.neglogp(ds['actions'][lo:hi], mu_, sig_, logstd_))
+                ratio = torch.exp(ds['old_logp_actions'][lo:hi] - nlp_)
+                d_ratio = torch.minimum((ratio - (1 + e_clip)).abs(), (ratio - (1 - e_clip)).abs()).min().item()
+                dv = (v_.reshape(-1) - ds['old_values'][lo:hi].reshape(-1)).abs()
+                d_value = (dv - e_clip).abs().min().item()
+            ref.append(oracle.minibatch_step(i))
+            ref[-1]['near'] = (d_ratio, d_value)
     steps = len(res[4])
     rows = agent._mb_scalars[:steps].cpu()
     for k, r in enumerate(ref):
-        print(f'   step {k}: a_loss {rows[k,0].item():+.6e} vs {float(r["a_loss"]):+.6e}  kl {rows[k,4].item():.6e} vs {float(r["kl"]):.6e}  lr(oracle) {r["lr"]:.3e}')
+        print(f'   step {k}: a_loss {rows[k,0].item():+.6e} vs {float(r["a_loss"]):+.6e}  kl {rows[k,4].item():.6e} vs {float(r["kl"]):.6e}  lr(oracle) {r["lr"]:.3e}'
+              f'  closest row to the ratio clip {r["near"][0]:.1e}, to the value clip {r["near"][1]:.1e}')
     final, want = agent.model.state_dict(), oracle.model.full_state_dict()
     name = 'a2c_network.actor_mlp.0.weight'
     rel = ((final[name].cpu() - want[name]).abs().mean() / want[name].abs().mean()).item()
