@@ -538,7 +538,8 @@ def main():
             comm = agent._ipc_comm or None
             out['config']['ranks_in_sync'] = in_sync
             out['config']['params_finite'] = params_finite
-            out['config']['allreduce'] = (('ipc-two-phase' if comm.two_phase else 'ipc') if comm is not None else 'rccl')
+            out['config']['allreduce'] = ((getattr(comm, 'kind', None) or ('ipc-two-phase' if comm.two_phase else 'ipc'))
+                                          if comm is not None else 'rccl')
             out['config']['allreduce_note'] = (
                 'in-graph hipIpc all-reduce kernel (csrc/ipc_allreduce.hip), inside the mini-epoch HIP graph'
                 if comm is not None else 'RCCL all-reduce via torch.distributed between two graph replays per step'

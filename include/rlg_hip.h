@@ -625,6 +625,22 @@ int rlg_ipc_allreduce_sum_norm(void* comm, float* data, long long n, double* nor
 int rlg_ipc_comm_status(void* comm, unsigned* launches_out, unsigned* timed_out_launch_out);
 int rlg_ipc_comm_destroy(void* comm);
 
+/* ---- RCCL behind the C ABI (csrc/rccl_wrap.hip) ---------------------------------------------------
+ * "plus an RCCL wrapper taking ncclComm_t".  The gradient all-reduce of
+ * A2CBase.trancate_gradients_and_step (rl_games/common/a2c_common.py:493-509) as a launch on the caller's stream
+ * - capturable into the mini-epoch HIP graph, unlike a collective issued through torch.distributed - for nodes on
+ * which the hipIpc kernel (rlg_ipc_*) is not available.  `comm` is an ncclComm_t; the unique id (rlg_rccl_unique_id_bytes()
+ * bytes, from rank 0's rlg_rccl_get_unique_id) travels through whatever channel the ranks share.  librccl is resolved
+ * with dlopen at first use: rlg_rccl_available() == 0 and hipErrorNotSupported from the others when there is none.
+ * Every rank receives the same bits; in place. */
+int rlg_rccl_available(void);
+int rlg_rccl_unique_id_bytes(void);
+int rlg_rccl_get_unique_id(void* id_out);
+int rlg_rccl_comm_create(const void* unique_id, int rank, int world, void** comm_out /* ncclComm_t */);
+int rlg_rccl_allreduce_sum(void* comm /* ncclComm_t */, float* data, long long n, void* stream);
+int rlg_rccl_allreduce_sum_f64(void* comm /* ncclComm_t */, double* data, long long n, void* stream);
+int rlg_rccl_comm_destroy(void* comm /* ncclComm_t */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,13 @@ _PROTOTYPES = {
     'rlg_adam_step': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
                       _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
                       _c_double, _c_double, _c_double, _P, _P, _P],
+    'rlg_rccl_available': [],
+    'rlg_rccl_unique_id_bytes': [],
+    'rlg_rccl_get_unique_id': [ctypes.c_char_p],
+    'rlg_rccl_comm_create': [ctypes.c_char_p, _c_int, _c_int, ctypes.POINTER(_P)],
+    'rlg_rccl_allreduce_sum': [_P, _P, _c_ll, _P],
+    'rlg_rccl_allreduce_sum_f64': [_P, _P, _c_ll, _P],
+    'rlg_rccl_comm_destroy': [_P],
     'rlg_adam_step_pack': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
                            _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
                            _c_double, _c_double, _c_double, _P, _P, _c_int, _P, _P, _P, _P, _P],

@@ -1167,21 +1167,34 @@ class A2CAgent:
             torch.autograd.backward([mu, values], [d_mu, d_val.view(mb, 1)])
 
     def _native_comm(self):
-        """The in-graph IPC all-reduce (csrc/ipc_allreduce.hip), created on first use; None when
-        `native_allreduce: False` or the peers' memory cannot be mapped (then RCCL is used)."""
+        """The in-graph gradient collective, created on first use: the hipIpc all-reduce kernel
+        (csrc/ipc_allreduce.hip; `native_allreduce: True`, the default), RCCL through the C ABI as a stream launch
+        (csrc/rccl_wrap.hip; `native_allreduce: 'rccl'`, or as the fallback of the former with `rccl_in_graph_fallback:
+        True`), or None: `native_allreduce: False` / nothing of the above could be set up - the collective then runs
+        through torch.distributed between two graph replays per step."""
         if self._ipc_comm is False:
             return None
         if self._ipc_comm is None:
             self._ipc_comm = False
-            if self.multi_gpu and self.config.get('native_allreduce', True):
-                try:
-                    from .ipc_allreduce import IpcAllReduce
-                    self._ipc_comm = IpcAllReduce(self.optimizer.flat_grads.numel(), self.ppo_device,
-                                                  timeout_s=self.config.get('native_allreduce_timeout_s'),
-                                                  two_phase=self.config.get('native_allreduce_two_phase'))
-                except Exception as e:
-                    print(f'rl_games_amd: native all-reduce unavailable ({type(e).__name__}: {e}); using RCCL')
-                    self._ipc_comm = False
+            want = self.config.get('native_allreduce', True)
+            if self.multi_gpu and want:
+                n = self.optimizer.flat_grads.numel()
+                if want != 'rccl':
+                    try:
+                        from .ipc_allreduce import IpcAllReduce
+                        self._ipc_comm = IpcAllReduce(n, self.ppo_device,
+                                                      timeout_s=self.config.get('native_allreduce_timeout_s'),
+                                                      two_phase=self.config.get('native_allreduce_two_phase'))
+                    except Exception as e:
+                        print(f'rl_games_amd: native all-reduce unavailable ({type(e).__name__}: {e}); using RCCL')
+                        self._ipc_comm = False
+                if not self._ipc_comm and (want == 'rccl' or self.config.get('rccl_in_graph_fallback', False)):
+                    try:
+                        from .rccl_allreduce import RcclAllReduce
+                        self._ipc_comm = RcclAllReduce(n, self.ppo_device)
+                    except Exception as e:
+                        print(f'rl_games_amd: in-graph RCCL unavailable ({type(e).__name__}: {e}); using torch.distributed')
+                        self._ipc_comm = False
         return self._ipc_comm or None
 
     def _all_reduce_grads(self):
@@ -1193,12 +1206,12 @@ class A2CAgent:
             comm.all_reduce_sum(self.optimizer.flat_grads, norm=self._all_reduce_norm_plan(comm))
         else:
             rdist.all_reduce_sum(self.optimizer.flat_grads)
-        self.last_allreduce = 'ipc' if comm is not None else 'rccl'
+        self.last_allreduce = getattr(comm, 'kind', 'ipc') if comm is not None else 'rccl'
 
     def _all_reduce_norm_plan(self, comm):
         """The `norm` argument of the native all-reduce launch; also tells the optimiser launch (eager or about
         to be captured) that the gradient norm partials will be there.  Launches nothing."""
-        if comm is None or not self.config.get('norm_in_allreduce', True):
+        if comm is None or not getattr(comm, 'supports_norm', True) or not self.config.get('norm_in_allreduce', True):
             return None
         opt = self.optimizer
         if self._ar_norm_partials is None:

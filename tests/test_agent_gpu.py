@@ -926,6 +926,46 @@ def test_folded_launches_match_the_separate_ones(graphs):
     assert (a[3] - b[3]).abs().max().item() <= 2.1 * 24 * 1e-2       # 24 Adam steps at lr <= max_lr
 
 
+def test_rccl_wrapper_of_the_c_abi_runs_inside_a_graph():
+    """the RCCL wrapper taking an ncclComm_t (csrc/rccl_wrap.hip, rl_games_amd/rccl_allreduce.py) - a
+    communicator of ONE rank (this box has one GPU, and RCCL refuses two ranks per device): unique id, comm create, an
+    fp32 and an fp64 all-reduce eagerly and as nodes of a captured HIP graph (what the agent's mini-epoch graph needs of
+    it), destroy.  The multi-rank behaviour is RCCL's own; the 2-rank agent tests cover the code around it with the
+    hipIpc kernel and with torch.distributed."""
+    from rl_games_amd import _lib
+    from rl_games_amd.rccl_allreduce import RcclAllReduce
+    if not _lib.load().rlg_rccl_available():
+        pytest.skip('no librccl in this process')
+    comm = RcclAllReduce(1 << 16, DEV, rank=0, world=1)
+    x = torch.randn(50000, device=DEV)
+    t = x.clone()
+    comm.all_reduce_sum(t)
+    d = torch.randn(777, device=DEV, dtype=torch.float64)
+    td = d.clone()
+    comm.all_reduce_sum(td)
+    torch.cuda.synchronize()
+    assert torch.equal(t, x) and torch.equal(td, d)
+    buf = torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.all_reduce_sum(buf)                       # (warm-up outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        buf.mul_(2.0)
+        comm.all_reduce_sum(buf)
+        buf.add_(1.0)
+    buf.copy_(x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, x * 2.0 + 1.0)
+    assert comm.status()[1] == 0
+    with pytest.raises(ValueError):
+        comm.all_reduce_sum(buf, norm=(None, 0, 1.0, None))
+    comm.close()
+
+
 @pytest.mark.parametrize('graphs', [True, False])
 def test_adam_written_planes_match_the_pack_launch(graphs):
     """Round 4: the Adam launch writes the split-bf16 chain's weight planes itself (adam_pack_kernel) - against the same
