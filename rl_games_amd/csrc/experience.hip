@@ -485,7 +485,11 @@ int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logst
   p.env_actions_out = env_actions_out;
   p.act_low = act_low;
   p.act_high = act_high;
-  hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + 255) / 256), dim3(256), 0,
+  // one wave per workgroup: 8,192 envs (a rank of 8) are 128 workgroups instead of 32 - the kernel is a chain of dependent
+  // memory round trips per workgroup, so it wants every CU (16 -> 8 us there); the layout of the work inside a
+  // workgroup (phase A one thread per env, phase B consecutive threads on consecutive addresses) is unchanged
+  constexpr int kHeadBlock = 64;
+  hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + kHeadBlock - 1) / kHeadBlock), dim3(kHeadBlock), 0,
                      static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();
 }

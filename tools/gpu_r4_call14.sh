@@ -1,0 +1,9 @@
+set -x
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r4call14
+rm -rf $OUT; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_agent_gpu.py -m gpu -q -x > $OUT/pytest_sel.txt 2>&1; tail -5 $OUT/pytest_sel.txt | cut -c1-250
+timeout 600 python tools/rank_shapes.py worlds=1,4,8 2>&1 | grep world | tee $OUT/rank_shapes.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof8 -o r -- python $GRAFT_REPO_ROOT/tools/rank_shapes.py worlds=8 > $OUT/prof_log8.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT/prof8/r_kernel_trace.csv 14 > $OUT/prof_summary_world8.txt; rm -rf $OUT/prof8; head -16 $OUT/prof_summary_world8.txt

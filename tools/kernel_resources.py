@@ -14,7 +14,9 @@ for o in objs:
     for f in (fat, co):
         if os.path.exists(f):
             os.remove(f)
-    subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objcopy', '--dump-section', f'.hip_fatbin={fat}', o], check=True)
+    if subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objcopy', '--dump-section', f'.hip_fatbin={fat}', o],
+                      capture_output=True).returncode != 0:
+        continue                       # (an object without device code)
     subprocess.run(['/opt/rocm/lib/llvm/bin/clang-offload-bundler', '--unbundle', '--type=o', f'--input={fat}',
                     '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--output={co}'], check=True)
     out += subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', co], capture_output=True, text=True).stdout
