@@ -537,6 +537,23 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
                            const rlg_ppo_loss_desc* ppo_loss_or_null, long long rows, int groups,
                            const void* weight_planes_or_null, void* stream);
 
+/* Forward + PPO loss + backward of one minibatch as ONE launch (round 4; csrc/mlp_chain.hip,
+ * mlp_chain_step_pipe_kernel): the arguments of rlg_mlp_chain_forward in its training form (every act_out given) and of
+ * rlg_mlp_chain_backward with a loss descriptor whose mu / values are the forward's heads and whose d_mu / d_values are
+ * `d_out`.  For minibatches below 16,384 rows (a data-parallel rank's 4,096 - 8,192): the loss tile's inputs are
+ * requested before the forward and arrive during it, and the launch boundary between the two halves is gone
+ * (a2c_continuous.py:136-234: model forward, calc_losses, loss.backward() up to the weight-gradient GEMMs).  Same device
+ * code as the two launches, same results.  Returns hipErrorNotSupported (801) when the shape is outside the kernel's
+ * envelope - the caller then issues rlg_mlp_chain_forward and rlg_mlp_chain_backward. */
+int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float* const* biases,
+                       const int* in_features, const int* out_features, const int* acts,
+                       float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                       const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                       const double* rms_batch, const long long* rms_count, double* rms_mean_out,
+                       double* rms_var_out, long long* rms_count_out, float* d_out, long long ld_dout,
+                       float* const* dz_out, const long long* dz_ld, double* const* bias_partials_or_null,
+                       const rlg_ppo_loss_desc* ppo_loss, long long rows, void* stream);
+
 /* Split-bf16 form of the chain (csrc/mlp_chain_bx.hip): every fp32 product as six exact bf16 plane products on
  * v_mfma_f32_16x16x32_bf16 (results within 3 * 2^-24 |x||w| per product of the exact-product kernels).  The weights
  * are split ONCE per optimizer step into plane fragments; the launch that is given them (weight_planes_or_null of

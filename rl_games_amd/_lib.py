@@ -87,6 +87,8 @@ _PROTOTYPES = {
     'rlg_mlp_chain_time_next': [_P, _P],
     'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                               _P, _P, _P, _P, _P, _c_ll, _c_int, _P, _P, _P],
+    'rlg_mlp_chain_step': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
+                           _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P, _P],
     # mlp_chain_bx.hip
     'rlg_mlp_chain_planes_bytes': [_c_int, _P, _P, _c_int],

@@ -1074,7 +1074,12 @@ class A2CAgent:
                             rms, fold = self.model.running_mean_std.fold_buffers(self._fold_index)
                         else:
                             self.model.running_mean_std.update(obs_batch)
-                    heads = eng.forward_obs(obs_batch, rms, self._obs_eps(), rms_fold=fold)
+                    # forward + loss + backward as ONE launch where the chain has that form (minibatches < 16,384 rows,
+                    # the loss evaluated by the backward launch): the forward is handed to eng.backward() below
+                    defer = (self.config.get('fused_step16', True) and self.config.get('fold_loss_finalize', True)
+                             and self.config.get('loss_in_backward', True)
+                             and not eng.chain.split_products(obs_batch.shape[0], 0))
+                    heads = eng.forward_obs(obs_batch, rms, self._obs_eps(), rms_fold=fold, defer=defer)
                     obs_n = None
                 elif self.is_rnn and eng.chain_rnn is not None and obs_batch.dtype == torch.float32:
                     # recurrent policy on the fused trunk: the statistics update stays its own (two) launches, the

@@ -524,15 +524,10 @@ struct PipeGeo {
   unsigned w_off;
 };
 
-template <int G, int HACT, int W = 4>
-__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
+template <int G, int HACT, int W>
+__device__ __forceinline__ void chain_fwd_pipe_body(const ChainArgs& a, float* lds) {
   using WholeTag = std::integral_constant<int, G>;
   using OneTag = std::integral_constant<int, 1>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: weight planes
-    if (threadIdx.x < 256) chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
-    return;
-  }
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const int q4 = 4 * (lane >> 4);
@@ -813,6 +808,16 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_fwd_pipe_kernel(ChainArgs a)
   }
 }
 
+template <int G, int HACT, int W = 4>
+__global__ __launch_bounds__(64 * W) void mlp_chain_fwd_pipe_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: weight planes
+    if (threadIdx.x < 256) chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
+    return;
+  }
+  chain_fwd_pipe_body<G, HACT, W>(a, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward (dX chain): layer[num_layers-1] is the head, its dZ is `x` (d heads) itself.
 // For L = num_layers-1 .. 1:  dZ_{L-1} = (dZ_L W_L) * act'_{L-1}(H_{L-1});  layer 0 needs no dX.
@@ -1011,15 +1016,15 @@ struct BwdPipeGeo {
   const float* w;
 };
 
-template <int W>
-__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_pipe_kernel(ChainArgs a, LossArgs loss) {
+template <int W, bool kPreloaded>
+__device__ __forceinline__ void chain_bwd_pipe_body(const ChainArgs& a, const LossArgs& loss, float* lds,
+                                                    const LossQuadInputs& preloaded) {
   constexpr std::integral_constant<int, 0> U0{};
   constexpr std::integral_constant<int, 1> U1{};
   constexpr std::integral_constant<int, 2> U2{};
   constexpr std::integral_constant<int, 3> U3{};
   constexpr std::integral_constant<int, 0> BA{};
   constexpr std::integral_constant<int, 1> BB{};
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const int q4 = 4 * (lane >> 4), r16 = lane & 15;
@@ -1080,7 +1085,8 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_pipe_kernel(ChainArgs a,
 
   // ---- the PPO loss of this row tile (training steps), as in mlp_chain_bwd_kernel
   if (a.with_loss) {
-    ppo_loss_tile<16, 64 * W>(loss, lds, blockIdx.x);
+    if constexpr (kPreloaded) ppo_loss_quad_run<16, 64 * W>(loss, lds, blockIdx.x, preloaded);   // (inputs requested long ago)
+    else ppo_loss_tile<16, 64 * W>(loss, lds, blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1254,6 +1260,37 @@ __global__ __launch_bounds__(64 * W) void mlp_chain_bwd_pipe_kernel(ChainArgs a,
     wr_cur = wr_nxt;
     hr_cur = hr_nxt;
   }
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_bwd_pipe_kernel(ChainArgs a, LossArgs loss) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  LossQuadInputs none;
+  chain_bwd_pipe_body<W, false>(a, loss, lds, none);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for forward + PPO loss + backward of a 16-row tile (round 4; minibatches < 16,384 rows).
+//
+// A data-parallel rank's optimiser step is five launches of 6 - 32 us, and two of the things it pays for exist only
+// because forward and backward are separate launches: the launch boundary itself (drain of the forward, ramp of the
+// backward: ~3 us), and the loss tile's input loads (actions, old mu / sigma, advantages, ... of the tile's 16 rows:
+// an HBM round trip with nothing to overlap with at the head of the backward launch, ~9 us at 16 rows per workgroup).
+// Here the loss inputs are requested FIRST and arrive during the forward (wave 0 keeps them in 37 registers), the
+// forward's heads are read back from the L2 they were just written to, and the backward's first weights and H fragment
+// are requested before the loss arithmetic like in its own launch.  Same device code as the two kernels, same results.
+// ------------------------------------------------------------------------------------------------
+template <int HACT, int W>
+__global__ __launch_bounds__(64 * W) void mlp_chain_step_pipe_kernel(ChainArgs fa, ChainArgs ba, LossArgs loss) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  LossQuadInputs pre;
+  ppo_loss_quad_load<16, 64 * W>(loss, blockIdx.x, pre);
+  chain_fwd_pipe_body<1, HACT, W>(fa, lds);
+  // the heads (mu, value) this workgroup has just stored are what its loss tile reads: stores acknowledged by the L2
+  // first (a workgroup barrier alone does not wait for global stores on gfx950), every wave past its last LDS access
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  chain_bwd_pipe_body<W, true>(ba, loss, lds, pre);
 }
 
 static bool vec4_ok_host(const void* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0; }
@@ -1581,6 +1618,7 @@ int rlg_mlp_chain_prepare(void) {
       reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<4>), reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<8>),
       reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny, 8>),
       reinterpret_cast<const void*>(mlp_chain_bwd_pipe_kernel<16>),
+      reinterpret_cast<const void*>(mlp_chain_step_pipe_kernel<kChElu, 8>), reinterpret_cast<const void*>(mlp_chain_step_pipe_kernel<kChAny, 8>),
       reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChElu, 16>), reinterpret_cast<const void*>(mlp_chain_fwd_pipe_kernel<1, kChAny, 16>)};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1870,6 +1908,154 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
     }
   }
   return chain_launch<1, true>(args, lds_bytes, st, lp);
+}
+
+
+// Forward + PPO loss + backward of a minibatch as ONE launch (mlp_chain_step_pipe_kernel): the arguments of
+// rlg_mlp_chain_forward (training form: every act_out given) and of rlg_mlp_chain_backward with a loss descriptor.
+// hipErrorNotSupported when the shape is outside the kernel's envelope (the caller then issues the two launches):
+// minibatches of >= 16,384 rows (they run the split-bf16 kernels), weights not in one arena, H / dZ rows not 16-byte
+// aligned, more than 32 actions, RLG_CHAIN_PIPE1=0 / RLG_CHAIN_STEP1=0.
+int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float* const* biases,
+                       const int* in_features, const int* out_features, const int* acts,
+                       float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                       const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                       const double* rms_batch, const long long* rms_count, double* rms_mean_out,
+                       double* rms_var_out, long long* rms_count_out, float* d_out, long long ld_dout,
+                       float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
+                       const rlg_ppo_loss_desc* ppo_loss, long long rows, void* stream) {
+  using namespace rlg;
+  static const bool enabled = [] { const char* e = std::getenv("RLG_CHAIN_STEP1"); return !(e && std::atoi(e) == 0); }();
+  if (rows <= 0) return 0;
+  if (!enabled || !chain_pipe1_enabled() || !chain_pipe_enabled() || chain_pipe1_waves() != 8 || g_chain_dbg != nullptr ||
+      num_layers < 2 || ppo_loss == nullptr || pick_groups(rows, 0, 0) != 1 || pick_groups(rows, 0, 1) != 1)
+    return static_cast<int>(hipErrorNotSupported);
+  // one 8-wave workgroup per CU (200 registers per wave): beyond one round of workgroups the two separate launches,
+  // which run two workgroups per CU, are faster (8,192 rows: 52.3 vs 50.0 ms per rank epoch, profiles/r4_rank_shapes.txt)
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return static_cast<int>(hipErrorNotSupported);
+    if ((rows + 15) / 16 > cus) return static_cast<int>(hipErrorNotSupported);
+  }
+  // ---- forward arguments (as rlg_mlp_chain_forward)
+  ChainArgs fa;
+  if (chain_fill(fa, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
+  for (int L = 0; L < num_layers; ++L) {
+    fa.layer[L].bias = biases[L];
+    fa.layer[L].h = act_out[L];
+    fa.layer[L].ldh = act_ld[L];
+    if (act_out[L] == nullptr) return static_cast<int>(hipErrorNotSupported);       // training form only
+  }
+  fa.x = x;
+  fa.ldx = ldx;
+  fa.rms_mean = rms_mean;
+  fa.rms_var = rms_mean ? rms_var : nullptr;
+  fa.rms_eps = rms_eps;
+  fa.rms_batch = rms_mean ? rms_batch : nullptr;
+  if (fa.rms_batch) {
+    if (!rms_count || !rms_mean_out || !rms_var_out || !rms_count_out || rms_mean_out == rms_mean ||
+        rms_var_out == rms_var || rms_count_out == rms_count)
+      return static_cast<int>(hipErrorInvalidValue);
+  }
+  fa.rms_count = rms_count;
+  fa.rms_mean_out = rms_mean_out;
+  fa.rms_var_out = rms_var_out;
+  fa.rms_count_out = rms_count_out;
+  fa.xn = xn_out;
+  fa.rows = rows;
+  fa.dbg = nullptr;
+  int fb = 0;
+  const int fwd_lds = chain_lds(num_layers, in_features, out_features, 1, 0, &fb);
+  if (fwd_lds < 0) return static_cast<int>(hipErrorNotSupported);
+  fa.lds_b_floats = fb;
+  fa.lds_split_floats = fwd_lds / 4 - chain_split_floats(1);
+  fa.no_ksplit = 0;
+  if (!chain_pipe_fill(fa, true)) return static_cast<int>(hipErrorNotSupported);
+  // ---- backward arguments (as rlg_mlp_chain_backward); H of the hidden layers = what the forward half writes
+  ChainArgs ba;
+  if (chain_fill(ba, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
+  for (int L = 0; L + 1 < num_layers; ++L) {
+    ba.layer[L].h = act_out[L];
+    ba.layer[L].ldh = act_ld[L];
+    ba.layer[L].dz = dz_out[L];
+    ba.layer[L].lddz = dz_ld[L];
+    ba.layer[L].bias_partials = bias_partials ? bias_partials[L] : nullptr;
+    if (dz_out[L] == nullptr) return static_cast<int>(hipErrorInvalidValue);
+    const ChainLayer& ly = ba.layer[L];
+    if (!(vec4_ok_host(ly.h, ly.ldh) && vec4_ok_host(ly.dz, ly.lddz) && (ly.out & 3) == 0 && ly.ldh < (1 << 20) && ly.lddz < (1 << 20)))
+      return static_cast<int>(hipErrorNotSupported);
+  }
+  ba.x = d_out;
+  ba.ldx = ld_dout;
+  ba.rms_mean = ba.rms_var = nullptr;
+  ba.rms_eps = 0.0f;
+  ba.rms_batch = nullptr;
+  ba.rms_count = nullptr;
+  ba.rms_mean_out = ba.rms_var_out = nullptr;
+  ba.rms_count_out = nullptr;
+  ba.xn = nullptr;
+  ba.rows = rows;
+  ba.with_loss = 1;
+  int bb = 0;
+  int bwd_lds = chain_lds(num_layers, in_features, out_features, 1, 1, &bb);
+  if (bwd_lds < 0) return static_cast<int>(hipErrorNotSupported);
+  ba.lds_b_floats = bb;
+  const rlg_ppo_loss_desc& d = *ppo_loss;
+  if (d.minibatch != rows || d.actions_num <= 0 || d.actions_num > 4 * kQuadK || (d.mask_or_null && !d.mask_sum_or_null) ||
+      !d.partials || !d.mu || !d.values || !d.d_mu || !d.d_values)
+    return d.actions_num > 4 * kQuadK ? static_cast<int>(hipErrorNotSupported) : static_cast<int>(hipErrorInvalidValue);
+  LossArgs loss = {};
+  loss.mu = d.mu;
+  loss.logstd = d.logstd;
+  loss.values = d.values;
+  loss.actions = d.actions;
+  loss.old_neglogp = d.old_neglogp;
+  loss.advantages = d.advantages;
+  loss.old_values = d.old_values;
+  loss.returns = d.returns;
+  loss.old_mu = d.old_mu;
+  loss.old_sigma = d.old_sigma;
+  loss.mask = d.mask_or_null;
+  loss.mask_sum = d.mask_sum_or_null;
+  loss.d_mu = d.d_mu;
+  loss.d_values = d.d_values;
+  loss.partials = d.partials;
+  loss.mb = d.minibatch;
+  loss.A = d.actions_num;
+  loss.ld_mu = d.ld_mu;
+  loss.ld_val = d.ld_values;
+  loss.ld_dmu = d.ld_d_mu;
+  loss.ld_dval = d.ld_d_values;
+  loss.e_clip = d.e_clip;
+  loss.critic_coef = d.critic_coef;
+  loss.bounds_coef = d.bounds_coef;
+  loss.clip_value = d.clip_value;
+  loss.smooth = d.use_smooth_clamp;
+  loss.bound_kind = d.bound_kind;
+  loss.write_back = d.write_back;
+  const int need = static_cast<int>(ppo_loss_lds_bytes(16, d.actions_num, 512));
+  int lds_bytes = fwd_lds > bwd_lds ? fwd_lds : bwd_lds;
+  if (need > lds_bytes) lds_bytes = need;
+  if (lds_bytes > 160 * 1024) return static_cast<int>(hipErrorNotSupported);
+  bool elu_only = true;
+  for (int L = 0; L < num_layers; ++L) elu_only = elu_only && (acts[L] == kChElu || acts[L] == kChIdentity);
+  const int grid = static_cast<int>((rows + 15) / 16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
+  g_chain_ev_start = g_chain_ev_stop = nullptr;
+  if (elu_only) {
+    if (ev0 != nullptr)
+      hipExtLaunchKernelGGL((mlp_chain_step_pipe_kernel<kChElu, 8>), dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0, fa, ba, loss);
+    else
+      hipLaunchKernelGGL((mlp_chain_step_pipe_kernel<kChElu, 8>), dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, fa, ba, loss);
+  } else {
+    if (ev0 != nullptr)
+      hipExtLaunchKernelGGL((mlp_chain_step_pipe_kernel<kChAny, 8>), dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0, fa, ba, loss);
+    else
+      hipLaunchKernelGGL((mlp_chain_step_pipe_kernel<kChAny, 8>), dim3(grid), dim3(512), static_cast<size_t>(lds_bytes), st, fa, ba, loss);
+  }
+  RLG_RETURN_LAUNCH_STATUS();
 }
 
 }  // extern "C"

@@ -390,11 +390,51 @@ __device__ __forceinline__ void ppo_loss_tile_rows(const LossArgs& p, float* lds
 // ------------------------------------------------------------------------------------------------
 constexpr int kQuadK = 8;
 
+// What a thread of the quad form needs of its row BEFORE the forward's outputs (mu, value) exist: requested first by the
+// fused forward + loss + backward launch (csrc/mlp_chain.hip), kept in registers through the forward.
+struct LossQuadInputs {
+  float r_adv, r_onlp, r_vo, r_ret, r_mask;
+  float e_x[kQuadK], e_omu[kQuadK], e_osg[kQuadK], e_ls[kQuadK];
+};
+
+template <int kRows, int kThreads>
+__device__ __forceinline__ void ppo_loss_quad_load(const LossArgs& p, int tile_index, LossQuadInputs& in) {
+  static_assert(kThreads >= 4 * kRows, "four threads per row");
+  const int A = p.A;
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, q = tid & 3;
+  const long long row0 = static_cast<long long>(tile_index) * kRows;
+  const int rows = static_cast<int>(min(static_cast<long long>(kRows), p.mb - row0));
+  const bool row_ok = r < rows;
+  const long long i = row0 + (row_ok ? r : 0);
+  in.r_adv = in.r_onlp = in.r_vo = in.r_ret = 0.0f;
+  in.r_mask = 1.0f;
+  if (row_ok) {
+    in.r_adv = p.advantages[i];
+    in.r_onlp = p.old_neglogp[i];
+    in.r_vo = p.old_values[i];
+    in.r_ret = p.returns[i];
+    if (p.mask) in.r_mask = p.mask[i];
+  }
+#pragma unroll
+  for (int k = 0; k < kQuadK; ++k) {
+    const int a = q + 4 * k;
+    in.e_x[k] = in.e_omu[k] = in.e_ls[k] = 0.0f;
+    in.e_osg[k] = 1.0f;
+    if (row_ok && a < A) {
+      in.e_ls[k] = p.logstd[a];
+      in.e_x[k] = p.actions[i * A + a];
+      in.e_omu[k] = p.old_mu[i * A + a];
+      in.e_osg[k] = p.old_sigma[i * A + a];
+    }
+  }
+}
+
 // handoff (optional, LDS, [kRows][handoff_ld] floats): the tile's d heads - column 0 d value, columns 1 .. A d mu - for a
 // caller that consumes them in the same workgroup (the fused backward: no store fence + re-load from global memory).
 template <int kRows, int kThreads>
-__device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds, int tile_index, float* handoff = nullptr,
-                                                   int handoff_ld = 0) {
+__device__ __forceinline__ void ppo_loss_quad_run(const LossArgs& p, float* lds, int tile_index, const LossQuadInputs& in,
+                                                  float* handoff = nullptr, int handoff_ld = 0) {
   static_assert(kThreads >= 4 * kRows, "four threads per row");
   constexpr int kWaves = kThreads / kWave;
   const int A = p.A;
@@ -408,29 +448,20 @@ __device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds
   double* red_cols = red;
   double* red_scal = red + kWaves * 2 * A;
 
-  // ---- every load of the tile, up front
-  float r_adv = 0.0f, r_onlp = 0.0f, r_v = 0.0f, r_vo = 0.0f, r_ret = 0.0f, r_mask = 1.0f;
+  // ---- the forward's outputs for this tile; everything else came with `in`
+  const float r_adv = in.r_adv, r_onlp = in.r_onlp, r_vo = in.r_vo, r_ret = in.r_ret, r_mask = in.r_mask;
+  float r_v = 0.0f;
   float e_mu[kQuadK], e_x[kQuadK], e_omu[kQuadK], e_osg[kQuadK], e_ls[kQuadK];
-  if (row_ok) {
-    r_adv = p.advantages[i];
-    r_onlp = p.old_neglogp[i];
-    r_v = p.values[i * p.ld_val];
-    r_vo = p.old_values[i];
-    r_ret = p.returns[i];
-    if (p.mask) r_mask = p.mask[i];
-  }
+  if (row_ok) r_v = p.values[i * p.ld_val];
 #pragma unroll
   for (int k = 0; k < kQuadK; ++k) {
     const int a = q + 4 * k;
-    e_mu[k] = e_x[k] = e_omu[k] = e_ls[k] = 0.0f;
-    e_osg[k] = 1.0f;
-    if (row_ok && a < A) {
-      e_ls[k] = p.logstd[a];
-      e_mu[k] = p.mu[i * p.ld_mu + a];
-      e_x[k] = p.actions[i * A + a];
-      e_omu[k] = p.old_mu[i * A + a];
-      e_osg[k] = p.old_sigma[i * A + a];
-    }
+    e_mu[k] = 0.0f;
+    e_x[k] = in.e_x[k];
+    e_omu[k] = in.e_omu[k];
+    e_osg[k] = in.e_osg[k];
+    e_ls[k] = in.e_ls[k];
+    if (row_ok && a < A) e_mu[k] = p.mu[i * p.ld_mu + a];
   }
   const float lo = 1.0f - p.e_clip, hi = 1.0f + p.e_clip;
   float denom_count = static_cast<float>(p.mb);
@@ -544,6 +575,15 @@ __device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds
     out[kLossScalars + set * A + a] = s2;
   }
   __syncthreads();                                       // the LDS is the caller's again
+}
+
+// load + run: the tile as one call (every load up front, as before the split)
+template <int kRows, int kThreads>
+__device__ __forceinline__ void ppo_loss_tile_quad(const LossArgs& p, float* lds, int tile_index, float* handoff = nullptr,
+                                                   int handoff_ld = 0) {
+  LossQuadInputs in;
+  ppo_loss_quad_load<kRows, kThreads>(p, tile_index, in);
+  ppo_loss_quad_run<kRows, kThreads>(p, lds, tile_index, in, handoff, handoff_ld);
 }
 
 // The tile by whichever form fits.  Returns true when the d heads were left in `handoff` (quad form only).

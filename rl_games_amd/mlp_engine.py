@@ -90,6 +90,8 @@ class ManualMLP:
         self.d_heads = torch.empty(max_rows, self.V + self.A, device=dev)
         self.nb = [ops.act_bwd_blocks(max_rows, w) for w in widths]
         self.chain = None
+        self._deferred = None            # arguments of a training forward that backward() will launch (forward_obs(defer=True))
+        self.last_step_fused = False     # the last backward() ran forward + loss + backward as one launch
         self._pending_backward = False
         self._fused_trunk = False
         if fused_chain and self.lstm is None:
@@ -236,25 +238,38 @@ class ManualMLP:
         return heads
 
     @torch.no_grad()
-    def forward_obs(self, obs, rms=None, eps=1e-5, keep=True, rms_fold=None):
+    def forward_obs(self, obs, rms=None, eps=1e-5, keep=True, rms_fold=None, defer=False):
         """Fused chain: obs [rows, in] RAW observations; rms = (running_mean, running_var) fp64 or None
         (normalize_input off).  One launch: normalise -> hidden layers -> heads.  keep=True retains
         the activations and the normalised observations for backward(); keep=False (rollout,
         get_values) writes nothing but the heads, so it cannot disturb a pending backward.
         rms_fold: RunningMeanStd.fold_buffers() - the statistics update of a training forward happens
-        in the launch's prologue."""
+        in the launch's prologue.  defer=True (training forward whose backward() follows with a ppo_loss descriptor):
+        nothing is launched yet - backward() issues forward + loss + backward as ONE launch where the chain has that
+        form (ops.MlpChain.step: minibatches < 16,384 rows), else the forward now-deferred and then the backward; the
+        returned heads view is where the values will be."""
         rows = obs.shape[0]
         heads = self.heads[:rows]
+        self._deferred = None
         if keep:
             acts = [h[:rows] for h in self.Hs]
             xn = self.xn[:rows] if rms is not None else None
-            self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn, rms_fold=rms_fold)
+            if defer:
+                self._deferred = dict(x=obs, heads=heads, act_out=acts, rms=rms, eps=eps, xn_out=xn, rms_fold=rms_fold)
+            else:
+                self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn, rms_fold=rms_fold)
             self._x = xn if rms is not None else obs
             self._rows, self._last = rows, acts[-1]
             self._pending_backward = True
         else:
             self.chain.forward(obs, heads, rms=rms, eps=eps)
         return heads
+
+    def _one_launch_step(self, fwd, d_heads, dzs, parts, ppo_loss):
+        ok = self.chain.step(fwd['x'], fwd['heads'], fwd['act_out'], d_heads, dzs, parts, ppo_loss, rms=fwd['rms'],
+                             eps=fwd['eps'], xn_out=fwd['xn_out'], rms_fold=fwd['rms_fold'])
+        self.last_step_fused = bool(ok)
+        return ok
 
     def gradient_elements(self):
         """Number of arena gradient elements that backward() + the loss finalise produce on the fused
@@ -291,7 +306,13 @@ class ManualMLP:
             acts = [h[:rows] for h in self.Hs]
             dzs = [d[:rows] for d in self.dA]
             parts = [p[:nblk * w.out_features] for p, w in zip(self.partials, self.linears)]
-            self.chain.backward(d_heads, acts, dzs, parts, ppo_loss=ppo_loss)
+            fwd, self._deferred = self._deferred, None
+            self.last_step_fused = False
+            if fwd is None or not (ppo_loss is not None and self._one_launch_step(fwd, d_heads, dzs, parts, ppo_loss)):
+                if fwd is not None:                     # (no one-launch form for this shape: the two launches)
+                    self.chain.forward(fwd['x'], fwd['heads'], act_out=fwd['act_out'], rms=fwd['rms'], eps=fwd['eps'],
+                                       xn_out=fwd['xn_out'], rms_fold=fwd['rms_fold'])
+                self.chain.backward(d_heads, acts, dzs, parts, ppo_loss=ppo_loss)
             jobs = [(d_heads, acts[-1], self.head_w_grad)]
             colsums = []
             for l in range(L - 1, -1, -1):

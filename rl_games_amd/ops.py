@@ -801,6 +801,55 @@ class MlpChain:
         if packed_both and self._weights_version is not None:
             self._planes_for = self._version()
 
+    def step(self, x, heads, act_out, d_heads, dz_out, bias_partials, ppo_loss, rms=None, eps=1e-5, xn_out=None,
+             rms_fold=None):
+        """forward(x, heads, act_out, ...) and backward(d_heads, act_out, dz_out, bias_partials, ppo_loss=...) as ONE
+        launch (rlg_mlp_chain_step: 16-row workgroups, minibatches < 16,384 rows).  Returns False - having launched
+        nothing - when the shape is outside that kernel's envelope; the caller then issues the two launches."""
+        rows = x.shape[0]
+        n = self.n
+        if act_out is None or any(t is None for t in act_out) or ppo_loss is None or n < 2:
+            return False
+        if self.split_products(rows, 0) or self.split_products(rows, 1) or self.groups(rows, 0) != 1 or self.groups(rows, 1) != 1:
+            return False
+        outs = list(act_out) + [heads]
+        ptrs = self._P(*[_need(t, F32, 'act_out', contiguous=False) for t in outs])
+        lds = self._L(*[t.stride(0) for t in outs])
+        _lib.require_gpu(x, 'x')
+        if x.dtype != F32 or (x.dim() == 2 and x.shape[1] != 1 and x.stride(1) != 1):
+            raise ValueError('x: fp32 rows with unit inner stride expected')
+        mean = var = None
+        if rms is not None:
+            mean, var = _need(rms[0], F64, 'running_mean'), _need(rms[1], F64, 'running_var')
+        fold = [None] * 5
+        if rms_fold is not None:
+            if rms is None:
+                raise ValueError('rms_fold needs rms')
+            row, cnt, mean_o, var_o, cnt_o = rms_fold
+            if row.numel() != 2 * self.ins[0] + 1:
+                raise ValueError('rms_fold: moments row of 2*in0+1 doubles expected')
+            fold = [_need(row, F64, 'moments row'), _need(cnt, torch.int64, 'count'), _need(mean_o, F64, 'mean out'),
+                    _need(var_o, F64, 'var out'), _need(cnt_o, torch.int64, 'count out')]
+        dz = self._P(*([_need(t, F32, 'dz', contiguous=False) for t in dz_out] + [None]))
+        dl = self._L(*([t.stride(0) for t in dz_out] + [0]))
+        bp = None
+        if bias_partials is not None:
+            bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
+        _time_chain_launch('step16')
+        err = _lib.load().rlg_mlp_chain_step(
+            n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
+            mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold,
+            _need(d_heads, F32, 'd_heads', contiguous=False), d_heads.stride(0), dz, dl, bp,
+            ctypes.addressof(ppo_loss), rows, _stream(x))
+        if err == 801:                                  # hipErrorNotSupported: outside the fused kernel's envelope
+            if chain_timers is not None and chain_timers.get('step16'):
+                chain_timers['step16'].pop()
+                _lib.load().rlg_mlp_chain_time_next(None, None)
+            return False
+        _lib.check(err, 'rlg_mlp_chain_step')
+        self._planes_fresh = None
+        return True
+
     def backward(self, d_heads, acts, dz_out, bias_partials=None, groups=0, ppo_loss=None, split_products=None):
         """d_heads [rows, out_last]; acts / dz_out: per hidden layer H_l (forward's act_out) and the
         dZ_l output; bias_partials: per hidden layer fp64 [num_blocks(rows, 1), out_l] or None.

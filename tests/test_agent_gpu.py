@@ -926,6 +926,35 @@ def test_folded_launches_match_the_separate_ones(graphs):
     assert (a[3] - b[3]).abs().max().item() <= 2.1 * 24 * 1e-2       # 24 Adam steps at lr <= max_lr
 
 
+@pytest.mark.parametrize('graphs', [True, False])
+def test_one_launch_step_in_the_agent_equals_the_two_launches(graphs):
+    """The agent's optimiser step with forward + loss + backward as ONE launch (fused_step16, the default for
+    minibatches below 16,384 rows) against the same agent with the two launches: bit-identical parameters, moments,
+    normaliser state and learning rate after three epochs - and the fused launch really ran."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for fused in (True, False):
+        params = configs.tiny(num_actors=96, horizon=8, hip_graphs=graphs, fused_step16=fused)
+        params['config']['minibatch_size'] = 256                      # 768 rows -> 3 minibatches
+        torch.manual_seed(11)
+        agent = A2CAgent('s', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for _ in range(3):
+            agent.update_epoch()
+            agent.train_epoch()
+        assert agent._engine.last_step_fused == fused
+        m = agent.model.running_mean_std
+        opt = agent.optimizer
+        res.append((opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), m.running_mean.clone(),
+                    m.running_var.clone(), opt.last_and_next_lr()))
+    a, b = res
+    assert a[5] == b[5]
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+
+
 def test_rccl_wrapper_of_the_c_abi_runs_inside_a_graph():
     """the RCCL wrapper taking an ncclComm_t (csrc/rccl_wrap.hip, rl_games_amd/rccl_allreduce.py) - a
     communicator of ONE rank (this box has one GPU, and RCCL refuses two ranks per device): unique id, comm create, an

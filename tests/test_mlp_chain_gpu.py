@@ -357,6 +357,87 @@ def test_backward_evaluates_ppo_loss_like_the_loss_kernel(rows, groups, variant)
         assert torch.allclose(out[True][k], ref, rtol=1e-6, atol=1e-7 * max(1.0, ref.abs().max().item())), k
 
 
+@pytest.mark.parametrize('rows', [4096, 1000, 37])
+@pytest.mark.parametrize('in_dim,units,A', [(108, [400, 200, 100], 21), (60, [256, 128, 64], 8), (12, [100, 52], 11)])
+def test_one_launch_step_equals_forward_then_backward(rows, in_dim, units, A):
+    """Round 4: forward + PPO loss + backward of a minibatch below 16,384 rows as ONE launch (rlg_mlp_chain_step,
+    mlp_chain_step_pipe_kernel: the loss tile's inputs requested before the forward, no launch boundary between the
+    halves) against rlg_mlp_chain_forward followed by rlg_mlp_chain_backward with the loss descriptor - the same device
+    code, so everything is bit-identical: heads, activations, normalised observations, the folded RunningMeanStd state,
+    d heads, every dZ, the bias partials, the loss partials and the mu / sigma write-back."""
+    from rl_games_amd import ops
+    V = 1
+    layers, g = _net(in_dim, units, V + A, 'elu', seed=rows + A)
+    chain = ops.MlpChain(layers, DEV)
+    x = (2 * torch.randn(rows, in_dim, generator=g) + 0.5).to(DEV)
+    logstd = (0.1 * torch.randn(A, generator=g) - 0.3).to(DEV)
+    gg = torch.Generator().manual_seed(rows + 1)
+    base = {'actions': torch.randn(rows, A, generator=gg), 'old_neglogp': 25 + torch.randn(rows, generator=gg),
+            'adv': torch.randn(rows, generator=gg), 'old_values': torch.randn(rows, generator=gg),
+            'returns': torch.randn(rows, generator=gg), 'old_mu': 0.3 * torch.randn(rows, A, generator=gg),
+            'old_sigma': 0.5 + torch.rand(rows, A, generator=gg)}
+    # training-mode statistics fold in the prologue: moments of this minibatch + a state to fold them into
+    moments, _ = ops.column_moments_segments(x, rows)
+    out = {}
+    for fused in (True, False):
+        d = {k: v.clone().to(DEV) for k, v in base.items()}
+        mean = torch.zeros(in_dim, dtype=torch.float64, device=DEV) + 0.25
+        var = torch.ones(in_dim, dtype=torch.float64, device=DEV) * 3.0
+        count = torch.tensor([1000], dtype=torch.int64, device=DEV)
+        mean2, var2, count2 = torch.zeros_like(mean), torch.zeros_like(var), torch.zeros_like(count)
+        heads = torch.full((rows, V + A), float('nan'), device=DEV)
+        acts = [torch.full((rows, u), float('nan'), device=DEV) for u in units]
+        xn = torch.full((rows, in_dim), float('nan'), device=DEV)
+        d_heads = torch.full((rows, V + A), float('nan'), device=DEV)
+        dzs = [torch.full((rows, u), float('nan'), device=DEV) for u in units]
+        nbw = chain.num_blocks(rows, 1)
+        parts = [torch.full((nbw * u,), float('nan'), dtype=torch.float64, device=DEV) for u in units]
+        partials = torch.full((nbw, ops.ppo_loss_partials_per_block(A)), float('nan'), dtype=torch.float64, device=DEV)
+        desc = ops.ppo_loss_desc(heads[:, V:], logstd, heads[:, 0], d['actions'], d['old_neglogp'], d['adv'], d['old_values'],
+                                 d['returns'], d['old_mu'], d['old_sigma'], d_heads[:, V:], d_heads[:, 0], partials, 0.2, 2.0,
+                                 1e-4, clip_value=True, smooth=False, bound_kind=1)
+        fold = (moments[0], count, mean2, var2, count2)
+        if fused:
+            assert chain.step(x, heads, acts, d_heads, dzs, parts, desc, rms=(mean, var), eps=1e-5, xn_out=xn, rms_fold=fold)
+        else:
+            chain.forward(x, heads, act_out=acts, rms=(mean, var), eps=1e-5, xn_out=xn, rms_fold=fold)
+            chain.backward(d_heads, acts, dzs, parts, ppo_loss=desc)
+        torch.cuda.synchronize()
+        out[fused] = [heads, xn, d_heads, d['old_mu'], d['old_sigma'], partials, mean2, var2, count2] + acts + dzs + parts
+    for k, (a, b) in enumerate(zip(out[True], out[False])):
+        assert torch.isfinite(a.double()).all(), k
+        assert torch.equal(a, b), k
+
+
+def test_one_launch_step_declines_what_it_does_not_cover():
+    """rlg_mlp_chain_step returns hipErrorNotSupported (MlpChain.step -> False, nothing launched) for minibatches that
+    run the split-bf16 kernels or need more than one round of workgroups (> 16 rows x CUs: two launches with two
+    workgroups per CU are faster there), for weights outside one arena and without a loss descriptor."""
+    from rl_games_amd import ops
+    layers, g = _net(60, [64, 32], 9, 'elu', seed=1)
+    chain = ops.MlpChain(layers, DEV)
+    rows = 16384
+    x = torch.randn(rows, 60, generator=g).to(DEV)
+    heads = torch.empty(rows, 9, device=DEV)
+    acts = [torch.empty(rows, u, device=DEV) for u in (64, 32)]
+    assert chain.step(x, heads, acts, torch.empty(rows, 9, device=DEV), [torch.empty_like(a) for a in acts], None, None) is False
+    loose, g = _net(60, [64, 32], 9, 'elu', seed=1, packed=False)
+    chain2 = ops.MlpChain(loose, DEV)
+    rows = 256
+    x = torch.randn(rows, 60, generator=g).to(DEV)
+    heads = torch.full((rows, 9), float('nan'), device=DEV)
+    acts = [torch.empty(rows, u, device=DEV) for u in (64, 32)]
+    d_heads = torch.empty(rows, 9, device=DEV)
+    partials = torch.empty(chain2.num_blocks(rows, 1), ops.ppo_loss_partials_per_block(8), dtype=torch.float64, device=DEV)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    desc = ops.ppo_loss_desc(heads[:, 1:], z(8), heads[:, 0], z(rows, 8), z(rows), z(rows), z(rows), z(rows), z(rows, 8),
+                             z(rows, 8) + 1, d_heads[:, 1:], d_heads[:, 0], partials, 0.2, 2.0, 1e-4, clip_value=True,
+                             smooth=False, bound_kind=1)
+    parts = [torch.empty(chain2.num_blocks(rows, 1) * u, dtype=torch.float64, device=DEV) for u in (64, 32)]
+    assert chain2.step(x, heads, acts, d_heads, [torch.empty_like(a) for a in acts], parts, desc) is False
+    assert torch.isnan(heads).all()                    # nothing ran
+
+
 def test_engine_fused_chain_equals_per_layer_engine():
     """ManualMLP with the fused chain vs the per-layer (library GEMM) engine: same heads, same
     gradients in the arena, on a BASELINE config #2 shaped network."""
