@@ -835,7 +835,9 @@ long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int targe
   const int batch = dw_split_products() ? kDwSplitBatch : kDwBatch;
   // default workgroup count (32,768 rows: 80 us at 256 / 89 us at 1,024 in the split form, 171 / 119 us with
   // f32 products, whose workgroups are 2.5x longer; a rank's 4,096-row minibatch wants <= 16 slices either way)
-  if (target_blocks <= 0) target_blocks = (dw_split_products() || rows <= 8192) ? 256 : 1024;
+  // (<= 4,096 rows - one rank of 8: 8 K-slices per layer, 416 workgroups of the humanoid network = ONE round of the 512
+  //  resident slots instead of 830 in 1.6 rounds: 31.1 -> 30.5 ms per rank epoch, profiles/r4_rank_shapes.txt)
+  if (target_blocks <= 0) target_blocks = rows <= 4096 ? 100 : ((dw_split_products() || rows <= 8192) ? 256 : 1024);
   int ksplit = 8;
   while (ksplit * 2 <= 64 && steps / (ksplit * 2 * 4) >= 2 * batch && tiles_o * tiles_i * ksplit < target_blocks)
     ksplit *= 2;
