@@ -237,22 +237,24 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
     };
     auto compute8 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
       RLG_DW_PIN();
+      // blocks are split two at a time where a lane's row vector holds two (dw_split8x2: packed residuals)
       u32x4 pb[BI][3];
+      if constexpr (BI >= 2) {
 #pragma unroll
-      for (int b = 0; b < BI; ++b) {
+        for (int b = 0; b < BI; b += 2) {
+          split_f32x2 x[8];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) x[u] = split_f32x2{dw_get<BI>(bv[u], b), dw_get<BI>(bv[u], b + 1)};
+          dw_split8x2(x, pb[b], pb[b + 1]);
+        }
+      } else {
         float x[8];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], b);
-        dw_split8(x, pb[b]);
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], 0);
+        dw_split8(x, pb[0]);
       }
-#pragma unroll
-      for (int a = 0; a < BO; ++a) {
-        float x[8];
-#pragma unroll
-        for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], a);
-        u32x4 pa[3];
-        dw_split8(x, pa);
-        // small terms first; consecutive MFMAs go to different accumulators
+      // small terms first; consecutive MFMAs go to different accumulators
+      auto products = [&](int a, const u32x4 (&pa)[3]) {
         constexpr int kPa[6] = {2, 0, 1, 1, 0, 0};
         constexpr int kPb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -263,6 +265,25 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
                                                                 __builtin_bit_cast(bf16x8, pb[b][kPb[t]]),
                                                                 acc[a][b], 0, 0, 0);
         }
+      };
+      if constexpr (BO >= 2) {
+#pragma unroll
+        for (int a = 0; a < BO; a += 2) {
+          split_f32x2 x[8];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) x[u] = split_f32x2{dw_get<BO>(av[u], a), dw_get<BO>(av[u], a + 1)};
+          u32x4 pa0[3], pa1[3];
+          dw_split8x2(x, pa0, pa1);
+          products(a, pa0);
+          products(a + 1, pa1);
+        }
+      } else {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], 0);
+        u32x4 pa[3];
+        dw_split8(x, pa);
+        products(0, pa);
       }
       RLG_DW_PIN();
     };

@@ -8,21 +8,69 @@ namespace rlg {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// 8 floats (the lane's 8 k values of one 16-wide block) -> 3 planes of 8 packed bf16.  The conversion is
-// an asm statement so that hipcc keeps ONE v_cvt_pk_bf16_f32 (RNE) per pair (it otherwise converts the low
-// half a second time for the shift) and leaves the residuals as plain v_sub_f32 (no v_pk_add_f32 + moves).
+#ifndef RLG_SPLIT_PK
+#define RLG_SPLIT_PK 1           // 0: scalar residuals (v_sub_f32), the round-2 form - same bits, 11 instead of 9 VALU per pair
+#endif
+
+typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+
+// One pair of fp32 values (an even-aligned register pair) -> its dword of each of the three planes.  Per pair: 3
+// v_cvt_pk_bf16_f32 (RNE; an asm statement so that hipcc keeps ONE conversion per pair - it otherwise converts the low
+// half a second time for the shift) and, for each of the two residuals, v_lshlrev + v_and + ONE v_pk_add_f32 with
+// negated second operand (exact: the residual has <= 16 (8) significant bits) = 9 VALU instructions; the splitting is
+// the largest VALU item of every split-product kernel and VALU time adds to MFMA time on gfx950.
+__device__ __forceinline__ void split_pair(split_f32x2 r, unsigned& p0, unsigned& p1, unsigned& p2) {
+  unsigned w;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  p0 = w;
+#if RLG_SPLIT_PK
+  r = r - split_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+#else
+  r[0] -= __uint_as_float(w << 16);
+  r[1] -= __uint_as_float(w & 0xffff0000u);
+#endif
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  p1 = w;
+#if RLG_SPLIT_PK
+  r = r - split_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+#else
+  r[0] -= __uint_as_float(w << 16);
+  r[1] -= __uint_as_float(w & 0xffff0000u);
+#endif
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  p2 = w;
+}
+
+// 8 floats (the lane's 8 k values of one 16-wide block) -> 3 planes of 8 packed bf16; x[2q], x[2q + 1] share a dword.
 __device__ __forceinline__ void dw_split8(const float (&x)[8], u32x4 (&plane)[3]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float lo = x[2 * q], hi = x[2 * q + 1];
+    unsigned p0, p1, p2;
+    split_pair(split_f32x2{x[2 * q], x[2 * q + 1]}, p0, p1, p2);
+    plane[0][q] = p0;
+    plane[1][q] = p1;
+    plane[2][q] = p2;
+  }
+}
+
+// Two blocks at once whose values sit side by side in the registers - xa[u], xb[u] = elements (a, a + 1) of the row
+// vector a lane loaded for k value u (the weight-gradient kernel): the packed residual pairs the two COLUMNS of a row
+// (adjacent registers as loaded - pairing the rows would cost two moves per pair), the conversion pairs the rows of a
+// column as the MFMA operand wants them.  Same values as two dw_split8 calls.
+__device__ __forceinline__ void dw_split8x2(const split_f32x2 (&x)[8], u32x4 (&plane_a)[3], u32x4 (&plane_b)[3]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    split_f32x2 r0 = x[2 * q], r1 = x[2 * q + 1];           // rows 2q, 2q + 1; [0] = column a, [1] = column a + 1
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      unsigned w;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
-      plane[p][q] = w;
+      unsigned wa, wb;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wa) : "v"(r0[0]), "v"(r1[0]));
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wb) : "v"(r0[1]), "v"(r1[1]));
+      plane_a[p][q] = wa;
+      plane_b[p][q] = wb;
       if (p < 2) {
-        lo -= __uint_as_float(w << 16);                  // exact: the residual has <= 16 (8) significant bits
-        hi -= __uint_as_float(w & 0xffff0000u);
+        r0 = r0 - split_f32x2{__uint_as_float(wa << 16), __uint_as_float(wb << 16)};
+        r1 = r1 - split_f32x2{__uint_as_float(wa & 0xffff0000u), __uint_as_float(wb & 0xffff0000u)};
       }
     }
   }
@@ -31,19 +79,8 @@ __device__ __forceinline__ void dw_split8(const float (&x)[8], u32x4 (&plane)[3]
 // 4 floats -> 3 planes of 2 dwords (4 packed bf16), same pairing as dw_split8
 __device__ __forceinline__ void split4_planes(const f32x4& x, unsigned (&plane)[3][2]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    float lo = x[2 * q], hi = x[2 * q + 1];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      unsigned w;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
-      plane[p][q] = w;
-      if (p < 2) {
-        lo -= __uint_as_float(w << 16);
-        hi -= __uint_as_float(w & 0xffff0000u);
-      }
-    }
-  }
+  for (int q = 0; q < 2; ++q)
+    split_pair(split_f32x2{x[2 * q], x[2 * q + 1]}, plane[0][q], plane[1][q], plane[2][q]);
 }
 
 }  // namespace rlg

@@ -421,19 +421,21 @@ def test_one_launch_step_declines_what_it_does_not_cover():
     heads = torch.empty(rows, 9, device=DEV)
     acts = [torch.empty(rows, u, device=DEV) for u in (64, 32)]
     assert chain.step(x, heads, acts, torch.empty(rows, 9, device=DEV), [torch.empty_like(a) for a in acts], None, None) is False
-    loose, g = _net(60, [64, 32], 9, 'elu', seed=1, packed=False)
+    # (52 x 60 floats = 12,480 bytes: the allocator rounds the block to 12,800, so nothing of the network can lie within
+    #  16 bytes behind the first matrix - with 64 x 60 = 30 x 512 bytes the bias may follow it and the launch is covered)
+    loose, g = _net(60, [52, 32], 9, 'elu', seed=1, packed=False)
     chain2 = ops.MlpChain(loose, DEV)
     rows = 256
     x = torch.randn(rows, 60, generator=g).to(DEV)
     heads = torch.full((rows, 9), float('nan'), device=DEV)
-    acts = [torch.empty(rows, u, device=DEV) for u in (64, 32)]
+    acts = [torch.empty(rows, u, device=DEV) for u in (52, 32)]
     d_heads = torch.empty(rows, 9, device=DEV)
     partials = torch.empty(chain2.num_blocks(rows, 1), ops.ppo_loss_partials_per_block(8), dtype=torch.float64, device=DEV)
     z = lambda *s: torch.zeros(*s, device=DEV)
     desc = ops.ppo_loss_desc(heads[:, 1:], z(8), heads[:, 0], z(rows, 8), z(rows), z(rows), z(rows), z(rows), z(rows, 8),
                              z(rows, 8) + 1, d_heads[:, 1:], d_heads[:, 0], partials, 0.2, 2.0, 1e-4, clip_value=True,
                              smooth=False, bound_kind=1)
-    parts = [torch.empty(chain2.num_blocks(rows, 1) * u, dtype=torch.float64, device=DEV) for u in (64, 32)]
+    parts = [torch.empty(chain2.num_blocks(rows, 1) * u, dtype=torch.float64, device=DEV) for u in (52, 32)]
     assert chain2.step(x, heads, acts, d_heads, [torch.empty_like(a) for a in acts], parts, desc) is False
     assert torch.isnan(heads).all()                    # nothing ran
 
