@@ -48,6 +48,12 @@ constexpr int kDwBatch = 4;        // k-steps (of 4 rows) per prefetch batch
 #define RLG_DW_SETS 3
 #endif
 constexpr int kDwSets = RLG_DW_SETS;   // register sets: kDwSets-1 batches of loads in flight
+#ifndef RLG_DW_PK_A
+#define RLG_DW_PK_A 1
+#endif
+#ifndef RLG_DW_PK_B
+#define RLG_DW_PK_B 1
+#endif
 constexpr int kDwSplitBatch = 8;       // k-steps per batch of the split-bf16 form (K = 32 of one bf16 MFMA)
 
 // RLG_DW_BF16=0 selects exact f32 products (the round-1 kernel: 1.3x slower, same accuracy class)
@@ -239,7 +245,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       RLG_DW_PIN();
       // blocks are split two at a time where a lane's row vector holds two (dw_split8x2: packed residuals)
       u32x4 pb[BI][3];
-      if constexpr (BI >= 2) {
+      if constexpr (BI >= 2 && RLG_DW_PK_B) {
 #pragma unroll
         for (int b = 0; b < BI; b += 2) {
           split_f32x2 x[8];
@@ -248,10 +254,13 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
           dw_split8x2(x, pb[b], pb[b + 1]);
         }
       } else {
-        float x[8];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], 0);
-        dw_split8(x, pb[0]);
+        for (int b = 0; b < BI; ++b) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], b);
+          dw_split8(x, pb[b]);
+        }
       }
       // small terms first; consecutive MFMAs go to different accumulators
       auto products = [&](int a, const u32x4 (&pa)[3]) {
@@ -266,7 +275,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
                                                                 acc[a][b], 0, 0, 0);
         }
       };
-      if constexpr (BO >= 2) {
+      if constexpr (BO >= 2 && RLG_DW_PK_A) {
 #pragma unroll
         for (int a = 0; a < BO; a += 2) {
           split_f32x2 x[8];
@@ -278,12 +287,15 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
           products(a + 1, pa1);
         }
       } else {
-        float x[8];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], 0);
-        u32x4 pa[3];
-        dw_split8(x, pa);
-        products(0, pa);
+        for (int a = 0; a < BO; ++a) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], a);
+          u32x4 pa[3];
+          dw_split8(x, pa);
+          products(a, pa);
+        }
       }
       RLG_DW_PIN();
     };

@@ -13,15 +13,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 
 typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 split_bf16x2 __attribute__((ext_vector_type(2)));
+
+// RNE conversion of a pair: ONE v_cvt_pk_bf16_f32.  NOT an asm statement (rounds 2 - 3 had one here): an instruction
+// inside inline asm is invisible to hipcc's hazard recogniser, and a VALU result needs 2 wait states before an MFMA may
+// read it as SrcA / SrcB - the weight-gradient kernel's (2, 2) tile ran some of its MFMAs one wait state behind the
+// conversion that produced their operand and picked up the previous batch's plane now and then (last-bit noise that
+// changed from run to run; tools/exp/determinism_probe.py).  hipcc places `s_nop 1` itself for the builtin form.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((split_f32x2{lo, hi}), split_bf16x2));
+}
 
 // One pair of fp32 values (an even-aligned register pair) -> its dword of each of the three planes.  Per pair: 3
-// v_cvt_pk_bf16_f32 (RNE; an asm statement so that hipcc keeps ONE conversion per pair - it otherwise converts the low
-// half a second time for the shift) and, for each of the two residuals, v_lshlrev + v_and + ONE v_pk_add_f32 with
-// negated second operand (exact: the residual has <= 16 (8) significant bits) = 9 VALU instructions; the splitting is
-// the largest VALU item of every split-product kernel and VALU time adds to MFMA time on gfx950.
+// v_cvt_pk_bf16_f32 (RNE) and, for each of the two residuals, v_lshlrev + v_and + ONE v_pk_add_f32 with negated second
+// operand (exact: the residual has <= 16 (8) significant bits) = 9 VALU instructions; the splitting is the largest
+// VALU item of every split-product kernel and VALU time adds to MFMA time on gfx950.
 __device__ __forceinline__ void split_pair(split_f32x2 r, unsigned& p0, unsigned& p1, unsigned& p2) {
-  unsigned w;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  unsigned w = cvt_pk_bf16(r[0], r[1]);
   p0 = w;
 #if RLG_SPLIT_PK
   r = r - split_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
@@ -29,7 +37,7 @@ __device__ __forceinline__ void split_pair(split_f32x2 r, unsigned& p0, unsigned
   r[0] -= __uint_as_float(w << 16);
   r[1] -= __uint_as_float(w & 0xffff0000u);
 #endif
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  w = cvt_pk_bf16(r[0], r[1]);
   p1 = w;
 #if RLG_SPLIT_PK
   r = r - split_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
@@ -37,7 +45,7 @@ __device__ __forceinline__ void split_pair(split_f32x2 r, unsigned& p0, unsigned
   r[0] -= __uint_as_float(w << 16);
   r[1] -= __uint_as_float(w & 0xffff0000u);
 #endif
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(r[0]), "v"(r[1]));
+  w = cvt_pk_bf16(r[0], r[1]);
   p2 = w;
 }
 
@@ -58,14 +66,23 @@ __device__ __forceinline__ void dw_split8(const float (&x)[8], u32x4 (&plane)[3]
 // (adjacent registers as loaded - pairing the rows would cost two moves per pair), the conversion pairs the rows of a
 // column as the MFMA operand wants them.  Same values as two dw_split8 calls.
 __device__ __forceinline__ void dw_split8x2(const split_f32x2 (&x)[8], u32x4 (&plane_a)[3], u32x4 (&plane_b)[3]) {
+#if !RLG_SPLIT_PK
+  float xa[8], xb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    xa[u] = x[u][0];
+    xb[u] = x[u][1];
+  }
+  dw_split8(xa, plane_a);
+  dw_split8(xb, plane_b);
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     split_f32x2 r0 = x[2 * q], r1 = x[2 * q + 1];           // rows 2q, 2q + 1; [0] = column a, [1] = column a + 1
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      unsigned wa, wb;
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wa) : "v"(r0[0]), "v"(r1[0]));
-      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wb) : "v"(r0[1]), "v"(r1[1]));
+      const unsigned wa = cvt_pk_bf16(r0[0], r1[0]), wb = cvt_pk_bf16(r0[1], r1[1]);
       plane_a[p][q] = wa;
       plane_b[p][q] = wb;
       if (p < 2) {

@@ -132,6 +132,27 @@ def test_mfma_audit_catches_the_hazards_it_is_meant_to():
     assert not [b for b in mod.audit_function(_listing(between))[1] if b[0].startswith('100:')]
 
 
+def test_mfma_audit_flags_a_valu_result_read_by_an_mfma_too_early():
+    """The second guard of the audit: a VGPR written by a VALU instruction needs 2 wait states before an MFMA reads
+    it as SrcA / SrcB / SrcC.  The defect it is there for: `v_cvt_pk_bf16_f32` inside an asm statement (invisible to
+    hipcc's hazard recogniser) one wait state in front of the MFMA that consumed the plane (rounds 2 - 3)."""
+    mod = _audit_module()
+    cvt = ('v_cvt_pk_bf16_f32', 'v43, v58, v43')
+    bf = ('v_mfma_f32_16x16x32_bf16', 'v[2:5], v[28:31], v[40:43], v[2:5]')
+    tail = [('s_nop', '15'), ('s_endpgm', '')]
+    assert [b[2] for b in mod.audit_valu_feeds(_listing([cvt, bf] + tail))] == [0]
+    assert [b[2] for b in mod.audit_valu_feeds(_listing([cvt, ('s_nop', '0'), bf] + tail))] == [1]
+    assert [b[2] for b in mod.audit_valu_feeds(_listing([cvt, ('v_and_b32_e32', 'v20, 0xffff0000, v39'), bf] + tail))] == [1]
+    assert not mod.audit_valu_feeds(_listing([cvt, ('s_nop', '1'), bf] + tail))
+    assert not mod.audit_valu_feeds(_listing([cvt, ('v_mov_b32_e32', 'v1, v0'), ('v_mov_b32_e32', 'v6, v0'), bf] + tail))
+    # SrcC counts; a VALU result nobody multiplies with does not; through a taken branch the distance is the path's
+    as_c = ('v_mfma_f32_16x16x32_bf16', 'v[40:43], v[28:31], v[32:35], v[40:43]')
+    assert len(mod.audit_valu_feeds(_listing([cvt, as_c] + tail))) == 1
+    assert not mod.audit_valu_feeds(_listing([('v_mov_b32_e32', 'v90, v0'), bf] + tail))
+    prog = [cvt, ('s_cbranch_execnz', '3'), ('s_nop', '3'), bf, ('s_endpgm', ''), bf] + tail
+    assert sorted(b[2] for b in mod.audit_valu_feeds(_listing(prog))) == [1]
+
+
 def test_dw_plan_defaults_follow_the_product_form():
     """rlg_mlp_dw_plan is host code: the default workgroup target (target_blocks <= 0) gives the split-bf16
     form (default) 16 / 16 / 32 / 64 K-slices for the BASELINE MLP at 32,768 rows and the exact-f32 form

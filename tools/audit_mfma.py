@@ -21,7 +21,13 @@ disassembly) and fails on a read of a result register inside the window.  A wait
 wave (4 cycles: the measured windows, 10 and 8, are the 40- and 32-cycle latencies of the two shapes); they
 are counted the way LLVM's hazard recognizer does - one per instruction, N + 1 for s_nop N - except that a
 following MFMA cannot start before the passes of the audited one have left the matrix core.  Exit status 1
-and a listing."""
+and a listing.
+
+Second guard (round 4): a VGPR written by a VALU instruction must not be read by an MFMA (SrcA / SrcB / SrcC) before 2
+wait states have gone by.  hipcc places the `s_nop 1` itself - for instructions it can see: rounds 2 - 3 produced the
+bf16 planes with `v_cvt_pk_bf16_f32` inside an asm statement, 78 MFMAs of the weight-gradient kernel ran one wait
+state behind the conversion of their operand, and its (2, 2) tile picked up the previous batch's plane now and then
+(csrc/split_bf16.hpp; tools/exp/determinism_probe.py).  The audit flags every such pair whatever produced it."""
 import os
 import re
 import shutil
@@ -175,6 +181,41 @@ def audit_function(func):
     return count, bad
 
 
+VALU_TO_MFMA_WAIT_STATES = 2
+
+
+def audit_valu_feeds(func):
+    """-> [(valu line, mfma line, wait states)]: MFMAs that read a VALU result too early."""
+    succ = _successors(func)
+    bad = []
+    for i, (addr, mn, ops) in enumerate(func):
+        if not mn.startswith('v_') or _window(mn) or mn.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
+            continue
+        o = _split_operands(ops)
+        dst = frozenset(r for r in _regs(o[0]) if r[0] in 'va') if o else frozenset()
+        if not dst:
+            continue
+        todo = [(j, 0) for j in succ[i]]
+        seen = set()
+        while todo:
+            j, ws = todo.pop()
+            if ws >= VALU_TO_MFMA_WAIT_STATES or (j, ws) in seen:
+                continue
+            seen.add((j, ws))
+            _, mn2, ops2 = func[j]
+            step = 1
+            if mn2 == 's_nop':
+                step = int(ops2.split()[0]) + 1
+            elif _window(mn2):
+                o2 = _split_operands(ops2)
+                if (_regs(o2[1]) | _regs(o2[2]) | _regs(o2[3] if len(o2) > 3 else '')) & dst:
+                    bad.append((f'{addr:x}: {mn} {ops}', f'{func[j][0]:x}: {mn2} {ops2}', ws))
+                continue            # (an MFMA in between is far more than two wait states)
+            for k in succ[j]:
+                todo.append((k, ws + step))
+    return bad
+
+
 def audit(lib_path):
     """-> (number of MFMA instructions, [offending 'mfma -> reader (wait states)' lines])."""
     work = tempfile.mkdtemp(prefix='rlg_audit_')
@@ -192,6 +233,7 @@ def audit(lib_path):
                 n, b = audit_function(func)
                 count += n
                 bad += [f'{m}  ->  {r}   ({ws} wait states)' for m, r, ws in b]
+                bad += [f'VALU result read by an MFMA: {v}  ->  {r}   ({ws} wait states)' for v, r, ws in audit_valu_feeds(func)]
         return count, bad
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -200,7 +242,7 @@ def audit(lib_path):
 if __name__ == '__main__':
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'rl_games_amd', 'librlg_hip.so')
     n, bad = audit(path)
-    print(f'{path}: {n} MFMA instructions, {len(bad)} result reads inside the hazard window')
+    print(f'{path}: {n} MFMA instructions, {len(bad)} reads inside a hazard window (MFMA result -> reader, VALU result -> MFMA)')
     for b in bad[:60]:
         print('   ', b)
     sys.exit(1 if bad else 0)
