@@ -554,6 +554,47 @@ int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float*
                        float* const* dz_out, const long long* dz_ld, double* const* bias_partials_or_null,
                        const rlg_ppo_loss_desc* ppo_loss, long long rows, void* stream);
 
+/* The 16-row launches of a data-parallel rank's minibatches (< 16,384 rows; rollouts of that size) in their LEAN form
+ * (round 4; csrc/mlp_chain.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as fp32 FRAGMENTS in
+ * the order each of the 8 waves of a workgroup consumes them - one linear stream per wave across blocks and layers, zero
+ * padding instead of out-of-range selects; the backward's fragments are the transposed matrices (one 16-byte load per lane and chunk where the row-major matrix
+ * needs four strided dword loads).  Same maths as rlg_mlp_chain_forward / rlg_mlp_chain_backward in their 16-row form
+ * (network_builder.py:447-512 and autograd's backward of it), the same products in the same order: results bit-identical
+ * to the pipelined kernels'.
+ *   rlg_mlp_chain_frags_bytes: size of one direction's fragment buffer (0 forward, 1 backward), < 0: shape
+ *     outside the format.
+ *   rlg_mlp_chain_pack_frags / _both: weights -> fragments, one launch (the bias pointers are not read); to be repeated behind every change of
+ *     the weights (an agent issues it behind its optimiser step).
+ *   rlg_mlp_chain_forward_lean / rlg_mlp_chain_backward_lean: the launches; arguments as their namesakes without the
+ *     weight pointers.  hipErrorNotSupported (801): shape outside the kernels' envelope (LDS, unaligned H / dZ
+ *     rows) - the caller then uses rlg_mlp_chain_forward / rlg_mlp_chain_backward. */
+long long rlg_mlp_chain_frags_bytes(int num_layers, const int* in_features, const int* out_features, int direction);
+int rlg_mlp_chain_pack_frags(int num_layers, const float* const* weights, const float* const* biases_or_null,
+                             const int* in_features, const int* out_features, int direction, void* frags, void* stream);
+int rlg_mlp_chain_pack_frags_both(int num_layers, const float* const* weights, const float* const* biases,
+                                  const int* in_features, const int* out_features, void* frags_fwd, void* frags_bwd_or_null,
+                                  void* stream);
+int rlg_mlp_chain_forward_lean(int num_layers, const float* const* biases, const int* in_features, const int* out_features,
+                               const int* acts, float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                               const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                               const double* rms_batch, const long long* rms_count, double* rms_mean_out,
+                               double* rms_var_out, long long* rms_count_out, long long rows, const void* frags,
+                               void* stream);
+/* forward + PPO loss + backward in ONE lean launch (the arguments of rlg_mlp_chain_step without the weight pointers;
+ * minibatches of at most 16 rows x CUs; 801 otherwise) */
+int rlg_mlp_chain_step_lean(int num_layers, const float* const* biases, const int* in_features, const int* out_features,
+                            const int* acts, float* const* act_out, const long long* act_ld, const float* x, long long ldx,
+                            const double* rms_mean, const double* rms_var, float rms_eps, float* xn_out,
+                            const double* rms_batch, const long long* rms_count, double* rms_mean_out,
+                            double* rms_var_out, long long* rms_count_out, float* d_out, long long ld_dout,
+                            float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
+                            const rlg_ppo_loss_desc* ppo_loss, long long rows, const void* frags_fwd, const void* frags_bwd,
+                            void* stream);
+int rlg_mlp_chain_backward_lean(int num_layers, const int* in_features, const int* out_features, const int* acts,
+                                const float* const* act_in, const long long* act_ld, const float* d_out, long long ld_dout,
+                                float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
+                                const rlg_ppo_loss_desc* ppo_loss, long long rows, const void* frags, void* stream);
+
 /* Split-bf16 form of the chain (csrc/mlp_chain_bx.hip): every fp32 product as six exact bf16 plane products on
  * v_mfma_f32_16x16x32_bf16 (results within 3 * 2^-24 |x||w| per product of the exact-product kernels).  The weights
  * are split ONCE per optimizer step into plane fragments; the launch that is given them (weight_planes_or_null of

@@ -90,6 +90,15 @@ _PROTOTYPES = {
     'rlg_mlp_chain_step': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                            _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P, _P],
+    # experimental lean 16-row forward (csrc/mlp_chain.hip, mlp_chain_fwd_lean_kernel)
+    'rlg_mlp_chain_frags_bytes': [_c_int, _P, _P, _c_int],
+    'rlg_mlp_chain_pack_frags': [_c_int, _P, _P, _P, _P, _c_int, _P, _P],
+    'rlg_mlp_chain_pack_frags_both': [_c_int, _P, _P, _P, _P, _P, _P, _P],
+    'rlg_mlp_chain_step_lean': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
+                                _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _P, _P, _P],
+    'rlg_mlp_chain_backward_lean': [_c_int, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _P, _P],
+    'rlg_mlp_chain_forward_lean': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
+                                   _P, _P, _P, _P, _P, _c_ll, _P, _P],
     # mlp_chain_bx.hip
     'rlg_mlp_chain_planes_bytes': [_c_int, _P, _P, _c_int],
     'rlg_mlp_chain_planes_offset': [_c_int, _P, _P, _c_int],
@@ -151,7 +160,8 @@ def exported_prototypes():
     return dict(_PROTOTYPES)
 
 
-_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan', 'rlg_stats_sync_flat_size', 'rlg_mlp_chain_planes_bytes', 'rlg_mlp_chain_planes_offset'}
+_RETURNS_LONG_LONG = {'rlg_mlp_dw_plan', 'rlg_stats_sync_flat_size', 'rlg_mlp_chain_planes_bytes', 'rlg_mlp_chain_planes_offset',
+                      'rlg_mlp_chain_frags_bytes'}
 
 
 def load():

@@ -135,6 +135,25 @@ class DeviceAverageMeter:
         self.mean = (self.mean * old_size + new_mean * size) / size_sum
 
 
+class _LeanChains:
+    """The fp32 weight fragments of the lean 16-row kernels of one or two ops.MlpChain objects, handled together."""
+
+    def __init__(self, chains):
+        self.chains = chains
+
+    def pack_frags(self, stream_of):
+        for c in self.chains:
+            c.pack_frags(stream_of)
+
+    def mark_frags(self, version):
+        for c in self.chains:
+            c.mark_frags(version)
+
+    def ensure_frags(self, stream_of):
+        for c in self.chains:
+            c.ensure_frags(stream_of)
+
+
 class A2CAgent:
     def __init__(self, base_name, params):
         self.config = config = params['config']
@@ -403,6 +422,7 @@ class A2CAgent:
         self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
         self._step_in_backward = False  # the finalise launch of the current minibatch performed the optimiser step itself
         self._adam_pack = None        # decided on first use (_adam_pack_chain)
+        self._lean_pack = None        # decided on first use (_lean_chain)
         self._roll_env_actions = None
         self._ar_norm_partials = None
         self._fold_index = None
@@ -1257,17 +1277,42 @@ class A2CAgent:
 
     def _optimizer_kernels(self):
         opt = self.optimizer
+        lean = self._lean_chain()
         if self._step_in_backward:
             # the weight-gradient finalise launch of this minibatch performed the step (fused_step_tail)
             self._step_in_backward = False
             self._norm_ready = None
             opt.step_done()
+            if lean is not None:
+                lean.pack_frags(opt.flat_params)
+                lean.mark_frags(opt.weights_version)
             return
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
         opt.step(norm_ready=self._norm_ready, skip_flag=skip, pack=self._adam_pack_chain(), **self._step_arguments())
         self._norm_ready = None
+        if lean is not None:
+            # the lean 16-row kernels read the weights as fp32 fragments: one launch behind every step keeps them current
+            # (inside the captured graphs too - no launch of this agent ever packs on demand)
+            lean.pack_frags(opt.flat_params)
+            lean.mark_frags(opt.weights_version)
+
+    def _lean_chain(self):
+        """The fused chains (the MLP's, or the trunk in front of a recurrent layer) whose launches run the lean 16-row
+        kernels at one of this agent's sizes (csrc/mlp_chain.hip: minibatches / rollouts of < 16,384 rows on exact
+        products), as one object with pack_frags / mark_frags / ensure_frags - or None."""
+        c = self._lean_pack
+        if c is None:
+            c = False
+            eng = self._engine
+            rows = (self.minibatch_size, self.num_actors * self.num_agents)
+            chains = [ch for ch in (getattr(eng, 'chain', None), getattr(eng, 'chain_rnn', None))
+                      if ch is not None and any(ch.lean_used(r, d) for r in rows for d in (0, 1))]
+            if chains:
+                c = _LeanChains(chains)
+            self._lean_pack = c
+        return c or None
 
     def _adam_pack_chain(self):
         """The fused chain whose bf16 weight planes the Adam launch writes itself (csrc/mlp_chain_bx.hip,
@@ -1291,6 +1336,8 @@ class A2CAgent:
         chain = self._adam_pack_chain()
         if chain is not None:
             chain.ensure_planes(self.optimizer.flat_params)
+        if self._lean_chain() is not None:
+            self._lean_chain().ensure_frags(self.optimizer.flat_params)
 
     # ------------------------------------------------------------------ HIP graphs
     def _with_fold(self, mb_index, fn, *args):
@@ -1386,6 +1433,9 @@ class A2CAgent:
             g.replay()
             self._norm_ready = None
             self.optimizer.step_done()
+            if self._lean_chain() is not None:
+                self._lean_chain().pack_frags(self.optimizer.flat_params)
+                self._lean_chain().mark_frags(self.optimizer.weights_version)
             return
         if self._graph_opt is None:
             # Captured BEFORE anything of this minibatch runs (a failed capture then leaves minibatch i untouched
@@ -1404,6 +1454,8 @@ class A2CAgent:
         self.optimizer.step_done()
         if self._adam_pack_chain() is not None and not self._graph_step_inside:
             self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
+        if self._lean_chain() is not None:
+            self._lean_chain().mark_frags(self.optimizer.weights_version)
 
     def _graph_mini_epoch(self, nmb):
         """Single-GPU runs with nothing to do on the host between minibatches (device-side or
@@ -1432,6 +1484,8 @@ class A2CAgent:
         self.optimizer.weights_version += nmb
         if self._adam_pack_chain() is not None and not self._fused_tail_in_graph:
             self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
+        if self._lean_chain() is not None:
+            self._lean_chain().mark_frags(self.optimizer.weights_version)
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,

@@ -625,6 +625,15 @@ def _time_chain_launch(kind):
     _lib.check(_lib.load().rlg_mlp_chain_time_next(ev.start, ev.stop), 'rlg_mlp_chain_time_next')
 
 
+def _untime_chain_launch(kind):
+    """The launch that _time_chain_launch(kind) announced did not happen (the entry declined the shape)."""
+    if chain_timers is None or torch.cuda.is_current_stream_capturing():
+        return
+    if chain_timers.get(kind):
+        chain_timers[kind].pop()
+    _lib.load().rlg_mlp_chain_time_next(None, None)
+
+
 class MlpChain:
     """The whole MLP (hidden layers + the fused value|mu head as the last layer) as ONE forward and
     ONE backward launch (csrc/mlp_chain.hip).  `layers`: list of (weight [out, in], bias [out], act
@@ -658,6 +667,16 @@ class MlpChain:
             if best == 0 and (direction == 0 or n > 1):
                 raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
             self.max_groups[direction] = best
+        # lean 16-row kernels (csrc/mlp_chain.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as
+        # fp32 fragments in each wave's consumption order; RLG_CHAIN_LEAN=0 keeps the pipelined kernels
+        self._lean = os.environ.get('RLG_CHAIN_LEAN', '1') != '0'
+        self._frag_bytes = [int(lib.rlg_mlp_chain_frags_bytes(n, self._in, self._out, 0)),
+                            int(lib.rlg_mlp_chain_frags_bytes(n, self._in, self._out, 1)) if n > 1 else -1]
+        if self._frag_bytes[0] < 0:
+            self._lean = False
+        self._frags = None         # [forward fragments | backward fragments], fp32
+        self._frags_for = None     # weights version the fragments hold
+        self._frags_once = False
         self._planes = None        # bf16 plane fragments of the weights, both directions (csrc/mlp_chain_bx.hip)
         self._bwd_offset = 0
         self._planes_fresh = None  # (rows, weights version) of the training forward that packed the backward planes
@@ -665,9 +684,48 @@ class MlpChain:
         self._planes_packed_once = False
 
     def invalidate_planes(self):
-        """The weights changed behind this object's back: backward() re-packs its planes."""
+        """The weights changed behind this object's back: backward() re-packs its planes (and the lean kernels'
+        fragments are packed again)."""
         self._planes_fresh = None
         self._planes_for = None
+        self._frags_for = None
+
+    # ---- fp32 fragments of the lean 16-row kernels
+    def lean_used(self, rows, direction, requested=0):
+        """True when the launch of this direction runs the lean 16-row kernel for `rows` rows (16-row workgroups, exact
+        products; the backward additionally needs 16-byte aligned H / dZ rows, checked at its launch)."""
+        if not self._lean or (direction == 1 and self._frag_bytes[1] < 0):
+            return False
+        return self.groups(rows, direction, requested) == 1 and not self.split_products(rows, direction, requested)
+
+    def _frag_buffer(self):
+        if self._frags is None:
+            fb, bb = self._frag_bytes[0], max(self._frag_bytes[1], 0)
+            self._frags = torch.empty((fb + bb) // 4, dtype=F32, device=self.device)
+        return self._frags
+
+    def _frags_ptr(self, direction):
+        return self._frag_buffer().data_ptr() + (self._frag_bytes[0] if direction == 1 else 0)
+
+    def pack_frags(self, stream_of):
+        """Weights (+ biases) -> the fragments of both directions, one launch.  Behind every change of the weights:
+        forward() / backward() do it themselves unless frags_current(); an agent issues it behind its optimiser step."""
+        lib = _lib.load()
+        _lib.check(lib.rlg_mlp_chain_pack_frags_both(self.n, self._w, self._b, self._in, self._out, self._frags_ptr(0),
+                                                     self._frags_ptr(1) if self._frag_bytes[1] >= 0 else None,
+                                                     _stream(stream_of)), 'rlg_mlp_chain_pack_frags_both')
+
+    def frags_current(self):
+        v = self._version()
+        return v is not None and self._frags_for == v
+
+    def mark_frags(self, version):
+        self._frags_for = version
+
+    def ensure_frags(self, stream_of):
+        if not self.frags_current():
+            self.pack_frags(stream_of)
+            self._frags_for = self._version()
 
     def planes_current(self):
         """Both directions' planes belong to the weights as they are now (needs a weights-version source)."""
@@ -778,6 +836,17 @@ class MlpChain:
         # A training forward also has the weights split for the backward launch that follows it: by the forward's own
         # pack launch when the forward runs on planes as well (one launch, both directions), else in extra workgroups
         # of the exact-product forward launch.  backward() uses those planes once; any other caller packs for itself.
+        if split_products is not False and groups in (0, 1) and self.lean_used(rows, 0):
+            self._planes_fresh = None
+            self.ensure_frags(x)
+            _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
+            err = _lib.load().rlg_mlp_chain_forward_lean(
+                n, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0), mean, var,
+                float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows, self._frags_ptr(0), _stream(x))
+            if err != 801:                              # (hipErrorNotSupported: the pipelined / unit-structured launch)
+                _lib.check(err, 'rlg_mlp_chain_forward_lean')
+                return
+            _untime_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         train = act_out is not None and self.n > 1
         bwd_split = train and self.split_products(rows, 1)
         planes = fwd_planes = None
@@ -812,6 +881,7 @@ class MlpChain:
             return False
         if self.split_products(rows, 0) or self.split_products(rows, 1) or self.groups(rows, 0) != 1 or self.groups(rows, 1) != 1:
             return False
+        lean = self.lean_used(rows, 0) and self.lean_used(rows, 1)
         outs = list(act_out) + [heads]
         ptrs = self._P(*[_need(t, F32, 'act_out', contiguous=False) for t in outs])
         lds = self._L(*[t.stride(0) for t in outs])
@@ -835,6 +905,22 @@ class MlpChain:
         bp = None
         if bias_partials is not None:
             bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
+        if lean:
+            # the lean form of the same launch (fp32 weight fragments); outside its envelope: the lean forward and the lean
+            # backward as two launches (the caller's fallback), which beat the pipelined one-launch step
+            self.ensure_frags(x)
+            _time_chain_launch('step16')
+            err = _lib.load().rlg_mlp_chain_step_lean(
+                n, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
+                mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold,
+                _need(d_heads, F32, 'd_heads', contiguous=False), d_heads.stride(0), dz, dl, bp,
+                ctypes.addressof(ppo_loss), rows, self._frags_ptr(0), self._frags_ptr(1), _stream(x))
+            if err == 801:
+                _untime_chain_launch('step16')
+                return False
+            _lib.check(err, 'rlg_mlp_chain_step_lean')
+            self._planes_fresh = None
+            return True
         _time_chain_launch('step16')
         err = _lib.load().rlg_mlp_chain_step(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
@@ -842,9 +928,7 @@ class MlpChain:
             _need(d_heads, F32, 'd_heads', contiguous=False), d_heads.stride(0), dz, dl, bp,
             ctypes.addressof(ppo_loss), rows, _stream(x))
         if err == 801:                                  # hipErrorNotSupported: outside the fused kernel's envelope
-            if chain_timers is not None and chain_timers.get('step16'):
-                chain_timers['step16'].pop()
-                _lib.load().rlg_mlp_chain_time_next(None, None)
+            _untime_chain_launch('step16')
             return False
         _lib.check(err, 'rlg_mlp_chain_step')
         self._planes_fresh = None
@@ -867,6 +951,17 @@ class MlpChain:
         if bias_partials is not None:
             bp = self._P(*([_need(t, F64, 'bias partials') for t in bias_partials] + [None]))
         _lib.require_gpu(d_heads, 'd_heads')
+        if split_products is not False and groups in (0, 1) and self.lean_used(rows, 1):
+            self._planes_fresh = None
+            self.ensure_frags(d_heads)
+            _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
+            err = _lib.load().rlg_mlp_chain_backward_lean(
+                n, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl, bp,
+                None if ppo_loss is None else ctypes.addressof(ppo_loss), rows, self._frags_ptr(1), _stream(d_heads))
+            if err != 801:
+                _lib.check(err, 'rlg_mlp_chain_backward_lean')
+                return
+            _untime_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         planes = None
         if split_products is not False and self.split_products(rows, 1, groups):
             if not self.planes_current() and (self._planes_fresh is None or self._planes_fresh != (rows, self._version())):

@@ -410,9 +410,10 @@ def test_one_launch_step_equals_forward_then_backward(rows, in_dim, units, A):
 
 
 def test_one_launch_step_declines_what_it_does_not_cover():
-    """rlg_mlp_chain_step returns hipErrorNotSupported (MlpChain.step -> False, nothing launched) for minibatches that
-    run the split-bf16 kernels or need more than one round of workgroups (> 16 rows x CUs: two launches with two
-    workgroups per CU are faster there), for weights outside one arena and without a loss descriptor."""
+    """rlg_mlp_chain_step / rlg_mlp_chain_step_lean return hipErrorNotSupported (MlpChain.step -> False, nothing launched)
+    for minibatches that run the split-bf16 kernels or need more than one round of workgroups (> 16 rows x CUs: two
+    launches with two workgroups per CU are faster there) and without a loss descriptor; the pipelined form also for
+    weights outside one arena."""
     from rl_games_amd import ops
     layers, g = _net(60, [64, 32], 9, 'elu', seed=1)
     chain = ops.MlpChain(layers, DEV)
@@ -425,6 +426,7 @@ def test_one_launch_step_declines_what_it_does_not_cover():
     #  16 bytes behind the first matrix - with 64 x 60 = 30 x 512 bytes the bias may follow it and the launch is covered)
     loose, g = _net(60, [52, 32], 9, 'elu', seed=1, packed=False)
     chain2 = ops.MlpChain(loose, DEV)
+    chain2._lean = False                  # (the lean form reads packed fragments: separately allocated weights are fine there)
     rows = 256
     x = torch.randn(rows, 60, generator=g).to(DEV)
     heads = torch.full((rows, 9), float('nan'), device=DEV)
