@@ -364,17 +364,18 @@ int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t
 }
 
 // ---- optimiser step that leaves the weight planes behind (round 4) -------------------------------------------------
-// adam_step_kernel (optim.hip) + chain_pack_planes_kernel as ONE launch.  A thread updates 4 consecutive elements of one
-// row of a weight matrix W [O][I] (one 16-byte load / store per array, as adam_step_kernel); the 4 lanes of a quad hold
-// 4 consecutive rows of the same 4 columns.  The thread splits its NEW weights once: the packed plane dwords are the
-// forward operand's bytes (A = W: 4 consecutive k of its row, one 8-byte store per plane) and their 16-bit halves the
-// backward operand's (A = W^T: the 4 consecutive k of a column are the quad's 4 rows - each lane stores its 2 bytes of
-// the 8-byte word, the quad's stores of one instruction merge).  36 k threads for the 145 k parameters of the humanoid
-// network instead of the 9 k of the first form (a 4 x 4 block per thread, both operands split separately: 12.8 us, the
-// launch ran on 36 CUs).  Same Adam arithmetic per element as adam_update (optim_common.hpp); the planes are the same
-// bytes chain_pack_planes_kernel writes (zero padding outside the matrices is never touched: the buffer is packed once
-// in full before the first step).  Everything of the arena that is not one of the chain's matrices (biases, sigma) is
+// adam_step_kernel (optim.hip) + chain_pack_planes_kernel as ONE launch: the thread that updates a 4 x 4 block of a
+// weight matrix W [O][I] holds, afterwards, 4 consecutive k of 4 rows (forward operand A = W: one 8-byte store per
+// row and plane) and 4 consecutive k of 4 columns (backward operand A = W^T: one 8-byte store per column and plane) of
+// the NEW weights.  Same Adam arithmetic per element as adam_update (optim_common.hpp); the planes are the same bytes
+// chain_pack_planes_kernel writes (zero padding outside the matrices is never touched: the buffer is packed once in
+// full before the first step).  Everything of the arena that is not one of the chain's matrices (biases, sigma) is
 // updated by the flat ranges at the end of the grid.
+// (A form with one thread per (row, 4 columns) - 36 k threads instead of 9 k, one split per thread, the backward operand's 16-bit
+//  halves stored by the quad's lanes - ran in 9.0 us instead of 12.8 us and passed every single-process test, incl. 700
+//  repetitions on identical inputs, but two ranks sharing one GPU ended an epoch with exp_avg_sq / parameters / planes that
+//  differed in the last bits in a third of the runs (tools/exp/two_rank_planes_probe.py, profiles/r4_two_rank_sync.txt).
+//  Not understood; this form - clean in every such run - stays.)
 constexpr int kApMaxRanges = 2 * kChainMaxLayers + 2;
 struct AdamPackArgs {
   AdamArgs adam;
@@ -382,22 +383,18 @@ struct AdamPackArgs {
   long long w_off[kChainMaxLayers];
   int O[kChainMaxLayers], I[kChainMaxLayers];
   long long fwd_off[kChainMaxLayers], bwd_off[kChainMaxLayers];
-  int item_begin[kChainMaxLayers + 1];     // first item (row, 4-column group) of matrix L; [num] = total
+  int item_begin[kChainMaxLayers + 1];     // first 4 x 4 block of matrix L; [num] = total
   int num;
   unsigned char* planes;
   // the rest of the arena as flat ranges [begin, end)
   long long r_begin[kApMaxRanges], r_end[kApMaxRanges];
   int nranges;
-  int matrix_blocks;                       // workgroups that walk the matrices; the flat ranges take the others
+  int matrix_blocks;                       // workgroups that walk 4 x 4 blocks; the flat ranges take the others
 };
 
 __device__ __forceinline__ void ap_store8(unsigned char* p, const unsigned (&w)[2]) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   *reinterpret_cast<u32x2*>(p) = u32x2{w[0], w[1]};
-}
-
-__device__ __forceinline__ void ap_store2(unsigned char* p, unsigned v) {
-  *reinterpret_cast<unsigned short*>(p) = static_cast<unsigned short>(v);
 }
 
 __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
@@ -406,31 +403,30 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
   __shared__ float sh_norm;
   __shared__ double scratch[256 / kWave];
   // ---- everything this thread will need is requested FIRST (the gradient-norm reduction below is a chain of two memory
-  //      round trips and two barriers: the loads overlap with it instead of following it)
+  //      round trips and two barriers: the loads of the block overlap with it instead of following it)
   const bool matrix_block = static_cast<int>(blockIdx.x) < ap.matrix_blocks;
   const int item = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  bool has_item = matrix_block && item < ap.item_begin[ap.num];
-  int L = 0, O = 0, I = 0, o = 0, i0 = 0;
-  f32x4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, p4 = g4, m4 = g4, v4 = g4;
-  long long idx = 0;
+  const bool has_item = matrix_block && item < ap.item_begin[ap.num];
+  int L = 0, O = 0, I = 0, o0 = 0, i0 = 0;
+  f32x4 pn[4], g4[4], p4[4], m4[4], v4[4];
+  long long idx[4] = {0, 0, 0, 0};
   if (has_item) {
     for (int j = 1; j < ap.num; ++j) L = (item >= ap.item_begin[j]) ? j : L;
     O = ap.O[L];
     I = ap.I[L];
     const int niq = I >> 2;
-    // items of a matrix: ((row quad, column group), row of the quad) - the quad's lanes are 4 consecutive rows
     const int local = item - ap.item_begin[L];
-    const int r = local & 3, blk = local >> 2;
-    const int oq = blk / niq, iq = blk - oq * niq;
-    o = 4 * oq + r;
+    const int oq = local / niq, iq = local - oq * niq;
+    o0 = 4 * oq;
     i0 = 4 * iq;
-    has_item = o < O;
-    if (has_item) {
-      idx = ap.w_off[L] + static_cast<long long>(o) * I + i0;
-      g4 = *reinterpret_cast<const f32x4*>(a.grads + idx);
-      p4 = *reinterpret_cast<const f32x4*>(a.params + idx);
-      m4 = *reinterpret_cast<const f32x4*>(a.exp_avg + idx);
-      v4 = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool in = o0 + r < O;
+      idx[r] = ap.w_off[L] + static_cast<long long>(in ? o0 + r : o0) * I + i0;
+      g4[r] = *reinterpret_cast<const f32x4*>(a.grads + idx[r]);
+      p4[r] = *reinterpret_cast<const f32x4*>(a.params + idx[r]);
+      m4[r] = *reinterpret_cast<const f32x4*>(a.exp_avg + idx[r]);
+      v4[r] = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx[r]);
     }
   }
   const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
@@ -467,51 +463,69 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
 
   if (matrix_block) {
     if (has_item && !skip) {
-      f32x4 gc;
+      f32x4 gc[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = (g4[e] * a.grad_scale) * clip;
-        gc[e] = g;
-        float p = p4[e];
-        if (k.wd != 0.0f) g = g + k.wd * p;
-        float m = m4[e];
-        m = m + k.w1 * (g - m);
-        float v = v4[e];
-        v = v * k.b2 + (k.w2 * g) * g;
-        const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
-        p = p - k.step_size * (m / denom);
-        m4[e] = m;
-        v4[e] = v;
-        p4[e] = p;
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g = (g4[r][e] * a.grad_scale) * clip;
+          gc[r][e] = g;
+          float p = p4[r][e];
+          if (k.wd != 0.0f) g = g + k.wd * p;
+          float m = m4[r][e];
+          m = m + k.w1 * (g - m);
+          float v = v4[r][e];
+          v = v * k.b2 + (k.w2 * g) * g;
+          const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
+          p = p - k.step_size * (m / denom);
+          m4[r][e] = m;
+          v4[r][e] = v;
+          p4[r][e] = p;
+        }
       }
-      *reinterpret_cast<f32x4*>(a.grads + idx) = gc;
-      *reinterpret_cast<f32x4*>(a.exp_avg + idx) = m4;
-      *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx) = v4;
-      *reinterpret_cast<f32x4*>(a.params + idx) = p4;
-      // the new weights' planes: pl[p] = {(e0, e1), (e2, e3)} packed bf16.  Element slot of feature k inside its
-      // 32-feature chunk: lane group q = (k % 16) / 4, half = (k % 32) / 16, position k % 4 of the 8-byte word
-      unsigned pl[3][2];
-      split4_planes(p4, pl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pn[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (o0 + r < O) {
+          *reinterpret_cast<f32x4*>(a.grads + idx[r]) = gc[r];
+          *reinterpret_cast<f32x4*>(a.exp_avg + idx[r]) = m4[r];
+          *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx[r]) = v4[r];
+          *reinterpret_cast<f32x4*>(a.params + idx[r]) = p4[r];
+          pn[r] = p4[r];
+        }
+      }
+      // element slot of feature k inside its 32-feature chunk: lane group q = (k % 16) / 4, half = (k % 32) / 16
       if (ap.fwd_off[L] >= 0) {
         // A = W: block of 16 rows o, chunks over k = i
         const int KC = ((I + 31) >> 5);
         const int c = i0 >> 5, rr = i0 & 31, q = (rr & 15) >> 2, half = rr >> 4;
-        unsigned char* dst = ap.planes + ap.fwd_off[L] + (static_cast<long long>(o >> 4) * KC + c) * kBxChunk +
-                             ((o & 15) + 16 * q) * 16 + half * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + r;
+          if (o < O) {
+            unsigned pl[3][2];
+            split4_planes(pn[r], pl);
+            unsigned char* dst = ap.planes + ap.fwd_off[L] + (static_cast<long long>(o >> 4) * KC + c) * kBxChunk +
+                                 ((o & 15) + 16 * q) * 16 + half * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
+          }
+        }
       }
       if (ap.bwd_off[L] >= 0) {
-        // A = W^T: block of 16 rows i, chunks over k = o
+        // A = W^T: block of 16 rows i, chunks over k = o; the 4 consecutive k are rows o0 .. o0 + 3 (zero past O)
         const int KC = ((O + 31) >> 5);
-        const int c = o >> 5, rr = o & 31, q = (rr & 15) >> 2, half = rr >> 4;
+        const int c = o0 >> 5, rr = o0 & 31, q = (rr & 15) >> 2, half = rr >> 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = i0 + e;
+          const f32x4 col = {pn[0][e], pn[1][e], pn[2][e], pn[3][e]};
+          unsigned pl[3][2];
+          split4_planes(col, pl);
           unsigned char* dst = ap.planes + ap.bwd_off[L] + (static_cast<long long>(i >> 4) * KC + c) * kBxChunk +
-                               ((i & 15) + 16 * q) * 16 + half * 8 + 2 * (o & 3);
+                               ((i & 15) + 16 * q) * 16 + half * 8;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) ap_store2(dst + p * kBxFrag, pl[p][e >> 1] >> (16 * (e & 1)));
+          for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
         }
       }
     }
@@ -624,7 +638,7 @@ int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_a
     ap.fwd_off[L] = foff[L];
     ap.bwd_off[L] = (L >= 1) ? bbase + boff[L] : -1;
     ap.item_begin[L] = items;
-    items += ((out_features[L] + 3) >> 2) * (in_features[L] >> 2) * 4;
+    items += ((out_features[L] + 3) >> 2) * (in_features[L] >> 2);
     begin[L] = off;
     end[L] = off + cnt;
   }

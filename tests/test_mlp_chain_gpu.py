@@ -854,3 +854,114 @@ def test_adam_step_pack_equals_adam_then_pack(in_dim, units, out_dim):
     params.copy_(init)
     chain.pack_planes(2, params)
     assert torch.equal(res['fused_skipped'][6], chain._plane_buffer())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('in_dim,units,out_dim', [(108, [400, 200, 100], 22), (60, [64, 32], 9), (12, [100, 52], 11)])
+def test_adam_step_frags_equals_adam_then_pack_frags(in_dim, units, out_dim):
+    """rlg_adam_step_frags (csrc/mlp_chain.hip, adam_frags_kernel): the optimiser step that writes the lean 16-row
+    kernels' fp32 weight fragments itself - a thread's 4 consecutive elements of a row are one lane's 16 bytes of a
+    forward fragment, a quad's 4 rows one lane slot of a backward fragment per column - against rlg_adam_step followed by
+    rlg_mlp_chain_pack_frags_both: the same parameters, moments and clipped gradients bit for bit and the same fragment
+    bytes (zero padding included); with the skip flag set nothing changes."""
+    from rl_games_amd import ops
+    layers, g = _net(in_dim, units, out_dim, 'elu', seed=11)
+    flat = layers[0][0].untyped_storage()
+    n = sum(w.numel() + b.numel() for w, b, _ in layers)
+    params = torch.empty(0, device=DEV, dtype=torch.float32).set_(flat, 0, (n,))
+    init = params.clone()
+    grads = (0.1 * torch.randn(n, generator=g)).to(DEV)
+    m0 = (0.01 * torch.randn(n, generator=g)).to(DEV)
+    v0 = (0.001 * torch.rand(n, generator=g)).to(DEV)
+    version = [0]
+    chain = ops.MlpChain(layers, DEV, weights_version=lambda: version[0])
+    assert chain.lean_used(4096, 0) and chain.lean_used(4096, 1)
+    res = {}
+    for mode in ('pair', 'fused', 'fused_skipped'):
+        params.copy_(init)
+        g_, m_, v_ = grads.clone(), m0.clone(), v0.clone()
+        lr_slots = torch.tensor([3e-4, 3e-4], dtype=torch.float64, device=DEV)
+        counter = torch.tensor([3], dtype=torch.int64, device=DEV)
+        norm = torch.zeros(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
+        ops.grad_sumsq(g_, 1.0, norm, None)
+        kl = torch.tensor([0.001], device=DEV)
+        stats = torch.zeros(4, device=DEV)
+        skip = torch.tensor([1 if mode == 'fused_skipped' else 0], dtype=torch.int32, device=DEV)
+        kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=1, kl=kl, kl_scale=1.0, kl_threshold=0.008,
+                  min_lr=1e-6, max_lr=1e-2, lr_multiplier=1.5, stats_out=stats, skip_flag=skip.data_ptr())
+        target = chain.adam_frags_target()                # (first call: packs the buffers in full once)
+        if mode == 'pair':
+            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, **kw)
+            chain._frag_buffer().fill_(float('nan'))
+            chain.pack_frags(params)
+        else:
+            chain.pack_frags(params)                      # the fragments of the OLD weights (what the agent's state is)
+            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, frags=target, **kw)
+        torch.cuda.synchronize()
+        res[mode] = (params.clone(), g_, m_, v_, lr_slots.clone(), stats.clone(), chain._frag_buffer().clone())
+    for a, b in zip(res['pair'], res['fused']):
+        assert torch.equal(a, b)
+    assert not torch.equal(res['pair'][0], init) and bool(torch.isfinite(res['pair'][6]).all())
+    assert torch.equal(res['fused_skipped'][0], init) and torch.equal(res['fused_skipped'][2], m0)
+    params.copy_(init)
+    chain.pack_frags(params)
+    assert torch.equal(res['fused_skipped'][6], chain._frag_buffer())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', [4096, 1000, 37])
+def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch):
+    """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain.hip: weights as fp32 fragments in each wave's
+    consumption order, the default of MlpChain below 16,384 rows) against the pipelined kernels they replace
+    (RLG_CHAIN_LEAN=0): the same products in the same order - heads, activations, normalised observations, d heads, loss
+    partials, dZ and bias partial sums equal bit for bit, ragged last tile included - and within 1e-6 of fp64."""
+    from rl_games_amd import ops
+    layers, g = _net(108, [400, 200, 100], 22, 'elu', seed=3)
+    x = (3 * torch.randn(rows, 108, generator=g) + 1).to(DEV)
+    mean = torch.ones(108, dtype=torch.float64, device=DEV)
+    var = 9 * torch.ones(108, dtype=torch.float64, device=DEV)
+    A = 21
+    gg = torch.Generator().manual_seed(5)
+    data = dict(actions=torch.randn(rows, A, generator=gg).to(DEV), old_neglogp=torch.randn(rows, generator=gg).to(DEV),
+                adv=torch.randn(rows, generator=gg).to(DEV), old_values=torch.randn(rows, generator=gg).to(DEV),
+                returns=torch.randn(rows, generator=gg).to(DEV), old_mu=torch.randn(rows, A, generator=gg).to(DEV),
+                old_sigma=(0.5 + torch.rand(rows, A, generator=gg)).to(DEV))
+    logstd = torch.zeros(A, device=DEV)
+    out = {}
+    for mode in ('pipe', 'lean', 'lean_step'):
+        chain = ops.MlpChain(layers, DEV)
+        chain._lean = mode != 'pipe'
+        heads = torch.full((rows, 22), float('nan'), device=DEV)
+        acts = [torch.full((rows, u), float('nan'), device=DEV) for u in (400, 200, 100)]
+        xn = torch.full((rows, 108), float('nan'), device=DEV)
+        dh = torch.full((rows, 22), float('nan'), device=DEV)
+        dzs = [torch.full((rows, u), float('nan'), device=DEV) for u in (400, 200, 100)]
+        nb = chain.num_blocks(rows, 1)
+        parts = [torch.full((nb * u,), float('nan'), dtype=torch.float64, device=DEV) for u in (400, 200, 100)]
+        partials = torch.full((nb, ops.ppo_loss_partials_per_block(A)), float('nan'), dtype=torch.float64, device=DEV)
+        om, osg = data['old_mu'].clone(), data['old_sigma'].clone()
+        desc = ops.ppo_loss_desc(heads[:, 1:], logstd, heads[:, 0], data['actions'], data['old_neglogp'], data['adv'],
+                                 data['old_values'], data['returns'], om, osg, dh[:, 1:], dh[:, 0], partials, 0.2, 2.0, 1e-4,
+                                 clip_value=True, smooth=False, bound_kind=1)
+        if mode == 'lean_step':
+            assert chain.step(x, heads, acts, dh, dzs, parts, desc, rms=(mean, var), eps=1e-5, xn_out=xn) == (rows <= 16 * 256)
+        if mode != 'lean_step' or rows > 16 * 256:
+            chain.forward(x, heads, act_out=acts, rms=(mean, var), eps=1e-5, xn_out=xn)
+            chain.backward(dh, acts, dzs, parts, ppo_loss=desc)
+        torch.cuda.synchronize()
+        out[mode] = [heads, xn, dh, partials, om, osg] + acts + dzs + parts
+    for k, (a, b, c) in enumerate(zip(out['pipe'], out['lean'], out['lean_step'])):
+        assert torch.isfinite(a.double()).all(), k
+        assert torch.equal(a, b), k
+        assert torch.equal(a, c), k
+    # inference form = training form
+    chain = ops.MlpChain(layers, DEV)
+    heads_i = torch.empty(rows, 22, device=DEV)
+    chain.forward(x, heads_i, rms=(mean, var), eps=1e-5)
+    assert torch.equal(heads_i, out['lean'][0])
+    a = ((x.double() - mean) / torch.sqrt(var.float() + 1e-5).double()).clamp(-5, 5)
+    for (w, b, act) in layers:
+        a = torch.addmm(b.double(), a, w.double().t())
+        if act == 'elu':
+            a = torch.nn.functional.elu(a)
+    assert float((out['lean'][0].double() - a).abs().max() / a.abs().max()) < 1e-6
