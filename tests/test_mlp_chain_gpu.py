@@ -913,7 +913,7 @@ def test_adam_step_frags_equals_adam_then_pack_frags(in_dim, units, out_dim):
 def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch):
     """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain.hip: weights as fp32 fragments in each wave's
     consumption order, the default of MlpChain below 16,384 rows) against the pipelined kernels they replace
-    (RLG_CHAIN_LEAN=0): the same products in the same order - heads, activations, normalised observations, d heads, loss
+    (RLG_CHAIN_LEAN=0; their own one-launch step included): the same products in the same order - heads, activations, normalised observations, d heads, loss
     partials, dZ and bias partial sums equal bit for bit, ragged last tile included - and within 1e-6 of fp64."""
     from rl_games_amd import ops
     layers, g = _net(108, [400, 200, 100], 22, 'elu', seed=3)
@@ -928,9 +928,9 @@ def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch)
                 old_sigma=(0.5 + torch.rand(rows, A, generator=gg)).to(DEV))
     logstd = torch.zeros(A, device=DEV)
     out = {}
-    for mode in ('pipe', 'lean', 'lean_step'):
+    for mode in ('pipe', 'pipe_step', 'lean', 'lean_step'):
         chain = ops.MlpChain(layers, DEV)
-        chain._lean = mode != 'pipe'
+        chain._lean = not mode.startswith('pipe')
         heads = torch.full((rows, 22), float('nan'), device=DEV)
         acts = [torch.full((rows, u), float('nan'), device=DEV) for u in (400, 200, 100)]
         xn = torch.full((rows, 108), float('nan'), device=DEV)
@@ -943,17 +943,18 @@ def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch)
         desc = ops.ppo_loss_desc(heads[:, 1:], logstd, heads[:, 0], data['actions'], data['old_neglogp'], data['adv'],
                                  data['old_values'], data['returns'], om, osg, dh[:, 1:], dh[:, 0], partials, 0.2, 2.0, 1e-4,
                                  clip_value=True, smooth=False, bound_kind=1)
-        if mode == 'lean_step':
+        if mode.endswith('_step'):
             assert chain.step(x, heads, acts, dh, dzs, parts, desc, rms=(mean, var), eps=1e-5, xn_out=xn) == (rows <= 16 * 256)
-        if mode != 'lean_step' or rows > 16 * 256:
+        if not mode.endswith('_step') or rows > 16 * 256:
             chain.forward(x, heads, act_out=acts, rms=(mean, var), eps=1e-5, xn_out=xn)
             chain.backward(dh, acts, dzs, parts, ppo_loss=desc)
         torch.cuda.synchronize()
         out[mode] = [heads, xn, dh, partials, om, osg] + acts + dzs + parts
-    for k, (a, b, c) in enumerate(zip(out['pipe'], out['lean'], out['lean_step'])):
+    for k, (a, b, c, d) in enumerate(zip(out['pipe'], out['lean'], out['lean_step'], out['pipe_step'])):
         assert torch.isfinite(a.double()).all(), k
         assert torch.equal(a, b), k
         assert torch.equal(a, c), k
+        assert torch.equal(a, d), k
     # inference form = training form
     chain = ops.MlpChain(layers, DEV)
     heads_i = torch.empty(rows, 22, device=DEV)
