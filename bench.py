@@ -476,9 +476,15 @@ def main():
         mbr = global_mb // world
         form = {True: 'split-bf16 (6 exact bf16 plane products per fp32 product on v_mfma_f32_16x16x32_bf16, fp32 '
                       'accumulation; dropped terms <= 3*2^-24 |x||w|)', False: 'exact fp32 (v_mfma_f32_16x16x4_f32)'}
-        chain_products = {'training_forward': form[bool(eng.chain.split_products(mbr, 0))],
-                          'backward': form[bool(eng.chain.split_products(mbr, 1))],
-                          'rollout_forward': form[bool(eng.chain.split_products(envs, 0))]}
+        def launch_form(rows, direction):
+            text = form[bool(eng.chain.split_products(rows, direction))]
+            if eng.chain.lean_used(rows, direction):
+                # (a data-parallel rank's sizes: 16-row workgroups reading the weights as fp32 fragments in each wave's
+                #  consumption order, csrc/mlp_chain.hip - bit-identical to the pipelined 16-row kernels)
+                text += ', lean 16-row kernel'
+            return text
+        chain_products = {'training_forward': launch_form(mbr, 0), 'backward': launch_form(mbr, 1),
+                          'rollout_forward': launch_form(envs, 0)}
     for key in ('roofline_fwd', 'roofline_fwd_infer', 'roofline_bwd'):
         r = chain_roof.get(key)
         if r is not None and 'issued_tflops_bf16' in r:
