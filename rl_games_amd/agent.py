@@ -883,6 +883,10 @@ class A2CAgent:
         step_time = 0.0
         mb_valid = None
         fast = self._fast_rollout_ok()
+        if fast:
+            # the step graphs contain no pack launch: the weights' derived forms (bf16 planes, fp32 fragments) must belong
+            # to the weights as they are - they do behind an optimiser step, not behind set_weights / a broadcast
+            self._planes_before_replay()
         if self.mask_autoreset_rows:
             mb_valid = torch.ones((self.horizon_length, self.num_actors * self.num_agents),
                                   dtype=torch.float32, device=self.ppo_device)
@@ -924,6 +928,8 @@ class A2CAgent:
         mb_valid = None
         rows = self.num_actors * self.num_agents
         fast = self._fast_rollout_ok()
+        if fast:
+            self._planes_before_replay()          # (see play_steps)
         if self.mask_autoreset_rows:
             mb_valid = torch.ones((self.horizon_length, rows), dtype=torch.float32, device=self.ppo_device)
         for n in range(self.horizon_length):

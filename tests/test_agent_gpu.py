@@ -892,6 +892,39 @@ def test_hip_graph_replays_are_bit_identical_to_eager_training(cfg):
     assert res[0][5] == res[1][5]
 
 
+def test_weights_set_between_epochs_reach_the_replayed_rollout_and_update_graphs():
+    """set_weights() behind captured graphs: the rollout's step graphs and the update graphs contain no launch that packs
+    the weights' derived forms (the lean 16-row kernels' fp32 fragments here, bf16 planes at the BASELINE sizes) - the
+    agent re-packs them in front of the first replay behind a change that was not an optimiser step.  Same seeds, graphs on
+    vs off, weights of epoch 2 put back behind epoch 4: bit-identical parameters, moments and statistics behind epoch 6."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for graphs in (True, False):
+        params = configs.tiny(num_actors=128, horizon=8, hip_graphs=graphs)
+        torch.manual_seed(11)
+        agent = A2CAgent('w', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        saved = None
+        for ep in range(6):
+            if ep == 2:
+                saved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in agent.get_weights()['model'].items()}
+            if ep == 4:
+                w = agent.get_weights()
+                w['model'] = saved
+                agent.set_weights(w)
+            agent.update_epoch()
+            agent.train_epoch()
+        assert (agent._graph_epoch is not None or bool(agent._graphs)) == graphs
+        if graphs:
+            assert agent._lean_chain() is not None and len(agent._rollout_graphs) > 0
+        res.append((agent.optimizer.flat_params.clone(), agent.optimizer.exp_avg.clone(), agent.optimizer.exp_avg_sq.clone(),
+                    agent.model.running_mean_std.running_mean.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('graphs', [True, False])
 def test_folded_launches_match_the_separate_ones(graphs):
     """The launches that round 2 merged away - observation statistics folded in the forward's prologue
