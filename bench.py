@@ -309,6 +309,13 @@ def main():
         params['config'].setdefault('native_allreduce_timeout_s', 120.0)
     params['config'].update(overrides)
     torch.manual_seed(42 + rank)
+    trace_rows = None
+    if os.environ.get('RLG_BENCH_ADAM_TRACE'):
+        # diagnostic runs only (an instrumented library, tools/exp/build_trace_libs.sh): one row per optimiser launch
+        sys.path.insert(0, os.path.join(ROOT, 'tools', 'exp'))
+        import adam_trace
+        trace_flags = int(os.environ['RLG_BENCH_ADAM_TRACE']) & 1
+        trace_rows = adam_trace.install(device, 4096, trace_flags)
     agent = A2CAgent('bench', params)
     agent.init_tensors()
     agent.obs = agent.env_reset()
@@ -354,6 +361,14 @@ def main():
         if not in_sync:
             sys.stderr.write(f'bench.py: rank {rank}: parameter probe {probe.tolist()} (min over ranks {lo.tolist()}, max {hi.tolist()}), '
                              f'ipc status {agent._ipc_comm.status() if agent._ipc_comm else None}\n')
+
+    if multi and os.environ.get('RLG_BENCH_SYNC_DIFF'):
+        sys.path.insert(0, os.path.join(ROOT, 'tools', 'exp'))
+        import adam_trace as _at
+        _at.diff_report(agent, rank, world, out=lambda s: sys.stderr.write(s + '\n'))
+    if trace_rows is not None:
+        adam_trace.report(trace_rows, int(agent.optimizer.step_counter.item()), rank, world, trace_flags,
+                          label=f'bench in_sync {in_sync}', out=lambda s: sys.stderr.write(s + '\n'))
 
     # the transports side by side - AFTER the timed region and the in-sync check, on communicators of their own that live
     # until the process exits (RLG_BENCH_PREFLIGHT=0 skips it)

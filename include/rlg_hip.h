@@ -441,39 +441,6 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       double* norm_partials_or_null, float grad_scale, long long* step_counter_or_null,
                       int* finalize_blocks_out_or_null, void* stream);
 
-/* The same weight-gradient launch with the WHOLE optimiser step behind it in one launch (round 4): finalise (K-slice
- * sums, bias gradients, loss partials) + gradient norm + clip_grad_norm_ + Adam + the KL-adaptive learning-rate rule -
- * what rlg_mlp_dw_launch(norm_partials) + rlg_adam_step do as a launch pair (a2c_common.py:493-514, :1557-1563,
- * schedulers.py:27-33).  Single GPU only (nothing may touch the gradients between the two halves), and only when this
- * launch writes EVERY gradient of the arena [grads, grads + n): a persistent grid of <= rlg_mlp_dw_step_tail_max_blocks()
- * workgroups exchanges one fp64 partial each through `sync_partials` (that many doubles) across ONE grid barrier on
- * `sync_state` (2 words, zeroed once by the caller, owned by this call chain), and every thread then updates exactly
- * the parameters whose gradients it wrote.  The device step counter is advanced by the launch; `truncate` = 0 skips the
- * clipping (max_norm unused); stats_out_or_null [4] = total_norm, clip_coef, lr used, lr next. */
-typedef struct rlg_adam_desc {
-  float* params;
-  float* grads;
-  float* exp_avg;
-  float* exp_avg_sq;
-  long long n;
-  float grad_scale, max_norm;
-  int truncate, schedule_kind;
-  double* lr_slots;
-  long long* step_counter;
-  double beta1, beta2, eps, weight_decay;
-  const float* kl;
-  float kl_scale;
-  double kl_threshold, min_lr, max_lr, lr_multiplier;
-  float* stats_out_or_null;
-} rlg_adam_desc;
-int rlg_mlp_dw_step_tail_max_blocks(void);
-int rlg_mlp_dw_launch_step(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
-                           float* const* grad, const int* out_features, const int* in_features,
-                           const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
-                           const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                           const rlg_loss_finalize_desc* loss_finalize, const rlg_adam_desc* adam,
-                           unsigned* sync_state, double* sync_partials, void* stream);
-
 /* ---- the MLP as one vertically fused chain on f32 MFMA (csrc/mlp_chain.hip) ------------------
  * forward : heads = head(act(... act(norm(x) W_0^T + b_0) ...)) for a row tile, every layer in ONE
  *           launch with the activations resident in LDS; replaces A2CBuilder.Network.forward

@@ -73,8 +73,6 @@ _PROTOTYPES = {
     'rlg_mlp_dw_plan': [_c_int, _c_int, _c_int, _c_int, _P],
     'rlg_mlp_dw_launch': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_float, _P,
                           _P, _P],
-    'rlg_mlp_dw_step_tail_max_blocks': [],
-    'rlg_mlp_dw_launch_step': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'rlg_narrow_dx': [_P, _c_ll, _P, _P, _c_ll, _c_ll, _c_int, _c_int, _P],
     'rlg_narrow_dw_blocks': [_c_ll],
     'rlg_narrow_dw': [_P, _c_ll, _P, _c_ll, _P, _P, _c_ll, _c_int, _c_int, _P],
@@ -210,19 +208,6 @@ class LossFinalizeDesc(ctypes.Structure):
                 ('entropy_coef', ctypes.c_float), ('bounds_coef', ctypes.c_float), ('scalars8', ctypes.c_void_p),
                 ('d_logstd', ctypes.c_void_p), ('kl_slot_or_null', ctypes.c_void_p),
                 ('d_mu_bias_or_null', ctypes.c_void_p), ('d_value_bias_or_null', ctypes.c_void_p)]
-
-
-class AdamDesc(ctypes.Structure):
-    """rlg_adam_desc (include/rlg_hip.h): the optimiser step of rlg_adam_step as a descriptor, for the launch
-    that performs it behind its own work (rlg_mlp_dw_launch_step)."""
-    _fields_ = [('params', ctypes.c_void_p), ('grads', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
-                ('exp_avg_sq', ctypes.c_void_p), ('n', ctypes.c_longlong), ('grad_scale', ctypes.c_float),
-                ('max_norm', ctypes.c_float), ('truncate', ctypes.c_int), ('schedule_kind', ctypes.c_int),
-                ('lr_slots', ctypes.c_void_p), ('step_counter', ctypes.c_void_p), ('beta1', ctypes.c_double),
-                ('beta2', ctypes.c_double), ('eps', ctypes.c_double), ('weight_decay', ctypes.c_double),
-                ('kl', ctypes.c_void_p), ('kl_scale', ctypes.c_float), ('kl_threshold', ctypes.c_double),
-                ('min_lr', ctypes.c_double), ('max_lr', ctypes.c_double), ('lr_multiplier', ctypes.c_double),
-                ('stats_out_or_null', ctypes.c_void_p)]
 
 
 def check(err, what):

@@ -412,15 +412,12 @@ class A2CAgent:
         self._graphs, self._graph_opt, self._graph_sig, self._graph_pool = {}, None, None, None
         self._graph_epoch = None
         self._graph_norm_state = None
-        self._graph_step_inside = False   # the per-minibatch graphs end with the optimiser step (fused_step_tail)
-        self._fused_tail_in_graph = False
         self.last_allreduce = None    # 'ipc' | 'rccl' once a multi-GPU step has run (bench.py reports it)
         self._graph_failed = False
         self._fold_ready = False      # this epoch's minibatch observation moments are precomputed
         self._fin_norm_ok = None      # decided on first use (_norm_in_finalize)
         self._fin_norm_partials = None
         self._norm_ready = None       # (partials, count) when the finalise / all-reduce launch produced the gradient norm
-        self._step_in_backward = False  # the finalise launch of the current minibatch performed the optimiser step itself
         self._adam_pack = None        # decided on first use (_adam_pack_chain)
         self._lean_pack = None        # decided on first use (_lean_chain)
         self._roll_env_actions = None
@@ -1176,20 +1173,11 @@ class A2CAgent:
                 # the loss partials are folded by the weight-gradient finalise launch (one launch less),
                 # and - single GPU, every gradient of the arena written by that launch - the sums of
                 # squares for clip_grad_norm_ with them (another one)
-                norm = step = None
+                norm = None
                 if self._norm_in_finalize():
                     norm = (self._fin_norm_partials, 1.0, opt.step_counter)
-                    if self.config.get('fused_step_tail', False):
-                        # ... and then the whole optimiser step as well: finalise + norm + clip + Adam + lr rule as
-                        # ONE launch (csrc/mlp_dw.hip, mlp_dw_finalize_adam_kernel); _optimizer_kernels then only
-                        # advances the host mirrors.  Opt-in: bit-identical to the launch pair, but measured SLOWER
-                        # (profiles/r4_step_tail.txt: a persistent grid walks its finalise blocks one after the other
-                        # where the pair has all 2,300 of them in flight: +25 us per step at 32,768 rows)
-                        step = opt.step_desc(**self._step_arguments())
-                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo,
-                                  step=step)
-                self._step_in_backward = nb == 'step'
-                self._norm_ready = (self._fin_norm_partials, nb) if (nb and nb != 'step') else None
+                nb = eng.backward(d_heads, loss_finalize=ops.loss_finalize_desc(*fin), norm=norm, ppo_loss=ppo)
+                self._norm_ready = (self._fin_norm_partials, nb) if nb else None
             else:
                 ops.ppo_loss_finalize(*fin)
                 if eng is not None:
@@ -1284,15 +1272,6 @@ class A2CAgent:
     def _optimizer_kernels(self):
         opt = self.optimizer
         lean = self._lean_chain()
-        if self._step_in_backward:
-            # the weight-gradient finalise launch of this minibatch performed the step (fused_step_tail)
-            self._step_in_backward = False
-            self._norm_ready = None
-            opt.step_done()
-            if lean is not None:
-                lean.pack_frags(opt.flat_params)
-                lean.mark_frags(opt.weights_version)
-            return
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
@@ -1302,7 +1281,7 @@ class A2CAgent:
         # (one process per GPU only: the row-per-thread Adam + pack form was seen to leave two ranks that SHARE a GPU a few
         #  ulps apart - csrc/mlp_chain_bx.hip, adam_pack_kernel's note; multi-GPU runs keep Adam and the pack apart)
         in_adam = lean.chains[0] if (lean is not None and len(lean.chains) == 1 and self._adam_pack_chain() is None
-                                     and not self.multi_gpu
+                                     and (not self.multi_gpu or self.config.get('adam_frags_multi_gpu', False))
                                      and lean.chains[0].adam_frags_target(opt.flat_params) is not None) else None
         opt.step(norm_ready=self._norm_ready, skip_flag=skip, pack=self._adam_pack_chain(), frags=in_adam,
                  **self._step_arguments())
@@ -1415,7 +1394,6 @@ class A2CAgent:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
                 body()
         except Exception as e:
-            self._step_in_backward = False
             raise GraphCaptureError('HIP graph capture failed') from e
         finally:
             if gc_was_enabled:
@@ -1438,18 +1416,7 @@ class A2CAgent:
             g = self._graphs[i] = self._capture(lambda: self._with_fold(i, self._forward_loss_backward, item,
                                                                        self._graph_rows[i]))
             self._graph_norm_state = self._norm_ready      # what the captured launches will have produced
-            self._graph_step_inside = self._step_in_backward
-            self._step_in_backward = False
         self._planes_before_replay()
-        if self._graph_step_inside:
-            # (fused_step_tail: the optimiser step is the last launch of graph g itself)
-            g.replay()
-            self._norm_ready = None
-            self.optimizer.step_done()
-            if self._lean_chain() is not None:
-                self._lean_chain().pack_frags(self.optimizer.flat_params)
-                self._lean_chain().mark_frags(self.optimizer.weights_version)
-            return
         if self._graph_opt is None:
             # Captured BEFORE anything of this minibatch runs (a failed capture then leaves minibatch i untouched
             # for the eager path), knowing which launch in front of it produces the gradient norm - the
@@ -1465,7 +1432,7 @@ class A2CAgent:
         self._norm_ready = None
         self._graph_opt.replay()
         self.optimizer.step_done()
-        if self._adam_pack_chain() is not None and not self._graph_step_inside:
+        if self._adam_pack_chain() is not None:
             self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
         if self._lean_chain() is not None:
             self._lean_chain().mark_frags(self.optimizer.weights_version)
@@ -1490,12 +1457,11 @@ class A2CAgent:
                 if self._fold_ready:
                     self.model.running_mean_std.fold_sync(nmb)
             self._graph_epoch = self._capture(body)
-            self._fused_tail_in_graph = bool(self.config.get('fused_step_tail', False)) and bool(self._fin_norm_ok)
         self._planes_before_replay()
         self._graph_epoch.replay()
         self.optimizer.step_count += nmb
         self.optimizer.weights_version += nmb
-        if self._adam_pack_chain() is not None and not self._fused_tail_in_graph:
+        if self._adam_pack_chain() is not None:
             self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
         if self._lean_chain() is not None:
             self._lean_chain().mark_frags(self.optimizer.weights_version)

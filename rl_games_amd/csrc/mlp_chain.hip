@@ -2117,6 +2117,12 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs ap) {
   __syncthreads();
   const float clip = sh_clip;
   const AdamScalars k = adam_scalars(a, step, lr);
+#ifdef RLG_ADAM_TRACE
+  AdamTraceAcc tr;
+  if (matrix_block && has_item && !skip) {
+    for (int e = 0; e < 4; ++e) adam_trace_in(tr, a, step, idx + e, g4[e], p4[e], m4[e], v4[e]);
+  }
+#endif
 
   if (matrix_block) {
     if (has_item && !skip) {
@@ -2141,6 +2147,9 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs ap) {
       *reinterpret_cast<f32x4*>(a.exp_avg + idx) = m4;
       *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx) = v4;
       *reinterpret_cast<f32x4*>(a.params + idx) = p4;
+#ifdef RLG_ADAM_TRACE
+      for (int e = 0; e < 4; ++e) adam_trace_out(tr, idx + e, gc[e], p4[e], m4[e], v4[e]);
+#endif
       // block ob of a step -> (wave, unit): whole blocks wave-major, then one remainder block per wave
       auto where = [](int ob, int full, int& w, int& j) {
         if (ob < kLeanW * full) {
@@ -2175,12 +2184,20 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs ap) {
     for (int r = 0; r < ap.nranges; ++r) {
       const long long len = ap.r_end[r] - ap.r_begin[r];
       if (t < len) {
+#ifdef RLG_ADAM_TRACE
+        adam_update_traced(tr, a, k, step, ap.r_begin[r] + t, clip);
+#else
         adam_update(a, k, ap.r_begin[r] + t, clip);
+#endif
         break;
       }
       t -= len;
     }
   }
+#ifdef RLG_ADAM_TRACE
+  adam_trace_flush(a, step, tr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) adam_trace_scalars(a, step, clip, sh_norm, lr);
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) adam_finish(a, cur, lr, skip, sh_norm, clip);
 }
 }  // namespace rlg
@@ -3059,6 +3076,7 @@ int rlg_adam_step_frags(float* params, float* grads, float* exp_avg, float* exp_
   a.lr_multiplier = lr_multiplier;
   a.stats_out = stats_out_or_null;
   a.skip_flag = skip_flag_or_null;
+  RLG_ADAM_TRACE_FILL(a);
   LeanPackArgs pf = {}, pb = {};
   if (chain_lean_plan(num_layers, in_features, out_features, 0, &pf) < 0) return static_cast<int>(hipErrorInvalidValue);
   const bool with_b = frags_bwd_or_null != nullptr && num_layers >= 2;

@@ -33,7 +33,6 @@
 // the same class as the library kernels it replaces; only the summation order differs.
 
 #include "rlg_device.hpp"
-#include "optim_common.hpp"
 #include "split_bf16.hpp"
 #include "rlg_hip.h"
 
@@ -564,13 +563,6 @@ constexpr int kFinElems = 16;
 constexpr int kFinGroups = 16;
 constexpr int kCsCols = 16;       // bias-gradient blocks: columns x row-slices of the per-block partials
 constexpr int kCsSlices = 16;
-// What a thread of a finalise block writes: `n` (0, 1 or 4) consecutive gradient elements from `p` on.  Pure index
-// arithmetic - the fused finalise + Adam launch asks again in its second phase, where every thread updates exactly
-// the parameters whose gradients it produced itself (no gradient crosses a workgroup, let alone an XCD's L2).
-struct FinOwned {
-  float* p;
-  int n;
-};
 struct FinWhere {         // the decoded work item of a (virtual) finalise block
   int kind;               // 0 loss item, 1 bias column sums, 2 weight-gradient elements
   int item;               // kind 1: colsum item; kind 2: layer
@@ -611,32 +603,7 @@ __device__ __forceinline__ FinWhere fin_where(int vb, const DwArgs& args, const 
   w.local = fin_block - base;
   return w;
 }
-__device__ __forceinline__ FinOwned fin_owned(const FinWhere& w, const DwArgs& args, const ColsumItems& cs,
-                                              const LossFinalizeItem& lf) {
-  FinOwned o = {nullptr, 0};
-  if (w.kind == 0) {
-    const rlg_loss_finalize_desc& d = lf.d;
-    const int slot = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    if (w.local == 0) {
-      if (threadIdx.x == 0 && d.d_value_bias_or_null) { o.p = d.d_value_bias_or_null; o.n = 1; }
-    } else if (slice == 0 && slot < kLfCols) {
-      const int a = kLfCols * (w.local - 1) + slot;
-      if (a < d.actions_num) { o.p = d.d_logstd + a; o.n = 1; }
-      else if (a < 2 * d.actions_num && d.d_mu_bias_or_null) { o.p = d.d_mu_bias_or_null + (a - d.actions_num); o.n = 1; }
-    }
-  } else if (w.kind == 1) {
-    const int col = w.local * kCsCols + (threadIdx.x & (kCsCols - 1));
-    if (threadIdx.x / kCsCols == 0 && col < cs.cols[w.item]) { o.p = cs.out[w.item] + col; o.n = 1; }
-  } else {
-    const DwLayer& L = args.layer[w.item];
-    const int e = w.local * kFinElems + (threadIdx.x & (kFinElems - 1));
-    if (threadIdx.x / kFinElems == 0 && e < ((L.No * L.Mi) >> 2)) { o.p = L.grad + 4 * static_cast<long long>(e); o.n = 4; }
-  }
-  return o;
-}
-
 // The work of finalise block `vb`; returns this thread's share of sum (g * grad_scale)^2 over what it wrote.
-// Ends with every thread past its last read of the shared scratch only when `sync_after` (callers that loop).
 __device__ __forceinline__ double fin_vblock(int vb, const DwArgs& args, const ColsumItems& cs, const LossFinalizeItem& lf,
                                              float grad_scale) {
   __shared__ f32x4 part[kFinGroups][kFinElems];
@@ -734,89 +701,6 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, Colsu
   }
 }
 
-// ---- fused optimiser-step tail (round 4): finalise + clip + Adam + learning-rate rule in ONE launch ----------------
-// Replaces the launch pair mlp_dw_finalize_kernel -> adam_step_kernel on one GPU when the finalise launch produces
-// EVERY gradient of the arena (the condition under which it already left the gradient-norm partials).  A persistent
-// grid (<= kTailMaxBlocks workgroups, all co-resident) walks the finalise blocks; every workgroup publishes ONE fp64
-// partial of sum g^2; one grid barrier; every workgroup sums the partials in index order (same total, same clip
-// coefficient everywhere) and applies Adam to exactly the elements its own threads wrote - they re-read their own
-// stores, so no gradient crosses a workgroup and no L2 write-back / invalidate is needed.  Everything that does
-// cross (partials, barrier words) moves by agent-scope atomics, which bypass the per-XCD L2s.
-constexpr int kTailMaxBlocks = 512;
-struct TailSync {
-  unsigned* state;      // [0] arrivals of the running launch, [1] barrier generation
-  double* partials;     // [kTailMaxBlocks]
-};
-
-__global__ __launch_bounds__(256) void mlp_dw_finalize_adam_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf,
-                                                                   int total_vb, AdamArgs ad, TailSync sync) {
-  __shared__ double nscratch[256 / kWave];
-  __shared__ float sh_clip, sh_norm;
-  __shared__ unsigned sh_gen;
-  if (threadIdx.x == 0) sh_gen = __hip_atomic_load(sync.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the Adam step this launch performs (block 0 writes the counter back BEHIND the barrier: everyone has read it)
-  const long long step = *ad.step_counter + 1;
-  const int cur = static_cast<int>((step - 1) & 1);
-  const double lr = ad.lr_slots[cur];
-
-  // ---- phase 1: the finalise blocks of this workgroup
-  double sq = 0.0;
-  for (int vb = blockIdx.x; vb < total_vb; vb += gridDim.x) {
-    sq += fin_vblock(vb, args, cs, lf, ad.grad_scale);
-    __syncthreads();                                 // the shared scratch is re-used by the next block
-  }
-  {
-    double one[1] = {sq};
-    block_sum<1, 256>(one, nscratch);
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(sync.partials + blockIdx.x, one[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partial is at the coherence point before the arrival
-      const unsigned gen = sh_gen;
-      const unsigned t = __hip_atomic_fetch_add(sync.state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == gridDim.x - 1) {
-        __hip_atomic_store(sync.state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(sync.state + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while (__hip_atomic_load(sync.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    __syncthreads();
-  }
-  // ---- the gradient norm: the workgroups' partials in index order (every workgroup computes the same sum)
-  {
-    double tot[1] = {0.0};
-    if (ad.norm_partials != nullptr) {               // (non-null = truncate_grads; the pointer itself is not read)
-      for (int b = threadIdx.x; b < static_cast<int>(gridDim.x); b += 256)
-        tot[0] += __hip_atomic_load(sync.partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      block_sum<1, 256>(tot, nscratch);
-    }
-    if (threadIdx.x == 0) {
-      float coef = 1.0f, total_norm = 0.0f;
-      if (ad.norm_partials != nullptr) {
-        total_norm = static_cast<float>(sqrt(tot[0]));
-        coef = adam_clip_coef(ad.max_norm, total_norm);
-      }
-      sh_clip = coef;
-      sh_norm = total_norm;
-    }
-    __syncthreads();
-  }
-  const float clip = sh_clip;
-  const AdamScalars k = adam_scalars(ad, step, lr);
-  // ---- phase 2: Adam on what this workgroup's threads wrote
-  for (int vb = blockIdx.x; vb < total_vb; vb += gridDim.x) {
-    const FinOwned o = fin_owned(fin_where(vb, args, cs, lf), args, cs, lf);
-    const long long i0 = o.p - ad.grads;
-    for (int e = 0; e < o.n; ++e) adam_update(ad, k, i0 + e, clip);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *const_cast<long long*>(ad.step_counter) = step;
-    adam_finish(ad, cur, lr, false, sh_norm, clip);
-  }
-}
-
-
 // Splits `width` columns into tiles of 64 / 32 / 16 (16*b, b = 4 / 2 / 1); `max_b` limits b by the
 // alignment of the operand rows (a b-float vector load per lane).  Returns the tile count.
 static int dw_split(int width, int max_b, short* start, signed char* b) {
@@ -884,14 +768,12 @@ long long rlg_mlp_dw_plan(int rows, int out_features, int in_features, int targe
 
 // All layers in one launch.  Arrays are indexed by layer; plans from rlg_mlp_dw_plan.  dz [rows, No]
 // and x [rows, Mi] are contiguous (row stride = width).
-// adam_or_null: the fused tail (finalise + clip + Adam + lr rule in one launch, see mlp_dw_finalize_adam_kernel).
 static int dw_launch_impl(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
                           float* const* grad, const int* out_features, const int* in_features,
                           const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
                           const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
                           const rlg_loss_finalize_desc* loss_finalize, double* norm_partials, float grad_scale,
-                          long long* step_counter, int* finalize_blocks_out, const rlg_adam_desc* adam,
-                          unsigned* sync_state, double* sync_partials, void* stream) {
+                          long long* step_counter, int* finalize_blocks_out, void* stream) {
   using namespace rlg;
   if (num_layers <= 0 || num_layers > kDwMaxLayers || rows <= 0 || num_colsums < 0 ||
       num_colsums > kDwMaxLayers)
@@ -942,60 +824,12 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
     lf.num_blocks = 1 + (2 * lf.d.actions_num + kLfCols - 1) / kLfCols;
   }
   const int total_vb = lf.num_blocks + cs_blocks + fin_blocks;
-  AdamArgs ad = {};
-  if (adam) {
-    // every gradient this launch writes must lie inside the arena the step updates
-    const uintptr_t g0 = reinterpret_cast<uintptr_t>(adam->grads), g1 = g0 + static_cast<uintptr_t>(adam->n) * 4;
-    auto inside = [&](const float* p, long long count) {
-      const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-      return p != nullptr && a >= g0 && a + static_cast<uintptr_t>(count) * 4 <= g1;
-    };
-    bool ok = adam->n > 0 && adam->params && adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->lr_slots &&
-              adam->step_counter && sync_state && sync_partials && loss_finalize != nullptr &&
-              (adam->schedule_kind != 1 || adam->kl != nullptr);
-    for (int l = 0; l < num_layers && ok; ++l) ok = inside(grad[l], static_cast<long long>(out_features[l]) * in_features[l]);
-    for (int k = 0; k < num_colsums && ok; ++k) ok = inside(colsum_out[k], colsum_cols[k]);
-    if (ok && lf.d.actions_num > 0) ok = inside(lf.d.d_logstd, lf.d.actions_num);
-    if (ok && lf.d.d_mu_bias_or_null) ok = inside(lf.d.d_mu_bias_or_null, lf.d.actions_num);
-    if (ok && lf.d.d_value_bias_or_null) ok = inside(lf.d.d_value_bias_or_null, 1);
-    if (!ok) return static_cast<int>(hipErrorInvalidValue);
-    ad.params = adam->params;
-    ad.grads = adam->grads;
-    ad.exp_avg = adam->exp_avg;
-    ad.exp_avg_sq = adam->exp_avg_sq;
-    ad.n = adam->n;
-    ad.norm_partials = adam->truncate ? sync_partials : nullptr;      // (a flag here: the kernel reads sync.partials)
-    ad.norm_blocks = 0;
-    ad.grad_scale = adam->grad_scale;
-    ad.max_norm = adam->max_norm;
-    ad.lr_slots = adam->lr_slots;
-    ad.step_counter = adam->step_counter;
-    ad.beta1 = adam->beta1;
-    ad.beta2 = adam->beta2;
-    ad.eps = adam->eps;
-    ad.weight_decay = adam->weight_decay;
-    ad.schedule_kind = adam->schedule_kind;
-    ad.kl = adam->kl;
-    ad.kl_scale = adam->kl_scale;
-    ad.kl_threshold = adam->kl_threshold;
-    ad.min_lr = adam->min_lr;
-    ad.max_lr = adam->max_lr;
-    ad.lr_multiplier = adam->lr_multiplier;
-    ad.stats_out = adam->stats_out_or_null;
-    ad.skip_flag = nullptr;
-  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dw_split_products()) hipLaunchKernelGGL(mlp_dw_bf16x6_kernel, dim3(blocks), dim3(256), 0, st, args);
   else hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
   if (finalize_blocks_out) *finalize_blocks_out = total_vb;
-  if (adam) {
-    TailSync sync = {sync_state, sync_partials};
-    const int grid = total_vb < kTailMaxBlocks ? total_vb : kTailMaxBlocks;
-    hipLaunchKernelGGL(mlp_dw_finalize_adam_kernel, dim3(grid), dim3(256), 0, st, args, cs, lf, total_vb, ad, sync);
-  } else {
-    NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
-    hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(total_vb), dim3(256), 0, st, args, cs, lf, nrm);
-  }
+  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(total_vb), dim3(256), 0, st, args, cs, lf, nrm);
   RLG_RETURN_LAUNCH_STATUS();
 }
 
@@ -1007,21 +841,7 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
                       long long* step_counter, int* finalize_blocks_out, void* stream) {
   return dw_launch_impl(num_layers, dz, x, partial, grad, out_features, in_features, plans4, rows, num_colsums,
                         colsum_partials, colsum_blocks, colsum_cols, colsum_out, loss_finalize, norm_partials, grad_scale,
-                        step_counter, finalize_blocks_out, nullptr, nullptr, nullptr, stream);
-}
-
-int rlg_mlp_dw_step_tail_max_blocks(void) { return rlg::kTailMaxBlocks; }
-
-int rlg_mlp_dw_launch_step(int num_layers, const float* const* dz, const float* const* x, float* const* partial,
-                           float* const* grad, const int* out_features, const int* in_features,
-                           const int* plans4, int rows, int num_colsums, const double* const* colsum_partials,
-                           const int* colsum_blocks, const int* colsum_cols, float* const* colsum_out,
-                           const rlg_loss_finalize_desc* loss_finalize, const rlg_adam_desc* adam,
-                           unsigned* sync_state, double* sync_partials, void* stream) {
-  if (!adam) return static_cast<int>(hipErrorInvalidValue);
-  return dw_launch_impl(num_layers, dz, x, partial, grad, out_features, in_features, plans4, rows, num_colsums,
-                        colsum_partials, colsum_blocks, colsum_cols, colsum_out, loss_finalize, nullptr, adam->grad_scale,
-                        nullptr, nullptr, adam, sync_state, sync_partials, stream);
+                        step_counter, finalize_blocks_out, stream);
 }
 
 }  // extern "C"

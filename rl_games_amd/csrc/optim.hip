@@ -20,6 +20,11 @@
 
 namespace rlg {
 
+#ifdef RLG_ADAM_TRACE
+unsigned long long* g_adam_trace_rows = nullptr;
+int g_adam_trace_cap = 0, g_adam_trace_flags = 0;
+#endif
+
 constexpr int kOptBlock = 256;
 
 // partial sum of squares of (grad * grad_scale), fp64, one value per block.  Also advances the
@@ -99,6 +104,12 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
   __syncthreads();
   const float clip = sh_clip;
   const AdamScalars k = adam_scalars(a, step, lr);
+#ifdef RLG_ADAM_TRACE
+  AdamTraceAcc tr;
+  if ((vec || one) && !skip) {
+    for (int e = 0; e < (vec ? 4 : 1); ++e) adam_trace_in(tr, a, step, (vec ? 4 * t : tail) + e, g4[e], p4[e], m4[e], v4[e]);
+  }
+#endif
 
   if ((vec || one) && !skip) {
     f32x4 gc;
@@ -132,13 +143,30 @@ __global__ __launch_bounds__(kOptBlock) void adam_step_kernel(AdamArgs a) {
       a.exp_avg_sq[tail] = v4[0];
       a.params[tail] = p4[0];
     }
+#ifdef RLG_ADAM_TRACE
+    for (int e = 0; e < cnt; ++e) adam_trace_out(tr, (vec ? 4 * t : tail) + e, gc[e], p4[e], m4[e], v4[e]);
+#endif
   }
+#ifdef RLG_ADAM_TRACE
+  adam_trace_flush(a, step, tr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) adam_trace_scalars(a, step, clip, sh_norm, lr);
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) adam_finish(a, cur, lr, skip, sh_norm, clip);
 }
 
 }  // namespace rlg
 
 extern "C" {
+
+#ifdef RLG_ADAM_TRACE
+// diagnostic builds only: rows = device buffer of cap x 32 u64 (zeroed by the caller), flags bit 0 = coherent re-reads
+int rlg_debug_adam_trace(unsigned long long* rows, int cap, int flags) {
+  rlg::g_adam_trace_rows = rows;
+  rlg::g_adam_trace_cap = cap;
+  rlg::g_adam_trace_flags = flags;
+  return 0;
+}
+#endif
 
 int rlg_grad_norm_num_blocks(long long n) {
   long long b = (n + rlg::kOptBlock * 8 - 1) / (rlg::kOptBlock * 8);
@@ -191,6 +219,7 @@ int rlg_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
   a.lr_multiplier = lr_multiplier;
   a.stats_out = stats_out_or_null;
   a.skip_flag = skip_flag_or_null;
+  RLG_ADAM_TRACE_FILL(a);
   // one thread per group of 4 parameters + one per tail element (the arenas are 16-byte aligned: torch allocations)
   if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
        reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 != 0)

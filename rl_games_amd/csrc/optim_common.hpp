@@ -26,6 +26,10 @@ struct AdamArgs {
   float* stats_out;        // [4]: total_norm, clip_coef, lr used, lr next
   const unsigned* skip_flag;  // device word or nullptr; non-zero: the gradients are invalid (a failed in-graph
                               // all-reduce) - nothing is updated, the learning rate is carried over unchanged
+#ifdef RLG_ADAM_TRACE
+  unsigned long long* trace_rows;   // diagnostic builds only (tools/exp/build_trace_libs.sh): see adam_trace.hpp
+  int trace_cap, trace_flags;
+#endif
 };
 
 // torch.optim.Adam (single-tensor path) scalar prologue, evaluated in double like Python
@@ -83,3 +87,5 @@ __device__ __forceinline__ void adam_finish(const AdamArgs& a, int cur, double l
 }
 
 }  // namespace rlg
+
+#include "adam_trace.hpp"

@@ -87,7 +87,6 @@ class FlatAdam(FlatArena):
         self.lr_slots = torch.tensor([float(lr), float(lr)], dtype=torch.float64, device=dev)
         self.norm_partials = torch.zeros(ops.grad_norm_blocks(self.numel), dtype=torch.float64, device=dev)
         self.stats = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._tail_sync = None
         self.param_groups = [{'params': self.params, 'lr': float(lr), 'betas': betas, 'eps': eps,
                               'weight_decay': weight_decay}]
 
@@ -157,27 +156,8 @@ class FlatAdam(FlatArena):
         elif frags is not None:
             frags.mark_frags(self.weights_version)
 
-    def step_desc(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0):
-        """The arguments of step() as (rlg_adam_desc, sync_state, sync_partials) for a launch that performs the step
-        behind its own work (ops.MlpDwPlan.launch(step=...)); the caller reports it with step_done()."""
-        from . import _lib
-        if self._tail_sync is None:
-            dev = self.flat_params.device
-            self._tail_sync = (torch.zeros(2, dtype=torch.int32, device=dev),
-                               torch.zeros(ops.step_tail_max_blocks(), dtype=torch.float64, device=dev))
-        kw = schedule or {}
-        desc = _lib.AdamDesc(
-            self.flat_params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            self.numel, float(grad_scale), 0.0 if max_norm is None else float(max_norm), 0 if max_norm is None else 1,
-            1 if schedule is not None else 0, self.lr_slots.data_ptr(), self.step_counter.data_ptr(),
-            float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-            self.kl_slot.data_ptr() if schedule is not None else None, float(kl_scale),
-            float(kw.get('kl_threshold', 0.0)), float(kw.get('min_lr', 0.0)), float(kw.get('max_lr', 0.0)),
-            float(kw.get('lr_multiplier', 1.0)), self.stats.data_ptr())
-        return desc, self._tail_sync[0], self._tail_sync[1]
-
     def step_done(self):
-        """Host mirrors after a launch that performed the step itself (step_desc)."""
+        """Host mirrors after a replayed graph performed the step (the captured launches advance the device counter)."""
         self.step_count += 1
         self.weights_version += 1
 

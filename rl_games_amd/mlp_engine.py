@@ -284,7 +284,7 @@ class ManualMLP:
         return heads[:, self.V:]
 
     @torch.no_grad()
-    def backward(self, d_heads, loss_finalize=None, norm=None, ppo_loss=None, step=None):
+    def backward(self, d_heads, loss_finalize=None, norm=None, ppo_loss=None):
         """d_heads [rows, V+A] = d loss / d heads.  Writes every weight/bias gradient of the trunk
         and the head WEIGHT gradient into the arena (head bias gradients are written by the loss
         finalise kernel).  The dX chain runs first; the weight gradients - which nothing in that
@@ -295,8 +295,7 @@ class ManualMLP:
         ops.MlpDwPlan.launch; returns the number of valid norm partials, or None when the gradient norm
         was not produced (a gradient of this step did not come out of that launch).  ppo_loss
         (ops.ppo_loss_desc, fused chain only): the backward launch evaluates the PPO loss first and so
-        produces d_heads itself.  step = FlatAdam.step_desc(...) (fused chain, single GPU): the finalise launch also
-        performs the optimiser step; returns 'step' when it did (the caller then only advances its host mirrors)."""
+        produces d_heads itself."""
         rows = self._rows
         L = len(self.linears)
         self._pending_backward = False
@@ -319,7 +318,7 @@ class ManualMLP:
                 lin = self.linears[l]
                 jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm, step)
+            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm)
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
@@ -373,7 +372,7 @@ class ManualMLP:
                 d = d_prev
         return self._weight_grads(jobs, rows, colsums, loss_finalize)
 
-    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None, step=None):
+    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None):
         """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
@@ -404,13 +403,9 @@ class ManualMLP:
                 #  launch takes over instead of an error in the middle of an epoch)
                 whole = (norm is not None and not slow and loss_finalize is not None
                          and norm[0].numel() >= plan.finalize_blocks(colsums, loss_finalize))
-                if whole and step is not None:
-                    plan.launch(fast, colsums, loss_finalize, step=step)
-                    norm_blocks = 'step'
-                else:
-                    norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
-                    if not whole:
-                        norm_blocks = None
+                norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
+                if not whole:
+                    norm_blocks = None
                 colsums = ()
                 loss_finalize = None
                 self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run

@@ -1001,10 +1001,6 @@ class MlpChain:
 
 # ------------------------------------------------------------------ MLP weight gradients (MFMA)
 
-def step_tail_max_blocks():
-    return int(_lib.load().rlg_mlp_dw_step_tail_max_blocks())
-
-
 class MlpDwPlan:
     """All weight-gradient GEMMs of one MLP backward as one launch (csrc/mlp_dw.hip).
 
@@ -1048,17 +1044,13 @@ class MlpDwPlan:
             n += 1 + (2 * loss_finalize.actions_num + 7) // 8
         return n
 
-    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None, step=None):
+    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None):
         """jobs: (dz, x, grad) per planned layer.  colsums: optional (partials fp64 [blocks*cols],
         blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch.
         loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well.
         norm = (partials fp64 [>= finalise blocks], grad_scale, step_counter int64 [1]): the finalise
         launch also leaves per-block sums of (g * grad_scale)^2 and advances the Adam step counter (what
         grad_sumsq does) - only meaningful when this launch writes every gradient of the arena.
-        step = (adam_desc, sync_state uint32 [2], sync_partials fp64 [step_tail_max_blocks()]) - FlatAdam.step_desc:
-        the finalise launch also performs the WHOLE optimiser step (norm, clip, Adam, lr rule; csrc/mlp_dw.hip,
-        mlp_dw_finalize_adam_kernel) - single GPU, every gradient of the arena written by this launch, loss_finalize
-        given; `norm` is ignored then.
         Returns the number of finalise blocks (= valid entries of the norm partials)."""
         import ctypes
         if len(jobs) != self.n:
@@ -1086,19 +1078,6 @@ class MlpDwPlan:
             self._dz[k] = _need(dz, F32, 'dz')
             self._x[k] = _need(x, F32, 'x')
             self._grad[k] = _need(grad, F32, 'grad')
-        if step is not None:
-            if loss_finalize is None:
-                raise ValueError('MlpDwPlan.launch(step=...) needs loss_finalize')
-            desc, sync_state, sync_partials = step
-            if sync_state.dtype != torch.int32 or sync_state.numel() < 2 or sync_partials.dtype != F64 or \
-                    sync_partials.numel() < step_tail_max_blocks():
-                raise ValueError('step: sync_state int32 [2] and sync_partials fp64 [step_tail_max_blocks()] expected')
-            _lib.check(_lib.load().rlg_mlp_dw_launch_step(
-                self.n, self._dz, self._x, self._ws, self._grad, self._no, self._mi, self._plans, self.rows, nc, cs_part,
-                cs_blocks, cs_cols, cs_out, ctypes.addressof(loss_finalize), ctypes.addressof(desc),
-                _need(sync_state, torch.int32, 'sync_state'), _need(sync_partials, F64, 'sync_partials'),
-                _lib.stream_handle(self._device)), 'rlg_mlp_dw_launch_step')
-            return self.finalize_blocks(colsums, loss_finalize)
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
                                                  cs_cols, cs_out,

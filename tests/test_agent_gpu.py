@@ -1062,39 +1062,6 @@ def test_adam_written_planes_match_the_pack_launch(graphs):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize('graphs', [True, False])
-def test_fused_step_tail_matches_the_launch_pair(graphs):
-    """Round 4: finalise + gradient norm + clip + Adam + lr rule as ONE launch (csrc/mlp_dw.hip,
-    mlp_dw_finalize_adam_kernel: persistent grid, one grid barrier, every thread updates the parameters whose
-    gradients it wrote) against the launch pair finalise -> adam_step on the same agent.  Identical gradients; the
-    gradient norm is summed over per-workgroup instead of per-finalise-block partials, so the clip coefficient may
-    differ in its last bit.  (The fused form is opt-in: correct - this test - but slower than the pair, see
-    profiles/r4_step_tail.txt.)"""
-    from rl_games_amd import configs
-    from rl_games_amd.agent import A2CAgent
-    res = []
-    for fused in (True, False):
-        params = configs.tiny(num_actors=96, horizon=8, hip_graphs=graphs, fused_step_tail=fused)
-        params['config']['minibatch_size'] = 256                      # 768 rows -> 3 minibatches
-        torch.manual_seed(11)
-        agent = A2CAgent('t', params)
-        agent.init_tensors()
-        agent.obs = agent.env_reset()
-        for _ in range(3):
-            agent.update_epoch()
-            agent.train_epoch()
-        opt = agent.optimizer
-        steps = 3 * agent.mini_epochs_num * 3
-        assert opt.step_count == steps and int(opt.step_counter.item()) == steps
-        assert bool(agent._fin_norm_ok)
-        res.append((opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.grads.clone(),
-                    opt.stats.clone(), opt.last_and_next_lr()))
-    a, b = res
-    assert a[5] == b[5]                                               # same learning-rate trajectory
-    for x, y, name in zip(a[:5], b[:5], ('params', 'exp_avg', 'exp_avg_sq', 'grads', 'stats')):
-        assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (name, (x - y).abs().max().item())
-
-
 @pytest.mark.parametrize('kind,collective', [('mlp', 'ipc'), ('lstm', 'ipc'), ('discrete', 'ipc'), ('central_value', 'ipc'),
                                              ('mlp', 'fallback'), ('mlp', 'ipc-two-phase'), ('lstm', 'fallback')])
 def test_two_rank_training_keeps_ranks_in_sync(kind, collective):
