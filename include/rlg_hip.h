@@ -341,23 +341,6 @@ int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_a
                        const unsigned* skip_flag_or_null, int num_layers, const float* const* weights,
                        const int* in_features, const int* out_features, void* planes, void* stream);
 
-/* The same step when the chain's 16-row launches run the LEAN kernels (rlg_mlp_chain_forward_lean ...): the launch also
- * writes the fp32 weight fragments of both directions for the new weights (csrc/mlp_chain.hip, adam_frags_kernel: one
- * launch instead of Adam + rlg_mlp_chain_pack_frags_both).  The fragment buffers must have been packed once in full
- * (their zero padding is never written here).  frags_bwd_or_null: forward fragments only. */
-/* 1 when rlg_adam_step_frags takes this arena / network (every matrix inside the arena at a 16-byte offset, in_features
- * multiples of 4, the fragment format fits), else 0: the caller then keeps rlg_adam_step + rlg_mlp_chain_pack_frags_both. */
-int rlg_adam_step_frags_supported(const float* params, long long n, int num_layers, const float* const* weights,
-                                  const int* in_features, const int* out_features);
-int rlg_adam_step_frags(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                        const double* norm_partials_or_null, int norm_blocks, float grad_scale, float max_norm,
-                        double* lr_slots, const long long* step_counter, double beta1, double beta2, double eps,
-                        double weight_decay, int schedule_kind, const float* kl_or_null, float kl_scale,
-                        double kl_threshold, double min_lr, double max_lr, double lr_multiplier, float* stats_out_or_null,
-                        const unsigned* skip_flag_or_null, int num_layers, const float* const* weights,
-                        const int* in_features, const int* out_features, void* frags_fwd, void* frags_bwd_or_null,
-                        void* stream);
-
 /* ------------------------------------------------------------------------------------
  * Manual MLP backward helpers
  *   replace, per hidden layer of A2CBuilder's MLP (rl_games/algos_torch/network_builder.py:

@@ -145,10 +145,6 @@ _PROTOTYPES = {
     'rlg_adam_step_pack': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
                            _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
                            _c_double, _c_double, _c_double, _P, _P, _c_int, _P, _P, _P, _P, _P],
-    'rlg_adam_step_frags_supported': [_P, _c_ll, _c_int, _P, _P, _P],
-    'rlg_adam_step_frags': [_P, _P, _P, _P, _c_ll, _P, _c_int, _c_float, _c_float, _P, _P,
-                            _c_double, _c_double, _c_double, _c_double, _c_int, _P, _c_float, _c_double,
-                            _c_double, _c_double, _c_double, _P, _P, _c_int, _P, _P, _P, _P, _P, _P],
 }
 
 _lib = None

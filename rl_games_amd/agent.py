@@ -1275,18 +1275,13 @@ class A2CAgent:
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
-        # the lean 16-row kernels read the weights as fp32 fragments: the Adam launch writes them (one chain, no bf16 planes
-        # to write as well), else one launch behind the step does - inside the captured graphs too: no launch of this
-        # agent ever packs on demand
-        # (one process per GPU only: the row-per-thread Adam + pack form was seen to leave two ranks that SHARE a GPU a few
-        #  ulps apart - csrc/mlp_chain_bx.hip, adam_pack_kernel's note; multi-GPU runs keep Adam and the pack apart)
-        in_adam = lean.chains[0] if (lean is not None and len(lean.chains) == 1 and self._adam_pack_chain() is None
-                                     and (not self.multi_gpu or self.config.get('adam_frags_multi_gpu', False))
-                                     and lean.chains[0].adam_frags_target(opt.flat_params) is not None) else None
-        opt.step(norm_ready=self._norm_ready, skip_flag=skip, pack=self._adam_pack_chain(), frags=in_adam,
-                 **self._step_arguments())
+        # the lean 16-row kernels read the weights as fp32 fragments: one pack launch behind the step writes them - inside
+        # the captured graphs too: no launch of this agent ever packs on demand.  (Round 4 had the Adam launch write them
+        # itself on one GPU, adam_frags_kernel; that kernel family left two ranks that SHARE a GPU one exp_avg_sq update
+        # apart and is gone - profiles/r5_two_rank_sync.txt.)
+        opt.step(norm_ready=self._norm_ready, skip_flag=skip, pack=self._adam_pack_chain(), **self._step_arguments())
         self._norm_ready = None
-        if lean is not None and in_adam is None:
+        if lean is not None:
             lean.pack_frags(opt.flat_params)
             lean.mark_frags(opt.weights_version)
 

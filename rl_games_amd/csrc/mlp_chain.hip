@@ -2032,174 +2032,6 @@ static long long chain_lean_plan(int num_layers, const int* in_features, const i
 static long long chain_lean_bytes(long long plan) { return plan < 0 ? plan : (plan & ((1LL << 40) - 1)); }
 static int chain_lean_tile_floats(long long plan) { return static_cast<int>(plan >> 40); }
 
-// ---- optimiser step that leaves the lean kernels' weight fragments behind (cf. adam_pack_kernel, csrc/mlp_chain_bx.hip) --------
-// adam_step_kernel + chain_pack_frags2_kernel as ONE launch: a thread updates 4 consecutive elements of one row of a weight
-// matrix W [O][I] - exactly one lane's 16 bytes of a FORWARD fragment (block o >> 4, chunk i >> 4, lane (o & 15) + 16 ((i & 15)
-// >> 2)) - and the 4 lanes of a quad hold 4 consecutive rows, i.e. the 4 elements of one lane slot of a BACKWARD fragment for
-// each of the thread's 4 columns (block i >> 4, chunk o >> 4, lane (i & 15) + 16 ((o & 15) >> 2), element o & 3): four 4-byte
-// stores per thread that the quad's lanes of one instruction complete to 16 bytes.  Same Adam arithmetic per element as
-// adam_update (optim_common.hpp), the same fragment bytes as the pack launch (the zero padding is never touched: the buffers
-// are packed once in full before the first step).  Everything of the arena outside the chain's matrices: flat ranges.
-constexpr int kAfMaxRanges = 2 * kChainMaxLayers + 2;
-struct AdamFragArgs {
-  AdamArgs adam;
-  long long w_off[kChainMaxLayers];
-  int O[kChainMaxLayers], I[kChainMaxLayers];
-  int item_begin[kChainMaxLayers + 1];
-  int num;
-  float* frags_f;
-  float* frags_b;                                    // or nullptr
-  unsigned seg_f[kLeanW][kChainMaxLayers], seg_b[kLeanW][kChainMaxLayers];   // first fragment of (wave, step)
-  unsigned char kc2_f[kChainMaxLayers], kc2_b[kChainMaxLayers], full_f[kChainMaxLayers], full_b[kChainMaxLayers];
-  long long r_begin[kAfMaxRanges], r_end[kAfMaxRanges];
-  int nranges;
-  int matrix_blocks;
-};
-
-__global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs ap) {
-  const AdamArgs& a = ap.adam;
-  __shared__ float sh_clip;
-  __shared__ float sh_norm;
-  __shared__ double scratch[256 / kWave];
-  const bool matrix_block = static_cast<int>(blockIdx.x) < ap.matrix_blocks;
-  const int item = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  bool has_item = matrix_block && item < ap.item_begin[ap.num];
-  int L = 0, O = 0, I = 0, o = 0, i0 = 0;
-  f32x4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, p4 = g4, m4 = g4, v4 = g4;
-  long long idx = 0;
-  if (has_item) {
-    for (int j = 1; j < ap.num; ++j) L = (item >= ap.item_begin[j]) ? j : L;
-    O = ap.O[L];
-    I = ap.I[L];
-    const int niq = I >> 2;
-    const int local = item - ap.item_begin[L];
-    const int r = local & 3, blk = local >> 2;
-    const int oq = blk / niq, iq = blk - oq * niq;
-    o = 4 * oq + r;
-    i0 = 4 * iq;
-    has_item = o < O;
-    if (has_item) {
-      idx = ap.w_off[L] + static_cast<long long>(o) * I + i0;
-      g4 = *reinterpret_cast<const f32x4*>(a.grads + idx);
-      p4 = *reinterpret_cast<const f32x4*>(a.params + idx);
-      m4 = *reinterpret_cast<const f32x4*>(a.exp_avg + idx);
-      v4 = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx);
-    }
-  }
-  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
-  const long long step = *a.step_counter;
-  const int cur = static_cast<int>((step - 1) & 1);
-  const double lr = a.lr_slots[cur];
-
-  double sq[1] = {0.0};
-  if (a.norm_partials) {           // (as adam_step_kernel: every workgroup computes the same sum in the same order)
-    int b = threadIdx.x;
-    for (; b + 3 * 256 < a.norm_blocks; b += 4 * 256) {
-      const double v0 = a.norm_partials[b], v1 = a.norm_partials[b + 256];
-      const double v2 = a.norm_partials[b + 2 * 256], v3 = a.norm_partials[b + 3 * 256];
-      sq[0] += v0;
-      sq[0] += v1;
-      sq[0] += v2;
-      sq[0] += v3;
-    }
-    for (; b < a.norm_blocks; b += 256) sq[0] += a.norm_partials[b];
-    block_sum<1, 256>(sq, scratch);
-  }
-  if (threadIdx.x == 0) {
-    float coef = 1.0f, total_norm = 0.0f;
-    if (a.norm_partials) {
-      total_norm = static_cast<float>(sqrt(sq[0]));
-      coef = adam_clip_coef(a.max_norm, total_norm);
-    }
-    sh_clip = coef;
-    sh_norm = total_norm;
-  }
-  __syncthreads();
-  const float clip = sh_clip;
-  const AdamScalars k = adam_scalars(a, step, lr);
-#ifdef RLG_ADAM_TRACE
-  AdamTraceAcc tr;
-  if (matrix_block && has_item && !skip) {
-    for (int e = 0; e < 4; ++e) adam_trace_in(tr, a, step, idx + e, g4[e], p4[e], m4[e], v4[e]);
-  }
-#endif
-
-  if (matrix_block) {
-    if (has_item && !skip) {
-      f32x4 gc;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = (g4[e] * a.grad_scale) * clip;
-        gc[e] = g;
-        float p = p4[e];
-        if (k.wd != 0.0f) g = g + k.wd * p;
-        float m = m4[e];
-        m = m + k.w1 * (g - m);
-        float v = v4[e];
-        v = v * k.b2 + (k.w2 * g) * g;
-        const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
-        p = p - k.step_size * (m / denom);
-        m4[e] = m;
-        v4[e] = v;
-        p4[e] = p;
-      }
-      *reinterpret_cast<f32x4*>(a.grads + idx) = gc;
-      *reinterpret_cast<f32x4*>(a.exp_avg + idx) = m4;
-      *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx) = v4;
-      *reinterpret_cast<f32x4*>(a.params + idx) = p4;
-#ifdef RLG_ADAM_TRACE
-      for (int e = 0; e < 4; ++e) adam_trace_out(tr, idx + e, gc[e], p4[e], m4[e], v4[e]);
-#endif
-      // block ob of a step -> (wave, unit): whole blocks wave-major, then one remainder block per wave
-      auto where = [](int ob, int full, int& w, int& j) {
-        if (ob < kLeanW * full) {
-          w = ob / full;
-          j = ob - w * full;
-        } else {
-          w = ob - kLeanW * full;
-          j = full;
-        }
-      };
-      {
-        // forward fragments: step L, block over o, chunk over i
-        int w, j;
-        where(o >> 4, ap.full_f[L], w, j);
-        const long long frag = ap.seg_f[w][L] + static_cast<long long>(j) * ap.kc2_f[L] + (i0 >> 4);
-        const int lane = (o & 15) + 16 * ((i0 & 15) >> 2);
-        *reinterpret_cast<f32x4*>(ap.frags_f + (frag * 64 + lane) * 4) = p4;
-      }
-      if (ap.frags_b != nullptr && L >= 1) {
-        // backward fragments: step t = num - 1 - L, block over i, chunk over o; the thread's 4 columns share the block
-        const int t = ap.num - 1 - L;
-        int w, j;
-        where(i0 >> 4, ap.full_b[t], w, j);
-        const long long frag = ap.seg_b[w][t] + static_cast<long long>(j) * ap.kc2_b[t] + (o >> 4);
-        float* dst = ap.frags_b + (frag * 64 + 16 * ((o & 15) >> 2)) * 4 + (o & 3);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(((i0 + e) & 15)) * 4] = p4[e];
-      }
-    }
-  } else if (!skip) {
-    long long t = (static_cast<long long>(blockIdx.x) - ap.matrix_blocks) * 256 + threadIdx.x;
-    for (int r = 0; r < ap.nranges; ++r) {
-      const long long len = ap.r_end[r] - ap.r_begin[r];
-      if (t < len) {
-#ifdef RLG_ADAM_TRACE
-        adam_update_traced(tr, a, k, step, ap.r_begin[r] + t, clip);
-#else
-        adam_update(a, k, ap.r_begin[r] + t, clip);
-#endif
-        break;
-      }
-      t -= len;
-    }
-  }
-#ifdef RLG_ADAM_TRACE
-  adam_trace_flush(a, step, tr);
-  if (blockIdx.x == 0 && threadIdx.x == 0) adam_trace_scalars(a, step, clip, sh_norm, lr);
-#endif
-  if (blockIdx.x == 0 && threadIdx.x == 0) adam_finish(a, cur, lr, skip, sh_norm, clip);
-}
 }  // namespace rlg
 
 // ---------------------------------------------------------------------------------
@@ -3010,127 +2842,6 @@ int rlg_mlp_chain_step_lean(int num_layers, const float* const* biases, const in
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * kLeanW), static_cast<size_t>(lds_bytes), st, ev0, ev1, 0, fa, fla, ba, bla, loss);
   else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kLeanW), static_cast<size_t>(lds_bytes), st, fa, fla, ba, bla, loss);
-  RLG_RETURN_LAUNCH_STATUS();
-}
-
-int rlg_adam_step_frags_supported(const float* params, long long n, int num_layers, const float* const* weights,
-                                  const int* in_features, const int* out_features) {
-  using namespace rlg;
-  if (params == nullptr || n <= 0 || num_layers < 1 || num_layers > kChainMaxLayers) return 0;
-  if (reinterpret_cast<uintptr_t>(params) % 16 != 0) return 0;
-  LeanPackArgs pk = {};
-  if (chain_lean_plan(num_layers, in_features, out_features, 0, &pk) < 0) return 0;
-  if (num_layers >= 2 && chain_lean_plan(num_layers, in_features, out_features, 1, &pk) < 0) return 0;
-  long long begin[kChainMaxLayers], end[kChainMaxLayers];
-  for (int L = 0; L < num_layers; ++L) {
-    const long long off = weights[L] - params;
-    const long long cnt = static_cast<long long>(in_features[L]) * out_features[L];
-    if (off < 0 || off + cnt > n || (off & 3) != 0 || (in_features[L] & 3) != 0) return 0;
-    begin[L] = off;
-    end[L] = off + cnt;
-  }
-  for (int x = 0; x < num_layers; ++x)
-    for (int y = 0; y < num_layers; ++y)
-      if (x != y && begin[x] < end[y] && begin[y] < end[x]) return 0;      // overlapping matrices
-  return 1;
-}
-
-int rlg_adam_step_frags(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                        const double* norm_partials_or_null, int norm_blocks, float grad_scale, float max_norm,
-                        double* lr_slots, const long long* step_counter, double beta1, double beta2, double eps,
-                        double weight_decay, int schedule_kind, const float* kl_or_null, float kl_scale,
-                        double kl_threshold, double min_lr, double max_lr, double lr_multiplier, float* stats_out_or_null,
-                        const unsigned* skip_flag_or_null, int num_layers, const float* const* weights,
-                        const int* in_features, const int* out_features, void* frags_fwd, void* frags_bwd_or_null,
-                        void* stream) {
-  using namespace rlg;
-  if (n <= 0 || !step_counter || num_layers < 1 || num_layers > kChainMaxLayers || frags_fwd == nullptr)
-    return static_cast<int>(hipErrorInvalidValue);
-  if (schedule_kind == 1 && !kl_or_null) return static_cast<int>(hipErrorInvalidValue);
-  if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
-       reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 != 0)
-    return static_cast<int>(hipErrorInvalidValue);
-  AdamFragArgs ap;
-  AdamArgs& a = ap.adam;
-  a.params = params;
-  a.grads = grads;
-  a.exp_avg = exp_avg;
-  a.exp_avg_sq = exp_avg_sq;
-  a.n = n;
-  a.norm_partials = norm_partials_or_null;
-  a.norm_blocks = norm_blocks;
-  a.grad_scale = grad_scale;
-  a.max_norm = max_norm;
-  a.lr_slots = lr_slots;
-  a.step_counter = step_counter;
-  a.beta1 = beta1;
-  a.beta2 = beta2;
-  a.eps = eps;
-  a.weight_decay = weight_decay;
-  a.schedule_kind = schedule_kind;
-  a.kl = kl_or_null;
-  a.kl_scale = kl_scale;
-  a.kl_threshold = kl_threshold;
-  a.min_lr = min_lr;
-  a.max_lr = max_lr;
-  a.lr_multiplier = lr_multiplier;
-  a.stats_out = stats_out_or_null;
-  a.skip_flag = skip_flag_or_null;
-  RLG_ADAM_TRACE_FILL(a);
-  LeanPackArgs pf = {}, pb = {};
-  if (chain_lean_plan(num_layers, in_features, out_features, 0, &pf) < 0) return static_cast<int>(hipErrorInvalidValue);
-  const bool with_b = frags_bwd_or_null != nullptr && num_layers >= 2;
-  if (with_b && chain_lean_plan(num_layers, in_features, out_features, 1, &pb) < 0) return static_cast<int>(hipErrorInvalidValue);
-  ap.num = num_layers;
-  ap.frags_f = static_cast<float*>(frags_fwd);
-  ap.frags_b = with_b ? static_cast<float*>(frags_bwd_or_null) : nullptr;
-  for (int w = 0; w < kLeanW; ++w) {
-    for (int t = 0; t < kChainMaxLayers; ++t) {
-      ap.seg_f[w][t] = pf.seg_begin[w][t];
-      ap.seg_b[w][t] = pb.seg_begin[w][t];
-    }
-  }
-  for (int t = 0; t < kChainMaxLayers; ++t) {
-    ap.kc2_f[t] = pf.la.kc2[t];
-    ap.full_f[t] = pf.la.full[t];
-    ap.kc2_b[t] = pb.la.kc2[t];
-    ap.full_b[t] = pb.la.full[t];
-  }
-  int items = 0;
-  long long begin[kChainMaxLayers], end[kChainMaxLayers];
-  for (int L = 0; L < num_layers; ++L) {
-    const long long off = weights[L] - params;
-    const long long cnt = static_cast<long long>(in_features[L]) * out_features[L];
-    if (off < 0 || off + cnt > n || (off & 3) != 0 || (in_features[L] & 3) != 0) return static_cast<int>(hipErrorInvalidValue);
-    ap.w_off[L] = off;
-    ap.O[L] = out_features[L];
-    ap.I[L] = in_features[L];
-    ap.item_begin[L] = items;
-    items += ((out_features[L] + 3) >> 2) * (in_features[L] >> 2) * 4;
-    begin[L] = off;
-    end[L] = off + cnt;
-  }
-  ap.item_begin[num_layers] = items;
-  for (int x = 0; x < num_layers; ++x)
-    for (int y = x + 1; y < num_layers; ++y)
-      if (begin[y] < begin[x]) { std::swap(begin[x], begin[y]); std::swap(end[x], end[y]); }
-  ap.nranges = 0;
-  long long pos = 0, flat = 0;
-  for (int x = 0; x <= num_layers; ++x) {
-    const long long stop = (x < num_layers) ? begin[x] : n;
-    if (stop < pos) return static_cast<int>(hipErrorInvalidValue);
-    if (stop > pos) {
-      if (ap.nranges >= kAfMaxRanges) return static_cast<int>(hipErrorInvalidValue);
-      ap.r_begin[ap.nranges] = pos;
-      ap.r_end[ap.nranges] = stop;
-      ++ap.nranges;
-      flat += stop - pos;
-    }
-    if (x < num_layers) pos = end[x];
-  }
-  ap.matrix_blocks = (items + 255) / 256;
-  const int grid = ap.matrix_blocks + static_cast<int>((flat + 255) / 256);
-  hipLaunchKernelGGL(adam_frags_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), ap);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -371,11 +371,11 @@ int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t
 // chain_pack_planes_kernel writes (zero padding outside the matrices is never touched: the buffer is packed once in
 // full before the first step).  Everything of the arena that is not one of the chain's matrices (biases, sigma) is
 // updated by the flat ranges at the end of the grid.
-// (A form with one thread per (row, 4 columns) - 36 k threads instead of 9 k, one split per thread, the backward operand's 16-bit
-//  halves stored by the quad's lanes - ran in 9.0 us instead of 12.8 us and passed every single-process test, incl. 700
-//  repetitions on identical inputs, but two ranks sharing one GPU ended an epoch with exp_avg_sq / parameters / planes that
-//  differed in the last bits in a third of the runs (tools/exp/two_rank_planes_probe.py, profiles/r4_two_rank_sync.txt).
-//  Not understood; this form - clean in every such run - stays.)
+// (Round 4 also had a form with one thread per (row, 4 columns) - 9.0 us instead of 12.8 us - and round 4's lean kernels an
+//  Adam + fp32-fragments launch of the same build, adam_frags_kernel.  Both are gone (round 5): two ranks sharing one GPU ended
+//  epochs with a 16-lane group's exp_avg_sq one update apart in 20 % / 80 - 100 % of the runs, while this form (0 of 49) and
+//  the plain rlg_adam_step (0 of 40) never did; the defect follows the compiled code of that kernel family, not any of its
+//  parts - profiles/r5_two_rank_sync.txt.)
 constexpr int kApMaxRanges = 2 * kChainMaxLayers + 2;
 struct AdamPackArgs {
   AdamArgs adam;
@@ -564,186 +564,6 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
 }
 
 
-// The row-per-thread form of the same launch (RLG_ADAM_PACK_ROWPT=1; round 4: withdrawn, see the note above; round 5:
-// back as a runtime choice for the diagnosis of that note - tools/exp/adam_trace_probe.py): a thread updates 4 consecutive
-// elements of ONE row, the 4 lanes of a quad hold 4 consecutive rows of the same 4 columns.  The thread splits its new
-// weights once: the packed plane dwords are the forward operand's bytes (one 8-byte store per plane) and their 16-bit
-// halves the backward operand's (the 4 consecutive k of a column are the quad's 4 rows: each lane stores its 2 bytes of the
-// 8-byte word).  item_begin counts (row quad, column group, row of the quad) items here.
-#ifndef RLG_ROWPT_VARIANT
-#define RLG_ROWPT_VARIANT 0      // diagnosis builds (tools/exp/build_rowpt_variants.sh): 1 = vmcnt(0) behind the Adam stores, 2 = the
-#endif                           // plane offsets loaded up front, 3 = no plane stores (wrong planes)
-__device__ __forceinline__ void ap_store2(unsigned char* p, unsigned v) {
-  *reinterpret_cast<unsigned short*>(p) = static_cast<unsigned short>(v);
-}
-
-__global__ __launch_bounds__(256) void adam_pack_rowpt_kernel(AdamPackArgs ap) {
-  const AdamArgs& a = ap.adam;
-  __shared__ float sh_clip;
-  __shared__ float sh_norm;
-  __shared__ double scratch[256 / kWave];
-  const bool matrix_block = static_cast<int>(blockIdx.x) < ap.matrix_blocks;
-  const int item = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  bool has_item = matrix_block && item < ap.item_begin[ap.num];
-  int L = 0, O = 0, I = 0, o = 0, i0 = 0;
-  f32x4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, p4 = g4, m4 = g4, v4 = g4;
-  long long idx = 0;
-#if RLG_ROWPT_VARIANT == 2
-  long long fo_early = -1, bo_early = -1;
-#endif
-  if (has_item) {
-    for (int j = 1; j < ap.num; ++j) L = (item >= ap.item_begin[j]) ? j : L;
-    O = ap.O[L];
-    I = ap.I[L];
-    const int niq = I >> 2;
-    const int local = item - ap.item_begin[L];
-#if RLG_ROWPT_VARIANT == 5
-    // diagnosis only (with no plane stores): plain row-major items - a wave covers 64 consecutive column groups of ONE row
-    o = local / niq;
-    i0 = 4 * (local - o * niq);
-#else
-    const int r = local & 3, blk = local >> 2;
-    const int oq = blk / niq, iq = blk - oq * niq;
-    o = 4 * oq + r;
-    i0 = 4 * iq;
-#endif
-    has_item = o < O;
-#if RLG_ROWPT_VARIANT == 2
-    fo_early = ap.fwd_off[L];
-    bo_early = ap.bwd_off[L];
-#endif
-    if (has_item) {
-      idx = ap.w_off[L] + static_cast<long long>(o) * I + i0;
-      g4 = *reinterpret_cast<const f32x4*>(a.grads + idx);
-      p4 = *reinterpret_cast<const f32x4*>(a.params + idx);
-      m4 = *reinterpret_cast<const f32x4*>(a.exp_avg + idx);
-      v4 = *reinterpret_cast<const f32x4*>(a.exp_avg_sq + idx);
-    }
-  }
-  const bool skip = a.skip_flag != nullptr && *a.skip_flag != 0u;
-  const long long step = *a.step_counter;
-  const int cur = static_cast<int>((step - 1) & 1);
-  const double lr = a.lr_slots[cur];
-
-  double sq[1] = {0.0};
-  if (a.norm_partials) {
-    int b = threadIdx.x;
-    for (; b + 3 * 256 < a.norm_blocks; b += 4 * 256) {
-      const double v0 = a.norm_partials[b], v1 = a.norm_partials[b + 256];
-      const double v2 = a.norm_partials[b + 2 * 256], v3 = a.norm_partials[b + 3 * 256];
-      sq[0] += v0;
-      sq[0] += v1;
-      sq[0] += v2;
-      sq[0] += v3;
-    }
-    for (; b < a.norm_blocks; b += 256) sq[0] += a.norm_partials[b];
-    block_sum<1, 256>(sq, scratch);
-  }
-  if (threadIdx.x == 0) {
-    float coef = 1.0f, total_norm = 0.0f;
-    if (a.norm_partials) {
-      total_norm = static_cast<float>(sqrt(sq[0]));
-      coef = adam_clip_coef(a.max_norm, total_norm);
-    }
-    sh_clip = coef;
-    sh_norm = total_norm;
-  }
-  __syncthreads();
-  const float clip = sh_clip;
-  const AdamScalars k = adam_scalars(a, step, lr);
-#ifdef RLG_ADAM_TRACE
-  AdamTraceAcc tr;
-  if (matrix_block && has_item && !skip) {
-    for (int e = 0; e < 4; ++e) adam_trace_in(tr, a, step, idx + e, g4[e], p4[e], m4[e], v4[e]);
-  }
-#endif
-
-  if (matrix_block) {
-    if (has_item && !skip) {
-      f32x4 gc;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = (g4[e] * a.grad_scale) * clip;
-        gc[e] = g;
-        float p = p4[e];
-        if (k.wd != 0.0f) g = g + k.wd * p;
-        float m = m4[e];
-        m = m + k.w1 * (g - m);
-        float v = v4[e];
-        v = v * k.b2 + (k.w2 * g) * g;
-        const float denom = sqrt_rn(v) / k.bc2_sqrt + k.eps;
-        p = p - k.step_size * (m / denom);
-        m4[e] = m;
-        v4[e] = v;
-        p4[e] = p;
-      }
-      *reinterpret_cast<f32x4*>(a.grads + idx) = gc;
-      *reinterpret_cast<f32x4*>(a.exp_avg + idx) = m4;
-      *reinterpret_cast<f32x4*>(a.exp_avg_sq + idx) = v4;
-      *reinterpret_cast<f32x4*>(a.params + idx) = p4;
-#ifdef RLG_ADAM_TRACE
-      for (int e = 0; e < 4; ++e) adam_trace_out(tr, idx + e, gc[e], p4[e], m4[e], v4[e]);
-#endif
-      // the new weights' planes: pl[p] = {(e0, e1), (e2, e3)} packed bf16.  Element slot of feature k inside its
-      // 32-feature chunk: lane group q = (k % 16) / 4, half = (k % 32) / 16, position k % 4 of the 8-byte word
-#if RLG_ROWPT_VARIANT == 1
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#if RLG_ROWPT_VARIANT == 2
-      const long long fwd_off_L = fo_early, bwd_off_L = bo_early;
-#else
-      const long long fwd_off_L = ap.fwd_off[L], bwd_off_L = ap.bwd_off[L];
-#endif
-      unsigned pl[3][2];
-      split4_planes(p4, pl);
-#if RLG_ROWPT_VARIANT != 3 && RLG_ROWPT_VARIANT != 5
-      if (fwd_off_L >= 0) {
-        const int KC = ((I + 31) >> 5);
-        const int c = i0 >> 5, rr = i0 & 31, q = (rr & 15) >> 2, half = rr >> 4;
-        unsigned char* dst = ap.planes + fwd_off_L + (static_cast<long long>(o >> 4) * KC + c) * kBxChunk +
-                             ((o & 15) + 16 * q) * 16 + half * 8;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
-      }
-      if (bwd_off_L >= 0) {
-        const int KC = ((O + 31) >> 5);
-        const int c = o >> 5, rr = o & 31, q = (rr & 15) >> 2, half = rr >> 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = i0 + e;
-          unsigned char* dst = ap.planes + bwd_off_L + (static_cast<long long>(i >> 4) * KC + c) * kBxChunk +
-                               ((i & 15) + 16 * q) * 16 + half * 8 + 2 * (o & 3);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) ap_store2(dst + p * kBxFrag, pl[p][e >> 1] >> (16 * (e & 1)));
-        }
-      }
-#else
-      // variant 3 (diagnosis only, WRONG planes): no plane stores at all
-      if (fwd_off_L == -12345 && bwd_off_L == -12345) a.params[0] = __uint_as_float(pl[0][0] ^ pl[1][1] ^ pl[2][0]);
-#endif
-    }
-  } else if (!skip) {
-    long long t = (static_cast<long long>(blockIdx.x) - ap.matrix_blocks) * 256 + threadIdx.x;
-    for (int r = 0; r < ap.nranges; ++r) {
-      const long long len = ap.r_end[r] - ap.r_begin[r];
-      if (t < len) {
-#ifdef RLG_ADAM_TRACE
-        adam_update_traced(tr, a, k, step, ap.r_begin[r] + t, clip);
-#else
-        adam_update(a, k, ap.r_begin[r] + t, clip);
-#endif
-        break;
-      }
-      t -= len;
-    }
-  }
-#ifdef RLG_ADAM_TRACE
-  adam_trace_flush(a, step, tr);
-  if (blockIdx.x == 0 && threadIdx.x == 0) adam_trace_scalars(a, step, clip, sh_norm, lr);
-#endif
-  if (blockIdx.x == 0 && threadIdx.x == 0) adam_finish(a, cur, lr, skip, sh_norm, clip);
-}
-
 }  // namespace rlg
 
 // ---------------------------------------------------------------------------------
@@ -819,10 +639,6 @@ int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_a
   a.stats_out = stats_out_or_null;
   a.skip_flag = skip_flag_or_null;
   RLG_ADAM_TRACE_FILL(a);
-  static const bool rowpt = [] {
-    const char* e = std::getenv("RLG_ADAM_PACK_ROWPT");
-    return e != nullptr && e[0] == '1';
-  }();
   unsigned foff[kChainMaxLayers], boff[kChainMaxLayers];
   const long long ftotal = chain_bx_plane_offsets(num_layers, in_features, out_features, 0, foff);
   const long long btotal = chain_bx_plane_offsets(num_layers, in_features, out_features, 1, boff);
@@ -843,7 +659,7 @@ int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_a
     ap.fwd_off[L] = foff[L];
     ap.bwd_off[L] = (L >= 1) ? bbase + boff[L] : -1;
     ap.item_begin[L] = items;
-    items += ((out_features[L] + 3) >> 2) * (in_features[L] >> 2) * (rowpt ? 4 : 1);
+    items += ((out_features[L] + 3) >> 2) * (in_features[L] >> 2);
     begin[L] = off;
     end[L] = off + cnt;
   }
@@ -867,8 +683,7 @@ int rlg_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_a
   }
   ap.matrix_blocks = (items + 255) / 256;
   const int grid = ap.matrix_blocks + static_cast<int>((flat + 255) / 256);
-  if (rowpt) hipLaunchKernelGGL(adam_pack_rowpt_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), ap);
-  else hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), ap);
+  hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), ap);
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -118,7 +118,7 @@ class FlatAdam(FlatArena):
 
     # ------------------------------------------------------------------ step
     def step(self, grad_scale=1.0, max_norm=None, schedule=None, kl_scale=1.0, norm_ready=None, skip_flag=None,
-             pack=None, frags=None):
+             pack=None):
         """grad_scale: 1/world_size after a SUM all-reduce.  max_norm: clip threshold or None.
         schedule: None or dict(kl_threshold, min_lr, max_lr, lr_multiplier) -> KL-adaptive lr
         driven by the KL in `kl_slot` (times kl_scale).  norm_ready = (partials fp64, count): the
@@ -127,9 +127,7 @@ class FlatAdam(FlatArena):
         address of the in-graph all-reduce's error word (IpcAllReduce.error_word): a step behind a failed
         collective leaves parameters, moments and learning rate untouched.  pack: an ops.MlpChain whose weights live
         in this arena - the launch also writes the chain's bf16 weight planes for the new weights (one launch instead of
-        Adam + pack; csrc/mlp_chain_bx.hip adam_pack_kernel).  frags: an ops.MlpChain whose 16-row launches run the lean
-        kernels - the launch writes their fp32 weight fragments instead (csrc/mlp_chain.hip adam_frags_kernel); `pack` wins
-        when both are given (the caller then packs the fragments with a launch of its own)."""
+        Adam + pack; csrc/mlp_chain_bx.hip adam_pack_kernel)."""
         self.step_count += 1
         self.weights_version += 1
         if norm_ready is None:
@@ -149,12 +147,9 @@ class FlatAdam(FlatArena):
                       self.step_counter, betas=self.betas, eps=self.eps,
                       weight_decay=self.weight_decay, schedule_kind=kind,
                       kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats,
-                      skip_flag=skip_flag, pack=None if pack is None else pack.adam_pack_target(),
-                      frags=None if (frags is None or pack is not None) else frags.adam_frags_target(), **kw)
+                      skip_flag=skip_flag, pack=None if pack is None else pack.adam_pack_target(), **kw)
         if pack is not None:
             pack.mark_planes(self.weights_version)
-        elif frags is not None:
-            frags.mark_frags(self.weights_version)
 
     def step_done(self):
         """Host mirrors after a replayed graph performed the step (the captured launches advance the device counter)."""

@@ -520,12 +520,10 @@ def grad_sumsq(grads, grad_scale, partials, step_counter=None):
 def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max_norm, lr_slots,
               step_counter, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=0,
               kl=None, kl_scale=1.0, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2,
-              lr_multiplier=1.5, stats_out=None, skip_flag=None, pack=None, frags=None):
+              lr_multiplier=1.5, stats_out=None, skip_flag=None, pack=None):
     """skip_flag: device address (int) of the in-graph all-reduce's error word, or None.
     pack = MlpChain.adam_pack_target() (n, weights, in, out, planes address): the launch also leaves the chain's
-    weight planes for the new weights (rlg_adam_step_pack, csrc/mlp_chain_bx.hip).
-    frags = MlpChain.adam_frags_target() (n, weights, in, out, forward fragments, backward fragments or None): the launch
-    also leaves the lean 16-row kernels' fp32 weight fragments (rlg_adam_step_frags, csrc/mlp_chain.hip).  One of the two."""
+    weight planes for the new weights (rlg_adam_step_pack, csrc/mlp_chain_bx.hip)."""
     lib = _lib.load()
     args = (
         _need(params, F32, 'params'), _need(grads, F32, 'grads'), _need(exp_avg, F32, 'exp_avg'),
@@ -536,14 +534,9 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, norm_partials, grad_scale, max
         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), schedule_kind,
         _opt(kl, F32, 'kl'), float(np.float32(kl_scale)), float(kl_threshold), float(min_lr),
         float(max_lr), float(lr_multiplier), _opt(stats_out, F32, 'stats_out'), skip_flag)
-    if pack is not None and frags is not None:
-        raise ValueError('adam_step: pack and frags are alternatives')
     if pack is not None:
         n, w, ins, outs, planes = pack
         _lib.check(lib.rlg_adam_step_pack(*args, n, w, ins, outs, planes, _stream(params)), 'rlg_adam_step_pack')
-    elif frags is not None:
-        n, w, ins, outs, ff, fb = frags
-        _lib.check(lib.rlg_adam_step_frags(*args, n, w, ins, outs, ff, fb, _stream(params)), 'rlg_adam_step_frags')
     else:
         _lib.check(lib.rlg_adam_step(*args, _stream(params)), 'rlg_adam_step')
 
@@ -721,23 +714,6 @@ class MlpChain:
         _lib.check(lib.rlg_mlp_chain_pack_frags_both(self.n, self._w, self._b, self._in, self._out, self._frags_ptr(0),
                                                      self._frags_ptr(1) if self._frag_bytes[1] >= 0 else None,
                                                      _stream(stream_of)), 'rlg_mlp_chain_pack_frags_both')
-
-    def adam_frags_target(self, arena=None):
-        """(n, weights, in, out, forward fragments, backward fragments or None) for ops.adam_step(frags=...), or None:
-        without a weights-version source, or when `arena` (the flat parameter tensor the step updates) / the network is
-        outside what rlg_adam_step_frags takes.  The first call packs the buffers once in full (the fragments' zero
-        padding)."""
-        if self._weights_version is None or not self._lean:
-            return None
-        if arena is not None and not _lib.load().rlg_adam_step_frags_supported(
-                _need(arena, F32, 'arena'), arena.numel(), self.n, self._w, self._in, self._out):
-            return None
-        if not self._frags_once:
-            self.pack_frags(self.layers[0][0])
-            self._frags_once = True
-            self._frags_for = self._version()
-        return (self.n, self._w, self._in, self._out, self._frags_ptr(0),
-                self._frags_ptr(1) if self._frag_bytes[1] >= 0 else None)
 
     def frags_current(self):
         v = self._version()

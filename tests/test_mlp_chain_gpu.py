@@ -857,58 +857,6 @@ def test_adam_step_pack_equals_adam_then_pack(in_dim, units, out_dim):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('in_dim,units,out_dim', [(108, [400, 200, 100], 22), (60, [64, 32], 9), (12, [100, 52], 11)])
-def test_adam_step_frags_equals_adam_then_pack_frags(in_dim, units, out_dim):
-    """rlg_adam_step_frags (csrc/mlp_chain.hip, adam_frags_kernel): the optimiser step that writes the lean 16-row
-    kernels' fp32 weight fragments itself - a thread's 4 consecutive elements of a row are one lane's 16 bytes of a
-    forward fragment, a quad's 4 rows one lane slot of a backward fragment per column - against rlg_adam_step followed by
-    rlg_mlp_chain_pack_frags_both: the same parameters, moments and clipped gradients bit for bit and the same fragment
-    bytes (zero padding included); with the skip flag set nothing changes."""
-    from rl_games_amd import ops
-    layers, g = _net(in_dim, units, out_dim, 'elu', seed=11)
-    flat = layers[0][0].untyped_storage()
-    n = sum(w.numel() + b.numel() for w, b, _ in layers)
-    params = torch.empty(0, device=DEV, dtype=torch.float32).set_(flat, 0, (n,))
-    init = params.clone()
-    grads = (0.1 * torch.randn(n, generator=g)).to(DEV)
-    m0 = (0.01 * torch.randn(n, generator=g)).to(DEV)
-    v0 = (0.001 * torch.rand(n, generator=g)).to(DEV)
-    version = [0]
-    chain = ops.MlpChain(layers, DEV, weights_version=lambda: version[0])
-    assert chain.lean_used(4096, 0) and chain.lean_used(4096, 1)
-    res = {}
-    for mode in ('pair', 'fused', 'fused_skipped'):
-        params.copy_(init)
-        g_, m_, v_ = grads.clone(), m0.clone(), v0.clone()
-        lr_slots = torch.tensor([3e-4, 3e-4], dtype=torch.float64, device=DEV)
-        counter = torch.tensor([3], dtype=torch.int64, device=DEV)
-        norm = torch.zeros(ops.grad_norm_blocks(n), dtype=torch.float64, device=DEV)
-        ops.grad_sumsq(g_, 1.0, norm, None)
-        kl = torch.tensor([0.001], device=DEV)
-        stats = torch.zeros(4, device=DEV)
-        skip = torch.tensor([1 if mode == 'fused_skipped' else 0], dtype=torch.int32, device=DEV)
-        kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, schedule_kind=1, kl=kl, kl_scale=1.0, kl_threshold=0.008,
-                  min_lr=1e-6, max_lr=1e-2, lr_multiplier=1.5, stats_out=stats, skip_flag=skip.data_ptr())
-        target = chain.adam_frags_target()                # (first call: packs the buffers in full once)
-        if mode == 'pair':
-            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, **kw)
-            chain._frag_buffer().fill_(float('nan'))
-            chain.pack_frags(params)
-        else:
-            chain.pack_frags(params)                      # the fragments of the OLD weights (what the agent's state is)
-            ops.adam_step(params, g_, m_, v_, norm, 1.0, 0.5, lr_slots, counter, frags=target, **kw)
-        torch.cuda.synchronize()
-        res[mode] = (params.clone(), g_, m_, v_, lr_slots.clone(), stats.clone(), chain._frag_buffer().clone())
-    for a, b in zip(res['pair'], res['fused']):
-        assert torch.equal(a, b)
-    assert not torch.equal(res['pair'][0], init) and bool(torch.isfinite(res['pair'][6]).all())
-    assert torch.equal(res['fused_skipped'][0], init) and torch.equal(res['fused_skipped'][2], m0)
-    params.copy_(init)
-    chain.pack_frags(params)
-    assert torch.equal(res['fused_skipped'][6], chain._frag_buffer())
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize('rows', [4096, 1000, 37])
 def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch):
     """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain.hip: weights as fp32 fragments in each wave's

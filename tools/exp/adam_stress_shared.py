@@ -1,6 +1,6 @@
 """One process repeats ONE optimiser launch on identical inputs while other processes use the same GPU (round 5): does the
 launch's result depend on what else runs on the device?
-    python tools/exp/adam_stress_shared.py MODE SECONDS      MODE = plain | pack | frags   (RLG_ADAM_PACK_ROWPT=1: the rowpt form of pack)
+    python tools/exp/adam_stress_shared.py MODE SECONDS      MODE = plain | pack
 Every repetition restores parameters / moments from device copies, launches the step and compares exp_avg_sq, exp_avg and the
 parameters with the first repetition's ON THE DEVICE (no host sync per repetition); the mismatch mask is read once at the end.
 Run it next to e.g. `python bench.py --steps 40 --no-cpu-baseline` (another process, same GPU) and alone."""
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from rl_games_amd import ops  # noqa: E402
 
 DEV = torch.device('cuda:0')
-mode = sys.argv[1] if len(sys.argv) > 1 else 'frags'
+mode = sys.argv[1] if len(sys.argv) > 1 else 'pack'
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 g = torch.Generator().manual_seed(7)
 shapes, last = [], 108
@@ -38,10 +38,9 @@ v0 = (1e-6 * torch.rand(n, generator=g) + 1e-8).to(DEV)
 version = [0]
 chain = ops.MlpChain(layers, DEV, weights_version=lambda: version[0])
 pack = chain.adam_pack_target() if mode == 'pack' else None
-frags = chain.adam_frags_target(flat) if mode == 'frags' else None
 if mode == 'pack':
     chain.pack_planes(2, flat)
-assert mode == 'plain' or pack is not None or frags is not None, 'target unavailable'
+assert mode == 'plain' or pack is not None, 'target unavailable'
 grads, m_, v_ = grads0.clone(), m0.clone(), v0.clone()
 lr_slots = torch.tensor([3e-4, 3e-4], dtype=torch.float64, device=DEV)
 counter = torch.tensor([3], dtype=torch.int64, device=DEV)
@@ -59,7 +58,7 @@ def one():
     v_.copy_(v0)
     lr_slots.fill_(3e-4)
     ops.adam_step(flat, grads, m_, v_, norm, 0.5, 1.0, lr_slots, counter, schedule_kind=1, kl=kl, stats_out=stats,
-                  pack=pack, frags=frags)
+                  pack=pack)
 
 
 one()
@@ -77,7 +76,7 @@ while time.time() - t0 < seconds:
     torch.cuda.synchronize()
 names = ('params', 'exp_avg', 'exp_avg_sq')
 total = [int(b.sum().item()) for b in bad]
-print(f'pid {os.getpid()} mode {mode} rowpt={os.environ.get("RLG_ADAM_PACK_ROWPT", "0")}: {reps} repetitions, mismatching '
+print(f'pid {os.getpid()} mode {mode}: {reps} repetitions, mismatching '
       f'(element, repetition) pairs {dict(zip(names, total))}', flush=True)
 for k, b in enumerate(bad):
     idx = b.nonzero().flatten()

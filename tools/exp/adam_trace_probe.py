@@ -57,8 +57,8 @@ def same(t):
 
 
 res = dict(params=same(opt.flat_params), exp_avg=same(opt.exp_avg), exp_avg_sq=same(opt.exp_avg_sq), grads=same(opt.grads))
-kind = 'adam_pack' if agent._adam_pack_chain() is not None else 'adam_step / adam_frags'
-label = f'launch {kind} rowpt={os.environ.get("RLG_ADAM_PACK_ROWPT", "0")} in_sync {res}'
+kind = 'adam_pack' if agent._adam_pack_chain() is not None else 'adam_step'
+label = f'launch {kind} in_sync {res}'
 if notrace:
     if rank == 0:
         print(f'RESULT world {world} steps {int(opt.step_counter.item())} {label} all {all(res.values())}', flush=True)
