@@ -1653,14 +1653,20 @@ class A2CAgent:
         if self.normalize_value and 'reward_mean_std' in weights:
             self.model.value_mean_std.load_state_dict(weights['reward_mean_std'])
 
+    def _plain_model(self):
+        """The policy module itself.  The reference Runner re-assigns `agent.model = torch.compile(agent.model)` unless the
+        config says `torch_compile: False` (torch_runner.py:283-307); nothing of this agent calls the wrapper's forward,
+        and checkpoints are written / read in the plain key format whichever object `self.model` is."""
+        return getattr(self.model, '_orig_mod', self.model)
+
     def get_weights(self):
         state = self.get_stats_weights()
-        state['model'] = self.model.state_dict()
+        state['model'] = self._plain_model().state_dict()
         return state
 
     def set_weights(self, weights):
         model_state = {k.replace('_orig_mod.', ''): v for k, v in weights['model'].items()}
-        self.model.load_state_dict(model_state)      # copy_ into the arena views: params stay flat
+        self._plain_model().load_state_dict(model_state)      # copy_ into the arena views: params stay flat
         self.optimizer.weights_changed()
         self.set_stats_weights(weights)
         self._seed_stats_sync_snapshots()

@@ -11,11 +11,14 @@ plus an absolute floor for scalars that are means of +-O(1) terms - a_loss of th
 6e-8 and the summation order (GPU block tree vs ATen's) alone moves the mean by ~1e-7.
 """
 import copy
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # (the exact-products worker runs this file as a script)
 from oracle import ppo_oracle as O
 from oracle.ppo_epoch_oracle import OracleAgent
 from rl_games_amd.synthetic_env import SyntheticTensorEnv
@@ -272,16 +275,58 @@ def _kl_fp64(mu, sigma, old_mu, old_sigma):
     return (c1 + c2 - 0.5).sum(dim=-1).mean()
 
 
-def _observations_moved_by_one_ulp(batch, seed=1):
-    """The same rollout with every observation moved to its upper or lower fp32 neighbour at random: what ANY two fp32
-    implementations of the forward differ by from the first layer on.  The reference algorithm run on it is the
-    yardstick for how far a correct implementation can be from the oracle after n optimiser steps."""
-    out = dict(batch)
-    x = batch['obses']
-    up = torch.rand(x.shape, generator=torch.Generator().manual_seed(seed)) < 0.5
-    out['obses'] = torch.where(up, torch.nextafter(x, torch.full_like(x, float('inf'))),
-                               torch.nextafter(x, torch.full_like(x, float('-inf'))))
+def _gemm_order_noise(oracle, seed=11, level=1e-6):
+    """Makes `oracle` a twin of the reference algorithm whose FIRST-LAYER pre-activations carry the relative noise two fp32
+    GEMM summation orders differ by (~1e-6 of each element, a fresh pattern every call): what ANY second fp32 implementation
+    of the same network looks like to the algorithm, and therefore the yardstick for how far one may drift from the oracle."""
+    gen = torch.Generator().manual_seed(seed)
+    first = oracle.model.a2c_network.actor_mlp[0]
+
+    def hook(_mod, _inp, out):
+        sign = torch.randint(0, 2, out.shape, generator=gen).to(out.dtype).mul_(2.0).sub_(1.0)
+        return out * (1.0 + level * sign)
+    first.register_forward_hook(hook)
+    return oracle
+
+
+def _epoch_deviation_rows(N, MB):
+    """One epoch of the 320-step job: the agent's per-step scalars, the oracle's on the same rollout, the captured rollout."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.humanoid_65536(num_actors=N, minibatch_size=MB, hip_graphs=True)
+    torch.manual_seed(5)
+    agent = A2CAgent('epoch', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    caps = _capture_rollout(agent)
+    agent._eager_epochs = 1
+    agent.update_epoch()
+    res = agent.train_epoch()
+    return params, agent, caps, res
+
+
+def _deviation_per_mini_epoch(rows, ref, NMB, ME):
+    cols = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
+    out = {}
+    for key, col in cols.items():
+        want = torch.stack([r[key].reshape(()).float() for r in ref])
+        d = (rows[:ME * NMB, col] - want).abs().reshape(ME, NMB).max(1).values
+        out[key] = [float(x) for x in d]
     return out
+
+
+def _exact_products_worker(N, MB):
+    """`python tests/test_headline_gpu.py exact N MB` in a process of its own with RLG_CHAIN_BX=0 RLG_DW_BF16=0 (the library
+    reads them once): the SAME job on exact fp32 products (v_mfma_f32_16x16x4_f32 in all three MFMA launches) against the
+    oracle on ITS rollout - max deviation per mini-epoch and scalar, as JSON on the last line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RLG_CHAIN_BX='0', RLG_DW_BF16='0')
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), 'exact', str(N), str(MB)], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 @pytest.mark.parametrize('N,MB', [(8192, 4096), (65536, 32768)], ids=['rank_8192x32_mb4096', 'benchmarked_65536x32_mb32768'])
@@ -302,10 +347,15 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
     of the clipped objective (ratio clip, value clip) when a step was taken: two fp32 implementations agree on a row's
     ratio to ~1e-6, so one of them clips such a row and the other does not, that step's gradient differs by ~1/minibatch
     of a row's contribution, and every later step inherits it (test_three_epochs_... has the anatomy of one such event).
-    Among 4,096 .. 32,768 rows there is nearly always a row that close, so over 320 steps the events add up.  The
-    agent must stay within a stated schedule per mini-epoch (or 5 x the twin's distance, whichever is larger) -
-    measured in round 4: a_loss 9e-8 / 2e-7 / 2e-7 / 2e-6 / 9e-6 absolute over the five mini-epochs at the rank shape,
-    3e-8 ... 7e-6 at the benchmarked one.  The learning rates of all 320 steps must agree unless a KL of the oracle
+    Among 4,096 .. 32,768 rows there is nearly always a row that close, so over 320 steps the events add up.  Round 5:
+    the bound of mini-epochs 2 - 5 is no list of literals any more but DERIVED IN THE TEST from two yardsticks - (i) a twin
+    of the oracle whose first-layer pre-activations carry the ~1e-6 relative noise two fp32 GEMM orders differ by
+    (_gemm_order_noise: how far the reference algorithm itself moves under a second implementation's rounding), and
+    (ii) at the benchmarked shape, where the agent runs on split-bf16 products, the SAME job on exact fp32 products in a
+    process of its own (RLG_CHAIN_BX=0 RLG_DW_BF16=0) against the oracle on its rollout: the agent's deviation envelope
+    must stay within 2 x the larger of the two envelopes (+ the first mini-epoch's floors) - in particular
+    deviation(split products) <= 2 x deviation(exact products): the product form is not what amplifies.
+    The learning rates of all 320 steps must agree unless a KL of the oracle
     lies within 1e-3 of a threshold of the rule.  End of epoch: every parameter tensor within max(1e-4 of its scale,
     3 x the twin's distance, 2e-5 absolute = lr / 15) on average."""
     from rl_games_amd import configs
@@ -336,8 +386,8 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
         vd = agent.dataset.values_dict
         for key in ('old_values', 'returns', 'advantages'):
             assert torch.allclose(vd[key].cpu().reshape(-1), oracle.dataset[key].reshape(-1), rtol=RTOL, atol=2e-6), key
-        twin = _oracle_for(params, caps[0], N, 108, 21)
-        ref2 = twin.update(_observations_moved_by_one_ulp(batch))
+        twin = _gemm_order_noise(_oracle_for(params, caps[0], N, 108, 21))
+        ref2 = twin.update(batch)
     finally:
         torch.set_num_threads(prev)
     cols = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
@@ -368,21 +418,29 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
             break
     assert margin_ok >= NMB, 'a learning-rate decision of the FIRST mini-epoch lies within 1e-3 of its threshold: pick another seed'
     assert traj[:margin_ok] == [r['lr'] for r in ref[:margin_ok]]
-    # ---- mini-epochs 2 .. 5: stated schedule, or 5 x what two runs of the reference algorithm differ by
-    schedule = {'a_loss': (2e-6, 2e-5, 1e-4, 2e-4), 'c_loss': (1e-5, 1e-5, 1e-4, 2e-4), 'entropy': (1e-4, 1e-4, 1e-4, 1e-4),
-                'b_loss': (1e-7, 1e-7, 1e-7, 1e-7), 'kl': (2e-6, 3e-6, 1e-5, 2e-5)}
+    # ---- mini-epochs 2 .. 5: within 2 x the envelope of the yardsticks (GEMM-noise twin; exact-product run of the same job)
+    dev = _deviation_per_mini_epoch(rows, ref, NMB, ME)
+    twin_dev = _deviation_per_mini_epoch(torch.stack([torch.stack([r[k].reshape(()).float() for k in cols]) for r in ref2]),
+                                         ref, NMB, ME)
+    split = bool(agent._engine.chain.split_products(MB, 0))
+    exact_dev = _exact_products_worker(N, MB) if split else None
     report = []
-    for m in range(1, ME):
-        if m * NMB >= margin_ok:
-            break                        # (the two sides may legitimately run on different learning rates from here on)
-        sl = slice(m * NMB, (m + 1) * NMB)
-        for key, col in cols.items():
-            want, got, other = stack(ref, key, sl), rows[sl, col], stack(ref2, key, sl)
-            dev = (got - want).abs().max().item()
-            twin_dev = (other - want).abs().max().item()
-            bound = max(schedule[key][m - 1], 5.0 * twin_dev) + RTOL * want.abs().max().item()
-            report.append((m + 1, key, dev, twin_dev, bound))
-            assert dev <= bound, report
+    for key in cols:
+        scale = max(abs(float(r[key])) for r in ref)
+        env_a = env_t = env_e = 0.0
+        for m in range(ME):
+            if m >= 1 and m * NMB >= margin_ok:
+                break                    # (the two sides may legitimately run on different learning rates from here on)
+            env_a = max(env_a, dev[key][m])
+            env_t = max(env_t, twin_dev[key][m])
+            env_e = max(env_e, exact_dev[key][m]) if exact_dev is not None else 0.0
+            bound = 2.0 * max(env_t, env_e) + RTOL * scale + (1e-4 * scale if key == 'kl' else 0.0) + ATOL[key]
+            report.append((m + 1, key, env_a, env_t, env_e, bound))
+            if m >= 1:
+                assert env_a <= bound, report
+    print('deviation envelopes (mini-epoch, scalar, agent, GEMM-noise twin, exact-product run, bound):')
+    for r in report:
+        print('   ', r)
     # ---- end of the epoch: parameters
     if margin_ok == NMB * ME:
         final, want, other = agent.model.state_dict(), oracle.model.full_state_dict(), twin.model.full_state_dict()
@@ -520,8 +578,10 @@ def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
     the whole mechanism.  Hence:
       * STRICT (losses rtol 1e-5 + floors, parameters 1e-6 of their scale on average) over the first epoch of a seed
         in which no row comes closer than 1e-6 to a kink - seeds are tried until one qualifies;
-      * ALWAYS, over all three epochs of that seed: losses within 2e-3, learning rates identical after every epoch,
-        parameters within 2e-3 of their scale on average (a handful of clip flips at learning rates up to 1e-2)."""
+      * over the two epochs that follow: learning rates identical after every epoch; losses within 2e-4 and parameters
+        within 1e-4 of their scale on average (the round-3 bounds) for as long as the oracle sees no row within 5e-6 of a
+        kink, 2e-3 (a handful of clip flips at learning rates up to 1e-2) from the epoch of such a row on; at most 4 seeds
+        may be skipped."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     N = 4096
@@ -553,21 +613,44 @@ def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
             if v.is_floating_point() and v.numel() >= 16:
                 rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / v.abs().mean().clamp_min(1e-12)).item()
                 assert rel <= 1e-6, (seed, name, rel)
-        # ---- always: two more epochs
+        # ---- two more epochs.  As long as the oracle has seen no row within 1e-6 of a kink, the round-3 bounds hold
+        #      (losses 2e-4, parameters 1e-4 of their scale); the loose bounds (2e-3) apply only from the epoch of a
+        #      detected near-kink row on
+        flipped = False
         for epoch in (1, 2):
             agent.update_epoch()
             res = agent.train_epoch()
             got = {'a_loss': torch.stack(res[4]).cpu(), 'c_loss': torch.stack(res[5]).cpu(), 'entropy': torch.stack(res[7]).cpu(),
                    'b_loss': torch.stack(res[6]).cpu()}
-            ref = oracle.update(caps[epoch]['batch'])
+            ref = _update_watching_the_kinks(oracle, caps[epoch]['batch'])
+            flipped = flipped or min(r['kink'] for r in ref) < 5e-6      # (a row 1.1e-6 away was seen to flip: 5 x that)
+            rtol, afac = (2e-3, 20) if flipped else (2e-4, 5)
             for key, g in got.items():
                 want = torch.stack([r[key].reshape(()) for r in ref])
-                assert torch.allclose(g, want, rtol=2e-3, atol=20 * ATOL[key]), (seed, epoch, key, (g - want).abs().max().item())
+                assert torch.allclose(g, want, rtol=rtol, atol=afac * ATOL[key]), (seed, epoch, flipped, key, (g - want).abs().max().item())
             assert agent.optimizer.last_and_next_lr()[1] == oracle.lr, (seed, epoch)
         final, want = agent.model.state_dict(), oracle.model.full_state_dict()
         for name, v in want.items():
             if v.is_floating_point() and v.numel() >= 16:
                 rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / v.abs().mean().clamp_min(1e-12)).item()
-                assert rel <= 2e-3, (seed, name, rel)
+                assert rel <= (2e-3 if flipped else 1e-4), (seed, flipped, name, rel)
+        assert len(tried) <= 5, f'more than 4 seeds skipped for near-kink rows in their first epoch: {tried}'
+        print(f'seeds tried (closest kink distance of the first epoch): {tried}; near-kink row in epochs 2 - 3: {flipped}')
         return
     pytest.fail(f'no seed with a first epoch free of near-kink rows: {tried}')
+
+
+
+if __name__ == '__main__':
+    # worker of _exact_products_worker: the job on whatever product form the environment selects, against the oracle
+    import json
+    import sys
+    if len(sys.argv) == 4 and sys.argv[1] == 'exact':
+        n_, mb_ = int(sys.argv[2]), int(sys.argv[3])
+        params_, agent_, caps_, _ = _epoch_deviation_rows(n_, mb_)
+        assert not agent_._engine.chain.split_products(mb_, 0), 'RLG_CHAIN_BX=0 expected'
+        rows_ = agent_._mb_scalars[:5 * 64].cpu()
+        torch.set_num_threads(_oracle_threads())
+        oracle_ = _oracle_for(params_, caps_[0], n_, 108, 21)
+        ref_ = oracle_.update(caps_[0]['batch'])
+        print(json.dumps(_deviation_per_mini_epoch(rows_, ref_, 64, 5)))
