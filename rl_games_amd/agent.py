@@ -772,8 +772,12 @@ class A2CAgent:
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
-                out = self._policy_step_kernels(*args)
+            cached0 = self._chain_cache_states()
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode='thread_local'):
+                    out = self._policy_step_kernels(*args)
+            finally:
+                self._restore_chain_cache_states(cached0)       # (launches of the body were recorded, not run)
             entry = self._rollout_graphs[(n, direct)] = (g, out)
         entry[0].replay()
         return entry[1]
@@ -1283,7 +1287,7 @@ class A2CAgent:
         self._norm_ready = None
         if lean is not None:
             lean.pack_frags(opt.flat_params)
-            lean.mark_frags(opt.weights_version)
+            lean.mark_frags(opt.weights_token())
 
     def _lean_chain(self):
         """The fused chains (the MLP's, or the trunk in front of a recurrent layer) whose launches run the lean 16-row
@@ -1379,7 +1383,9 @@ class A2CAgent:
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
-        count0 = self.optimizer.step_count
+        count0, version0 = self.optimizer.step_count, self.optimizer.weights_version
+        # ... and what the chains believe their planes / fragments hold: the body's pack launches are recorded, not run
+        cached0 = self._chain_cache_states()
         # No automatic garbage collection while the stream is capturing: a cycle that owns device objects of an
         # earlier graph (torch.cuda.graph collects once on entry, but the body allocates hundreds of Python objects)
         # would be finalised in the middle of the capture, and releasing device resources there aborts the process.
@@ -1393,8 +1399,19 @@ class A2CAgent:
         finally:
             if gc_was_enabled:
                 gc.enable()
-            self.optimizer.step_count = count0
+            self.optimizer.step_count, self.optimizer.weights_version = count0, version0
+            self._restore_chain_cache_states(cached0)
         return g
+
+    def _chain_cache_states(self):
+        eng = self._engine
+        chains = [c for c in (getattr(eng, 'chain', None), getattr(eng, 'chain_rnn', None)) if c is not None]
+        return [(c, c.cache_state()) for c in chains]
+
+    @staticmethod
+    def _restore_chain_cache_states(states):
+        for c, state in states:
+            c.restore_cache_state(state)
 
     def _graph_minibatch(self, i):
         """Replay (capturing on first use) the forward/loss/backward graph of minibatch i, run the
@@ -1428,9 +1445,9 @@ class A2CAgent:
         self._graph_opt.replay()
         self.optimizer.step_done()
         if self._adam_pack_chain() is not None:
-            self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
+            self._adam_pack_chain().mark_planes(self.optimizer.weights_token())
         if self._lean_chain() is not None:
-            self._lean_chain().mark_frags(self.optimizer.weights_version)
+            self._lean_chain().mark_frags(self.optimizer.weights_token())
 
     def _graph_mini_epoch(self, nmb):
         """Single-GPU runs with nothing to do on the host between minibatches (device-side or
@@ -1457,9 +1474,9 @@ class A2CAgent:
         self.optimizer.step_count += nmb
         self.optimizer.weights_version += nmb
         if self._adam_pack_chain() is not None:
-            self._adam_pack_chain().mark_planes(self.optimizer.weights_version)
+            self._adam_pack_chain().mark_planes(self.optimizer.weights_token())
         if self._lean_chain() is not None:
-            self._lean_chain().mark_frags(self.optimizer.weights_version)
+            self._lean_chain().mark_frags(self.optimizer.weights_token())
 
     def _host_schedule(self, kl_value):
         lr, self.entropy_coef = self.scheduler.update(self._host_lr, self.entropy_coef, self.epoch_num,

@@ -61,6 +61,15 @@ class FlatArena:
         """Call after writing parameter values by any other way than FlatAdam.step."""
         self.weights_version += 1
 
+    def weights_token(self):
+        """What derived copies of the weights (ops.MlpChain's planes / fragments) are stamped with: the counter above -
+        bumped by this package's own writers, whose kernels write through raw pointers - together with the autograd
+        version counters of the parameters and of the arena, which every in-place torch write bumps
+        (`model.load_state_dict`, `p.copy_()`, `p.mul_()` under no_grad, writes to `flat_params`): a write from outside
+        the package invalidates the copies without having to call weights_changed().  (`p.data.copy_()` has no version
+        counter to bump - the one way left that needs the explicit call.)"""
+        return (self.weights_version, self.flat_params._version, sum(p._version for p in self.params))
+
     def span(self, first, last):
         """(params view, grads view) of the contiguous arena range covering parameters `first`
         .. `last` (which must be physically adjacent, in that order)."""
@@ -149,7 +158,7 @@ class FlatAdam(FlatArena):
                       kl=self.kl_slot if kind else None, kl_scale=kl_scale, stats_out=self.stats,
                       skip_flag=skip_flag, pack=None if pack is None else pack.adam_pack_target(), **kw)
         if pack is not None:
-            pack.mark_planes(self.weights_version)
+            pack.mark_planes(self.weights_token())
 
     def step_done(self):
         """Host mirrors after a replayed graph performed the step (the captured launches advance the device counter)."""

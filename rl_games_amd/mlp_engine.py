@@ -98,7 +98,7 @@ class ManualMLP:
             try:
                 layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
                 layers.append((self.head_w, self.head_b, 'None'))
-                self.chain = ops.MlpChain(layers, dev, weights_version=lambda: arena.weights_version)
+                self.chain = ops.MlpChain(layers, dev, weights_version=arena.weights_token)
             except NotImplementedError:
                 self.chain = None
         # Recurrent policies (round 3): the trunk IN FRONT of the LSTM - observation normaliser, hidden layers and
@@ -110,7 +110,7 @@ class ManualMLP:
                 self.bias_sum = torch.empty(4 * self.Hr, device=dev)
                 layers = [(l.weight, l.bias, self.act_name) for l in self.linears]
                 layers.append((self.lstm.weight_ih_l0, self.bias_sum, 'None'))
-                self.chain_rnn = ops.MlpChain(layers, dev, weights_version=lambda: arena.weights_version)
+                self.chain_rnn = ops.MlpChain(layers, dev, weights_version=arena.weights_token)
             except NotImplementedError:
                 self.chain_rnn = None
         if self.chain is not None or self.chain_rnn is not None:

@@ -645,7 +645,7 @@ class MlpChain:
         self.n = n = len(layers)
         self.layers = layers
         self.device = device
-        # callable -> a number that changes whenever the referenced weights change (FlatArena.weights_version):
+        # callable -> a value that changes whenever the referenced weights change (FlatArena.weights_token):
         # planes packed by a training forward are re-used by backward() only for the SAME weights
         self._weights_version = weights_version
         self.ins = [int(w.shape[1]) for w, _, _ in layers]
@@ -676,7 +676,6 @@ class MlpChain:
             self._lean = False
         self._frags = None         # [forward fragments | backward fragments], fp32
         self._frags_for = None     # weights version the fragments hold
-        self._frags_once = False
         self._planes = None        # bf16 plane fragments of the weights, both directions (csrc/mlp_chain_bx.hip)
         self._bwd_offset = 0
         self._planes_fresh = None  # (rows, weights version) of the training forward that packed the backward planes
@@ -689,6 +688,15 @@ class MlpChain:
         self._planes_fresh = None
         self._planes_for = None
         self._frags_for = None
+
+    def cache_state(self):
+        """Host-side record of what the derived copies hold - for callers that issue launches WITHOUT running them
+        (HIP-graph capture): taken in front of the capture, put back behind it (restore_cache_state), so that a pack
+        launch that was only recorded never counts as done."""
+        return (self._planes_fresh, self._planes_for, self._frags_for, self._planes_packed_once)
+
+    def restore_cache_state(self, state):
+        self._planes_fresh, self._planes_for, self._frags_for, self._planes_packed_once = state
 
     # ---- fp32 fragments of the lean 16-row kernels
     def lean_used(self, rows, direction, requested=0):

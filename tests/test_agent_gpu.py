@@ -925,6 +925,86 @@ def test_weights_set_between_epochs_reach_the_replayed_rollout_and_update_graphs
         assert torch.equal(a, b)
 
 
+def test_weights_written_from_outside_the_package_invalidate_the_derived_copies():
+    """A write to the parameters that never calls weights_changed() - `model.load_state_dict` / `p.copy_()` by a user, a
+    test, another restore path: the chains' planes / fragments are stamped with FlatArena.weights_token (the package's own
+    counter + the autograd version counters), so the next forward packs again instead of running on the old weights.
+    load_state_dict straight into the model behind epoch 3 against set_weights (which announces the change): bit-identical
+    rollout outputs and parameters behind epoch 5, graphs on."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for how in ('set_weights', 'load_state_dict', 'param_copy'):
+        params = configs.tiny(num_actors=128, horizon=8, hip_graphs=True)
+        torch.manual_seed(11)
+        agent = A2CAgent('w', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        saved = None
+        for ep in range(5):
+            if ep == 1:
+                saved = {k: v.clone() for k, v in agent._plain_model().state_dict().items()}
+            if ep == 3:
+                if how == 'set_weights':
+                    w = agent.get_weights()
+                    w['model'] = saved
+                    agent.set_weights(w)
+                elif how == 'load_state_dict':
+                    agent._plain_model().load_state_dict(saved)
+                else:
+                    with torch.no_grad():
+                        for k, p in agent._plain_model().named_parameters():
+                            p.copy_(saved[k])
+                    for k, b in agent._plain_model().named_buffers():
+                        b.copy_(saved[k])
+                probe = agent.get_action_values({'obs': agent.obs['obs']})
+                res_probe = (probe['mus'].clone(), probe['values'].clone())
+            agent.update_epoch()
+            agent.train_epoch()
+        assert agent._lean_chain() is not None and len(agent._rollout_graphs) > 0
+        res.append(res_probe + (agent.optimizer.flat_params.clone(), agent.optimizer.exp_avg_sq.clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
+def test_a_failed_capture_leaves_nothing_marked_as_packed(monkeypatch):
+    """_capture puts the host mirrors back behind a capture that failed part-way: the optimiser's step count AND
+    weights_version, and what the chains believe their planes / fragments hold (the body's pack launches were recorded,
+    never run).  The third minibatch of the first captured mini-epoch raises; the epoch continues eagerly and ends bit for
+    bit where an agent without graphs ends."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = []
+    for fail in (True, False):
+        params = configs.tiny(num_actors=128, horizon=8, hip_graphs=fail)
+        torch.manual_seed(11)
+        agent = A2CAgent('w', params)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        if fail:
+            real = agent._optimizer_kernels
+            calls = [0]
+
+            def flaky():
+                if torch.cuda.is_current_stream_capturing():
+                    calls[0] += 1
+                    if calls[0] == 3:
+                        raise RuntimeError('injected failure inside the capture')
+                return real()
+            monkeypatch.setattr(agent, '_optimizer_kernels', flaky)
+        for ep in range(3):
+            agent.update_epoch()
+            agent.train_epoch()
+        if fail:
+            assert agent._graph_failed and calls[0] == 3
+            assert agent.optimizer.step_count == int(agent.optimizer.step_counter.item())
+        res.append((agent.optimizer.flat_params.clone(), agent.optimizer.exp_avg.clone(), agent.optimizer.exp_avg_sq.clone(),
+                    agent.model.running_mean_std.running_mean.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('graphs', [True, False])
 def test_folded_launches_match_the_separate_ones(graphs):
     """The launches that round 2 merged away - observation statistics folded in the forward's prologue
