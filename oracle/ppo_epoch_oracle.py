@@ -192,8 +192,10 @@ class OracleAgent:
                         'sigma': batch['sigmas'].clone(), 'rnn_masks': batch.get('rnn_masks')}
         return self.dataset
 
-    def minibatch_step(self, i):
-        """calc_gradients + trancate_gradients_and_step + per-minibatch lr (python floats)."""
+    def minibatch_backward(self, i):
+        """calc_gradients up to loss.backward() (a2c_continuous.py:136-211): the unclipped gradients of minibatch i are left
+        in p.grad; KL (:215-221) and the mu / sigma write-back (a2c_common.py:1556) as well - they only use this forward's
+        outputs.  Nothing is stepped."""
         cfg, ds = self.cfg, self.dataset
         lo, hi = i * self.mb, (i + 1) * self.mb
         mbd = {k: (None if v is None else v[lo:hi]) for k, v in ds.items()}
@@ -212,21 +214,33 @@ class OracleAgent:
         for p in net.parameters():
             p.grad = None
         loss.backward()
-        if cfg.get('truncate_grads', False):
-            nn.utils.clip_grad_norm_(net.parameters(), cfg['grad_norm'])
-        self.optimizer.step()
         with torch.no_grad():
             kl = O.policy_kl(mu.detach(), sigma.detach(), mbd['mu'], mbd['sigma'], mask)
         ds['mu'][lo:hi] = mu.detach()
         ds['sigma'][lo:hi] = sigma.detach()
+        return {'a_loss': a.detach(), 'c_loss': c.detach(), 'entropy': e.detach(), 'b_loss': b.detach(), 'kl': kl}
+
+    def minibatch_apply(self, kl_value):
+        """trancate_gradients_and_step behind the (optional) gradient exchange (a2c_common.py:510-514) + the per-minibatch
+        lr rule on `kl_value` (:1557-1563, python floats).  Returns the lr the step used."""
+        cfg = self.cfg
+        net = self.model.a2c_network
+        if cfg.get('truncate_grads', False):
+            nn.utils.clip_grad_norm_(net.parameters(), cfg['grad_norm'])
+        self.optimizer.step()
         lr_used = self.lr
         if self.adaptive:
-            self.lr = O.adaptive_lr(self.lr, kl.item(), cfg['kl_threshold'], cfg.get('min_lr', 1e-6),
+            self.lr = O.adaptive_lr(self.lr, kl_value, cfg['kl_threshold'], cfg.get('min_lr', 1e-6),
                                     cfg.get('max_lr', 1e-2), cfg.get('lr_multiplier', 1.5))
             for g in self.optimizer.param_groups:
                 g['lr'] = self.lr
-        return {'a_loss': a.detach(), 'c_loss': c.detach(), 'entropy': e.detach(), 'b_loss': b.detach(),
-                'kl': kl, 'lr': lr_used}
+        return lr_used
+
+    def minibatch_step(self, i):
+        """calc_gradients + trancate_gradients_and_step + per-minibatch lr (python floats)."""
+        out = self.minibatch_backward(i)
+        out['lr'] = self.minibatch_apply(out['kl'].item())
+        return out
 
     def update(self, batch):
         self.prepare_dataset(batch)
@@ -245,3 +259,29 @@ class OracleAgent:
         results = self.update(batch)
         t2 = time.perf_counter()
         return {'play_time': t1 - t0, 'update_time': t2 - t1, 'total_time': t2 - t0, 'results': results}
+
+
+def data_parallel_minibatch_step(agents, i):
+    """One optimiser step of `len(agents)` data-parallel ranks (one OracleAgent per rank, each on its own env shard's
+    dataset, the same parameters): what A2CBase.trancate_gradients_and_step does under multi_gpu
+    (rl_games/common/a2c_common.py:493-514) - every gradient summed over the ranks (the all_reduce of the flattened
+    buffer), divided by world_size, copied back into p.grad, THEN clip_grad_norm_ and the Adam step on every rank - and
+    the per-minibatch lr rule on the KL averaged over the ranks (:1557-1563: all_reduce(kl, SUM); av_kls /= world_size).
+    The observation statistics stay per rank inside the epoch (merge_rank_stats pools them once per epoch, :1578).
+    Returns the per-rank dicts of minibatch_backward plus 'lr' and 'kl_mean'."""
+    world = len(agents)
+    outs = [a.minibatch_backward(i) for a in agents]
+    for ps in zip(*[list(a.model.a2c_network.parameters()) for a in agents]):
+        total = ps[0].grad.detach().clone()
+        for p in ps[1:]:
+            total += p.grad                      # (rank order; two ranks: commutative, any order gives these bits)
+        for p in ps:
+            p.grad = total / world
+    kl = outs[0]['kl'].clone()
+    for o in outs[1:]:
+        kl += o['kl']
+    kl /= world
+    for a, o in zip(agents, outs):
+        o['kl_mean'] = kl
+        o['lr'] = a.minibatch_apply(kl.item())
+    return outs

@@ -1172,6 +1172,29 @@ def test_two_rank_training_keeps_ranks_in_sync(kind, collective):
     assert f'TWO_RANK_ALLREDUCE {want}' in res.stdout, res.stdout[-600:]
 
 
+@pytest.mark.parametrize('shape,collective', [('tiny', 'ipc'), ('humanoid', 'ipc'), ('tiny', 'fallback')])
+def test_two_rank_steps_match_the_mean_of_two_oracle_ranks(shape, collective):
+    """Rank-vs-oracle, not only rank-vs-rank: 2 ranks on this box's single GPU, different env shards, the optimiser steps
+    of the first mini-epoch through the multi_gpu code path (gradient arena + KL slot through the in-graph all-reduce or
+    the torch.distributed fallback, then clip + Adam + the lr rule on the averaged KL) against two oracle ranks stepped
+    together by oracle.ppo_epoch_oracle.data_parallel_minibatch_step - the restatement of a2c_common.py:493-514 /
+    :1557-1563 that tests/test_distributed_cpu.py pins to the reference method under gloo.  Per step: this rank's
+    losses, the averaged clipped gradients (1e-5 of each tensor's scale), the parameters, the learning rate (exact).
+    'humanoid': a rank of 8's 4,096-row minibatches of BASELINE config #4 (the lean 16-row kernels)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    over = {'ipc': '{}', 'fallback': '{"native_allreduce": false}'}[collective]
+    os.environ['RLG_TWO_RANK_CONFIG'] = over
+    try:
+        res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_oracle_check.py'), shape], timeout=900)
+    finally:
+        os.environ.pop('RLG_TWO_RANK_CONFIG', None)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert f'TWO_RANK_ORACLE_CHECK {shape} ok' in res.stdout, res.stdout[-1500:]
+    want = {'ipc': 'allreduce ipc', 'fallback': 'allreduce rccl'}[collective]
+    assert want in res.stdout, res.stdout[-1500:]
+
+
 class _HostVecEnv:
     """A CPU vector env behind the IVecEnv seam (rl_games/common/ivecenv.py:1-36).  numpy=True hands out
     what a gym-style CPU env does (float64 observations / rewards, bool dones, numpy actions expected,

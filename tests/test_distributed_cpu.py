@@ -213,3 +213,77 @@ def test_stats_sync_mode_validation():
     assert rdist.resolve_stats_sync_mode('pooled') == 'pooled'
     with pytest.raises(ValueError):
         rdist.resolve_stats_sync_mode('ring')
+
+
+# ----------------------------------------------------------------------------- the oracle's data-parallel step (round 5)
+
+def _dp_oracle_agents(world):
+    """One OracleAgent per rank on its own env shard (different seeds), the same parameters, datasets prepared."""
+    import copy
+    from oracle.ppo_epoch_oracle import OracleAgent
+    from rl_games_amd import configs
+    from rl_games_amd.synthetic_env import SyntheticTensorEnv
+    params = configs.tiny(num_actors=64, horizon=8, obs_dim=7, act_dim=3, device='cpu')
+    agents = []
+    for r in range(world):
+        env = SyntheticTensorEnv(64, 7, 3, device='cpu', seed=20 + r)
+        a = OracleAgent(copy.deepcopy(params), env, seed=5)         # (seed 5 everywhere: identical initial parameters)
+        a.obs = env.reset()
+        torch.manual_seed(100 + r)                                  # rank-local action noise
+        a.prepare_dataset(a.play_steps())
+        agents.append(a)
+    return agents
+
+
+def _dp_oracle_worker(rank, world):
+    """oracle.ppo_epoch_oracle.data_parallel_minibatch_step against the REAL reference method: every rank computes its
+    own minibatch gradients with the oracle, then runs rl_games' A2CBase.trancate_gradients_and_step (a2c_common.py:
+    493-514: cat -> all_reduce(SUM) -> / world_size -> copy back -> clip_grad_norm_ -> optimizer.step) under gloo on a
+    stand-in object with exactly the attributes that method reads.  The oracle's single-process restatement of the same
+    step must leave the same gradients and parameters, bit for bit, for all steps of a mini-epoch."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, 'golden'))
+    import ref_import
+    ref_import.enable()
+    from rl_games.common import a2c_common
+    from oracle.ppo_epoch_oracle import data_parallel_minibatch_step
+    import types
+    mine = _dp_oracle_agents(world)[rank]               # the reference run: this rank's agent only
+    both = _dp_oracle_agents(world)                     # the oracle run: all ranks in this process
+    assert all(torch.equal(p, q) for p, q in zip(both[0].model.a2c_network.parameters(),
+                                                 both[1].model.a2c_network.parameters()))
+    cfg = mine.cfg
+    stub = types.SimpleNamespace(multi_gpu=True, world_size=world, model=mine.model.a2c_network,
+                                 truncate_grads=cfg['truncate_grads'], grad_norm=cfg['grad_norm'], optimizer=mine.optimizer)
+    for i in range(mine.B // mine.mb):
+        out = mine.minibatch_backward(i)
+        a2c_common.A2CBase.trancate_gradients_and_step(stub)
+        kl = out['kl'].clone()
+        dist.all_reduce(kl)                                             # a2c_common.py:1559-1561
+        kl /= world
+        want = data_parallel_minibatch_step(both, i)
+        assert torch.equal(kl, want[rank]['kl_mean'])
+        for k in ('a_loss', 'c_loss', 'entropy', 'b_loss', 'kl'):
+            assert torch.equal(out[k], want[rank][k]), (i, k)
+        mine_lr = mine.lr
+        # the lr rule on the averaged KL (python floats), like minibatch_apply does for the oracle ranks
+        mine.lr = O.adaptive_lr(mine.lr, kl.item(), cfg['kl_threshold'], cfg.get('min_lr', 1e-6), cfg.get('max_lr', 1e-2),
+                                cfg.get('lr_multiplier', 1.5))
+        for g in mine.optimizer.param_groups:
+            g['lr'] = mine.lr
+        assert want[rank]['lr'] == mine_lr and both[rank].lr == mine.lr
+        for (n, p), q in zip(mine.model.a2c_network.named_parameters(), both[rank].model.a2c_network.parameters()):
+            assert torch.equal(p.grad, q.grad), (i, n)                  # averaged, clipped
+            assert torch.equal(p, q), (i, n)                            # stepped
+    # the ranks of the oracle run stay identical
+    for p, q in zip(both[0].model.a2c_network.parameters(), both[1].model.a2c_network.parameters()):
+        assert torch.equal(p, q)
+
+
+def test_oracle_data_parallel_step_equals_the_reference_method_two_ranks():
+    sys_path_ok = os.path.isdir('/root/reference/rl_games') or os.path.isfile(
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'rl_games_ref.zip'))
+    if not sys_path_ok:
+        pytest.skip('reference not present')
+    _spawn(_dp_oracle_worker, 2)
