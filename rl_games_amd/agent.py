@@ -338,7 +338,9 @@ class A2CAgent:
         self.bound_loss_type = config.get('bound_loss_type', 'bound')
         layout = None
         self._grads_overwritten = False
-        self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True)
+        # (value_size > 1: the fused loss kernels carry one value column - that agent takes autograd through
+        #  rl_games_amd/torch_fallback.py instead, SURVEY 8a'-13)
+        self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True) and self.value_size == 1
                             and not self.model.a2c_network.is_separate_critic()
                             and (not self.is_rnn or config.get('manual_lstm', True)))
         if self._use_engine:
@@ -992,7 +994,7 @@ class A2CAgent:
         rnn_masks = batch_dict.get('rnn_masks', None)
         B = returns.shape[0]
         if self.value_size != 1:
-            raise NotImplementedError('value_size > 1 is not implemented in prepare_dataset')
+            return self._prepare_dataset_general(batch_dict)
         fused = batch_dict.get('_fused')
         values_flat = values.reshape(-1)
         returns_flat = returns.reshape(-1)
@@ -1053,6 +1055,86 @@ class A2CAgent:
                 'obs': batch_dict['states'], 'dones': batch_dict['dones'], 'rnn_masks': rnn_masks,
             })
 
+    def _prepare_dataset_general(self, batch_dict):
+        """prepare_dataset for value_size > 1 (returns / values [B, V]): the reference's operation sequence
+        (a2c_common.py:1598-1634) with the normaliser modules and torch ops - the fused prepare kernels carry one value
+        column.  advantages = returns - values BEFORE the value normalisation, summed over V behind it (:1622)."""
+        from . import torch_fallback as tf
+        returns, values = batch_dict['returns'], batch_dict['values']
+        rnn_masks = batch_dict.get('rnn_masks', None)
+        advantages = returns - values                                                   # :1598
+        if self.normalize_value:
+            vms = self.value_mean_std
+            if self.config.get('freeze_critic', False):                                 # :1601-1604
+                vms.eval()
+                values, returns = vms(values), vms(returns)
+            elif rnn_masks is not None:                                                 # :1605-1615
+                valid = rnn_masks.reshape(-1).bool()
+                vms.train()
+                vms(values[valid])
+                vms(returns[valid])
+                vms.eval()
+                values, returns = vms(values), vms(returns)
+            else:                                                                       # :1616-1620
+                vms.train()
+                values = vms(values)
+                returns = vms(returns)
+                vms.eval()
+        advantages = torch.sum(advantages, dim=1)                                       # :1622
+        if self.normalize_advantage:
+            if self.normalize_rms_advantage:
+                advantages = self.advantage_mean_std(advantages, mask=rnn_masks)
+            else:
+                advantages = tf.normalize_advantages(advantages, rnn_masks)
+        dataset_dict = {
+            'old_values': values, 'old_logp_actions': batch_dict['neglogpacs'], 'advantages': advantages,
+            'returns': returns, 'actions': batch_dict['actions'], 'obs': batch_dict['obses'],
+            'dones': batch_dict['dones'], 'rnn_states': batch_dict.get('rnn_states', None), 'rnn_masks': rnn_masks,
+            'mu': batch_dict['mus'], 'sigma': batch_dict['sigmas'],
+        }
+        self.dataset.update_values_dict(dataset_dict)
+        if self.has_central_value:
+            self.central_value_net.update_dataset({
+                'old_values': values, 'advantages': advantages, 'returns': returns, 'actions': batch_dict['actions'],
+                'obs': batch_dict['states'], 'dones': batch_dict['dones'], 'rnn_masks': rnn_masks,
+            })
+
+    def _forward_loss_backward_general(self, input_dict, row):
+        """calc_gradients up to the gradients in the arena for value_size > 1: forward with autograd, the losses as torch
+        ops (rl_games_amd/torch_fallback.py: a2c_continuous.py:97-134, :173-221), loss.backward() into the arena views.
+        Leaves the same things behind as the fused path: the five scalars in `row`, the KL in the arena's tail slot (the
+        device-side lr rule and the multi-GPU average read it there), mu / sigma written back into the dataset."""
+        from . import torch_fallback as tf
+        opt = self.optimizer
+        batch = {'is_train': True, 'prev_actions': input_dict['actions'], 'obs': self._preproc_obs(input_dict['obs'])}
+        if self.is_rnn:
+            batch['rnn_states'] = input_dict['rnn_states']
+            batch['seq_length'] = self.seq_length
+            if self.zero_rnn_on_done:
+                batch['dones'] = input_dict['dones']
+        rnn_masks = input_dict.get('rnn_masks', None)
+        mask = None if rnn_masks is None else rnn_masks.reshape(-1).float()
+        opt.zero_grad()
+        mu, logstd, values, _ = self.model.forward_heads(batch)
+        mb = mu.shape[0]
+        kind = 0 if self.bounds_loss_coef is None else ops.BOUND_KINDS.get(self.bound_loss_type, 0)
+        loss, scalars, sigma = tf.ppo_loss(
+            mu, logstd, values.reshape(mb, -1), input_dict['actions'], input_dict['old_logp_actions'], input_dict['advantages'],
+            input_dict['old_values'].reshape(mb, -1), input_dict['returns'].reshape(mb, -1), e_clip=self.e_clip,
+            critic_coef=self.critic_coef if self.has_value_loss else 0.0, entropy_coef=self.entropy_coef,
+            bounds_coef=self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0, bound_kind=kind,
+            clip_value=self.clip_value, smooth=self.use_smooth_clamp, mask=mask)
+        loss.backward()
+        with torch.no_grad():
+            sig = sigma.detach().expand_as(mu)
+            kl = tf.policy_kl(mu.detach(), sig, input_dict['mu'], input_dict['sigma'], mask)
+            row[0], row[1], row[2], row[3], row[4] = (scalars['a_loss'], scalars['c_loss'], scalars['entropy'],
+                                                      scalars['b_loss'], kl)
+            opt.kl_slot.copy_(kl.reshape(1))
+            input_dict['mu'].copy_(mu.detach())                                         # datasets.py:33-43
+            input_dict['sigma'].copy_(sig)
+        self._norm_ready = None
+
     # ================================================================== update
     def train_actor_critic(self, input_dict):
         self.set_train()
@@ -1074,6 +1156,8 @@ class A2CAgent:
         """Everything of calc_gradients up to (and including) the gradients in the arena.  No
         host-side scalars change between calls for a given minibatch slice, so this body is what
         gets captured into a HIP graph per minibatch index."""
+        if self.value_size != 1:
+            return self._forward_loss_backward_general(input_dict, row)
         opt = self.optimizer
         net = self.model.a2c_network
         obs_batch = self._preproc_obs(input_dict['obs'])

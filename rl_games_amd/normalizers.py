@@ -130,3 +130,25 @@ class GeneralizedMovingStats(nn.Module):
     def get_mean_std(self):
         var = self.sqrs - self.mean.pow(2)
         return self.mean, torch.sqrt(torch.clamp_min(var, 1 / self.max ** 2) + self.eps)
+
+    def forward(self, input, mask=None, denorm=False):
+        """The module call of the reference (moving_mean_std.py:102-150, 'mean_std'), as torch ops: what the agent uses
+        where the fused prepare kernels do not apply (value_size > 1, rl_games_amd/torch_fallback.py); the BASELINE
+        configurations update and apply these statistics inside rlg_prepare_finalize / rlg_prepare_apply
+        (kernel_state()).  Training mode: one EMA update from the valid rows (none valid: no update), every update
+        weighs the same whatever its row count; output clamp((x - mean) / std, -5, 5)."""
+        if self.training:
+            x = input
+            if mask is not None:
+                valid = mask.reshape(-1) > 0
+                x = input[valid] if bool(valid.any()) else None
+            if x is not None:
+                self.step += 1
+                keep = self.decay
+                self.mean.mul_(keep).add_((1 - keep) * x.mean(dim=0))
+                self.sqrs.mul_(keep).add_((1 - keep) * (x * x).mean(dim=0))
+        mean, std = self.get_mean_std()
+        if denorm:
+            return input * std + mean
+        return ((input - mean) / std).clamp(-5.0, 5.0)
+

@@ -1195,6 +1195,82 @@ def test_two_rank_steps_match_the_mean_of_two_oracle_ranks(shape, collective):
     assert want in res.stdout, res.stdout[-1500:]
 
 
+def test_value_size_two_runs_on_the_torch_forms_and_matches_the_oracle_functions():
+    """value_size > 1 (rewards / values / returns [B, V]; a2c_common.py:1622 sums the advantages over V) no longer raises:
+    the rollout's kernels carry V columns, GAE runs per (env, value), and the update takes autograd through
+    rl_games_amd/torch_fallback.py (pinned to the reference's own calc_losses on the CPU, tests/test_vs_reference_cpu.py).
+    Here, on the device, V = 2: returns against the oracle scan bit for bit, the prepared dataset against the oracle's
+    prepare_dataset, the first optimiser step's losses / KL / clipped gradients against the oracle's loss functions
+    applied to a copy of the model, then two whole epochs."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    N, H, V = 64, 8, 2
+    params = configs.tiny(num_actors=N, horizon=H, obs_dim=10, act_dim=4)
+    params['config']['env_config']['value_size'] = V
+    torch.manual_seed(3)
+    agent = A2CAgent('v2', copy.deepcopy(params))
+    assert agent.value_size == V and agent._engine is None
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps()
+    assert batch['values'].shape == (N * H, V) and batch['returns'].shape == (N * H, V)
+    tb = agent.experience_buffer.tensor_dict
+    assert tb['rewards'].shape == (H, N, V)
+    last_values = agent.get_values(agent.obs)
+    advs = O.gae_scan(tb['rewards'].cpu(), tb['values'].cpu(), tb['dones'].cpu().float(), last_values.cpu(),
+                      agent.dones.cpu().float(), 0.99, 0.95)
+    assert torch.equal(batch['returns'].cpu(), O.flatten_env_major(advs + tb['values'].cpu()))
+    vms = agent.value_mean_std
+    stats0 = {k: getattr(vms, k).detach().cpu().clone() for k in ('running_mean', 'running_var', 'count')}
+    assert stats0['running_mean'].shape == (V,)
+    cpu = {k: v.detach().cpu().clone() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    want = O.prepare_dataset(cpu['returns'], cpu['values'], stats0, normalize_value=True, normalize_advantage=True)
+    vd = agent.dataset.values_dict
+    for key in ('old_values', 'returns', 'advantages'):
+        assert vd[key].shape == want[key].shape
+        assert torch.allclose(vd[key].cpu(), want[key], rtol=1e-5, atol=2e-6), key
+    assert torch.allclose(vms.running_mean.cpu(), want['value_stats']['running_mean'], rtol=1e-6, atol=1e-9)
+    assert vms.count.item() == 1 + 2 * N * H
+    # ---- the first optimiser step against the oracle's loss functions on a copy of the model
+    twin = copy.deepcopy(agent._plain_model())
+    twin.train()
+    item = agent.dataset[0]
+    old_mu, old_sigma = item['mu'].clone(), item['sigma'].clone()
+    mu, logstd, values, _ = twin.forward_heads({'is_train': True, 'prev_actions': item['actions'], 'obs': item['obs']})
+    sigma = torch.exp(logstd)
+    ent = O.normal_entropy(mu, mu * 0 + sigma)
+    nlp = torch.squeeze(O.neglogp(item['actions'], mu, mu * 0 + sigma, mu * 0 + logstd))
+    cfg = params['config']
+    loss, a, c, e, b = O.ppo_losses(item['old_logp_actions'], nlp, item['advantages'], item['old_values'], values,
+                                    item['returns'], mu, ent, cfg['e_clip'], cfg['critic_coef'], cfg['entropy_coef'],
+                                    cfg['bounds_loss_coef'], cfg['clip_value'])
+    loss.backward()
+    want_kl = O.policy_kl(mu.detach(), (mu * 0 + sigma).detach(), old_mu, old_sigma)
+    norm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in twin.parameters() if p.grad is not None)).item()
+    coef = min(1.0, cfg['grad_norm'] / (norm + 1e-6))
+    res = agent.train_actor_critic(item)
+    for got, ref in ((res[0], a), (res[1], c), (res[2], e), (res[8], b)):
+        assert np.isclose(got.item(), ref.item(), rtol=1e-5, atol=2e-6), (got.item(), ref.item())
+    assert np.isclose(res[3].item(), want_kl.item(), rtol=1e-4, atol=2e-6)
+    assert torch.allclose(item['mu'], mu.detach(), rtol=1e-6, atol=1e-7)              # update_mu_sigma (datasets.py:33-43)
+    refp = dict(twin.named_parameters())
+    for name, p in agent._plain_model().named_parameters():
+        g_ref = refp[name].grad * coef
+        scale = g_ref.abs().max().item()
+        assert (p.grad - g_ref).abs().max().item() <= 1e-4 * scale + 1e-9, name
+    # ---- whole epochs through the public entry point
+    for _ in range(2):
+        agent.update_epoch()
+        out = agent.train_epoch()
+    assert all(torch.isfinite(x).all() for x in out[4] + out[5])
+    assert torch.isfinite(agent.optimizer.flat_params).all()
+    assert agent.game_rewards.mean.shape[-1] == V
+
+
 class _HostVecEnv:
     """A CPU vector env behind the IVecEnv seam (rl_games/common/ivecenv.py:1-36).  numpy=True hands out
     what a gym-style CPU env does (float64 observations / rewards, bool dones, numpy actions expected,

@@ -3,7 +3,7 @@
   * FlatArena.weights_token - the stamp ops.MlpChain's derived copies of the weights (bf16 planes, fp32 fragments)
     carry: it must change for every way the parameter VALUES can change (this package's own writers, and torch
     in-place writes from outside the package), and must not change for anything else the training loop does.
-  * prepare_dataset's value_size > 1 arithmetic (a2c_common.py:1598-1634) - see test further down.
+(The torch forms of the value_size > 1 path are held to the reference's own functions in tests/test_vs_reference_cpu.py.)
 """
 import copy
 

@@ -425,3 +425,92 @@ def test_staged_reference_archive_is_the_reference_byte_for_byte():
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
     assert 'staged archive' in res.stdout and 'rl_games_ref.zip' in res.stdout
+
+
+# ----------------------------------------------------------------------------- value_size > 1 torch forms (round 5)
+
+@pytest.mark.parametrize('V,masked,smooth,bound', [(1, False, False, 'bound'), (2, False, False, 'bound'), (3, True, False, 'regularisation'),
+                                                   (2, True, True, 'bound'), (2, False, True, None)])
+def test_torch_fallback_losses_equal_the_reference_agent_functions(V, masked, smooth, bound):
+    """rl_games_amd/torch_fallback.py (the value_size > 1 path of the agent) against the reference's OWN calc_losses
+    (a2c_continuous.py:97-134, called unbound on a stand-in with exactly the attributes it reads), its model epilogue
+    (models.py:329-364) and policy_kl - loss, the four scalars, KL, and the gradients w.r.t. mu / logstd / values."""
+    import types
+    from rl_games.algos_torch import a2c_continuous, torch_ext
+    from rl_games.algos_torch.models import ModelA2CContinuousLogStd
+    from rl_games.common import common_losses
+    from rl_games_amd import torch_fallback as tf
+    g = gen(3 + V)
+    mb, A = 512, 5
+    mu0 = 1.3 * torch.randn(mb, A, generator=g)
+    logstd0 = 0.2 * torch.randn(A, generator=g)
+    values0 = torch.randn(mb, V, generator=g)
+    actions = mu0 + torch.randn(mb, A, generator=g)
+    old_nlp = 0.5 * torch.randn(mb, generator=g) + 6.0
+    adv = torch.randn(mb, generator=g)
+    old_values = values0 + 0.3 * torch.randn(mb, V, generator=g)
+    returns = torch.randn(mb, V, generator=g)
+    old_mu = mu0 + 0.1 * torch.randn(mb, A, generator=g)
+    old_sigma = torch.exp(0.2 * torch.randn(mb, A, generator=g))
+    mask = (torch.rand(mb, generator=g) < 0.7).float() if masked else None
+    coef_b = None if bound is None else 1e-3
+    kind = {None: 0, 'bound': 1, 'regularisation': 2}[bound]
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (mu0, logstd0, values0)]
+    # ---- ours
+    mu, logstd, values = leaves()
+    loss, sc, sigma = tf.ppo_loss(mu, logstd, values, actions, old_nlp, adv, old_values, returns, e_clip=0.2, critic_coef=2.0,
+                                  entropy_coef=0.01, bounds_coef=coef_b if coef_b is not None else 0.0, bound_kind=kind,
+                                  clip_value=True, smooth=smooth, mask=mask)
+    loss.backward()
+    ours = (loss.detach(), sc, [t.grad.clone() for t in (mu, logstd, values)])
+    kl = tf.policy_kl(mu.detach(), sigma.detach().expand_as(mu), old_mu, old_sigma, mask)
+    # ---- the reference: epilogue as ModelA2CContinuousLogStd.Network.forward computes it, then calc_losses
+    mu, logstd, values = leaves()
+    logstd_full = mu * 0.0 + logstd                                                    # network_builder.py:506-512
+    sigma_full = torch.exp(logstd_full)
+    distr = torch.distributions.Normal(mu, sigma_full, validate_args=False)
+    entropy = distr.entropy().sum(dim=-1)
+    nlp = torch.squeeze(ModelA2CContinuousLogStd.Network.neglogp(None, actions, mu, sigma_full, logstd_full))
+    stub = types.SimpleNamespace(ppo=True, has_value_loss=True, model=None, clip_value=True,
+                                 bound_loss_type=bound, bounds_loss_coef=coef_b, critic_coef=2.0, entropy_coef=0.01,
+                                 ppo_device='cpu')
+    stub.bound_loss = types.MethodType(a2c_continuous.A2CAgent.bound_loss, stub)
+    stub.reg_loss = types.MethodType(a2c_continuous.A2CAgent.reg_loss, stub)
+    stub.bounds_loss_coef = coef_b
+    fn = common_losses.smoothed_actor_loss if smooth else common_losses.actor_loss
+    ref_loss, a, c, e, b, _ = a2c_continuous.A2CAgent.calc_losses(stub, fn, old_nlp, nlp, adv, 0.2, old_values, values, returns,
+                                                               mu, entropy, mask)
+    ref_loss.backward()
+    for got, want in ((ours[0], ref_loss.detach()), (ours[1]['a_loss'], a), (ours[1]['c_loss'], c), (ours[1]['entropy'], e),
+                      (ours[1]['b_loss'], b.reshape(()) if bound is None else b)):
+        assert torch.allclose(got, want.detach(), rtol=1e-6, atol=1e-7), (got, want)
+    for got, leaf in zip(ours[2], (mu, logstd, values)):
+        assert torch.allclose(got, leaf.grad, rtol=1e-5, atol=1e-8)
+    ref_kl = torch_ext.policy_kl(mu.detach(), sigma_full.detach(), old_mu, old_sigma, mask is None)
+    if mask is not None:
+        ref_kl = (ref_kl * mask).sum() / mask.sum()                                     # a2c_continuous.py:218-221
+    assert torch.allclose(kl, ref_kl, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_torch_fallback_advantage_normalisation_and_ema_equal_the_reference(masked):
+    from rl_games.algos_torch import torch_ext
+    from rl_games.algos_torch.moving_mean_std import GeneralizedMovingStats as RefStats
+    from rl_games_amd import torch_fallback as tf
+    from rl_games_amd.normalizers import GeneralizedMovingStats
+    g = gen(11)
+    adv = 3 * torch.randn(4096, generator=g) + 0.5
+    mask = (torch.rand(4096, generator=g) < 0.6).float() if masked else None
+    assert torch.allclose(tf.normalize_advantages(adv, mask), torch_ext.normalization_with_masks(adv, mask), rtol=1e-6, atol=1e-7)
+    ours, ref = GeneralizedMovingStats((1,), decay=0.5), RefStats((1,), decay=0.5)
+    for k in range(3):
+        x = (k + 1) * torch.randn(4096, generator=g) - k
+        assert torch.allclose(ours(x, mask=mask), ref(x, mask=mask), rtol=1e-6, atol=1e-7)
+    for name in ('mean', 'sqrs', 'step'):
+        assert torch.equal(getattr(ours, name), getattr(ref, name))
+    # nothing valid: no update
+    before = (ours.mean.clone(), ours.step.clone())
+    ours(adv, mask=torch.zeros(4096))
+    assert torch.equal(ours.mean, before[0]) and torch.equal(ours.step, before[1])
