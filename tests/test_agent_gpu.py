@@ -1186,7 +1186,7 @@ def test_two_rank_steps_match_the_mean_of_two_oracle_ranks(shape, collective):
     over = {'ipc': '{}', 'fallback': '{"native_allreduce": false}'}[collective]
     os.environ['RLG_TWO_RANK_CONFIG'] = over
     try:
-        res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_oracle_check.py'), shape], timeout=900)
+        res = _run_two_ranks([os.path.join(root, 'tools', 'two_rank_oracle_check.py'), shape], timeout=360)
     finally:
         os.environ.pop('RLG_TWO_RANK_CONFIG', None)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]

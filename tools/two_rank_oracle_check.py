@@ -39,6 +39,7 @@ else:
     params = configs.tiny(num_actors=N, horizon=H, multi_gpu=True, hip_graphs=False)
 params['config']['env_config']['seed'] = 10 + rank          # different data per rank
 params['config'].update(json.loads(os.environ.get('RLG_TWO_RANK_CONFIG', '{}')))
+params['config'].setdefault('native_allreduce_timeout_s', 60.0)      # (a peer that died: give up, do not hang the box)
 agent = A2CAgent('dp', copy.deepcopy(params))
 agent.init_tensors()
 agent.obs = agent.env_reset()
