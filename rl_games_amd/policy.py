@@ -336,6 +336,11 @@ class ContinuousA2CLogStdModel(nn.Module):
         mu = net.mu_act(net.mu(out))
         return mu, net.sigma_act(net.sigma), value, states
 
+    # The reference Runner wraps `agent.model` in torch.compile unless the config says otherwise (torch_runner.py:283-307).
+    # The normalisers of this model launch HIP kernels through ctypes on torch's current stream - nothing Dynamo can trace -
+    # so the forward is marked opaque: the wrapper then calls it eagerly (the rollout's slow path, get_action_values /
+    # get_values of an agent outside the fused envelope, players).
+    @torch.compiler.disable
     def forward(self, input_dict):
         is_train = input_dict.get('is_train', True)
         prev_actions = input_dict.get('prev_actions', None)
@@ -386,6 +391,7 @@ class DiscreteA2CModel(ContinuousA2CLogStdModel):
             logits = torch.cat(logits, dim=1)
         return logits, net.value_act(net.value(net.critic_features(obs, out)))
 
+    @torch.compiler.disable       # (see ContinuousA2CLogStdModel: launches behind ctypes are opaque to Dynamo)
     def forward(self, input_dict):
         is_train = input_dict.get('is_train', True)
         action_masks = input_dict.get('action_masks', None)
@@ -418,6 +424,7 @@ class CentralValueModel(ContinuousA2CLogStdModel):
     """The reference's `ModelCentralValue.Network` contract (models.py:425-464): normalised states in,
     {'values', 'rnn_states'} out; values de-normalised outside training."""
 
+    @torch.compiler.disable       # (see ContinuousA2CLogStdModel: launches behind ctypes are opaque to Dynamo)
     def forward(self, input_dict):
         is_train = input_dict.get('is_train', True)
         obs = self.norm_obs(input_dict['obs'])

@@ -141,7 +141,7 @@ def test_reference_runner_trains_our_discrete_agent_on_a_numpy_vec_env(tmp_path)
     """BASELINE.json configs[0] through the same seam: a2c_discrete on a CPU vec-env that speaks numpy with next_step
     autoreset (gymnasium_vecenv.py:245 => mask_autoreset_rows, a2c_common.py:347-348 => the masked path), 3 epochs."""
     from rl_games_amd import configs
-    params = configs.cartpole_discrete(num_actors=16, device=DEV, max_epochs=3, train_dir=str(tmp_path),
+    params = configs.cartpole_discrete(num_actors=16, device=DEV, max_epochs=3, train_dir=str(tmp_path), save_best_after=0,
                                        full_experiment_name='runner_cartpole', torch_compile=False)
     _reference()                                             # (puts the gymnasium stub on sys.path)
     env = _HostVecEnv(16, 4, 2)
