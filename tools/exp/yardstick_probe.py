@@ -29,7 +29,8 @@ COLS = ('a_loss', 'c_loss', 'entropy', 'b_loss', 'kl')
 
 
 def run_agent(**over):
-    params = configs.humanoid_65536(num_actors=N, minibatch_size=MB, hip_graphs=True, **over)
+    over.setdefault('hip_graphs', True)
+    params = configs.humanoid_65536(num_actors=N, minibatch_size=MB, **over)
     torch.manual_seed(5)
     agent = A2CAgent('epoch', copy.deepcopy(params))
     agent.init_tensors()
@@ -73,16 +74,6 @@ for k in range(ME * NMB):
                        cfg.get('lr_multiplier', 1.5))
 print('agent lr trajectory: first mismatch with the oracle at step', next((k for k in range(ME * NMB) if traj[k] != lrs[k]), None))
 print('AGENT (fused)      ', fmt(T._deviation_per_mini_epoch(rows, ref, NMB, ME)))
-# the same job on the per-layer engine, against the oracle on ITS rollout (same seeds: the rollouts agree unless the
-# rollout kernels differ)
-p2, a2, c2, rows2 = run_agent(fused_mlp=False)
-o2 = T._oracle_for(p2, c2[0], N, 108, 21)
-ref2 = o2.update(c2[0]['batch'])
-print('AGENT (per-layer)  ', fmt(T._deviation_per_mini_epoch(rows2, ref2, NMB, ME)), ' chain', a2._engine.chain is not None)
-same_rollout = all(torch.equal(caps[0]['batch'][k], c2[0]['batch'][k]) for k in caps[0]['batch'])
-print('per-layer run played the same rollout:', same_rollout)
-
-
 def twin_rows(make):
     tw = make(T._oracle_for(params, caps[0], N, 108, 21))
     r = tw.update(caps[0]['batch'])
@@ -96,3 +87,15 @@ for name, make in (('gemm 1e-6 s11', lambda o: T._gemm_order_noise(o, 11)), ('ge
     tr, tl = twin_rows(make)
     mism = next((k for k in range(len(lrs)) if tl[k] != lrs[k]), None)
     print(f'TWIN {name:14s}', fmt(T._deviation_per_mini_epoch(tr, ref, NMB, ME)), ' first lr mismatch', mism)
+
+
+# the same job on the per-layer engine, against the oracle on ITS rollout (same seeds: the rollouts agree unless the
+# rollout kernels differ)
+p2, a2, c2, rows2 = run_agent(fused_mlp=False, hip_graphs=False)      # (library GEMMs are not capturable: eager)
+o2 = T._oracle_for(p2, c2[0], N, 108, 21)
+ref2 = o2.update(c2[0]['batch'])
+print('AGENT (per-layer)  ', fmt(T._deviation_per_mini_epoch(rows2, ref2, NMB, ME)), ' chain', a2._engine.chain is not None)
+same_rollout = all(torch.equal(caps[0]['batch'][k], c2[0]['batch'][k]) for k in caps[0]['batch'])
+print('per-layer run played the same rollout:', same_rollout)
+
+
