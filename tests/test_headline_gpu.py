@@ -291,7 +291,7 @@ def _gemm_order_noise(oracle, seed=11, level=1e-6):
 
 def _row_sum_order_noise(oracle, seed):
     """Makes `oracle` a twin whose rows' neglogp carry ONE ULP of relative noise (a fresh +-2^-24 pattern every minibatch):
-    what summing a row's A squared terms in another order does to it - the fused loss tile adds four partial sums by
+    what summing a row's A squared terms in another order does to it (6e-8 = one ulp) - the fused loss tile adds four partial sums by
     butterflies where torch adds a = 0 .. A-1.  With neglogp ~ 30 that moves a row's ratio by ~2e-6: enough to put a row
     that sits within 2e-6 of a clip kink on the other side (profiles/r5_parity_yardstick_probe.txt: such twins end the
     fifth mini-epoch of the rank-shaped job between 4e-6 and 2e-4 from the oracle in a_loss, the agent at 1e-5, the
@@ -300,7 +300,7 @@ def _row_sum_order_noise(oracle, seed):
 
     def hook(nlp):
         sign = torch.randint(0, 2, nlp.shape, generator=gen).to(nlp.dtype).mul_(2.0).sub_(1.0)
-        return nlp * (1.0 + 2.0 ** -24 * sign)
+        return nlp * (1.0 + 6e-8 * sign)              # (2^-24 = 5.96e-8; the value the probe ran with)
     oracle.nlp_hook = hook
     return oracle
 
