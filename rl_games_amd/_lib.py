@@ -88,7 +88,7 @@ _PROTOTYPES = {
     'rlg_mlp_chain_step': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                            _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _P],
     'rlg_mlp_chain_backward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _P, _P, _c_ll, _c_int, _P, _P],
-    # experimental lean 16-row forward (csrc/mlp_chain.hip, mlp_chain_fwd_lean_kernel)
+    # lean 16-row forward (csrc/mlp_chain_lean.hip, mlp_chain_fwd_lean_kernel)
     'rlg_mlp_chain_frags_bytes': [_c_int, _P, _P, _c_int],
     'rlg_mlp_chain_pack_frags': [_c_int, _P, _P, _P, _P, _c_int, _P, _P],
     'rlg_mlp_chain_pack_frags_both': [_c_int, _P, _P, _P, _P, _P, _P, _P],

@@ -667,7 +667,7 @@ class MlpChain:
             if best == 0 and (direction == 0 or n > 1):
                 raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
             self.max_groups[direction] = best
-        # lean 16-row kernels (csrc/mlp_chain.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as
+        # lean 16-row kernels (csrc/mlp_chain_lean.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as
         # fp32 fragments in each wave's consumption order; RLG_CHAIN_LEAN=0 keeps the pipelined kernels
         self._lean = os.environ.get('RLG_CHAIN_LEAN', '1') != '0'
         self._frag_bytes = [int(lib.rlg_mlp_chain_frags_bytes(n, self._in, self._out, 0)),

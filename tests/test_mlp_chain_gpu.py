@@ -859,7 +859,7 @@ def test_adam_step_pack_equals_adam_then_pack(in_dim, units, out_dim):
 @pytest.mark.gpu
 @pytest.mark.parametrize('rows', [4096, 1000, 37])
 def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch):
-    """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain.hip: weights as fp32 fragments in each wave's
+    """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain_lean.hip: weights as fp32 fragments in each wave's
     consumption order, the default of MlpChain below 16,384 rows) against the pipelined kernels they replace
     (RLG_CHAIN_LEAN=0; their own one-launch step included): the same products in the same order - heads, activations, normalised observations, d heads, loss
     partials, dZ and bias partial sums equal bit for bit, ragged last tile included - and within 1e-6 of fp64."""
