@@ -1375,7 +1375,7 @@ class A2CAgent:
 
     def _lean_chain(self):
         """The fused chains (the MLP's, or the trunk in front of a recurrent layer) whose launches run the lean 16-row
-        kernels at one of this agent's sizes (csrc/mlp_chain.hip: minibatches / rollouts of < 16,384 rows on exact
+        kernels at one of this agent's sizes (csrc/mlp_chain_lean.hip: minibatches / rollouts of < 16,384 rows on exact
         products), as one object with pack_frags / mark_frags / ensure_frags - or None."""
         c = self._lean_pack
         if c is None:

@@ -407,9 +407,10 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
         for key in ('old_values', 'returns', 'advantages'):
             assert torch.allclose(vd[key].cpu().reshape(-1), oracle.dataset[key].reshape(-1), rtol=RTOL, atol=2e-6), key
         # the yardstick twins: first-layer GEMM-order noise, and one-ulp noise on the rows' neglogp (three patterns at the
-        # rank's shape, where an oracle epoch takes 3 s; two at the benchmarked shape)
+        # rank's shape, where an oracle epoch takes 3 s; one at the benchmarked shape, where it takes 30 s and the exact-product
+        # run is the third yardstick)
         twins = [_gemm_order_noise(_oracle_for(params, caps[0], N, 108, 21))]
-        twins += [_row_sum_order_noise(_oracle_for(params, caps[0], N, 108, 21), seed) for seed in ((1, 2, 3) if N <= 8192 else (1, 2))]
+        twins += [_row_sum_order_noise(_oracle_for(params, caps[0], N, 108, 21), seed) for seed in ((1, 2, 3) if N <= 8192 else (1,))]
         refs2 = [t.update(batch) for t in twins]
     finally:
         torch.set_num_threads(prev)
