@@ -416,7 +416,7 @@ def test_staged_reference_archive_is_the_reference_byte_for_byte():
         for n in names:
             data = z.read(n)
             assert hashlib.sha256(data).hexdigest() == manifest['files'][n]
-            assert data == open(os.path.join('/root/reference', n), 'rb').read(), n
+            assert data == open(os.path.join(ref_import.REFERENCE, n), 'rb').read(), n
     # a process that cannot see the checkout imports the archive
     code = ("import sys; sys.path.insert(0, %r); from oracle import reference_baseline as RB; assert RB.available(); "
             "ri = RB._ref_import(); ri.enable(); import rl_games.algos_torch.a2c_continuous as m; "
