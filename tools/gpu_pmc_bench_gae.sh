@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gae_bench
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o v -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o v -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-row > $OUT/$C.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, os
