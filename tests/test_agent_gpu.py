@@ -590,7 +590,9 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
     for k in ('old_values', 'returns', 'advantages'):
         assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
     cv = agent.central_value_net
+    assert cv._engine is not None               # (round 5: the critic's MLP on the fused chain kernels, not autograd)
     cv.train_net()
+    assert cv._engine.last_dw_path is not None
     n_cv = cv.mini_epoch * cv.num_minibatches
     assert torch.allclose(cv._rows[:n_cv, 5].cpu(), cap['cv_losses'], rtol=1e-5, atol=1e-6)
     agent.set_train()
@@ -611,6 +613,50 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
         for k, v in want.items():
             tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
             assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+
+
+@pytest.mark.parametrize('state_dim,units', [(9, [32, 16]), (24, [64, 32, 16])])
+def test_central_value_chain_gradients_equal_autograd(state_dim, units):
+    """The central value network on the fused chain kernels (central_value._ValueChain: one forward launch, one backward
+    launch, MFMA weight gradients where a layer's input width is a multiple of 4) against the autograd path it replaces
+    (`fused_mlp: False`), same weights, same minibatch: values, loss, every gradient to 1e-5 of its scale, the state
+    statistics bit for bit, and the parameters behind the optimiser step."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    res = {}
+    for fused in (True, False):
+        params = configs.tiny(num_actors=64, horizon=8)
+        params['config']['central_value_config'] = {
+            'minibatch_size': 256, 'mini_epochs': 1, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
+            'truncate_grads': True, 'grad_norm': 1.0, 'fused_mlp': fused,
+            'network': {'name': 'actor_critic', 'central_value': True,
+                        'mlp': {'units': units, 'activation': 'elu', 'initializer': {'name': 'default'}}}}
+        params['config']['env_config']['state_dim'] = state_dim
+        torch.manual_seed(21)
+        agent = A2CAgent('cvg', copy.deepcopy(params))
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        agent.set_eval()
+        with torch.no_grad():
+            batch = agent.play_steps()
+        agent.set_train()
+        agent.prepare_dataset(batch)
+        cv = agent.central_value_net
+        assert (cv._engine is not None) == fused
+        loss = cv.train_critic(cv.dataset[0]).clone()
+        grads = {n: p.grad.clone() for n, p in cv.model.named_parameters()}       # (clipped, as the Adam launch leaves them)
+        res[fused] = (loss, grads, {n: p.detach().clone() for n, p in cv.model.named_parameters()},
+                      cv.model.running_mean_std.running_mean.clone(), cv.model.running_mean_std.count.clone())
+    a, b = res[True], res[False]
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-7)
+    for n in a[1]:
+        scale = b[1][n].abs().max().item()
+        assert (a[1][n] - b[1][n]).abs().max().item() <= 1e-5 * scale + 1e-9, n
+        # the first Adam step is lr * sign(g): compare it where the gradient is above rounding noise
+        solid = b[1][n].abs() > 1e-3 * scale
+        assert torch.allclose(a[2][n][solid], b[2][n][solid], rtol=1e-4, atol=1e-6), n
+        assert (a[2][n] - b[2][n]).abs().max().item() <= 2.0 * 5e-4 * (1 + 1e-5), n
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
 def test_central_value_train_epoch_and_checkpoint(tmp_path):
