@@ -615,19 +615,21 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
             assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
 
 
-@pytest.mark.parametrize('state_dim,units', [(9, [32, 16]), (24, [64, 32, 16])])
-def test_central_value_chain_gradients_equal_autograd(state_dim, units):
+@pytest.mark.parametrize('state_dim,units,envs,mb', [(9, [32, 16], 64, 256), (24, [64, 32, 16], 64, 256),
+                                                     (48, [256, 128, 64], 2048, 16384)])
+def test_central_value_chain_gradients_equal_autograd(state_dim, units, envs, mb):
     """The central value network on the fused chain kernels (central_value._ValueChain: one forward launch, one backward
     launch, MFMA weight gradients where a layer's input width is a multiple of 4) against the autograd path it replaces
     (`fused_mlp: False`), same weights, same minibatch: values, loss, every gradient to 1e-5 of its scale, the state
-    statistics bit for bit, and the parameters behind the optimiser step."""
+    statistics bit for bit, and the parameters behind the optimiser step.  The 16,384-row case runs the split-bf16 chain
+    kernels and the split-product weight-gradient launch with the one-column head as the chain's last layer."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     res = {}
     for fused in (True, False):
-        params = configs.tiny(num_actors=64, horizon=8)
+        params = configs.tiny(num_actors=envs, horizon=8)
         params['config']['central_value_config'] = {
-            'minibatch_size': 256, 'mini_epochs': 1, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
+            'minibatch_size': mb, 'mini_epochs': 1, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
             'truncate_grads': True, 'grad_norm': 1.0, 'fused_mlp': fused,
             'network': {'name': 'actor_critic', 'central_value': True,
                         'mlp': {'units': units, 'activation': 'elu', 'initializer': {'name': 'default'}}}}
@@ -643,6 +645,8 @@ def test_central_value_chain_gradients_equal_autograd(state_dim, units):
         agent.prepare_dataset(batch)
         cv = agent.central_value_net
         assert (cv._engine is not None) == fused
+        if fused and mb >= 16384:
+            assert cv._engine.chain.split_products(mb, 0) and cv._engine.chain.split_products(mb, 1)
         loss = cv.train_critic(cv.dataset[0]).clone()
         grads = {n: p.grad.clone() for n, p in cv.model.named_parameters()}       # (clipped, as the Adam launch leaves them)
         res[fused] = (loss, grads, {n: p.detach().clone() for n, p in cv.model.named_parameters()},
