@@ -33,15 +33,17 @@ Prints ONE JSON line on rank 0 with the contract keys plus
   * `roofline_mfma`: the weight-gradient launch against the dense MFMA peak of the instruction it issues
     (bf16 for the default split-product form, with the fp32-equivalent rate beside it),
   * `roofline_fwd` / `roofline_bwd`: the two dominant kernels of the epoch (fused forward / fused backward chain,
-    csrc/mlp_chain.hip) against the dense fp32 MFMA peak: useful flops / mean launch duration over ALL their
+    csrc/mlp_chain_bx*.hip) against the dense MFMA peak of the instruction they issue (bf16 for the split-product
+    kernels: 6 x the padded-tile flops; the fp32-equivalent rate beside it): mean launch duration over ALL their
     launches of one eager epoch run after the timed region (HIP events bound to each dispatch, like the GAE
     launch; inside the timed region they are nodes of a replayed HIP graph and cannot carry events),
   * at N>1 `config.allreduce` ("ipc" | "ipc-two-phase" | "rccl": the collective that ran), `config.ipc_self_test`,
     `config.ranks_in_sync`,
-  * at N=1 `cpu_baseline`: the CPU port of the reference epoch (oracle/ppo_epoch_oracle.py) timed on
-    this box's host cores on a bounded sample, at the reference's default threading AND on all
-    cores, with the port -> untouched-reference calibration measured in the build container
-    (profiles/cpu_baseline_calibration.json, tools/cpu_reference_baseline.py).
+  * at N=1 `cpu_baseline` (kind "reference"): the UNTOUCHED reference - rl_games' A2CAgent.train_epoch, imported from
+    the archive oracle/stage_reference.py stages under the git-ignored oracle/_ref/ - timed on this box's host
+    cores in the same run on a bounded sample (1/16 of the envs, 4 minibatches per mini-epoch), at the
+    reference's default 4 torch threads and at min(cores, 16); kind "port" (the oracle's restatement) only
+    where the archive is missing.
 """
 import argparse
 import datetime
@@ -463,13 +465,17 @@ def main():
                     'kernel': 'rlg::mlp_chain_fwd_bx_kernel (' + ('training forward: statistics fold + normalise + every layer '
                               '+ heads, activations written' if key == 'roofline_fwd' else 'rollout inference forward') +
                               '; split-bf16 products on pre-split weight planes)',
+                    # priced on the unit the kernel issues on: 6 x padded-tile flops against the dense bf16 MFMA peak
+                    'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'frac': issued / BF16_MFMA_PEAK_TFLOPS,
+                    'algorithmic_flops_per_launch': 6 * 2.0 * rows * pad,
+                    'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': tf / FP32_MFMA_PEAK_TFLOPS,
                     'issued_tflops_bf16': issued, 'issued_frac_of_bf16_peak': issued / BF16_MFMA_PEAK_TFLOPS,
                     'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
                               'timed region (= rocprofv3 --kernel-trace begin/end; the plane-pack launch in front of it '
                               'is not included); six exact bf16 plane products per fp32 product on '
-                              'v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx_fwd.hip); achieved / frac = useful fp32 flops '
-                              '2*rows*sum(in*out) against the fp32 MFMA peak, issued_* = 6 x the padded-tile flops '
-                              'against the dense bf16 peak'})
+                              'v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx_fwd.hip); achieved / frac = the ISSUED flops - '
+                              '6 x the padded-tile flops - against the dense bf16 MFMA peak (the unit the kernel issues '
+                              'on); fp32_equivalent_* = useful fp32 flops 2*rows*sum(in*out) against the fp32 MFMA peak'})
             if key == 'roofline_bwd' and eng.chain.split_products(rows, 1):
                 # the split-bf16 kernel: fp32-equivalent flops against the fp32 peak (comparable with the other rows)
                 # and what it ISSUES - six bf16 plane products per product over 16 x 32 padded tiles - on the bf16 peak
@@ -478,12 +484,15 @@ def main():
                 chain_roof[key].update({
                     'kernel': 'rlg::mlp_chain_bwd_bx_kernel (PPO loss tile + dX chain on split-bf16 products + activation '
                               'backward + bias partials; weight planes packed by the forward launch)',
+                    'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'frac': issued / BF16_MFMA_PEAK_TFLOPS,
+                    'algorithmic_flops_per_launch': 6 * 2.0 * rows * pad,
+                    'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': tf / FP32_MFMA_PEAK_TFLOPS,
                     'issued_tflops_bf16': issued, 'issued_frac_of_bf16_peak': issued / BF16_MFMA_PEAK_TFLOPS,
                     'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
                               'timed region (= rocprofv3 --kernel-trace begin/end); six exact bf16 plane products per fp32 '
-                              'product on v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx.hip); achieved / frac = useful fp32 '
-                              'flops 2*rows*sum(in*out) against the fp32 MFMA peak, issued_* = 6 x the padded-tile flops '
-                              'against the dense bf16 peak'})
+                              'product on v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx.hip); achieved / frac = the ISSUED '
+                              'flops - 6 x the padded-tile flops - against the dense bf16 MFMA peak; fp32_equivalent_* = '
+                              'useful fp32 flops 2*rows*sum(in*out) against the fp32 MFMA peak'})
 
     # what arithmetic the forward / backward chain launches of the timed region ran on
     chain_products = None
@@ -505,7 +514,7 @@ def main():
         if r is not None and 'issued_tflops_bf16' in r:
             # the scheme's own ceiling: six bf16 products per useful fp32 product
             r['split_ceiling_tflops'] = BF16_MFMA_PEAK_TFLOPS / 6.0
-            r['split_ceiling_frac'] = r['achieved'] / (BF16_MFMA_PEAK_TFLOPS / 6.0)
+            r['split_ceiling_frac'] = r['fp32_equivalent_tflops'] / (BF16_MFMA_PEAK_TFLOPS / 6.0)
 
     traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
     try:

@@ -172,6 +172,11 @@ class A2CAgent:
         self.multi_gpu_sync_stats = config.get('multi_gpu_sync_stats', True)
         self.multi_gpu_sync_stats_mode = rdist.resolve_stats_sync_mode(
             config.get('multi_gpu_sync_stats_mode', 'pooled'))
+        # once per epoch: do all ranks hold the same parameter / Adam-moment bits?  'raise' (default) | 'rebroadcast'
+        # (rank 0's optimiser state wins, a warning is printed) | False
+        self.multi_gpu_param_check = config.get('multi_gpu_param_check', 'raise')
+        if self.multi_gpu_param_check not in ('raise', 'rebroadcast', False, None):
+            raise ValueError("multi_gpu_param_check must be 'raise', 'rebroadcast' or False")
         self.local_rank = self.global_rank = 0
         self.world_size = 1
         if self.multi_gpu:
@@ -1658,6 +1663,7 @@ class A2CAgent:
             self._host_schedule(float(torch.stack(kls).mean().item()))
         self._fold_ready = False
         self.sync_running_stats()
+        self._check_ranks_in_sync()
         if self._ipc_comm:
             # one host read per epoch; the verdict is collective, so that every rank raises in the same epoch
             # instead of one rank leaving the others to hang in their next collective
@@ -1719,6 +1725,26 @@ class A2CAgent:
         sync = self._stats_sync()
         if sync is not None:
             sync.seed()
+
+    def _check_ranks_in_sync(self):
+        """Guard against silent rank drift (round 5: two ranks ended epochs with `exp_avg_sq` one update apart in 16
+        elements, profiles/r5_two_rank_sync.txt - found by bench.py's probe only): an exact checksum of parameters and
+        Adam moments, one tiny all-reduce per epoch."""
+        if not self.multi_gpu or not self.multi_gpu_param_check:
+            return
+        o = self.optimizer
+        if rdist.ranks_in_sync([o.flat_params, o.exp_avg, o.exp_avg_sq]):
+            return
+        if self.multi_gpu_param_check == 'rebroadcast':
+            print(f'rl_games_amd: rank {self.global_rank}: parameters / Adam moments differ between the ranks after epoch '
+                  f'{self.epoch_num}; taking rank 0\'s', flush=True)
+            import torch.distributed as dist
+            for t in (o.flat_params, o.exp_avg, o.exp_avg_sq):
+                dist.broadcast(t, 0)
+            o.weights_changed()
+            return
+        raise RuntimeError(f'rank {self.global_rank}: parameters / Adam moments are no longer bit-identical across the ranks '
+                           f'(epoch {self.epoch_num}); multi_gpu_param_check: \'rebroadcast\' re-aligns them instead of raising')
 
     def sync_running_stats(self):
         """a2c_common.py:782-808."""
@@ -1859,6 +1885,9 @@ class A2CAgent:
         self.optimizer.weights_changed()
         if self.has_central_value:
             dist.broadcast(self.central_value_net.optimizer.flat_params, 0)
+            # (c10d collectives write in place WITHOUT bumping the tensor's version counter: the chain's planes /
+            #  fragments of the pre-broadcast weights have to be invalidated by hand, like the actor's above)
+            self.central_value_net.optimizer.weights_changed()
         sync = self._stats_sync()
         if sync is not None:
             sync.adopt_rank0(rdist.broadcast_from_rank0)

@@ -61,6 +61,20 @@ def broadcast_from_rank0(t):
     return t
 
 
+def ranks_in_sync(tensors):
+    """True when `tensors` (fp32 arenas: parameters, Adam moments) hold the same BITS on every rank.  Each tensor is
+    reduced to an exact checksum - the int64 sum of its bit patterns, order-independent - and the checksums are
+    compared by ONE all-reduce (MAX of [c, -c] = [max c, -min c]).  The reference keeps its ranks aligned by
+    construction and never checks (a2c_common.py:493-514); here the ranks run a hand-written in-graph collective and
+    rank-ordered sums, so the agent asks once per epoch (`multi_gpu_param_check`) - a desynchronisation that is not a
+    crash would otherwise only show as a slowly diverging policy."""
+    sums = torch.stack([t.detach().contiguous().view(torch.int32).sum(dtype=torch.int64) for t in tensors])
+    both = torch.cat([sums, -sums])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    n = sums.numel()
+    return bool((both[:n] == -both[n:]).all().item())
+
+
 def resolve_stats_sync_mode(mode):
     if mode in STATS_SYNC_MODES:
         return mode

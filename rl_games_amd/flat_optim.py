@@ -66,8 +66,10 @@ class FlatArena:
         bumped by this package's own writers, whose kernels write through raw pointers - together with the autograd
         version counters of the parameters and of the arena, which every in-place torch write bumps
         (`model.load_state_dict`, `p.copy_()`, `p.mul_()` under no_grad, writes to `flat_params`): a write from outside
-        the package invalidates the copies without having to call weights_changed().  (`p.data.copy_()` has no version
-        counter to bump - the one way left that needs the explicit call.)"""
+        the package invalidates the copies without having to call weights_changed().  Two kinds of writes have no
+        version counter to bump and need the explicit call: `p.data.copy_()`, and c10d's in-place collectives
+        (`dist.broadcast` / `all_reduce` on `flat_params` leave `_version` untouched - `A2CAgent.broadcast_parameters`
+        calls weights_changed() behind both of its broadcasts)."""
         return (self.weights_version, self.flat_params._version, sum(p._version for p in self.params))
 
     def span(self, first, last):

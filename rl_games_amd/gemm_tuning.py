@@ -1,7 +1,9 @@
-"""hipBLASLt / rocBLAS solution selection for the policy MLP's fp32 GEMMs.
+"""hipBLASLt / rocBLAS solution selection for the fp32 GEMMs that still go through torch.
 
-The MLP GEMMs stay on the vendor libraries through torch.  Their default
-heuristics pick poor kernels for this path's skinny shapes (e.g. dW = dZ^T A with K = 32,768 and
+Since round 2 the MLP and LSTM configurations run every product in this library's own MFMA kernels; library GEMMs are
+left only on the fall-back paths (the per-layer engine of `fused_mlp: False`, policy shapes outside the engines'
+envelope, the discrete agent's autograd trunks, a central value network's first layer over a state width that is no
+multiple of 4).  The libraries' default heuristics pick poor kernels for this path's skinny shapes (e.g. dW = dZ^T A with K = 32,768 and
 a 400x200 output ran at ~36 TFLOP/s); PyTorch's TunableOp facility benchmarks the libraries'
 own solutions per shape and remembers the best one.  `tuning/tunableop_gfx950.csv` holds the
 selections for the BASELINE.json shapes on MI355X (this image's library versions - the file's

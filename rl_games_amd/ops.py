@@ -692,7 +692,16 @@ class MlpChain:
     def cache_state(self):
         """Host-side record of what the derived copies hold - for callers that issue launches WITHOUT running them
         (HIP-graph capture): taken in front of the capture, put back behind it (restore_cache_state), so that a pack
-        launch that was only recorded never counts as done."""
+        launch that was only recorded never counts as done.  The persistent plane / fragment buffers are allocated HERE
+        if they are not yet: a tensor first created inside torch.cuda.graph would live in the graph's private pool and
+        dangle behind a capture that fails and is discarded."""
+        if self._lean and self._frags is None and self._frag_bytes[0] >= 0:
+            self._frag_buffer()
+        if self._planes is None:
+            try:
+                self._plane_buffer()
+            except ValueError:
+                pass                      # (a network the split-product kernels do not take: they never ask for planes)
         return (self._planes_fresh, self._planes_for, self._frags_for, self._planes_packed_once)
 
     def restore_cache_state(self, state):

@@ -8,8 +8,12 @@ parameter names match the reference (`a2c_network.actor_mlp.<2i>.weight`, `a2c_n
 `a2c_network.value`, `a2c_network.sigma`, `running_mean_std.*`, `value_mean_std.*`), so
 `state_dict()`s are interchangeable with reference checkpoints.
 
-The GEMMs stay on rocBLAS/hipBLASLt through `torch.nn.Linear`; the
-normalisers and - in training - the whole distribution/loss epilogue run in the HIP kernels.
+The module tree only HOLDS the parameters (views of the optimiser's flat arena): for the MLP and LSTM
+configurations every product of rollout and update runs in this library's fused MFMA kernels
+(`mlp_engine.ManualMlpEngine` over `ops.MlpChain` / `ops.MlpDwPlan`, csrc/mlp_chain*.hip, mlp_dw.hip), the
+normalisers and - in training - the whole distribution/loss epilogue in its HIP kernels as well.  The
+`torch.nn.Linear` forward of the modules (library GEMMs) is what runs for shapes outside the engines' envelope
+(`rl_games_amd: manual MLP engine unavailable (...)` is printed when that happens) and on the CPU for checkpoints.
 `forward(input_dict)` keeps the reference's dict-in/dict-out contract; `forward_heads` is the
 raw (mu, logstd, value) path the fused loss kernel consumes.
 """

@@ -149,6 +149,34 @@ def _stats_worker(rank, world):
     assert m3.count.item() == ref.count.item()
 
 
+def _ranks_in_sync_worker(rank, world):
+    """distributed.ranks_in_sync: identical bits -> True on every rank; ONE element one ulp apart on one rank (the
+    round-5 desynchronisation: 16 exp_avg_sq elements one update apart) -> False on every rank, in one collective; -0.0
+    against +0.0 counts as different (bits, not values)."""
+    from rl_games_amd import distributed as rdist
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(1000, generator=g), torch.rand(77, generator=g)
+    assert rdist.ranks_in_sync([a, b])
+    b2 = b.clone()
+    if rank == 1:
+        b2[13] = torch.nextafter(b2[13], torch.tensor(2.0))
+    assert not rdist.ranks_in_sync([a, b2])
+    assert rdist.ranks_in_sync([a])
+    z = torch.zeros(4)
+    if rank == 0:
+        z[2] = -0.0
+    assert not rdist.ranks_in_sync([z])
+    # two differences that cancel in a plain sum of VALUES do not cancel in the checksum of bit patterns
+    c = torch.ones(8)
+    if rank == 1:
+        c[0], c[1] = 1.5, 0.5
+    assert not rdist.ranks_in_sync([c])
+
+
+def test_ranks_in_sync_checksum_two_ranks():
+    _spawn(_ranks_in_sync_worker, 2)
+
+
 def test_flat_arena_allreduce_two_ranks():
     _spawn(_grad_worker, 2)
 
