@@ -132,9 +132,6 @@ class OracleAgent:
         self.meters = {'mean': [torch.zeros(1), torch.zeros(1), torch.zeros(1)], 'n': [0, 0, 0]}
         self.games_to_track = cfg.get('games_to_track', 100)
         self.obs = None
-        # tests only: a callable applied to the minibatch's neglogp (a twin of the algorithm under a second implementation's
-        # rounding of the row sums, tests/test_headline_gpu.py); None = the reference's arithmetic
-        self.nlp_hook = None
 
     # ------------------------------------------------------------------ rollout
     def play_steps(self):
@@ -208,8 +205,6 @@ class OracleAgent:
         sigma = torch.exp(logstd)
         entropy = O.normal_entropy(mu, sigma)
         nlp = torch.squeeze(O.neglogp(mbd['actions'], mu, sigma, logstd))
-        if self.nlp_hook is not None:
-            nlp = self.nlp_hook(nlp)
         mask = mbd.get('rnn_masks')
         loss, a, c, e, b = O.ppo_losses(
             mbd['old_logp_actions'], nlp, mbd['advantages'], mbd['old_values'], values, mbd['returns'],

@@ -12,6 +12,23 @@ constexpr int kLossSmallBatch = 8192;   // short phases, so a small minibatch wa
 constexpr int kLossThreads = 256;  // threads per block: all walk the tile, the first kLossRows own a row
 constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
 
+// The five sums of a row over its A actions (z^2, KL terms, bound terms, log sigma, entropy terms: `.sum(dim=-1)` in the
+// reference, models.py:361-364, torch_ext.py:31, a2c_continuous.py:241-253) are accumulated in fp64 and rounded to fp32 ONCE:
+// the correctly rounded value of the exact sum of the fp32 terms.  There is no "reference order" to reproduce - ATen's CPU sum
+// over a contiguous last dimension is a vectorised cascade whose grouping depends on the host's vector width, a GPU build of
+// the reference reduces in yet another order; measured on 200,000 rows of A = 21 (profiles/r6_row_sum_order.txt): the order
+// a = 0 .. A-1 reproduces the bits of torch.sum on the AVX-512 host in 38 % of the rows, four partial sums + butterfly
+// (rounds 3 - 5) in 51 %, the correctly rounded sum in 56 % - and it is the only one of them that is within half an ulp
+// of EVERY fp32 summation order's target, on any machine.  RLG_LOSS_ROWSUM_F64=0: fp32 partial sums (the round-5 bits).
+#ifndef RLG_LOSS_ROWSUM_F64
+#define RLG_LOSS_ROWSUM_F64 1
+#endif
+#if RLG_LOSS_ROWSUM_F64
+typedef double row_acc_t;
+#else
+typedef float row_acc_t;
+#endif
+
 struct LossArgs {
   // network outputs
   const float* mu;         // [mb, A]
@@ -266,33 +283,40 @@ __device__ __forceinline__ void ppo_loss_tile_rows(const LossArgs& p, float* lds
   double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
   if constexpr (kPart == 4) {
-    // every sum by ONE thread in the order a = 0 .. A-1 (the bits of the one-thread-per-row form), the five of a row
-    // by the four threads of its quad at the same time; then each thread of the quad collects all five
+    // every sum by ONE thread (row_acc_t: see below), the five of a row by the four threads of its quad at the same time;
+    // then each thread of the quad collects all five
     const int rr = prow < rows ? prow : 0;
-    float mine = 0.0f, mine2 = 0.0f;
+    row_acc_t mine = 0, mine2 = 0;
     if (ppart == 3) {
       for (int a = 0; a < A; ++a) {
-        mine += col_logstd[a];
-        mine2 += col_ent[a];
+        mine += static_cast<row_acc_t>(col_logstd[a]);
+        mine2 += static_cast<row_acc_t>(col_ent[a]);
       }
     } else {
       const float* tile = ppart == 0 ? t_z2 : (ppart == 1 ? t_kl : t_b);
-      for (int a = 0; a < A; ++a) mine += tile[rr * AP + a];
+      for (int a = 0; a < A; ++a) mine += static_cast<row_acc_t>(tile[rr * AP + a]);
     }
+    const float mine_f = static_cast<float>(mine), mine2_f = static_cast<float>(mine2);
     const int quad = static_cast<int>(threadIdx.x & 63) & ~3;
-    s_z2 = __shfl(mine, quad + 0, kWave);
-    s_kl = __shfl(mine, quad + 1, kWave);
-    s_b = __shfl(mine, quad + 2, kWave);
-    s_ls = __shfl(mine, quad + 3, kWave);
-    s_ent = __shfl(mine2, quad + 3, kWave);
+    s_z2 = __shfl(mine_f, quad + 0, kWave);
+    s_kl = __shfl(mine_f, quad + 1, kWave);
+    s_b = __shfl(mine_f, quad + 2, kWave);
+    s_ls = __shfl(mine_f, quad + 3, kWave);
+    s_ent = __shfl(mine2_f, quad + 3, kWave);
   } else if (prow < rows) {
+    row_acc_t d_z2 = 0, d_kl = 0, d_b = 0, d_ls = 0, d_ent = 0;
     for (int a = 0; a < A; ++a) {
-      s_z2 += t_z2[prow * AP + a];
-      s_kl += t_kl[prow * AP + a];
-      s_b += t_b[prow * AP + a];
-      s_ls += col_logstd[a];
-      s_ent += col_ent[a];
+      d_z2 += static_cast<row_acc_t>(t_z2[prow * AP + a]);
+      d_kl += static_cast<row_acc_t>(t_kl[prow * AP + a]);
+      d_b += static_cast<row_acc_t>(t_b[prow * AP + a]);
+      d_ls += static_cast<row_acc_t>(col_logstd[a]);
+      d_ent += static_cast<row_acc_t>(col_ent[a]);
     }
+    s_z2 = static_cast<float>(d_z2);
+    s_kl = static_cast<float>(d_kl);
+    s_b = static_cast<float>(d_b);
+    s_ls = static_cast<float>(d_ls);
+    s_ent = static_cast<float>(d_ent);
   }
   if (prow < rows && ppart == 0) {
     const long long i = row0 + prow;
@@ -385,8 +409,8 @@ __device__ __forceinline__ void ppo_loss_tile_rows(const LossArgs& p, float* lds
 // front, the row's five sums by two butterfly steps inside the quad, the row-level maths redundantly in its four
 // threads, d mu / write-back straight from the registers, the column sums over the rows by butterflies over the
 // lanes that share q (fp64) and one exchange between the waves: two barriers.
-// Same formulas (ppo_loss_row, the element expressions); the fp32 sums over a row's actions associate differently
-// ((q-partial sums) + butterfly instead of a = 0 .. A-1), so results differ from the tile form in the last bits.
+// Same formulas (ppo_loss_row, the element expressions) and - since round 6, with the row sums accumulated in fp64 and rounded
+// once (row_acc_t above) - the same bits as the tile form.
 // ------------------------------------------------------------------------------------------------
 constexpr int kQuadK = 8;
 
@@ -469,7 +493,7 @@ __device__ __forceinline__ void ppo_loss_quad_run(const LossArgs& p, float* lds,
 
   // ---- element-wise: the terms of the row's five sums
   float e_z[kQuadK], e_sg[kQuadK];
-  float s_z2 = 0.0f, s_kl = 0.0f, s_b = 0.0f, s_ls = 0.0f, s_ent = 0.0f;
+  row_acc_t s_z2 = 0, s_kl = 0, s_b = 0, s_ls = 0, s_ent = 0;
 #pragma unroll
   for (int k = 0; k < kQuadK; ++k) {
     const int a = q + 4 * k;
@@ -479,24 +503,24 @@ __device__ __forceinline__ void ppo_loss_quad_run(const LossArgs& p, float* lds,
       const float ls = row_ok ? e_ls[k] : p.logstd[a];
       const float sg = expf(ls);                                              // models.py:296
       e_sg[k] = sg;
-      s_ls += ls;
-      s_ent += 1.4189385332046727f + logf(sg);        // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale)
+      s_ls += static_cast<row_acc_t>(ls);
+      s_ent += static_cast<row_acc_t>(1.4189385332046727f + logf(sg));      // Normal.entropy(): 0.5 + 0.5*log(2*pi) + log(scale)
       if (row_ok) {
         const float mu = e_mu[k], x = e_x[k], omu = e_omu[k], osg = e_osg[k];
         const float z = (x - mu) / sg;                                        // models.py:362
         e_z[k] = z;
-        s_z2 += z * z;
+        s_z2 += static_cast<row_acc_t>(z * z);
         // policy_kl(p0 = new, p1 = old)                                      torch_ext.py:28-31
         const float c1 = logf(osg / sg + 1e-5f);
         const float dm = omu - mu;
         const float c2 = (sg * sg + dm * dm) / (2.0f * (osg * osg + 1e-5f));
-        s_kl += (c1 + c2) + (-0.5f);
+        s_kl += static_cast<row_acc_t>((c1 + c2) + (-0.5f));
         if (p.bound_kind == 1) {                                              // a2c_continuous.py:248-253
           const float hi_t = fmaxf(mu - 1.1f, 0.0f);
           const float lo_t = fminf(mu + 1.1f, 0.0f);
-          s_b += lo_t * lo_t + hi_t * hi_t;
+          s_b += static_cast<row_acc_t>(lo_t * lo_t + hi_t * hi_t);
         } else if (p.bound_kind == 2) {                                       // :241-246
-          s_b += mu * mu;
+          s_b += static_cast<row_acc_t>(mu * mu);
         }
         if (p.write_back) {                                                   // datasets.py:42-43
           p.old_mu[i * A + a] = mu;
@@ -505,22 +529,24 @@ __device__ __forceinline__ void ppo_loss_quad_run(const LossArgs& p, float* lds,
       }
     }
   }
-  // the quad's four partial sums -> the row's sums, the same bits in all four threads: (s0 + s1) + (s2 + s3)
-  auto quad_sum = [&](float v) -> float {
+  // the quad's four partial sums -> the row's sums, the same bits in all four threads: (s0 + s1) + (s2 + s3); in fp64 the
+  // grouping does not matter (A <= 32 fp32 terms: every partial sum is exact or within 2^-53), the ONE rounding to fp32
+  // below makes each row sum the correctly rounded value of its terms' exact sum
+  auto quad_sum = [&](row_acc_t v) -> float {
     v += __shfl_xor(v, 1, kWave);
     v += __shfl_xor(v, 2, kWave);
-    return v;
+    return static_cast<float>(v);
   };
-  s_z2 = quad_sum(s_z2);
-  s_kl = quad_sum(s_kl);
-  s_b = quad_sum(s_b);
-  s_ls = quad_sum(s_ls);
-  s_ent = quad_sum(s_ent);
+  const float r_z2 = quad_sum(s_z2);
+  const float r_kl = quad_sum(s_kl);
+  const float r_b = quad_sum(s_b);
+  const float r_ls = quad_sum(s_ls);
+  const float r_ent = quad_sum(s_ent);
 
   // ---- the row
   double acc[kLossScalars] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double none[kLossScalars];
-  const LossRow R = ppo_loss_row(p, A, s_z2, s_kl, s_b, s_ls, s_ent, r_adv, r_onlp, r_v, r_vo, r_ret, r_mask, lo, hi, denom_count,
+  const LossRow R = ppo_loss_row(p, A, r_z2, r_kl, r_b, r_ls, r_ent, r_adv, r_onlp, r_v, r_vo, r_ret, r_mask, lo, hi, denom_count,
                                  (row_ok && q == 0) ? acc : none);
   if (row_ok && q == 0) {
     p.d_values[i * p.ld_dval] = R.dv;

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 RTOL = 1e-5
-ATOL = {'a_loss': 2e-6, 'c_loss': 2e-6, 'entropy': 2e-6, 'b_loss': 1e-7, 'kl': 2e-7}
+ATOL = {'a_loss': 2e-7, 'c_loss': 2e-7, 'entropy': 2e-6, 'b_loss': 1e-7, 'kl': 2e-7}
 
 
 def _make_agent(cap, **over):
@@ -95,6 +95,20 @@ def _oracle_for(params, cap, N, obs_dim, act_dim):
     oracle = OracleAgent(cpu_params, SyntheticTensorEnv(N, obs_dim, act_dim, device='cpu', seed=1))
     oracle.model.load_full_state_dict(cap['state'])
     return oracle
+
+
+def _truth_for(params, cap, N, obs_dim, act_dim):
+    """The oracle evaluated in fp64: same operation sequence, same fp32 inputs (rollout tensors, initial parameters, the
+    normalisers' fp32 constants), every intermediate, gradient and Adam moment in double precision - the exact-arithmetic
+    trajectory of the algorithm, as far as an fp64 run can tell, that every fp32 implementation is an approximation of."""
+    truth = _oracle_for(params, cap, N, obs_dim, act_dim)
+    truth.model.a2c_network.double()
+    truth.optimizer = torch.optim.Adam(truth.model.a2c_network.parameters(), truth.lr, eps=1e-08)
+    return truth
+
+
+def _batch64(batch):
+    return {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in batch.items()}
 
 
 @pytest.mark.parametrize('graphs', [True, False])
@@ -275,36 +289,6 @@ def _kl_fp64(mu, sigma, old_mu, old_sigma):
     return (c1 + c2 - 0.5).sum(dim=-1).mean()
 
 
-def _gemm_order_noise(oracle, seed=11, level=1e-6):
-    """Makes `oracle` a twin of the reference algorithm whose FIRST-LAYER pre-activations carry the relative noise two fp32
-    GEMM summation orders differ by (~1e-6 of each element, a fresh pattern every call): what ANY second fp32 implementation
-    of the same network looks like to the algorithm, and therefore the yardstick for how far one may drift from the oracle."""
-    gen = torch.Generator().manual_seed(seed)
-    first = oracle.model.a2c_network.actor_mlp[0]
-
-    def hook(_mod, _inp, out):
-        sign = torch.randint(0, 2, out.shape, generator=gen).to(out.dtype).mul_(2.0).sub_(1.0)
-        return out * (1.0 + level * sign)
-    first.register_forward_hook(hook)
-    return oracle
-
-
-def _row_sum_order_noise(oracle, seed):
-    """Makes `oracle` a twin whose rows' neglogp carry ONE ULP of relative noise (a fresh +-2^-24 pattern every minibatch):
-    what summing a row's A squared terms in another order does to it (6e-8 = one ulp) - the fused loss tile adds four partial sums by
-    butterflies where torch adds a = 0 .. A-1.  With neglogp ~ 30 that moves a row's ratio by ~2e-6: enough to put a row
-    that sits within 2e-6 of a clip kink on the other side (profiles/r5_parity_yardstick_probe.txt: such twins end the
-    fifth mini-epoch of the rank-shaped job between 4e-6 and 2e-4 from the oracle in a_loss, the agent at 1e-5, the
-    per-layer engine - whose loss kernel sums in torch's order - at 6e-8)."""
-    gen = torch.Generator().manual_seed(seed)
-
-    def hook(nlp):
-        sign = torch.randint(0, 2, nlp.shape, generator=gen).to(nlp.dtype).mul_(2.0).sub_(1.0)
-        return nlp * (1.0 + 6e-8 * sign)              # (2^-24 = 5.96e-8; the value the probe ran with)
-    oracle.nlp_hook = hook
-    return oracle
-
-
 def _epoch_deviation_rows(N, MB):
     """One epoch of the 320-step job: the agent's per-step scalars, the oracle's on the same rollout, the captured rollout."""
     from rl_games_amd import configs
@@ -331,18 +315,37 @@ def _deviation_per_mini_epoch(rows, ref, NMB, ME):
     return out
 
 
-def _exact_products_worker(N, MB):
-    """`python tests/test_headline_gpu.py exact N MB` in a process of its own with RLG_CHAIN_BX=0 RLG_DW_BF16=0 (the library
-    reads them once): the SAME job on exact fp32 products (v_mfma_f32_16x16x4_f32 in all three MFMA launches) against the
-    oracle on ITS rollout - max deviation per mini-epoch and scalar, as JSON on the last line."""
-    import json
-    import subprocess
-    import sys
-    env = dict(os.environ, RLG_CHAIN_BX='0', RLG_DW_BF16='0')
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), 'exact', str(N), str(MB)], env=env, capture_output=True,
-                         text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+TRUTH_FACTOR = 1.5      # the agent may be this much farther from the fp64 trajectory than the reference's own fp32 arithmetic
+CEILING = 1e-3           # ... and never farther than this fraction of a scalar's scale, whatever the yardstick says
+
+
+def _scalar_rows(results, dtype=torch.float64):
+    return torch.stack([torch.stack([r[k].reshape(()).to(dtype) for k in COLS]) for r in results])
+
+
+COLS = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
+
+
+def _check_against_truth(rows, ref, tru, groups, what):
+    """The criterion of the kernel-level tests (tests/test_ops_gpu.py: fp64 truth, the kernel as accurate as the fp32
+    reference) at agent level.  rows / ref / tru: [steps, 5] scalars of the agent, of the oracle (the reference's fp32
+    arithmetic) and of the oracle evaluated in fp64 on the same rollout; `groups`: consecutive step ranges (mini-epochs,
+    epochs).  Within every group and for every scalar the agent must EITHER agree with the oracle at rtol 1e-5 (+ the
+    stated floor) OR be no farther from the fp64 trajectory than TRUTH_FACTOR x the oracle itself is (running maxima
+    over the groups so far) - and in no case farther than CEILING of the scalar's scale.  Nothing in the bound comes
+    from the product, from noise models or from seeds."""
+    report, env_a, env_o = [], {k: 0.0 for k in COLS}, {k: 0.0 for k in COLS}
+    for g, sl in enumerate(groups):
+        for key, c in COLS.items():
+            a, o, t = rows[sl, c].double(), ref[sl, c].double(), tru[sl, c].double()
+            scale = float(ref[:, c].abs().max())
+            strict = bool(((a - o).abs() <= (1e-4 if key == 'kl' else RTOL) * o.abs() + ATOL[key]).all())
+            env_a[key] = max(env_a[key], float((a - t).abs().max()))
+            env_o[key] = max(env_o[key], float((o - t).abs().max()))
+            report.append((g + 1, key, float((a - o).abs().max()), env_a[key], env_o[key], strict))
+            assert strict or env_a[key] <= TRUTH_FACTOR * env_o[key] + ATOL[key], (what, report[-1])
+            assert env_a[key] <= CEILING * scale + ATOL[key], (what, 'ceiling', report[-1])
+    return report
 
 
 @pytest.mark.parametrize('N,MB', [(8192, 4096), (65536, 32768)], ids=['rank_8192x32_mb4096', 'benchmarked_65536x32_mb32768'])
@@ -352,32 +355,24 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
     replayed mini-epoch HIP graph:
       * 65,536 envs x 32, minibatch 32,768 - BASELINE.json configs[2] EXACTLY as bench.py times it (split-bf16 chain
         kernels, weight planes written by the Adam launch);
-      * 8,192 envs x 32, minibatch 4,096 - what ONE of 8 data-parallel ranks runs for configs[3] (the pipelined 16-row
+      * 8,192 envs x 32, minibatch 4,096 - what ONE of 8 data-parallel ranks runs for configs[3] (the lean 16-row
         exact-product chain kernels).
     First mini-epoch: the 64 per-minibatch (a_loss, c_loss, entropy, b_loss) at rtol 1e-5 (+ the stated floors), KL at
     1e-4 (test_kl_conditioning_fp64_demonstration), the learning-rate trajectory step for step.
-    Mini-epochs 2 - 5: the deviation grows from step to step, and the test shows that this is not the algorithm's
-    doing: the oracle is run a second time on the same rollout with every observation moved by ONE ULP at random, and
-    that twin stays within 1e-7 of the first run through all 320 steps (profiles/r4_parity_drift.txt) - the reference
-    algorithm does not amplify last-bit perturbations.  What grows is the number of rows that sat within ~1e-6 of a kink
-    of the clipped objective (ratio clip, value clip) when a step was taken: two fp32 implementations agree on a row's
-    ratio to ~1e-6, so one of them clips such a row and the other does not, that step's gradient differs by ~1/minibatch
-    of a row's contribution, and every later step inherits it (test_three_epochs_... has the anatomy of one such event).
-    Among 4,096 .. 32,768 rows there is nearly always a row that close, so over 320 steps the events add up.  Round 5:
-    the bound of mini-epochs 2 - 5 is no list of literals any more but DERIVED IN THE TEST from yardsticks run on the same
-    rollout - (i) twins of the oracle under a second implementation's rounding: one whose first-layer pre-activations carry
-    the ~1e-6 relative noise two fp32 GEMM orders differ by (_gemm_order_noise), and several whose rows' neglogp carry one
-    ulp (_row_sum_order_noise: the loss tile sums a row's actions in another order than torch).  The first kind never
-    moves a row across a kink in this job (the twin stays at 1e-7 through all 320 steps, as the per-layer engine does);
-    the second kind does, and ends the fifth mini-epoch anywhere between 4e-6 and 2e-4 from the oracle depending on the
-    noise pattern (profiles/r5_parity_yardstick_probe.txt) - that spread IS the algorithm's sensitivity to last-bit
-    differences at this learning rate (mean KL 0.10 in the first mini-epoch against a threshold of 0.008), and the fused
-    kernels sit inside it (1e-5);  (ii) at the benchmarked shape, where the agent runs on split-bf16 products, the SAME
-    job on exact fp32 products in a process of its own (RLG_CHAIN_BX=0 RLG_DW_BF16=0) against the oracle on its rollout.
-    The agent's deviation envelope must stay within 2 x the largest of these envelopes (+ the first mini-epoch's floors).
-    The learning rates of all 320 steps must agree unless a KL of the oracle
-    lies within 1e-3 of a threshold of the rule.  End of epoch: every parameter tensor within max(1e-4 of its scale,
-    3 x the farthest twin's distance, 2e-5 absolute = lr / 15) on average."""
+    Mini-epochs 2 - 5 (round 6): against the FP64 TRAJECTORY.  The clipped objective has kinks; among 4,096 .. 32,768
+    rows there is nearly always one within ~1e-6 of a clip boundary, two fp32 evaluations of a row's ratio differ by
+    ~1e-6, so now and then one implementation clips a row the other does not and every later step inherits that step's
+    difference (test_three_epochs_...).  Which of the two then left the algorithm's trajectory?  The oracle is run a
+    second time in double precision on the same rollout (_truth_for) and both fp32 runs are measured against it
+    (profiles/r6_truth_probe.txt): at the rank's shape the agent ends the fifth mini-epoch 1.0e-6 from the fp64 a_loss
+    and the ORACLE 9.5e-6 - the 9.8e-6 between agent and oracle that rounds 4 - 5 built tolerance schedules and noise
+    twins for is the reference's own fp32 arithmetic leaving the trajectory, not the kernels; at the benchmarked shape
+    both are ~2e-5 away, the agent the closer of the two.  _check_against_truth: per mini-epoch and scalar the agent
+    agrees with the oracle at rtol 1e-5, or is at most 1.5 x as far from the fp64 run as the oracle is, and never
+    farther than 1e-3 of the scalar's scale.  No twins, no product-derived yardstick, no seed search.
+    The learning rates of all 320 steps must agree with the oracle's unless a KL of the oracle lies within 1e-3 of a
+    threshold of the rule.  End of epoch: every parameter tensor, on average, within max(1e-4 of its scale, 1.5 x the
+    oracle's own distance from the fp64 parameters, 2e-5 absolute = lr / 15) of the fp64 parameters."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     H, NMB, ME = 32, 64, 5
@@ -394,7 +389,7 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
     res = agent.train_epoch()
     assert agent._graph_epoch is not None and not agent._graph_failed
     assert agent._engine.last_dw_path == 'mfma' and agent._engine.last_dw_library_jobs == 0
-    rows = agent._mb_scalars[:ME * NMB].cpu()          # [a_loss, c_loss, entropy, b_loss, kl, ...] per optimiser step
+    rows = agent._mb_scalars[:ME * NMB, :5].cpu()      # [a_loss, c_loss, entropy, b_loss, kl] per optimiser step
     assert len(res[4]) == ME * NMB
 
     prev = torch.get_num_threads()
@@ -406,20 +401,15 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
         vd = agent.dataset.values_dict
         for key in ('old_values', 'returns', 'advantages'):
             assert torch.allclose(vd[key].cpu().reshape(-1), oracle.dataset[key].reshape(-1), rtol=RTOL, atol=2e-6), key
-        # the yardstick twins: first-layer GEMM-order noise, and one-ulp noise on the rows' neglogp (three patterns at the
-        # rank's shape, where an oracle epoch takes 3 s; one at the benchmarked shape, where it takes 30 s and the exact-product
-        # run is the third yardstick)
-        twins = [_gemm_order_noise(_oracle_for(params, caps[0], N, 108, 21))]
-        twins += [_row_sum_order_noise(_oracle_for(params, caps[0], N, 108, 21), seed) for seed in ((1, 2, 3) if N <= 8192 else (1,))]
-        refs2 = [t.update(batch) for t in twins]
+        truth = _truth_for(params, caps[0], N, 108, 21)
+        tru = truth.update(_batch64(batch))
     finally:
         torch.set_num_threads(prev)
-    cols = {'a_loss': 0, 'c_loss': 1, 'entropy': 2, 'b_loss': 3, 'kl': 4}
     stack = lambda rs, key, sl: torch.stack([r[key].reshape(()).float() for r in rs[sl]])
     # ---- first mini-epoch: the strict bounds
     first = slice(0, NMB)
     for key in ('a_loss', 'c_loss', 'entropy', 'b_loss'):
-        want, got = stack(ref, key, first), rows[first, cols[key]]
+        want, got = stack(ref, key, first), rows[first, COLS[key]]
         assert torch.allclose(got, want, rtol=RTOL, atol=ATOL[key]), (key, (got - want).abs().max().item(), got[:3], want[:3])
     want_kl = stack(ref, 'kl', first)
     assert torch.allclose(rows[first, 4], want_kl, rtol=1e-4, atol=ATOL['kl']), (rows[:4, 4], want_kl[:4])
@@ -442,40 +432,25 @@ def test_whole_epoch_of_320_steps_matches_oracle(N, MB):
             break
     assert margin_ok >= NMB, 'a learning-rate decision of the FIRST mini-epoch lies within 1e-3 of its threshold: pick another seed'
     assert traj[:margin_ok] == [r['lr'] for r in ref[:margin_ok]]
-    # ---- mini-epochs 2 .. 5: within 2 x the envelope of the yardsticks (GEMM-noise twin; exact-product run of the same job)
-    dev = _deviation_per_mini_epoch(rows, ref, NMB, ME)
-    twin_devs = [_deviation_per_mini_epoch(torch.stack([torch.stack([r[k].reshape(()).float() for k in cols]) for r in ref2]),
-                                           ref, NMB, ME) for ref2 in refs2]
-    twin_dev = {key: [max(d[key][m] for d in twin_devs) for m in range(ME)] for key in cols}
-    split = bool(agent._engine.chain.split_products(MB, 0))
-    exact_dev = _exact_products_worker(N, MB) if split else None
-    report = []
-    for key in cols:
-        scale = max(abs(float(r[key])) for r in ref)
-        env_a = env_t = env_e = 0.0
-        for m in range(ME):
-            if m >= 1 and m * NMB >= margin_ok:
-                break                    # (the two sides may legitimately run on different learning rates from here on)
-            env_a = max(env_a, dev[key][m])
-            env_t = max(env_t, twin_dev[key][m])
-            env_e = max(env_e, exact_dev[key][m]) if exact_dev is not None else 0.0
-            bound = 2.0 * max(env_t, env_e) + RTOL * scale + (1e-4 * scale if key == 'kl' else 0.0) + ATOL[key]
-            report.append((m + 1, key, env_a, env_t, env_e, bound))
-            if m >= 1:
-                assert env_a <= bound, report
-    print('deviation envelopes (mini-epoch, scalar, agent, largest twin, exact-product run, bound):')
+    # ---- all five mini-epochs against the fp64 trajectory (as far as the three runs share their learning rates)
+    lr_shared = next((k for k in range(ME * NMB) if not (traj[k] == ref[k]['lr'] == tru[k]['lr'])), ME * NMB)
+    groups = [slice(m * NMB, (m + 1) * NMB) for m in range(ME) if (m + 1) * NMB <= max(lr_shared, NMB)]
+    report = _check_against_truth(rows, _scalar_rows(ref), _scalar_rows(tru), groups, f'{N} x 32, minibatch {MB}')
+    print('mini-epoch, scalar, max |agent - oracle|, envelope |agent - fp64|, envelope |oracle - fp64|, strict vs the oracle:')
     for r in report:
         print('   ', r)
-    # ---- end of the epoch: parameters
-    if margin_ok == NMB * ME:
-        final, want, others = agent.model.state_dict(), oracle.model.full_state_dict(), [t.model.full_state_dict() for t in twins]
-        for name, v in want.items():
+    assert len(groups) == ME or lr_shared < ME * NMB
+    # ---- end of the epoch: parameters against the fp64 run's
+    if lr_shared == NMB * ME:
+        final, ref_sd, tru_sd = agent.model.state_dict(), oracle.model.full_state_dict(), truth.model.full_state_dict()
+        for name, v in tru_sd.items():
             if not v.is_floating_point() or v.numel() < 16:
                 continue
+            v = v.double()
             scale = v.abs().mean().clamp_min(1e-12)
-            rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / scale).item()
-            twin_rel = max(((other[name] - v).abs().mean() / scale).item() for other in others)
-            assert rel <= max(1e-4, 3.0 * twin_rel, 2e-5 / scale.item()), (name, rel, twin_rel)
+            rel = ((final[name].cpu().double() - v).abs().mean() / scale).item()
+            ref_rel = ((ref_sd[name].double() - v).abs().mean() / scale).item()
+            assert rel <= max(1e-4, TRUTH_FACTOR * ref_rel, 2e-5 / scale.item()), (name, rel, ref_rel)
 
 
 def test_kl_conditioning_fp64_demonstration():
@@ -558,124 +533,65 @@ def test_gradients_after_first_step_match_oracle_autograd():
         assert step_gpu.abs().max().item() <= 3e-4 * (1 + 1e-5)
 
 
-def _update_watching_the_kinks(oracle, batch):
-    """oracle.update(batch), step by step, with - in front of every optimiser step - the distance of the CLOSEST row of
-    the minibatch to a kink of the PPO objective: the ratio clip at 1 +- e_clip (common_losses.py:64-82) and the value
-    clip at |v - v_old| = e_clip (:16-29).  A row closer to a kink than two fp32 implementations agree on its ratio
-    (~1e-6: the ratio is the exp of a sum of 2A squared, sigma-scaled differences) is clipped by one of them and not by
-    the other; that step's gradient then differs by ~1/minibatch of a row's contribution and every later step inherits
-    the difference.  Returns the per-step dicts of minibatch_step plus 'kink' = that distance."""
-    oracle.prepare_dataset(batch)
-    ref, nmb = [], oracle.B // oracle.mb
-    e_clip = oracle.hp['e_clip']
-    for _ in range(oracle.mini_epochs):
-        for i in range(nmb):
-            ds = oracle.dataset
-            lo, hi = i * oracle.mb, (i + 1) * oracle.mb
-            with torch.no_grad():
-                saved = copy.deepcopy(oracle.model.obs_stats)     # (training-mode normalisation, as the step itself sees it)
-                oracle.model.obs_stats_training = True
-                mu, logstd, v = oracle.model.a2c_network(oracle.model.norm_obs(ds['obs'][lo:hi]))
-                oracle.model.obs_stats = saved
-                sigma = torch.exp(logstd)
-                nlp = torch.squeeze(O.neglogp(ds['actions'][lo:hi], mu, sigma, logstd))
-                ratio = torch.exp(ds['old_logp_actions'][lo:hi] - nlp)
-                d_ratio = torch.minimum((ratio - (1 + e_clip)).abs(), (ratio - (1 - e_clip)).abs()).min().item()
-                d_value = ((v.reshape(-1) - ds['old_values'][lo:hi].reshape(-1)).abs() - e_clip).abs().min().item()
-            ref.append(oracle.minibatch_step(i))
-            ref[-1]['kink'] = min(d_ratio, d_value)
-    return ref
-
-
 def test_three_epochs_on_config2_stay_on_the_oracle_trajectory():
     """Drift: BASELINE configs[1] (4,096 x 16, obs 60, act 8, [256,128,64], minibatch 32,768, 4 mini-epochs) for
     THREE consecutive epochs on the same env stream.  The agent plays; the oracle is fed each epoch's rollout and
     continues from ITS OWN parameters, normaliser statistics, Adam moments and learning rate, so every difference
-    accumulates.
-
-    What can be asked of such a run, measured in round 4 (profiles/r4_parity_drift.txt, tools/exp/rollout_consistency.py):
-    the clipped objective has kinks, and among 32,768 rows there is nearly always one within 1e-6 .. 1e-5 of a clip
-    boundary.  Two fp32 implementations agree on a row's ratio to ~1e-6, so now and then one of them clips a row the other
-    does not; that step's gradient differs by ~1/32,768 of a row's contribution, and from there on the two runs are
-    2e-5 apart in their parameters instead of 1e-8 (seed 9, epoch 2, step 6: closest row 1.1e-6 from the ratio clip in
-    front of the step, parameters 8e-9 apart before and 2.5e-5 after).  The reference algorithm itself does not amplify
-    last-bit perturbations (two runs of the oracle on inputs one ulp apart stay within 1e-7 for 320 steps), so this is
-    the whole mechanism.  Hence:
-      * STRICT (losses rtol 1e-5 + floors, parameters 1e-6 of their scale on average) over the first epoch of a seed
-        in which no row comes closer than 1e-6 to a kink - seeds are tried until one qualifies;
-      * over the two epochs that follow: learning rates identical after every epoch; losses within 2e-4 and parameters
-        within 1e-4 of their scale on average (the round-3 bounds) for as long as the oracle sees no row within 5e-6 of a
-        kink, 2e-3 (a handful of clip flips at learning rates up to 1e-2) from the epoch of such a row on; at most 4 seeds
-        may be skipped."""
+    accumulates - and so does a third run, the oracle in double precision (_truth_for), the yardstick of
+    _check_against_truth: per epoch and scalar the agent agrees with the oracle at rtol 1e-5, or is at most 1.5 x as far
+    from the fp64 trajectory as the oracle's fp32 arithmetic is (running maxima), never farther than 1e-3 of the scalar's
+    scale.  The first epoch must hold the strict bounds against the oracle outright.  One seed, no search (rounds 4 - 5
+    tried seeds until the oracle saw no row within 1e-6 of a clip kink and fell back to 2e-3 behind such a row: when a row
+    lands on the other side of a kink the question is which run left the trajectory, and the fp64 run answers it).
+    Learning rates: identical to the oracle's after every epoch unless the oracle itself disagrees with the fp64 run
+    (a KL within rounding of a threshold of the rule).  Parameters after the third epoch: on average within max(1e-4 of
+    the tensor's scale, 1.5 x the oracle's own distance) of the fp64 parameters."""
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
-    N = 4096
-    tried = []
-    for seed in (9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
-        params = configs.ant_4096(hip_graphs=True)
-        torch.manual_seed(seed)
-        agent = A2CAgent('drift', copy.deepcopy(params))
-        agent.init_tensors()
-        agent.obs = agent.env_reset()
-        caps = _capture_rollout(agent)
+    N, seed = 4096, 9
+    params = configs.ant_4096(hip_graphs=True)
+    torch.manual_seed(seed)
+    agent = A2CAgent('drift', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    caps = _capture_rollout(agent)
+    oracle = truth = None
+    rows, ref, tru, groups = [], [], [], []
+    for epoch in range(3):
         agent.update_epoch()
         res = agent.train_epoch()
-        got0 = {'a_loss': torch.stack(res[4]).cpu(), 'c_loss': torch.stack(res[5]).cpu(), 'entropy': torch.stack(res[7]).cpu(),
-                'b_loss': torch.stack(res[6]).cpu()}
-        oracle = _oracle_for(params, caps[0], N, 60, 8)
-        ref0 = _update_watching_the_kinks(oracle, caps[0]['batch'])
-        closest = min(r['kink'] for r in ref0)
-        tried.append((seed, closest))
-        if closest < 1e-6:
-            continue                                    # not a well-posed strict comparison: next seed
-        # ---- strict: the first epoch
-        for key, g in got0.items():
-            want = torch.stack([r[key].reshape(()) for r in ref0])
-            assert torch.allclose(g, want, rtol=RTOL, atol=ATOL[key]), (seed, key, (g - want).abs().max().item())
-        assert agent.optimizer.last_and_next_lr()[1] == oracle.lr, seed
-        final, want = agent.model.state_dict(), oracle.model.full_state_dict()
-        for name, v in want.items():
+        got = torch.stack([torch.stack(res[4]), torch.stack(res[5]), torch.stack(res[7]), torch.stack(res[6])], 1).cpu()
+        if oracle is None:
+            oracle = _oracle_for(params, caps[0], N, 60, 8)
+            truth = _truth_for(params, caps[0], N, 60, 8)
+        r32 = oracle.update(caps[epoch]['batch'])
+        r64 = truth.update(_batch64(caps[epoch]['batch']))
+        n = got.shape[0]
+        assert n == len(r32)
+        # (per-minibatch KL is not part of train_epoch's result: the three loss scalars + b_loss; KL column = the oracle's)
+        kl32 = torch.stack([r['kl'].reshape(()).double() for r in r32])
+        rows.append(torch.cat([got.double(), kl32[:, None]], 1))
+        ref.append(_scalar_rows(r32))
+        tru.append(_scalar_rows(r64))
+        groups.append(slice(epoch * n, (epoch + 1) * n))
+        if epoch == 0:
+            for key in ('a_loss', 'c_loss', 'entropy', 'b_loss'):
+                g, want = rows[0][:, COLS[key]].float(), ref[0][:, COLS[key]].float()
+                assert torch.allclose(g, want, rtol=RTOL, atol=ATOL[key]), (key, (g - want).abs().max().item())
+        lr = agent.optimizer.last_and_next_lr()[1]
+        assert lr == oracle.lr or oracle.lr != truth.lr, (epoch, lr, oracle.lr, truth.lr)
+        if oracle.lr != truth.lr or lr != oracle.lr:
+            break                                   # (the runs are on different learning rates from here on)
+    report = _check_against_truth(torch.cat(rows), torch.cat(ref), torch.cat(tru), groups, 'config #2, three epochs')
+    print('epoch, scalar, max |agent - oracle|, envelope |agent - fp64|, envelope |oracle - fp64|, strict vs the oracle:')
+    for r in report:
+        print('   ', r)
+    if len(groups) == 3:
+        final, ref_sd, tru_sd = agent.model.state_dict(), oracle.model.full_state_dict(), truth.model.full_state_dict()
+        for name, v in tru_sd.items():
             if v.is_floating_point() and v.numel() >= 16:
-                rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / v.abs().mean().clamp_min(1e-12)).item()
-                assert rel <= 1e-6, (seed, name, rel)
-        # ---- two more epochs.  As long as the oracle has seen no row within 1e-6 of a kink, the round-3 bounds hold
-        #      (losses 2e-4, parameters 1e-4 of their scale); the loose bounds (2e-3) apply only from the epoch of a
-        #      detected near-kink row on
-        flipped = False
-        for epoch in (1, 2):
-            agent.update_epoch()
-            res = agent.train_epoch()
-            got = {'a_loss': torch.stack(res[4]).cpu(), 'c_loss': torch.stack(res[5]).cpu(), 'entropy': torch.stack(res[7]).cpu(),
-                   'b_loss': torch.stack(res[6]).cpu()}
-            ref = _update_watching_the_kinks(oracle, caps[epoch]['batch'])
-            flipped = flipped or min(r['kink'] for r in ref) < 5e-6      # (a row 1.1e-6 away was seen to flip: 5 x that)
-            rtol, afac = (2e-3, 20) if flipped else (2e-4, 5)
-            for key, g in got.items():
-                want = torch.stack([r[key].reshape(()) for r in ref])
-                assert torch.allclose(g, want, rtol=rtol, atol=afac * ATOL[key]), (seed, epoch, flipped, key, (g - want).abs().max().item())
-            assert agent.optimizer.last_and_next_lr()[1] == oracle.lr, (seed, epoch)
-        final, want = agent.model.state_dict(), oracle.model.full_state_dict()
-        for name, v in want.items():
-            if v.is_floating_point() and v.numel() >= 16:
-                rel = ((final[name].cpu().to(v.dtype) - v).abs().mean() / v.abs().mean().clamp_min(1e-12)).item()
-                assert rel <= (2e-3 if flipped else 1e-4), (seed, flipped, name, rel)
-        assert len(tried) <= 5, f'more than 4 seeds skipped for near-kink rows in their first epoch: {tried}'
-        print(f'seeds tried (closest kink distance of the first epoch): {tried}; near-kink row in epochs 2 - 3: {flipped}')
-        return
-    pytest.fail(f'no seed with a first epoch free of near-kink rows: {tried}')
-
-
-
-if __name__ == '__main__':
-    # worker of _exact_products_worker: the job on whatever product form the environment selects, against the oracle
-    import json
-    import sys
-    if len(sys.argv) == 4 and sys.argv[1] == 'exact':
-        n_, mb_ = int(sys.argv[2]), int(sys.argv[3])
-        params_, agent_, caps_, _ = _epoch_deviation_rows(n_, mb_)
-        assert not agent_._engine.chain.split_products(mb_, 0), 'RLG_CHAIN_BX=0 expected'
-        rows_ = agent_._mb_scalars[:5 * 64].cpu()
-        torch.set_num_threads(_oracle_threads())
-        oracle_ = _oracle_for(params_, caps_[0], n_, 108, 21)
-        ref_ = oracle_.update(caps_[0]['batch'])
-        print(json.dumps(_deviation_per_mini_epoch(rows_, ref_, 64, 5)))
+                v = v.double()
+                scale = v.abs().mean().clamp_min(1e-12)
+                rel = ((final[name].cpu().double() - v).abs().mean() / scale).item()
+                ref_rel = ((ref_sd[name].double() - v).abs().mean() / scale).item()
+                assert rel <= max(1e-4, TRUTH_FACTOR * ref_rel), (name, rel, ref_rel)
