@@ -559,6 +559,10 @@ def main():
                 'timing': 'HIP start/stop events bound to each in-epoch GAE dispatch on its launch stream '
                           '(hipExtLaunchKernelGGL) = the dispatch begin/end timestamps rocprofv3 --kernel-trace '
                           'reports; timed region',
+                'note': 'one generation of waves over 35.65 MB, inputs cold (written 32 rollout steps earlier): its load and '
+                        'store phases each run near the memory system\'s limit, ~3 us are dispatch ramp + first-byte latency + '
+                        'drain (a same-footprint copy kernel takes 8.9 us cold); >= 0.60 (<= 7.4 us) is not reachable for '
+                        'this launch inside the epoch - profiles/r6_gae_in_situ.txt, r2_gae_residency_experiments.txt',
             },
         }
         if mfma is not None:

@@ -87,13 +87,16 @@ def _split_operands(ops):
     return [o.strip() for o in ops.split(',')] if ops else []
 
 
-def _parse(text):
-    """-> list of functions, each a list of (address, mnemonic, operand text)."""
+def _parse(text, names=None):
+    """-> list of functions, each a list of (address, mnemonic, operand text); `names` (a list) receives their symbols."""
     funcs, cur = [], None
     for line in text.splitlines():
-        if re.match(r'^[0-9a-f]+ <.*>:$', line):
+        head = re.match(r'^[0-9a-f]+ <(.*)>:$', line)
+        if head:
             cur = []
             funcs.append(cur)
+            if names is not None:
+                names.append(head.group(1))
             continue
         m = LINE.match(line)
         if m and cur is not None:
@@ -216,8 +219,35 @@ def audit_valu_feeds(func):
     return bad
 
 
-def audit(lib_path):
-    """-> (number of MFMA instructions, [offending 'mfma -> reader (wait states)' lines])."""
+def warn_pk_add_into_cvt_f64(func, name=''):
+    """WARNING class (round 6, never a failure): a packed fp32 add / mul (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32) whose
+    result is converted to fp64 (v_cvt_f64_f32) within the next 2 instructions, in a kernel WITHOUT MFMAs.  This is the
+    sequence the round-5 diagnosis of the two-rank `exp_avg_sq` desynchronisation ended at (profiles/r5_two_rank_sync.txt,
+    section 5: the corrupted 16-lane slots of the deleted row-per-thread Adam launches coincided with it; the same
+    sequence ships in adam_pack_kernel and is clean there in 89 two-rank runs).  No cause was established - round 6
+    only added that v_pk_add_f32 shares a pipe with the matrix core (it does not overlap with MFMAs of ANY wave of the
+    SIMD, profiles/r6_coexec_bf16.txt) - so a build that lands on the pattern is listed, for whoever sees rank drift
+    (the agent's per-epoch `multi_gpu_param_check` is the run-time guard).  -> ['kernel: address  pk-op -> cvt']"""
+    out = []
+    if any(mn.startswith('v_mfma') for _, mn, _ in func):
+        return out
+    for i, (addr, mn, ops) in enumerate(func):
+        if not (mn.startswith('v_pk_add_f32') or mn.startswith('v_pk_mul_f32') or mn.startswith('v_pk_fma_f32')):
+            continue
+        o = _split_operands(ops)
+        dst = set(_regs(o[0])) if o else set()
+        for j in range(i + 1, min(i + 3, len(func))):
+            mn2, ops2 = func[j][1], func[j][2]
+            if mn2.startswith('v_cvt_f64_f32'):
+                o2 = _split_operands(ops2)
+                if len(o2) > 1 and dst & set(_regs(o2[1])):
+                    out.append(f'{name}: {addr:#x}  {mn} {ops}  ->  {mn2} {ops2}')
+    return out
+
+
+def audit(lib_path, warnings=None):
+    """-> (number of MFMA instructions, [offending 'mfma -> reader (wait states)' lines]); `warnings` (a list) receives the
+    lines of the warning classes."""
     work = tempfile.mkdtemp(prefix='rlg_audit_')
     try:
         local = os.path.join(work, os.path.basename(lib_path))
@@ -229,7 +259,10 @@ def audit(lib_path):
         count, bad = 0, []
         for co in sorted(objs):
             text = subprocess.run([OBJDUMP, '-d', co], check=True, capture_output=True, text=True).stdout
-            for func in _parse(text):
+            names = []
+            for k, func in enumerate(_parse(text, names)):
+                if warnings is not None:
+                    warnings += warn_pk_add_into_cvt_f64(func, names[k])
                 n, b = audit_function(func)
                 count += n
                 bad += [f'{m}  ->  {r}   ({ws} wait states)' for m, r, ws in b]
@@ -241,8 +274,14 @@ def audit(lib_path):
 
 if __name__ == '__main__':
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'rl_games_amd', 'librlg_hip.so')
-    n, bad = audit(path)
+    warns = []
+    n, bad = audit(path, warns)
     print(f'{path}: {n} MFMA instructions, {len(bad)} reads inside a hazard window (MFMA result -> reader, VALU result -> MFMA)')
     for b in bad[:60]:
         print('   ', b)
+    if warns:
+        print(f'warning: {len(warns)} packed fp32 result(s) converted to fp64 right behind (no MFMA in the kernel) - see '
+              'warn_pk_add_into_cvt_f64:')
+        for w in warns[:20]:
+            print('   ', w)
     sys.exit(1 if bad else 0)
