@@ -255,7 +255,10 @@ int rlg_ppo_loss_partials_per_block(int actions);
  * the new mu/sigma when write_back).  Emits d_mu [mb,A], d_values [mb] (already scaled by
  * 1/mb or mask/sum(mask)) and fp64 partials [blocks][rlg_ppo_loss_partials_per_block(A)].
  * mu/values/d_mu/d_values take row strides ld_* (elements) so they can be column views of a fused
- * [mb, 1+A] head buffer.  bound_kind 0 none / 1 'bound' / 2 'regularisation'. */
+ * [mb, 1+A] head buffer.  bound_kind 0 none / 1 'bound' / 2 'regularisation'.
+ * use_smooth_clamp selects the actor loss of rl_games/common/common_losses.py:39-82: 0 = actor_loss (clipped PPO),
+ * 1 = smoothed_actor_loss (`use_smooth_clamp: True`), 2 = `ppo: False` (a_loss = neglogp * advantage, either function's
+ * else branch; round 6) - here and in every entry point / descriptor that carries the flag. */
 int rlg_ppo_loss_fused(const float* mu, const float* logstd, const float* values,
                        const float* actions, const float* old_neglogp, const float* advantages,
                        const float* old_values, const float* returns, float* old_mu,

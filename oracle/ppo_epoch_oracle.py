@@ -117,7 +117,7 @@ class OracleAgent:
         self.hp = {'e_clip': cfg['e_clip'], 'critic_coef': cfg['critic_coef'], 'entropy_coef': cfg['entropy_coef'],
                    'bounds_loss_coef': cfg.get('bounds_loss_coef'), 'clip_value': cfg['clip_value'],
                    'use_smooth_clamp': cfg.get('use_smooth_clamp', False),
-                   'bound_loss_type': cfg.get('bound_loss_type', 'bound')}
+                   'bound_loss_type': cfg.get('bound_loss_type', 'bound'), 'ppo': cfg.get('ppo', True)}
         self.adaptive = cfg.get('lr_schedule') == 'adaptive'
         self.ema_state = O.new_moving_stats(1) if (cfg['normalize_advantage'] and
                                                     cfg.get('normalize_rms_advantage', False)) else None
@@ -210,7 +210,7 @@ class OracleAgent:
             mbd['old_logp_actions'], nlp, mbd['advantages'], mbd['old_values'], values, mbd['returns'],
             mu, entropy, self.hp['e_clip'], self.hp['critic_coef'], self.hp['entropy_coef'],
             self.hp['bounds_loss_coef'], self.hp['clip_value'], mask, self.hp['use_smooth_clamp'],
-            self.hp['bound_loss_type'])
+            self.hp['bound_loss_type'], self.hp['ppo'])
         for p in net.parameters():
             p.grad = None
         loss.backward()

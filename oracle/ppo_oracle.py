@@ -297,10 +297,10 @@ def masked_means(losses, mask=None):
 
 def ppo_losses(old_neglogp, new_neglogp, advantage, old_values, values, returns, mu, entropy,
                e_clip, critic_coef, entropy_coef, bounds_coef, clip_value=True, mask=None,
-               smooth=False, bound_kind='bound'):
-    """rl_games/algos_torch/a2c_continuous.py:97-134 (calc_losses).
+               smooth=False, bound_kind='bound', ppo=True):
+    """rl_games/algos_torch/a2c_continuous.py:97-134 (calc_losses); ppo = the agent's `self.ppo` (:111).
     Returns (loss, a_loss, c_loss, entropy, b_loss)."""
-    a = actor_loss(old_neglogp, new_neglogp, advantage, e_clip, True, smooth)
+    a = actor_loss(old_neglogp, new_neglogp, advantage, e_clip, ppo, smooth)
     c = critic_loss(old_values, values, e_clip, returns, clip_value)
     if bounds_coef is None:
         b = torch.zeros(mu.shape[0]) if bound_kind == 'bound' else torch.zeros(mu.shape[0])
@@ -340,7 +340,7 @@ def distribution_loss_and_grads(mu, logstd, values, batch, hp, mask=None):
         batch['old_logp_actions'], nlp, batch['advantages'], batch['old_values'], values,
         batch['returns'], mu, ent, hp['e_clip'], hp['critic_coef'], hp['entropy_coef'],
         hp.get('bounds_loss_coef'), hp.get('clip_value', True), mask,
-        hp.get('use_smooth_clamp', False), hp.get('bound_loss_type', 'bound'))
+        hp.get('use_smooth_clamp', False), hp.get('bound_loss_type', 'bound'), hp.get('ppo', True))
     loss.backward()
     with torch.no_grad():
         kl = policy_kl(mu.detach(), sigma.detach(), batch['mu'], batch['sigma'], mask)
@@ -378,7 +378,7 @@ def categorical_loss_and_grads(logits, values, batch, hp, mask=None, branch_size
         cat, h = masked_categorical(lg, am)
         nlp = nlp + (-cat.log_prob(acts[:, b]))
         ent = ent + h
-    a = actor_loss(batch['old_logp_actions'], nlp, batch['advantages'], hp['e_clip'], True,
+    a = actor_loss(batch['old_logp_actions'], nlp, batch['advantages'], hp['e_clip'], hp.get('ppo', True),
                    hp.get('use_smooth_clamp', False))
     c = critic_loss(batch['old_values'], values, hp['e_clip'], batch['returns'], hp.get('clip_value', True))
     (a_m, c_m, e_m), _ = masked_means([a.unsqueeze(1), c, ent.unsqueeze(1)], mask)

@@ -229,9 +229,7 @@ class A2CAgent:
         self.print_stats = config.get('print_stats', True)
         self.epochs_between_resets = config.get('epochs_between_resets', 0)
         self.rnn_states = None
-        self.ppo = config.get('ppo', True)
-        if not self.ppo:
-            raise NotImplementedError('ppo: False (plain A2C loss) is not implemented')
+        self.ppo = config.get('ppo', True)      # False: a_loss = neglogp * advantage (common_losses.py:59, 80) - surrogate kind 2
         self.max_epochs = config.get('max_epochs', -1)
         self.max_frames = max(config.get('max_frames', -1), config.get('max_steps', -1))
         self.stop_fn = config.get('stop_fn', None)
@@ -324,6 +322,8 @@ class A2CAgent:
         self.writer = None
         self.value_bootstrap = config.get('value_bootstrap', True)
         self.use_smooth_clamp = config.get('use_smooth_clamp', False)
+        # which actor loss the kernels evaluate (ops.SURROGATE_*): clipped PPO / smooth clamp / none (ppo: False)
+        self.surrogate = 2 if not self.ppo else (1 if self.use_smooth_clamp else 0)
         self.is_tensor_obses = False
         self.aux_loss_dict = {}
 
@@ -1128,7 +1128,7 @@ class A2CAgent:
             input_dict['old_values'].reshape(mb, -1), input_dict['returns'].reshape(mb, -1), e_clip=self.e_clip,
             critic_coef=self.critic_coef if self.has_value_loss else 0.0, entropy_coef=self.entropy_coef,
             bounds_coef=self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0, bound_kind=kind,
-            clip_value=self.clip_value, smooth=self.use_smooth_clamp, mask=mask)
+            clip_value=self.clip_value, smooth=self.surrogate, mask=mask)
         loss.backward()
         with torch.no_grad():
             sig = sigma.detach().expand_as(mu)
@@ -1247,7 +1247,7 @@ class A2CAgent:
                          input_dict['old_values'].reshape(-1), input_dict['returns'].reshape(-1),
                          input_dict['mu'], input_dict['sigma'], d_mu, d_val[:, 0] if eng is not None else d_val,
                          self._loss_partials, self.e_clip, coef_c, coef_b, self.clip_value,
-                         self.use_smooth_clamp, kind, True, mask, mask_sum)
+                         self.surrogate, kind, True, mask, mask_sum)
             fold = eng is not None and self.config.get('fold_loss_finalize', True)
             # On the fused chain the backward launch evaluates the loss of its own row tiles first (no loss
             # launch; one partial row per backward workgroup).
@@ -1457,7 +1457,7 @@ class A2CAgent:
         sched = (getattr(s, 'kl_threshold', None), getattr(s, 'min_lr', None), getattr(s, 'max_lr', None),
                  getattr(s, 'lr_multiplier', None))
         return (ptrs, self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-                self.bound_loss_type, self.clip_value, self.use_smooth_clamp, self.grad_norm,
+                self.bound_loss_type, self.clip_value, self.surrogate, self.grad_norm,
                 self.truncate_grads, self.schedule_type, self.is_adaptive_lr, sched, self.world_size,
                 self._fold_ready and self.model.running_mean_std._mb_table.data_ptr())
 

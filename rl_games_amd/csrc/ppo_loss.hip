@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
     const float old_nlp = p.old_neglogp[i];
     const float ratio = expf(old_nlp - nlp);
     float l2, dl2;
-    if (p.smooth) {
+    if (p.smooth == kSurrogateSmooth) {
       l2 = adv * smooth_clamp_f(ratio, lo, hi);
       dl2 = smooth_clamp_grad(ratio, lo, hi);
     } else {
@@ -215,10 +215,14 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
       dl2 = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
     }
     const float n1 = -(adv * ratio), n2 = -l2;
-    const float a_loss = fmaxf(n1, n2);
+    float a_loss = fmaxf(n1, n2);
     float w1, w2;
     if (n1 > n2) { w1 = 1.0f; w2 = 0.0f; } else if (n2 > n1) { w1 = 0.0f; w2 = 1.0f; } else { w1 = w2 = 0.5f; }
-    const float g_nlp = adv * (w1 + w2 * dl2) * ratio;
+    float g_nlp = adv * (w1 + w2 * dl2) * ratio;
+    if (p.smooth == kSurrogateNone) {                                       // ppo: False   common_losses.py:59, 80
+      a_loss = nlp * adv;
+      g_nlp = adv;
+    }
     const float v = p.values[i], vo = p.old_values[i], R = p.returns[i];
     float c_loss, g_v;
     if (p.clip_value) {

@@ -11,6 +11,8 @@ constexpr int kLossRowsSmall = 16; // ... and for minibatches of at most kLossSm
 constexpr int kLossSmallBatch = 8192;   // short phases, so a small minibatch wants more, smaller tiles
 constexpr int kLossThreads = 256;  // threads per block: all walk the tile, the first kLossRows own a row
 constexpr int kLossScalars = 7;  // a_loss, c_loss, entropy, b_loss, kl, mask sum, sum d_value
+// the `use_smooth_clamp` argument of the C entry points: which actor loss (rl_games/common/common_losses.py:39-82)
+constexpr int kSurrogateClip = 0, kSurrogateSmooth = 1, kSurrogateNone = 2;
 
 // The five sums of a row over its A actions (z^2, KL terms, bound terms, log sigma, entropy terms: `.sum(dim=-1)` in the
 // reference, models.py:361-364, torch_ext.py:31, a2c_continuous.py:241-253) are accumulated in fp64 and rounded to fp32 ONCE:
@@ -52,7 +54,7 @@ struct LossArgs {
   int ld_mu, ld_val, ld_dmu, ld_dval;   // row strides (elements) of mu / values / d_mu / d_values
   float e_clip, critic_coef, bounds_coef;
   int clip_value;          // default_critic_loss clip flag
-  int smooth;              // use_smooth_clamp
+  int smooth;              // surrogate kind: 0 clipped PPO, 1 smooth clamp (use_smooth_clamp), 2 none (ppo: False)
   int bound_kind;          // 0 none (coef None), 1 'bound', 2 'regularisation'
   int write_back;          // overwrite old_mu/old_sigma with the new policy's
 };
@@ -87,7 +89,7 @@ __device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float 
   const float ratio = expf(r_onlp - nlp);                                   // common_losses.py:75
   const float surr1 = adv * ratio;
   float l2, dl2_dratio;  // second branch and its derivative w.r.t. ratio (without the -adv)
-  if (p.smooth) {
+  if (p.smooth == kSurrogateSmooth) {
     l2 = adv * smooth_clamp_f(ratio, lo, hi);
     dl2_dratio = smooth_clamp_grad(ratio, lo, hi);
   } else {
@@ -95,7 +97,7 @@ __device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float 
     dl2_dratio = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
   }
   const float n1 = -surr1, n2 = -l2;
-  const float a_loss = fmaxf(n1, n2);                                       // :78
+  float a_loss = fmaxf(n1, n2);                                             // :78
   // torch.max backward: the larger branch takes the gradient, equal branches split it
   float w1, w2;
   if (n1 > n2) {
@@ -109,7 +111,11 @@ __device__ __forceinline__ LossRow ppo_loss_row(const LossArgs& p, int A, float 
     w2 = 0.5f;
   }
   // d a_loss / d ratio = -adv*(w1 + w2*dl2) ; d ratio / d nlp = -ratio
-  const float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
+  float g_nlp = adv * (w1 + w2 * dl2_dratio) * ratio;
+  if (p.smooth == kSurrogateNone) {                                         // ppo: False - plain A2C   common_losses.py:59, 80
+    a_loss = nlp * adv;
+    g_nlp = adv;
+  }
 
   // critic                                                                 common_losses.py:20-27
   const float v = r_v, vo = r_vo, R = r_ret;

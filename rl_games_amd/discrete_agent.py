@@ -104,7 +104,7 @@ class DiscreteA2CAgent(A2CAgent):
                                   input_dict['advantages'], input_dict['old_values'].reshape(-1),
                                   input_dict['returns'].reshape(-1), d_logits, d_val, self._loss_partials,
                                   self.e_clip, self.critic_coef if self.has_value_loss else 0.0,
-                                  self.entropy_coef, self.clip_value, self.use_smooth_clamp, mask, mask_sum,
+                                  self.entropy_coef, self.clip_value, self.surrogate, mask, mask_sum,
                                   branch_sizes=self.branch_sizes, action_masks=input_dict.get('action_masks'))
             ops.ppo_loss_finalize(self._loss_partials, ops.ppo_loss_discrete_blocks(mb), 0, mb,
                                   mask is not None, self.critic_coef if self.has_value_loss else 0.0,

@@ -351,6 +351,18 @@ def _rows_view(t, name):
     raise ValueError(f'{name}: expected 1-D or 2-D')
 
 
+SURROGATE_CLIP, SURROGATE_SMOOTH, SURROGATE_NONE = 0, 1, 2
+
+
+def _surrogate_kind(smooth):
+    """The `smooth` argument of the loss launches: False / True (`use_smooth_clamp`) or one of SURROGATE_* -
+    SURROGATE_NONE is `ppo: False`, the plain A2C actor loss neglogp * advantage (common_losses.py:59, 80)."""
+    k = int(smooth)
+    if k not in (SURROGATE_CLIP, SURROGATE_SMOOTH, SURROGATE_NONE):
+        raise ValueError(f'surrogate kind {smooth!r}')
+    return k
+
+
 def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_values, returns,
                    old_mu, old_sigma, d_mu, d_values, partials, e_clip, critic_coef, bounds_coef,
                    clip_value=True, smooth=False, bound_kind=1, write_back=True, mask=None,
@@ -370,7 +382,7 @@ def ppo_loss_fused(mu, logstd, values, actions, old_neglogp, advantages, old_val
         _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), dmu_p,
         dval_p, _need(partials, F64, 'partials'), mb, A, ld_mu, ld_val, ld_dmu, ld_dval,
         float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(bounds_coef)),
-        1 if clip_value else 0, 1 if smooth else 0, bound_kind, 1 if write_back else 0, _stream(mu)),
+        1 if clip_value else 0, _surrogate_kind(smooth), bound_kind, 1 if write_back else 0, _stream(mu)),
         'rlg_ppo_loss_fused')
 
 
@@ -393,7 +405,7 @@ def ppo_loss_desc(mu, logstd, values, actions, old_neglogp, advantages, old_valu
         _need(old_sigma, F32, 'old_sigma'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'), dmu_p, dval_p,
         _need(partials, F64, 'partials'), mb, A, ld_mu, ld_val, ld_dmu, ld_dval,
         float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(bounds_coef)),
-        1 if clip_value else 0, 1 if smooth else 0, bound_kind, 1 if write_back else 0)
+        1 if clip_value else 0, _surrogate_kind(smooth), bound_kind, 1 if write_back else 0)
 
 
 def value_loss(values, old_values, returns, d_values, partials, e_clip, clip_value=True, mask=None, mask_sum=None):
@@ -443,7 +455,7 @@ def ppo_loss_discrete(logits, values, actions, old_neglogp, advantages, old_valu
         _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'),
         _need(d_logits, F32, 'd_logits'), _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'),
         mb, float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(entropy_coef)),
-        1 if clip_value else 0, 1 if smooth else 0, _stream(logits)), 'rlg_ppo_loss_discrete')
+        1 if clip_value else 0, _surrogate_kind(smooth), _stream(logits)), 'rlg_ppo_loss_discrete')
 
 
 def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, critic_coef,

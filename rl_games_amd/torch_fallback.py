@@ -25,15 +25,19 @@ def ppo_loss(mu, logstd, values, actions, old_neglogp, advantages, old_values, r
              entropy_coef, bounds_coef, bound_kind, clip_value, smooth, mask=None):
     """The model epilogue + calc_losses of the continuous agent (models.py:329-364, a2c_continuous.py:97-134,
     common_losses.py:16-82) for a fixed-sigma policy: mu [mb, A], logstd [A] (the parameter), values / old_values /
-    returns [mb, V].  bound_kind: 0 none, 1 'bound', 2 'regularisation' (ops.BOUND_KINDS).
+    returns [mb, V].  bound_kind: 0 none, 1 'bound', 2 'regularisation' (ops.BOUND_KINDS); smooth: ops.SURROGATE_* (False /
+    True / 2 = ppo: False).
     Returns (loss, dict of the detached scalars a_loss / c_loss / entropy / b_loss, sigma [A])."""
     mb, A = mu.shape
     sigma = torch.exp(logstd)
     z = (actions - mu) / sigma
     neglogp = 0.5 * (z * z).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * A + logstd.sum(dim=-1)
     entropy = (0.5 + 0.5 * math.log(2.0 * math.pi) + torch.log(sigma)).sum(dim=-1).expand(mb)
-    ratio = torch.exp(old_neglogp - neglogp)
-    a_rows = torch.max(-advantages * ratio, -advantages * _clip_surrogate(ratio, 1.0 - e_clip, 1.0 + e_clip, smooth))
+    if int(smooth) == 2:                                    # ppo: False   common_losses.py:59, 80
+        a_rows = neglogp * advantages
+    else:
+        ratio = torch.exp(old_neglogp - neglogp)
+        a_rows = torch.max(-advantages * ratio, -advantages * _clip_surrogate(ratio, 1.0 - e_clip, 1.0 + e_clip, int(smooth) == 1))
     if clip_value:
         clipped = old_values + (values - old_values).clamp(-e_clip, e_clip)
         c_rows = torch.max((values - returns) ** 2, (clipped - returns) ** 2)

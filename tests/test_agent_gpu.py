@@ -155,6 +155,45 @@ def test_full_train_epoch_runs_and_matches_oracle_on_same_rollout():
     assert agent.game_lengths.current_size > 0
 
 
+def test_plain_a2c_loss_when_ppo_is_false_matches_oracle():
+    """`ppo: False` (a2c_common.py:280; the else branch of common_losses.actor_loss :80: a_loss = neglogp * advantage)
+    through the fused backward launch's loss tile (surrogate kind 2): every minibatch step of an epoch against the
+    oracle - losses, KL, learning rate, and after the epoch the parameters."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=128, horizon=8, obs_dim=10, act_dim=4)
+    params['config']['ppo'] = False
+    agent = A2CAgent('test', copy.deepcopy(params))
+    assert agent.surrogate == 2 and agent._engine is not None
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps()
+    oracle = OracleAgent(copy.deepcopy(params), SyntheticTensorEnv(128, 10, 4, device='cpu', seed=1))
+    assert oracle.hp['ppo'] is False
+    oracle.model.load_full_state_dict({k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()})
+    ref = oracle.update({k: v.detach().cpu().clone() for k, v in batch.items() if isinstance(v, torch.Tensor)})
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    k = 0
+    for _ in range(agent.mini_epochs_num):
+        for i in range(len(agent.dataset)):
+            a, c, e, kl, lr, lr_mul, mu, sigma, b = agent.train_actor_critic(agent.dataset[i])
+            r = ref[k]
+            for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
+                assert np.isclose(got.item(), r[key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), r[key].item())
+            k += 1
+    # the plain A2C loss really ran: it is not the clipped surrogate's value (|neglogp * adv| is O(10), the surrogate O(1))
+    assert abs(ref[0]['a_loss'].item()) > 0.05
+    assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
+    want = oracle.model.full_state_dict()
+    for name, v in agent.model.state_dict().items():
+        if v.is_floating_point() and v.numel() >= 16 and name in want:
+            w = want[name]
+            assert ((v.cpu().to(w.dtype) - w).abs().mean() / w.abs().mean().clamp_min(1e-12)).item() <= 1e-4, name
+
+
 def test_checkpoint_round_trip(tmp_path):
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent

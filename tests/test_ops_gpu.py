@@ -257,7 +257,7 @@ def _loss_inputs(mb, A, seed):
 
 
 @pytest.mark.parametrize('mb,A', [(4096, 21), (1000, 8), (300, 1), (257, 33), (32768, 21)])
-@pytest.mark.parametrize('variant', ['bound', 'smooth_reg', 'noclip_nobound', 'masked'])
+@pytest.mark.parametrize('variant', ['bound', 'smooth_reg', 'noclip_nobound', 'masked', 'ppo_false'])
 def test_ppo_loss_forward_backward_kl(mb, A, variant):
     from rl_games_amd import ops
     mu, logstd, values, batch = _loss_inputs(mb, A, seed=mb + A)
@@ -270,6 +270,8 @@ def test_ppo_loss_forward_backward_kl(mb, A, variant):
         hp.update(clip_value=False, bounds_loss_coef=None)
     elif variant == 'masked':
         mask = (torch.rand(mb, generator=g(7)) < 0.8).float()
+    elif variant == 'ppo_false':
+        hp.update(ppo=False)                # a_loss = neglogp * advantage (common_losses.py:59, 80): surrogate kind 2
     ref = O.distribution_loss_and_grads(mu, logstd, values, batch, hp, mask)
 
     d = lambda t: t.contiguous().to(DEV)
@@ -289,7 +291,8 @@ def test_ppo_loss_forward_backward_kl(mb, A, variant):
                        d(batch['old_logp_actions']), d(batch['advantages']),
                        d(batch['old_values'].reshape(-1)), d(batch['returns'].reshape(-1)), old_mu,
                        old_sigma, d_mu, d_val, partials, hp['e_clip'], hp['critic_coef'], coef_b,
-                       hp['clip_value'], hp['use_smooth_clamp'], kind, True, mask_d, mask_sum)
+                       hp['clip_value'], ops.SURROGATE_NONE if not hp.get('ppo', True) else hp['use_smooth_clamp'], kind, True,
+                       mask_d, mask_sum)
     ops.ppo_loss_finalize(partials, nb, A, mb, mask is not None, hp['critic_coef'], hp['entropy_coef'],
                           coef_b, scalars, d_logstd, kl_slot)
     s = scalars.cpu()

@@ -48,6 +48,7 @@ def test_losses_and_kl_equal_reference_functions(seed):
     assert torch.equal(O.actor_loss(old_nlp, nlp, adv, 0.2), common_losses.actor_loss(old_nlp, nlp, adv, True, 0.2))
     assert torch.equal(O.actor_loss(old_nlp, nlp, adv, 0.2, smooth=True),
                        common_losses.smoothed_actor_loss(old_nlp, nlp, adv, True, 0.2))
+    assert torch.equal(O.actor_loss(old_nlp, nlp, adv, 0.2, ppo=False), common_losses.actor_loss(old_nlp, nlp, adv, False, 0.2))
     for clip in (True, False):
         assert torch.equal(O.critic_loss(v_old, v, 0.2, R, clip),
                            common_losses.default_critic_loss(v_old, v, 0.2, R, clip))
@@ -430,7 +431,8 @@ def test_staged_reference_archive_is_the_reference_byte_for_byte():
 # ----------------------------------------------------------------------------- value_size > 1 torch forms (round 5)
 
 @pytest.mark.parametrize('V,masked,smooth,bound', [(1, False, False, 'bound'), (2, False, False, 'bound'), (3, True, False, 'regularisation'),
-                                                   (2, True, True, 'bound'), (2, False, True, None)])
+                                                   (2, True, True, 'bound'), (2, False, True, None),
+                                                   (1, True, 2, 'bound'), (2, False, 2, None)])
 def test_torch_fallback_losses_equal_the_reference_agent_functions(V, masked, smooth, bound):
     """rl_games_amd/torch_fallback.py (the value_size > 1 path of the agent) against the reference's OWN calc_losses
     (a2c_continuous.py:97-134, called unbound on a stand-in with exactly the attributes it reads), its model epilogue
@@ -473,13 +475,14 @@ def test_torch_fallback_losses_equal_the_reference_agent_functions(V, masked, sm
     distr = torch.distributions.Normal(mu, sigma_full, validate_args=False)
     entropy = distr.entropy().sum(dim=-1)
     nlp = torch.squeeze(ModelA2CContinuousLogStd.Network.neglogp(None, actions, mu, sigma_full, logstd_full))
-    stub = types.SimpleNamespace(ppo=True, has_value_loss=True, model=None, clip_value=True,
+    # (smooth == 2: `ppo: False`, the plain A2C actor loss - round 6)
+    stub = types.SimpleNamespace(ppo=(smooth != 2), has_value_loss=True, model=None, clip_value=True,
                                  bound_loss_type=bound, bounds_loss_coef=coef_b, critic_coef=2.0, entropy_coef=0.01,
                                  ppo_device='cpu')
     stub.bound_loss = types.MethodType(a2c_continuous.A2CAgent.bound_loss, stub)
     stub.reg_loss = types.MethodType(a2c_continuous.A2CAgent.reg_loss, stub)
     stub.bounds_loss_coef = coef_b
-    fn = common_losses.smoothed_actor_loss if smooth else common_losses.actor_loss
+    fn = common_losses.smoothed_actor_loss if smooth == 1 else common_losses.actor_loss
     ref_loss, a, c, e, b, _ = a2c_continuous.A2CAgent.calc_losses(stub, fn, old_nlp, nlp, adv, 0.2, old_values, values, returns,
                                                                mu, entropy, mask)
     ref_loss.backward()
