@@ -345,7 +345,10 @@ class A2CAgent:
         self._grads_overwritten = False
         # (value_size > 1: the fused loss kernels carry one value column - that agent takes autograd through
         #  rl_games_amd/torch_fallback.py instead, SURVEY 8a'-13)
-        self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True) and self.value_size == 1
+        # (... and so does a state-dependent sigma head, fixed_sigma False: the kernels carry log sigma as a parameter vector)
+        self._general_forms = (not self.is_discrete) and (self.value_size != 1
+                                                          or not getattr(self.model.a2c_network, 'fixed_sigma', True))
+        self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True) and not self._general_forms
                             and not self.model.a2c_network.is_separate_critic()
                             and (not self.is_rnn or config.get('manual_lstm', True)))
         if self._use_engine:
@@ -1161,7 +1164,7 @@ class A2CAgent:
         """Everything of calc_gradients up to (and including) the gradients in the arena.  No
         host-side scalars change between calls for a given minibatch slice, so this body is what
         gets captured into a HIP graph per minibatch index."""
-        if self.value_size != 1:
+        if self._general_forms:
             return self._forward_loss_backward_general(input_dict, row)
         opt = self.optimizer
         net = self.model.a2c_network

@@ -115,9 +115,11 @@ class ActorCriticNetwork(nn.Module):
         if 'continuous' not in space:
             raise NotImplementedError("network 'space' must be continuous or discrete")
         self.space_config = space['continuous']
-        self.fixed_sigma = self.space_config['fixed_sigma']
-        if not self.fixed_sigma:
-            raise NotImplementedError('state-dependent sigma (fixed_sigma: False) is not implemented')
+        # fixed_sigma False (round 6): a Linear sigma head over the trunk's features (network_builder.py:341-344, :508-511).
+        # The fused kernels carry log sigma as a parameter vector, so such a policy runs the reference's operation sequence
+        # as torch ops with autograd around this library's rollout, GAE, dataset and optimiser kernels
+        # (agent._forward_loss_backward_general, torch_fallback.py; pinned to the reference on the CPU).
+        self.fixed_sigma = bool(self.space_config['fixed_sigma'])
         if self.space_config.get('sigma_parametrization', 'exp') != 'exp' or \
                 self.space_config.get('logstd_bounds') is not None or \
                 float(self.space_config.get('min_sigma', 0.0)) > 0:
@@ -158,7 +160,10 @@ class ActorCriticNetwork(nn.Module):
         self.mu = nn.Linear(out_size, actions_num)
         self.mu_act = _activation(self.space_config['mu_activation'])
         self.sigma_act = _activation(self.space_config['sigma_activation'])
-        self.sigma = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
+        if self.fixed_sigma:
+            self.sigma = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
+        else:
+            self.sigma = nn.Linear(out_size, actions_num)
 
         mlp_init = _initializer(mlp['initializer'])
         for m in self.modules():
@@ -167,7 +172,16 @@ class ActorCriticNetwork(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
         _initializer(self.space_config['mu_init'])(self.mu.weight)
-        _initializer(self.space_config['sigma_init'])(self.sigma)
+        if self.fixed_sigma:
+            _initializer(self.space_config['sigma_init'])(self.sigma)
+        elif (self.space_config.get('sigma_init') or {}).get('name') == 'const_initializer':
+            # init_state_dependent_sigma_head (network_builder.py:14-25): a constant initialiser means a uniform initial
+            # log sigma - the BIAS - over zeroed weights
+            si = self.space_config['sigma_init']
+            nn.init.zeros_(self.sigma.weight)
+            nn.init.constant_(self.sigma.bias, si.get('val', si.get('value', 0.0)))
+        else:
+            _initializer(self.space_config['sigma_init'])(self.sigma.weight)
 
     def _init_central_value(self, net_params, input_shape, value_size, num_seqs):
         """`central_value: True` networks (network_builder.py:497,556): MLP trunk + value head only."""
@@ -282,8 +296,11 @@ class ActorCriticNetwork(nn.Module):
         if self.is_discrete:                                   # (logits, value, states) :431-436,:500-504
             return self.head_logits(out), value, states
         mu = self.mu_act(self.mu(out))
-        sigma = self.sigma_act(self.sigma)
-        return mu, mu * 0 + sigma, value, states
+        return mu, mu * 0 + self.logstd_of(out), value, states
+
+    def logstd_of(self, out):
+        """log sigma: the parameter vector [A], or the sigma head of the trunk's features [B, A] (network_builder.py:508-511)."""
+        return self.sigma_act(self.sigma) if self.fixed_sigma else self.sigma_act(self.sigma(out))
 
 
 class ContinuousA2CLogStdModel(nn.Module):
@@ -331,14 +348,15 @@ class ContinuousA2CLogStdModel(nn.Module):
 
     def forward_heads(self, input_dict):
         """Training fast path: normalise (and update) observations, run the trunk, return the
-        raw heads (mu [B,A], logstd parameter [A], value [B,V], rnn states)."""
+        raw heads (mu [B,A], logstd - the parameter [A] or, with fixed_sigma False, the sigma head's [B,A] - value [B,V],
+        rnn states)."""
         obs = self.norm_obs(input_dict['obs'])
         net = self.a2c_network
         out, states = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
                                 input_dict.get('seq_length', 1))
         value = net.value_act(net.value(net.critic_features(obs, out)))
         mu = net.mu_act(net.mu(out))
-        return mu, net.sigma_act(net.sigma), value, states
+        return mu, net.logstd_of(out), value, states
 
     # The reference Runner wraps `agent.model` in torch.compile unless the config says otherwise (torch_runner.py:283-307).
     # The normalisers of this model launch HIP kernels through ctypes on torch's current stream - nothing Dynamo can trace -

@@ -83,7 +83,7 @@ def _clone(x):
     return x
 
 
-def make_epoch():
+def make_epoch(variants=None, filename='epoch.pt'):
     """One full train_epoch of the REAL reference A2CAgent (a2c_continuous.py / a2c_common.py) on
     CPU, driven by the synthetic tensor env, recorded tensor by tensor."""
     import copy
@@ -93,7 +93,7 @@ def make_epoch():
     from rl_games_amd import configs
     from rl_games_amd.synthetic_env import SyntheticTensorEnv
 
-    variants = {
+    variants = variants or {
         'default': dict(),
         'smooth_reg_ema': dict(use_smooth_clamp=True, bound_loss_type='regularisation', bounds_loss_coef=0.01,
                                normalize_rms_advantage=True, entropy_coef=0.01, critic_coef=1.0),
@@ -105,10 +105,13 @@ def make_epoch():
         N, H, O_, A = 64, 8, 12, 3
         over = dict(over)
         rnn = over.pop('_rnn', None)
+        space = over.pop('_space', None)
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', games_to_track=100, **over)
         if rnn is not None:
             params['network']['rnn'] = rnn
+        if space is not None:
+            params['network']['space']['continuous'].update(space)
         params['seed'] = 7
         env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=1234)
         params['config']['env_info'] = env.get_env_info()
@@ -169,8 +172,18 @@ def make_epoch():
         cap['env'] = {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 1234}
         out[name] = cap
         print('epoch', name, 'minibatches', len(a_losses), 'lrs', cap['lrs'][:4], 'kl', cap['mini_epoch_kls'].tolist())
-    torch.save(out, os.path.join(HERE, 'epoch.pt'))
-    print('epoch.pt written', os.path.getsize(os.path.join(HERE, 'epoch.pt')) // 1024, 'KiB')
+    torch.save(out, os.path.join(HERE, filename))
+    print(filename, 'written', os.path.getsize(os.path.join(HERE, filename)) // 1024, 'KiB')
+
+
+def make_epoch_extra():
+    """Round 6: epochs of the real reference agent for the API corners that left the NotImplementedError list -
+    a state-dependent sigma head (fixed_sigma False, network_builder.py:341-344) and the plain A2C loss (ppo False,
+    common_losses.py:80).  A file of its own: epoch.pt keeps its bytes."""
+    make_epoch({
+        'state_sigma': dict(_space={'fixed_sigma': False, 'sigma_init': {'name': 'const_initializer', 'val': -0.5}}),
+        'ppo_false': dict(ppo=False),
+    }, 'epoch_extra.pt')
 
 
 def make_discrete():
@@ -452,7 +465,7 @@ def make_lstm_full():
 
 
 SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'checkpoint': make_checkpoint,
-            'central_value': make_central_value, 'lstm_full': make_lstm_full}
+            'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':
     only = sys.argv[1:] or list(SECTIONS)

@@ -34,10 +34,17 @@ def _to_dev(batch):
     return {k: v.to(DEV) for k, v in batch.items()}
 
 
-@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema'])
+@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema', 'state_sigma', 'ppo_false'])
 def test_update_matches_reference_epoch(golden, variant):
-    cap = golden('epoch.pt')[variant]
+    """An epoch's update against the recording of the REAL reference agent's train_epoch on the same rollout
+    (tests/golden/make_golden.py).  Round 6 (epoch_extra.pt): 'state_sigma' - a state-dependent sigma head
+    (fixed_sigma False: the policy runs the reference's operation sequence as torch ops with autograd around this library's
+    dataset / optimiser kernels, agent._forward_loss_backward_general) - and 'ppo_false' - the plain A2C actor loss inside
+    the fused loss tile."""
+    extra = variant in ('state_sigma', 'ppo_false')
+    cap = golden('epoch_extra.pt' if extra else 'epoch.pt')[variant]
     agent = _make_agent(cap)
+    assert (agent._engine is None) == (variant == 'state_sigma')
     agent.model.load_state_dict(cap['state_after_rollout'])
     batch = _to_dev(cap['batch'])
     agent.set_train()

@@ -325,7 +325,9 @@ def test_ppo_loss_forward_backward_kl(mb, A, variant):
         assert key == 'd_logstd' or outliers <= 5e-3, (key, outliers)   # d_logstd: A sums, atol only
         err_kernel = (got.double() - r64).abs().max().item()
         err_oracle = (r32.double() - r64).abs().max().item()
-        assert err_kernel <= 8 * err_oracle + 1e-9 * scale, (key, err_kernel, err_oracle)
+        # (+ 1e-6 of the tensor's scale: with ppo False the loss is linear in neglogp, the fp32 oracle lands within 1e-10
+        #  of the fp64 value and "8 x the oracle's error" would ask the kernel for more than fp32 products can give)
+        assert err_kernel <= 8 * err_oracle + 1e-9 * scale + 1e-6 * r64.abs().max().item(), (key, err_kernel, err_oracle)
     # update_mu_sigma write-back (datasets.py:42-43): bit-exact copies of the new policy
     assert torch.equal(old_mu.cpu(), mu)
     # sigma = exp(logstd): device expf and the host's exp may differ in the last bit

@@ -19,9 +19,10 @@ def _agent(cap):
     return agent
 
 
-@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema'])
+@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema', 'ppo_false'])
 def test_oracle_update_matches_reference_epoch(golden, variant):
-    cap = golden('epoch.pt')[variant]
+    # ('ppo_false': the plain A2C actor loss, recorded from the real reference in round 6 - epoch_extra.pt)
+    cap = golden('epoch_extra.pt' if variant == 'ppo_false' else 'epoch.pt')[variant]
     agent = _agent(cap)
     agent.model.load_full_state_dict(cap['state_after_rollout'])
     batch = {k: v.clone() for k, v in cap['batch'].items()}

@@ -6,6 +6,7 @@ Pins the rows SURVEY 8c lists as 'parity unpinned' (clipped surrogate, value los
 policy_kl, advantage normalisation) to outputs of the reference functions themselves on seeded
 inputs, plus RunningMeanStd / GeneralizedMovingStats / apply_masks / schedulers / PPODataset /
 ExperienceBuffer semantics."""
+import copy
 import os
 import sys
 
@@ -432,7 +433,8 @@ def test_staged_reference_archive_is_the_reference_byte_for_byte():
 
 @pytest.mark.parametrize('V,masked,smooth,bound', [(1, False, False, 'bound'), (2, False, False, 'bound'), (3, True, False, 'regularisation'),
                                                    (2, True, True, 'bound'), (2, False, True, None),
-                                                   (1, True, 2, 'bound'), (2, False, 2, None)])
+                                                   (1, True, 2, 'bound'), (2, False, 2, None),
+                                                   (1, False, False, 'bound-rowsigma'), (2, True, True, 'regularisation-rowsigma')])
 def test_torch_fallback_losses_equal_the_reference_agent_functions(V, masked, smooth, bound):
     """rl_games_amd/torch_fallback.py (the value_size > 1 path of the agent) against the reference's OWN calc_losses
     (a2c_continuous.py:97-134, called unbound on a stand-in with exactly the attributes it reads), its model epilogue
@@ -444,8 +446,12 @@ def test_torch_fallback_losses_equal_the_reference_agent_functions(V, masked, sm
     from rl_games_amd import torch_fallback as tf
     g = gen(3 + V)
     mb, A = 512, 5
+    # ('-rowsigma': a state-dependent sigma head, fixed_sigma False - log sigma per row [mb, A]; round 6)
+    row_sigma = bound is not None and bound.endswith('-rowsigma')
+    if row_sigma:
+        bound = bound[:-len('-rowsigma')]
     mu0 = 1.3 * torch.randn(mb, A, generator=g)
-    logstd0 = 0.2 * torch.randn(A, generator=g)
+    logstd0 = 0.2 * torch.randn(*((mb, A) if row_sigma else (A,)), generator=g)
     values0 = torch.randn(mb, V, generator=g)
     actions = mu0 + torch.randn(mb, A, generator=g)
     old_nlp = 0.5 * torch.randn(mb, generator=g) + 6.0
@@ -517,3 +523,49 @@ def test_torch_fallback_advantage_normalisation_and_ema_equal_the_reference(mask
     before = (ours.mean.clone(), ours.step.clone())
     ours(adv, mask=torch.zeros(4096))
     assert torch.equal(ours.mean, before[0]) and torch.equal(ours.step, before[1])
+
+
+def test_state_dependent_sigma_network_equals_the_reference_builder():
+    """fixed_sigma False (network_builder.py:341-344, :508-511, init_state_dependent_sigma_head :14-25): the policy module
+    builds the same parameters as the reference's A2CBuilder network - names, shapes, the constant-initialiser rule (bias =
+    val, weights zero) - and, on the reference's weights, returns the same (mu, log sigma, value) and the same model outputs
+    (neglogp, entropy) bit for bit."""
+    from rl_games.algos_torch import network_builder
+    from rl_games.algos_torch.models import ModelA2CContinuousLogStd
+    from rl_games_amd.policy import ActorCriticNetwork, ContinuousA2CLogStdModel
+    net_params = {'name': 'actor_critic', 'separate': False,
+                  'space': {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None',
+                                           'mu_init': {'name': 'default'}, 'sigma_init': {'name': 'const_initializer', 'val': -0.7},
+                                           'fixed_sigma': False}},
+                  'mlp': {'units': [32, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}
+    builder = network_builder.A2CBuilder()
+    builder.load(copy.deepcopy(net_params))
+    torch.manual_seed(4)
+    ref_net = builder.build('a2c', actions_num=3, input_shape=(7,), value_size=1, num_seqs=8)
+    ours = ActorCriticNetwork(copy.deepcopy(net_params), actions_num=3, input_shape=(7,), value_size=1, num_seqs=8)
+    ref_sd, our_sd = ref_net.state_dict(), ours.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {k: tuple(v.shape) for k, v in our_sd.items()}
+    assert torch.equal(our_sd['sigma.bias'], torch.full((3,), -0.7)) and not our_sd['sigma.weight'].any()
+    assert torch.equal(ref_sd['sigma.bias'], our_sd['sigma.bias']) and torch.equal(ref_sd['sigma.weight'], our_sd['sigma.weight'])
+    with torch.no_grad():
+        for k, v in ref_sd.items():
+            if k.startswith('sigma.'):
+                ref_sd[k] = v + 0.1 * torch.randn(v.shape, generator=gen(9))      # a sigma head that does depend on the state
+    ref_net.load_state_dict(ref_sd)
+    ours.load_state_dict(ref_sd)
+    obs = torch.randn(8, 7, generator=gen(10))
+    want = ref_net({'obs': obs, 'rnn_states': None})
+    got = ours({'obs': obs, 'rnn_states': None})
+    for w, g_ in zip(want[:3], got[:3]):
+        assert torch.equal(w, g_)
+    assert got[1].shape == (8, 3) and (got[1][0] != got[1][1]).any()
+    # the model epilogue around it (models.py:329-364)
+    ref_model = ModelA2CContinuousLogStd.Network(ref_net, obs_shape=(7,), normalize_value=False, normalize_input=False, value_size=1)
+    our_model = ContinuousA2CLogStdModel(ours, (7,), False, False, 1)
+    acts = torch.randn(8, 3, generator=gen(11))
+    a = ref_model({'is_train': True, 'prev_actions': acts, 'obs': obs, 'rnn_states': None})
+    b = our_model({'is_train': True, 'prev_actions': acts, 'obs': obs, 'rnn_states': None})
+    for key in ('prev_neglogp', 'values', 'entropy', 'mus', 'sigmas'):
+        assert torch.equal(a[key], b[key]), key
+    mu, logstd, value, _ = our_model.forward_heads({'obs': obs})
+    assert torch.equal(logstd, got[1]) and torch.equal(mu, got[0])
