@@ -349,6 +349,7 @@ class A2CAgent:
         self._general_forms = (not self.is_discrete) and (self.value_size != 1
                                                           or not getattr(self.model.a2c_network, 'fixed_sigma', True))
         self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True) and not self._general_forms
+                            and getattr(self.model.a2c_network, 'plain_trunk', True)
                             and not self.model.a2c_network.is_separate_critic()
                             and (not self.is_rnn or config.get('manual_lstm', True)))
         if self._use_engine:

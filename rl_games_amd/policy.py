@@ -92,8 +92,56 @@ class RnnWithDones(nn.Module):
         return torch.cat(outs, dim=0), st
 
 
+class D2RLNet(nn.Module):
+    """Dense-to-dense trunk (rl_games/algos_torch/d2rl.py:3-33): every layer behind the first sees the previous layer's
+    output concatenated with the network input.  Parameter names as in the reference (`linears.N`, `norm_layers.N`)."""
+
+    def __init__(self, input_size, units, activation, norm_func_name=None):
+        super().__init__()
+        self.activations = nn.ModuleList([_activation(activation) for _ in units])
+        self.linears = nn.ModuleList([])
+        self.norm_layers = nn.ModuleList([])
+        self.num_layers = len(units)
+        last = input_size
+        for u in units:
+            self.linears.append(nn.Linear(last, u))
+            last = u + input_size
+            self.norm_layers.append(nn.LayerNorm(u) if norm_func_name == 'layer_norm' else nn.Identity())
+
+    def forward(self, x0):
+        x = self.norm_layers[0](self.activations[0](self.linears[0](x0)))            # (:25-27: act, then norm)
+        for i in range(1, self.num_layers):
+            x = self.activations[i](self.norm_layers[i](self.linears[i](torch.cat([x, x0], dim=1))))   # (:29-32: norm, then act)
+        return x
+
+
+def build_trunk(input_size, units, activation, norm_func_name=None, norm_only_first_layer=False, d2rl=False):
+    """network_builder.py:105-145 (_build_sequential_mlp / _build_mlp), statement for statement - including that `in_size` is
+    only advanced while a normalisation layer is still to come when `norm_only_first_layer` is set."""
+    if norm_func_name not in (None, 'layer_norm'):
+        raise NotImplementedError(f"normalization '{norm_func_name}' (only layer_norm is implemented on this path)")
+    if d2rl:
+        return D2RLNet(input_size, units, activation, norm_func_name)
+    in_size, layers, need_norm = input_size, [], True
+    for unit in units:
+        layers.append(nn.Linear(in_size, unit))
+        layers.append(_activation(activation))
+        if not need_norm:
+            continue
+        if norm_only_first_layer and norm_func_name is not None:
+            need_norm = False
+        if norm_func_name == 'layer_norm':
+            layers.append(nn.LayerNorm(unit))
+        in_size = unit
+    return nn.Sequential(*layers)
+
+
 class ActorCriticNetwork(nn.Module):
-    """`a2c_network`: MLP trunk (+ optional RNN after it) with mu / value heads."""
+    """`a2c_network`: MLP trunk (+ optional RNN) with mu / value heads.  The plain layouts - Linear + activation trunks,
+    a single-layer LSTM behind the trunk - run on this library's fused kernels (`plain_trunk`); layer normalisation, D2RL
+    trunks, an RNN in front of the MLP, concatenated RNN inputs / outputs and layer norm behind the RNN (round 6) are
+    built like the reference builds them and run as torch modules with autograd between the HIP rollout, dataset, loss
+    and optimiser kernels."""
 
     def __init__(self, net_params, actions_num, input_shape, value_size=1, num_seqs=1):
         super().__init__()
@@ -125,8 +173,8 @@ class ActorCriticNetwork(nn.Module):
                 float(self.space_config.get('min_sigma', 0.0)) > 0:
             raise NotImplementedError('only the plain exp sigma parametrisation is implemented')
         mlp = net_params['mlp']
-        if mlp.get('d2rl', False) or net_params.get('normalization'):
-            raise NotImplementedError('d2rl / normalisation layers are not implemented on this path')
+        self._trunk_kw = dict(activation=mlp['activation'], norm_func_name=net_params.get('normalization'),
+                              norm_only_first_layer=mlp.get('norm_only_first_layer', False), d2rl=mlp.get('d2rl', False))
         self.units = list(mlp['units'])
         self.value_size = value_size
         self.num_seqs = num_seqs
@@ -135,26 +183,34 @@ class ActorCriticNetwork(nn.Module):
         in_size = input_shape[0]
 
         self.has_rnn = 'rnn' in net_params
-        layers = []
-        last = in_size
-        for u in self.units:
-            layers.append(nn.Linear(last, u))
-            layers.append(_activation(mlp['activation']))
-            last = u
-        self.actor_mlp = nn.Sequential(*layers)
-        if self.separate:                                      # network_builder.py:292-293
-            self.critic_mlp = self._mlp_like(in_size, mlp['activation'])
-        out_size = last
+        # sizes as network_builder.py:250-272
+        mlp_in = in_size
+        out_size = self.units[-1] if self.units else in_size
+        self.rnn_before_mlp = self.rnn_concat_input = self.rnn_concat_output = self.rnn_ln = False
         if self.has_rnn:
             rnn = net_params['rnn']
-            if rnn.get('before_mlp', False) or rnn.get('concat_input', False) or \
-                    rnn.get('concat_output', False) or rnn.get('layer_norm', False):
-                raise NotImplementedError('only the plain RNN-after-MLP layout is implemented')
             self.rnn_name = rnn['name']
             self.rnn_units = rnn['units']
             self.rnn_layers = rnn['layers']
-            self.rnn = RnnWithDones(self.rnn_name, out_size, self.rnn_units, self.rnn_layers)
-            out_size = self.rnn_units
+            self.rnn_ln = bool(rnn.get('layer_norm', False))
+            self.rnn_before_mlp = bool(rnn.get('before_mlp', False))
+            self.rnn_concat_input = bool(rnn.get('concat_input', False))
+            self.rnn_concat_output = bool(rnn.get('concat_output', False))
+            if not self.rnn_before_mlp:
+                rnn_in = out_size + (in_size if self.rnn_concat_input else 0)
+                out_size = self.rnn_units + (in_size if self.rnn_concat_output else 0)
+            else:
+                rnn_in = in_size
+                mlp_in = self.rnn_units + (in_size if self.rnn_concat_output else 0)
+            self.rnn = RnnWithDones(self.rnn_name, rnn_in, self.rnn_units, self.rnn_layers)
+            if self.rnn_ln:
+                self.layer_norm = nn.LayerNorm(self.rnn_units)
+        self.actor_mlp = build_trunk(mlp_in, self.units, **self._trunk_kw)
+        if self.separate:                                      # network_builder.py:292-293
+            self.critic_mlp = build_trunk(mlp_in, self.units, **self._trunk_kw)
+        # what the fused engines take (mlp_engine.ManualMLP): Linear + activation pairs, the RNN plainly behind them
+        self.plain_trunk = (not self._trunk_kw['d2rl'] and self._trunk_kw['norm_func_name'] is None and
+                            not (self.rnn_before_mlp or self.rnn_concat_input or self.rnn_concat_output or self.rnn_ln))
         self.value = nn.Linear(out_size, value_size)
         self.value_act = _activation(net_params.get('value_activation', 'None'))
         self.mu = nn.Linear(out_size, actions_num)
@@ -206,21 +262,19 @@ class ActorCriticNetwork(nn.Module):
     def _init_discrete(self, net_params, actions_num, input_shape, value_size, num_seqs):
         """Categorical head (network_builder.py:298-299): `logits` Linear in place of mu/sigma."""
         mlp = net_params['mlp']
-        if mlp.get('d2rl', False) or net_params.get('normalization'):
-            raise NotImplementedError('d2rl / normalisation layers are not implemented on this path')
         if 'rnn' in net_params:
             raise NotImplementedError('recurrent discrete policies are not implemented on this path')
         self.units = list(mlp['units'])
         self.value_size, self.num_seqs, self.actions_num = value_size, num_seqs, actions_num
         self.has_rnn = False
         assert len(input_shape) == 1, 'flat observations only'
-        layers, last = [], input_shape[0]
-        for u in self.units:
-            layers += [nn.Linear(last, u), _activation(mlp['activation'])]
-            last = u
-        self.actor_mlp = nn.Sequential(*layers)
+        kw = dict(activation=mlp['activation'], norm_func_name=net_params.get('normalization'),
+                  norm_only_first_layer=mlp.get('norm_only_first_layer', False), d2rl=mlp.get('d2rl', False))
+        self.plain_trunk = not kw['d2rl'] and kw['norm_func_name'] is None
+        last = self.units[-1] if self.units else input_shape[0]
+        self.actor_mlp = build_trunk(input_shape[0], self.units, **kw)
         if self.separate:
-            self.critic_mlp = self._mlp_like(input_shape[0], mlp['activation'])
+            self.critic_mlp = build_trunk(input_shape[0], self.units, **kw)
         self.value = nn.Linear(last, value_size)
         self.value_act = _activation(net_params.get('value_activation', 'None'))
         if self.is_multi_discrete:                              # network_builder.py:303-304
@@ -270,9 +324,14 @@ class ActorCriticNetwork(nn.Module):
         return self.critic_mlp(obs) if self.separate else actor_out
 
     def trunk(self, obs, states=None, dones=None, seq_length=1):
-        out = self.actor_mlp(obs)
+        """network_builder.py:447-500 (the shared-trunk branch)."""
         if not self.has_rnn:
-            return out, states
+            return self.actor_mlp(obs), states
+        out = obs
+        if not self.rnn_before_mlp:
+            out = self.actor_mlp(out)
+            if self.rnn_concat_input:
+                out = torch.cat([out, obs], dim=1)
         batch = out.shape[0]
         num_seqs = batch // seq_length
         out = out.reshape(num_seqs, seq_length, -1).transpose(0, 1)
@@ -282,6 +341,12 @@ class ActorCriticNetwork(nn.Module):
             states = tuple()
         out, states = self.rnn(out, states, dones)
         out = out.transpose(0, 1).contiguous().reshape(batch, -1)
+        if self.rnn_ln:
+            out = self.layer_norm(out)
+        if self.rnn_concat_output:
+            out = torch.cat([out, obs], dim=1)
+        if self.rnn_before_mlp:
+            out = self.actor_mlp(out)
         if not isinstance(states, tuple):
             states = (states,)
         return out, states

@@ -106,12 +106,19 @@ def make_epoch(variants=None, filename='epoch.pt'):
         over = dict(over)
         rnn = over.pop('_rnn', None)
         space = over.pop('_space', None)
+        net_over = over.pop('_network', None)
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', games_to_track=100, **over)
         if rnn is not None:
             params['network']['rnn'] = rnn
         if space is not None:
             params['network']['space']['continuous'].update(space)
+        if net_over is not None:
+            for k, v in net_over.items():
+                if isinstance(v, dict) and isinstance(params['network'].get(k), dict):
+                    params['network'][k].update(v)
+                else:
+                    params['network'][k] = v
         params['seed'] = 7
         env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=1234)
         params['config']['env_info'] = env.get_env_info()
@@ -179,10 +186,12 @@ def make_epoch(variants=None, filename='epoch.pt'):
 def make_epoch_extra():
     """Round 6: epochs of the real reference agent for the API corners that left the NotImplementedError list -
     a state-dependent sigma head (fixed_sigma False, network_builder.py:341-344) and the plain A2C loss (ppo False,
-    common_losses.py:80).  A file of its own: epoch.pt keeps its bytes."""
+    common_losses.py:80) - and a D2RL trunk with layer normalisation (d2rl.py, network_builder.py:105-145).  A file of its own:
+    epoch.pt keeps its bytes."""
     make_epoch({
         'state_sigma': dict(_space={'fixed_sigma': False, 'sigma_init': {'name': 'const_initializer', 'val': -0.5}}),
         'ppo_false': dict(ppo=False),
+        'd2rl_layer_norm': dict(_network={'mlp': {'d2rl': True}, 'normalization': 'layer_norm'}),
     }, 'epoch_extra.pt')
 
 

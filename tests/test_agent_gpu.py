@@ -34,17 +34,18 @@ def _to_dev(batch):
     return {k: v.to(DEV) for k, v in batch.items()}
 
 
-@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema', 'state_sigma', 'ppo_false'])
+@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema', 'state_sigma', 'ppo_false', 'd2rl_layer_norm'])
 def test_update_matches_reference_epoch(golden, variant):
     """An epoch's update against the recording of the REAL reference agent's train_epoch on the same rollout
     (tests/golden/make_golden.py).  Round 6 (epoch_extra.pt): 'state_sigma' - a state-dependent sigma head
     (fixed_sigma False: the policy runs the reference's operation sequence as torch ops with autograd around this library's
-    dataset / optimiser kernels, agent._forward_loss_backward_general) - and 'ppo_false' - the plain A2C actor loss inside
-    the fused loss tile."""
-    extra = variant in ('state_sigma', 'ppo_false')
+    dataset / optimiser kernels, agent._forward_loss_backward_general), 'ppo_false' - the plain A2C actor loss inside the
+    fused loss tile - and 'd2rl_layer_norm' - a D2RL trunk with layer normalisation: torch modules + autograd between this
+    library's loss, statistics and optimiser kernels."""
+    extra = variant in ('state_sigma', 'ppo_false', 'd2rl_layer_norm')
     cap = golden('epoch_extra.pt' if extra else 'epoch.pt')[variant]
     agent = _make_agent(cap)
-    assert (agent._engine is None) == (variant == 'state_sigma')
+    assert (agent._engine is None) == (variant in ('state_sigma', 'd2rl_layer_norm'))
     agent.model.load_state_dict(cap['state_after_rollout'])
     batch = _to_dev(cap['batch'])
     agent.set_train()
@@ -199,6 +200,40 @@ def test_plain_a2c_loss_when_ppo_is_false_matches_oracle():
         if v.is_floating_point() and v.numel() >= 16 and name in want:
             w = want[name]
             assert ((v.cpu().to(w.dtype) - w).abs().mean() / w.abs().mean().clamp_min(1e-12)).item() <= 1e-4, name
+
+
+@pytest.mark.parametrize('rnn', [{'name': 'gru', 'units': 16, 'layers': 2},
+                                 {'name': 'lstm', 'units': 16, 'layers': 1, 'layer_norm': True, 'concat_input': True, 'concat_output': True},
+                                 {'name': 'lstm', 'units': 16, 'layers': 1, 'before_mlp': True}],
+                         ids=['gru_two_layers', 'lstm_layer_norm_concat', 'lstm_before_mlp'])
+def test_recurrent_layouts_outside_the_engine_train_on_the_device(rnn):
+    """GRU / multi-layer RNNs and the RNN layout options of network_builder.py:250-276 (construction and outputs pinned to the
+    reference builder on the CPU: tests/test_vs_reference_cpu.py::test_network_zoo_layouts_...): two epochs through
+    play_steps_rnn and the update on the device - torch modules with autograd around this library's rollout, GAE, dataset,
+    loss and optimiser kernels - finite losses, a small KL in an epoch's first minibatch (the policy that played is the one
+    evaluated), parameters that move."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=64, horizon=8, obs_dim=10, act_dim=3, seq_length=4)
+    params['network']['rnn'] = dict(rnn)
+    agent = A2CAgent('zoo', copy.deepcopy(params))
+    assert agent.is_rnn and agent._engine is None
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    before = {k: v.detach().clone() for k, v in agent.model.state_dict().items() if v.is_floating_point()}
+    for epoch in range(3):
+        first = agent._mb_index % agent._mb_scalars.shape[0]
+        agent.update_epoch()
+        out = agent.train_epoch()
+        for x in out[4] + out[5] + out[7]:
+            assert torch.isfinite(x).all()
+    # (the third epoch: by then the observation statistics - which the training forward updates BEFORE it normalises, and
+    #  which feed the heads directly under concat_output - have settled; in the very first minibatch they jump from (0, 1)
+    #  to the batch's moments, in the reference as here)
+    first_kl = float(agent._mb_scalars[first, 4])
+    assert 0.0 <= first_kl < 0.05, first_kl
+    after = agent.model.state_dict()
+    assert any(not torch.equal(after[k], v) for k, v in before.items() if 'running' not in k)
 
 
 def test_checkpoint_round_trip(tmp_path):

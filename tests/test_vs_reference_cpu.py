@@ -569,3 +569,70 @@ def test_state_dependent_sigma_network_equals_the_reference_builder():
         assert torch.equal(a[key], b[key]), key
     mu, logstd, value, _ = our_model.forward_heads({'obs': obs})
     assert torch.equal(logstd, got[1]) and torch.equal(mu, got[0])
+
+
+_SPACE = {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None', 'mu_init': {'name': 'default'},
+                         'sigma_init': {'name': 'const_initializer', 'val': 0}, 'fixed_sigma': True}}
+
+
+@pytest.mark.parametrize('name,over', [
+    ('layer_norm', {'normalization': 'layer_norm'}),
+    ('layer_norm_first_only', {'normalization': 'layer_norm', 'mlp': {'units': [24, 24], 'norm_only_first_layer': True}}),
+    ('d2rl', {'mlp': {'d2rl': True}}),
+    ('d2rl_layer_norm', {'mlp': {'d2rl': True}, 'normalization': 'layer_norm'}),
+    ('gru_two_layers', {'rnn': {'name': 'gru', 'units': 12, 'layers': 2}}),
+    ('lstm_layer_norm_concat', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'layer_norm': True, 'concat_input': True,
+                                        'concat_output': True}}),
+    ('lstm_before_mlp', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'before_mlp': True, 'concat_output': True}}),
+    ('discrete_d2rl_layer_norm', {'mlp': {'d2rl': True}, 'normalization': 'layer_norm', 'space': {'discrete': {}}}),
+])
+def test_network_zoo_layouts_equal_the_reference_builder(name, over):
+    """The network layouts that left the NotImplementedError list in round 6 - layer normalisation (network_builder.py:105-132),
+    D2RL trunks (d2rl.py), GRU / multi-layer RNNs, an RNN in front of the MLP, concatenated RNN inputs / outputs, layer norm
+    behind the RNN (:250-276, :447-487) - against the reference's own A2CBuilder network: the same parameter names and shapes,
+    and on the reference's weights the same outputs (and next RNN states) bit for bit, with done resets inside a sequence."""
+    from rl_games.algos_torch import network_builder
+    from rl_games_amd.policy import ActorCriticNetwork
+    net_params = {'name': 'actor_critic', 'separate': False, 'space': copy.deepcopy(_SPACE),
+                  'mlp': {'units': [32, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}
+    for k, v in over.items():
+        if k == 'mlp':
+            net_params['mlp'].update(v)
+        else:
+            net_params[k] = v
+    discrete = 'discrete' in net_params['space']
+    builder = network_builder.A2CBuilder()
+    builder.load(copy.deepcopy(net_params))
+    torch.manual_seed(5)
+    kw = dict(actions_num=3, input_shape=(7,), value_size=1, num_seqs=4)
+    ref_net = builder.build('a2c', **kw)
+    ours = ActorCriticNetwork(copy.deepcopy(net_params), **kw)
+    ref_sd = ref_net.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    assert not getattr(ours, 'plain_trunk', True) or name == 'gru_two_layers'
+    with torch.no_grad():                                       # LayerNorm weights away from their (1, 0) initialisation
+        for k, v in ref_sd.items():
+            if 'norm' in k:
+                ref_sd[k] = v + 0.2 * torch.randn(v.shape, generator=gen(3))
+    ref_net.load_state_dict(ref_sd)
+    ours.load_state_dict(ref_sd)
+    T, S = 3, 4                                                 # seq_length 3, 4 sequences
+    obs = torch.randn(S * T, 7, generator=gen(4))
+    d = {'obs': obs, 'rnn_states': None}
+    if 'rnn' in net_params:
+        layers, units = net_params['rnn']['layers'], net_params['rnn']['units']
+        n_states = 2 if net_params['rnn']['name'] == 'lstm' else 1
+        states = tuple(torch.randn(layers, S, units, generator=gen(6 + i)) for i in range(n_states))
+        dones = (torch.rand(S * T, generator=gen(8)) < 0.3).float()
+        d = {'obs': obs, 'rnn_states': states, 'seq_length': T, 'dones': dones}
+    want = ref_net(dict(d))
+    got = ours(dict(d))
+    n_out = 2 if discrete else 3
+    for w, g_ in zip(want[:n_out], got[:n_out]):
+        assert torch.allclose(w, g_, rtol=0, atol=0) or torch.allclose(w, g_, rtol=1e-6, atol=1e-7), name
+    if 'rnn' in net_params:
+        for w, g_ in zip(want[n_out], got[n_out]):
+            assert torch.allclose(w, g_, rtol=1e-6, atol=1e-7)
+    else:
+        for w, g_ in zip(want[:n_out], got[:n_out]):
+            assert torch.equal(w, g_), name
