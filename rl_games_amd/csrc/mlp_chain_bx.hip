@@ -3,8 +3,9 @@
 // sum of six exact bf16 plane products on v_mfma_f32_16x16x32_bf16 (the scheme of mlp_dw.hip, split_bf16.hpp):
 // 6 x 16 cycles per 16x16x32 tile instead of 8 x 32 on the f32 MFMA.
 //
-// The f32 MFMA kernels are bound by everything that is NOT an MFMA (VALU and MFMA never co-execute on a CDNA4 SIMD,
-// profiles/r3_coexec_and_launch_probes.txt), so the split must not cost inner-loop VALU:
+// The f32 MFMA kernels are bound by everything that is NOT an MFMA (v_mfma_f32_16x16x4_f32 and VALU instructions do not
+// co-execute, profiles/r3_coexec_and_launch_probes.txt; beside the bf16 MFMA of this file one or two PLAIN VALU instructions
+// per MFMA do, v_pk_add_f32 does not - profiles/r6_coexec_bf16.txt), so the split must not cost inner-loop VALU:
 //   * the WEIGHTS are split once per optimizer step by rlg_mlp_chain_pack_planes into fragment order: fragment
 //     (block ib, chunk c, plane p) = 64 lanes x 8 bf16 = 1 KiB, lane l holds A[16 ib + (l & 15)][k] for its 8 k slots
 //     of chunk c.  A wave's A operands of a chunk are three 16-byte buffer loads at SCALAR addresses (no address VALU),

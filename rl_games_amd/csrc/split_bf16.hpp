@@ -27,7 +27,11 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // One pair of fp32 values (an even-aligned register pair) -> its dword of each of the three planes.  Per pair: 3
 // v_cvt_pk_bf16_f32 (RNE) and, for each of the two residuals, v_lshlrev + v_and + ONE v_pk_add_f32 with negated second
 // operand (exact: the residual has <= 16 (8) significant bits) = 9 VALU instructions; the splitting is the largest
-// VALU item of every split-product kernel and VALU time adds to MFMA time on gfx950.
+// VALU item of every split-product kernel.  (Round 6, profiles/r6_coexec_bf16.txt: beside v_mfma_f32_16x16x32_bf16 plain
+// VALU instructions overlap, v_pk_add_f32 does NOT - one per MFMA costs + 16.5 cycles.  The loops that call this split do not
+// interleave it with MFMAs - they split, then multiply - and with RLG_SPLIT_PK=0 -fno-slp-vectorize (scalar residuals) they
+// measured 3 us faster in the weight-gradient launch and 4 us slower in the forward: the packed form stays the default; a loop
+// that DOES deal the split out between MFMAs must use the scalar form.)
 __device__ __forceinline__ void split_pair(split_f32x2 r, unsigned& p0, unsigned& p1, unsigned& p2) {
   unsigned w = cvt_pk_bf16(r[0], r[1]);
   p0 = w;
