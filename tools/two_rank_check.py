@@ -53,8 +53,10 @@ dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 ok = bool(torch.equal(lo, hi)) and bool(torch.isfinite(p).all())
 if rank == 0:
-    print('TWO_RANK_ALLREDUCE', agent.last_allreduce, 'two_phase' if (agent._ipc_comm and agent._ipc_comm.two_phase) else 'one_shot', flush=True)
-    print('TWO_RANK_CHECK', kind, 'in_sync' if ok else f'OUT_OF_SYNC {lo.tolist()} {hi.tolist()}', flush=True)
+    phase = 'two_phase' if (agent._ipc_comm and agent._ipc_comm.two_phase) else 'one_shot'
+    verdict = 'in_sync' if ok else f'OUT_OF_SYNC {lo.tolist()} {hi.tolist()}'
+    sys.stdout.write(f'TWO_RANK_ALLREDUCE {agent.last_allreduce} {phase}\nTWO_RANK_CHECK {kind} {verdict}\n')     # (one write)
+    sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

@@ -114,10 +114,15 @@ in_sync = bool(torch.equal(lo, hi))
 ok = in_sync and not problems
 oks = [None] * world
 dist.all_gather_object(oks, ok)
-print(f'TWO_RANK_ORACLE rank {rank} {shape} steps {nmb} allreduce {agent.last_allreduce} in_sync {in_sync} '
-      f'problems {problems[:6]}', flush=True)
+# (one write per line, the verdict behind a barrier: two ranks share the pipe, and print() hands its arguments over piece
+#  by piece - a test once read "TWO_RANK_ORACLE_CHECK \nhumanoid ok" with the other rank's newline in the middle)
+sys.stdout.write(f'TWO_RANK_ORACLE rank {rank} {shape} steps {nmb} allreduce {agent.last_allreduce} in_sync {in_sync} '
+                 f'problems {problems[:6]}\n')
+sys.stdout.flush()
+dist.barrier()
 if rank == 0:
-    print('TWO_RANK_ORACLE_CHECK', shape, 'ok' if all(oks) else 'FAILED', flush=True)
+    sys.stdout.write(f"TWO_RANK_ORACLE_CHECK {shape} {'ok' if all(oks) else 'FAILED'}\n")
+    sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if all(oks) else 1)
