@@ -291,6 +291,17 @@ int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float*
                           const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
                           float* d_values, double* partials, int minibatch, float e_clip, float critic_coef,
                           float entropy_coef, int clip_value, int use_smooth_clamp, void* stream);
+/* The same launch over heads that live inside wider rows (the fused chain's [value | logits] head matrix and its
+ * gradient): values / d_values with an element stride, d_logits with a row stride.  rlg_ppo_loss_discrete is this with
+ * ld_values = ld_d_values = 1, ld_d_logits = n. */
+int rlg_ppo_loss_discrete_strided(const float* logits, long long ld_logits, const float* values, long long ld_values,
+                                  const long long* actions, const unsigned char* action_masks_or_null,
+                                  const int* branch_sizes, int num_branches, const float* old_neglogp,
+                                  const float* advantages, const float* old_values, const float* returns,
+                                  const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
+                                  long long ld_d_logits, float* d_values, long long ld_d_values, double* partials,
+                                  int minibatch, float e_clip, float critic_coef, float entropy_coef, int clip_value,
+                                  int use_smooth_clamp, void* stream);
 
 /* scalars8 = {a_loss, c_loss, entropy, b_loss, kl, loss, sum(mask), 0}; d_logstd [A];
  * kl_slot_or_null receives the KL as well (e.g. the tail slot of the flat gradient arena);

@@ -109,6 +109,8 @@ _PROTOTYPES = {
     'rlg_ppo_loss_discrete_num_blocks': [_c_int],
     'rlg_ppo_loss_discrete': [_P, _c_ll, _P, _P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int,
                               _c_float, _c_float, _c_float, _c_int, _c_int, _P],
+    'rlg_ppo_loss_discrete_strided': [_P, _c_ll, _P, _c_ll, _P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P,
+                                      _c_ll, _P, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int, _P],
     'rlg_ppo_loss_finalize': [_P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _P,
                               _P, _P, _P, _P, _P],
     # mlp_fused.hip

@@ -360,6 +360,8 @@ class A2CAgent:
             # with the engine every gradient slot is overwritten (GEMM out=, column-sum and loss
             # finalise kernels), so the per-step zero fill of the arena is skipped
             self._grads_overwritten = len(rest) == 0
+        else:
+            layout = self._arena_layout(config)
         self.optimizer = FlatAdam(self.model.parameters(), self.last_lr, eps=1e-08,
                                   weight_decay=self.weight_decay, layout=layout)
         self._engine = None
@@ -374,6 +376,7 @@ class A2CAgent:
                 print(f'rl_games_amd: manual MLP engine unavailable ({e}); using autograd')
                 self._engine = None
                 self._grads_overwritten = False
+        self._init_chains(config)
         self.dataset = PPODataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn,
                                   dev, self.seq_length)
         self.central_value_net = None
@@ -456,6 +459,14 @@ class A2CAgent:
         dev = self.ppo_device
         self.actions_low = torch.from_numpy(np.asarray(action_space.low).copy()).float().to(dev)
         self.actions_high = torch.from_numpy(np.asarray(action_space.high).copy()).float().to(dev)
+
+    def _arena_layout(self, config):
+        """Physical order of the parameters inside the optimiser's arena for agents outside the continuous engine
+        (None: parameters() order)."""
+        return None
+
+    def _init_chains(self, config):
+        """Hook behind the optimiser: the discrete agent puts its trunks on the fused chain kernels here."""
 
     def _alloc_loss_scratch(self, mb, dev):
         A = self.actions_num

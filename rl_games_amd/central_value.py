@@ -9,7 +9,7 @@ Same kernels as the actor path: the state normaliser and value de-normaliser are
 (`FlatAdam`, csrc/optim.hip) with one in-place all-reduce per step in multi-GPU runs.  Round 5: the MLP itself runs on
 the actor path's fused chain kernels - state normaliser + hidden layers + value head as ONE forward launch, the dX /
 activation-backward / bias-sum chain as ONE backward launch (csrc/mlp_chain*.hip), the hidden layers' weight gradients as
-the MFMA launch of csrc/mlp_dw.hip (`_ValueChain` below) - where the network has that form (plain Linear + ELU / ReLU /
+the MFMA launch of csrc/mlp_dw.hip (chain_net.ChainNet) - where the network has that form (plain Linear + ELU / ReLU /
 tanh trunk, widths that are multiples of 4, one value column); anything else keeps autograd around the loss kernel
 (`fused_mlp: False` in the central-value config forces that path).
 
@@ -21,99 +21,21 @@ from torch import nn
 
 from . import distributed as rdist
 from . import ops
+from .chain_net import ChainNet
 from .flat_optim import FlatAdam
 from .lr_control import IdentityScheduler, LinearScheduler
 from .minibatch import PPODataset
 
 
-class _ValueChain:
-    """Trunk + value head of a central value network on the fused chain kernels (ops.MlpChain): what autograd does for
-    `CentralValueTrain.calc_gradients` (rl_games/algos_torch/central_value.py:278-335) between the loss kernel and the
-    optimiser - forward with activations kept, dZ of every hidden layer + bias-gradient column sums, weight gradients.
-    Raises NotImplementedError for networks outside the kernels' envelope (the caller keeps autograd then)."""
-
-    def __init__(self, net, arena, max_rows):
-        self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
-        acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
-        if not self.linears or len(acts) != len(self.linears):
-            raise NotImplementedError('unexpected MLP structure')
-        name = {nn.ELU: 'elu', nn.ReLU: 'relu', nn.Tanh: 'tanh', nn.Identity: 'None'}.get(type(acts[0]))
-        if name is None or any(type(a) is not type(acts[0]) for a in acts):
-            raise NotImplementedError('elu / relu / tanh / identity trunks only')
-        if isinstance(acts[0], nn.ELU) and acts[0].alpha != 1.0:
-            raise NotImplementedError('elu alpha != 1')
-        if not isinstance(net.value_act, nn.Identity) or net.value.out_features != 1:
-            raise NotImplementedError('one linear value column only')
-        if any(l.out_features % 4 for l in self.linears):
-            raise NotImplementedError('hidden widths must be multiples of 4')
-        self.value = net.value
-        dev = net.value.weight.device
-        widths = [l.out_features for l in self.linears]
-        layers = [(l.weight, l.bias, name) for l in self.linears] + [(net.value.weight, net.value.bias, 'None')]
-        self.chain = ops.MlpChain(layers, dev, weights_version=arena.weights_token)
-        self.Hs = [torch.empty(max_rows, w, device=dev) for w in widths]
-        self.dA = [torch.empty(max_rows, w, device=dev) for w in widths]
-        self.heads = torch.empty(max_rows, 1, device=dev)
-        self.d_heads = torch.empty(max_rows, 1, device=dev)
-        self.xn = torch.empty(max_rows, self.linears[0].in_features, device=dev)
-        nb = (max_rows + 15) // 16                          # one partial row per 16-row group at most
-        self.partials = [torch.empty(nb * w, dtype=torch.float64, device=dev) for w in widths]
-        self._plans = {}
-        self._rows = 0
-        self._x = None
-        self.last_dw_path = None
-
-    @torch.no_grad()
-    def forward(self, states, rms, eps):
-        """states [rows, in] RAW; rms = (running_mean, running_var) or None.  Returns values [rows, 1]."""
-        rows = states.shape[0]
-        if not states.is_contiguous():
-            states = states.contiguous()
-        heads = self.heads[:rows]
-        xn = self.xn[:rows] if rms is not None else None
-        self.chain.forward(states, heads, act_out=[h[:rows] for h in self.Hs], rms=rms, eps=eps, xn_out=xn)
-        self._rows, self._x = rows, (xn if rms is not None else states)
-        return heads
-
-    @torch.no_grad()
-    def backward(self):
-        """d loss / d values in self.d_heads[:rows] -> every gradient of the network in the arena."""
-        rows, L = self._rows, len(self.linears)
-        d_heads = self.d_heads[:rows]
-        acts = [h[:rows] for h in self.Hs]
-        dzs = [d[:rows] for d in self.dA]
-        nblk = self.chain.num_blocks(rows, 1)
-        parts = [p[:nblk * l.out_features] for p, l in zip(self.partials, self.linears)]
-        self.chain.backward(d_heads, acts, dzs, parts)
-        # the head: one output column - a weighted column sum of the last activations, and the sum of d values
-        torch.mv(acts[-1].t(), d_heads.view(-1), out=self.value.weight.grad.view(-1))
-        torch.sum(d_heads, dim=0, out=self.value.bias.grad)
-        jobs, colsums = [], []
-        for l in range(L - 1, -1, -1):
-            lin = self.linears[l]
-            jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
-            colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-        fast = [j for j in jobs if j[2].shape[1] % 4 == 0 and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in j)]
-        slow = [j for j in jobs if not any(j is f for f in fast)]
-        plan = None
-        if fast:
-            key = (rows,) + tuple(tuple(g.shape) for _, _, g in fast)
-            plan = self._plans.get(key)
-            if plan is None:
-                try:
-                    plan = ops.MlpDwPlan([tuple(g.shape) for _, _, g in fast], rows, fast[0][2].device)
-                except NotImplementedError:
-                    plan = False
-                self._plans[key] = plan
-        if plan:
-            plan.launch(fast, colsums)                      # (bias gradients finished by the same finalise launch)
-        else:
-            slow = jobs
-            for part, nb, cols, out in colsums:
-                ops.colsum_finalize(part, nb, cols, out)
-        self.last_dw_path = 'mfma' if plan else 'library'
-        for dz, x, g in slow:                               # e.g. a first layer over 9 state features: not a multiple of 4
-            torch.mm(dz.t(), x, out=g)
+def _value_chain(net, arena, max_rows):
+    """Trunk + value head of a central value network on the fused chain kernels (chain_net.ChainNet): what autograd does
+    for `CentralValueTrain.calc_gradients` (rl_games/algos_torch/central_value.py:278-335) between the loss kernel and
+    the optimiser.  Raises NotImplementedError for networks outside the kernels' envelope (the caller keeps autograd)."""
+    if not isinstance(net.value_act, nn.Identity) or net.value.out_features != 1:
+        raise NotImplementedError('one linear value column only')
+    if not getattr(net, 'plain_trunk', True):
+        raise NotImplementedError('plain Linear + activation trunks only')
+    return ChainNet(net.actor_mlp, [net.value], arena, max_rows)
 
 
 class CentralValueTrain(nn.Module):
@@ -160,7 +82,7 @@ class CentralValueTrain(nn.Module):
         self._engine = None
         if config.get('fused_mlp', True) and value_size == 1:
             try:
-                self._engine = _ValueChain(self.model.a2c_network, self.optimizer, self.minibatch_size)
+                self._engine = _value_chain(self.model.a2c_network, self.optimizer, self.minibatch_size)
             except NotImplementedError as e:
                 print(f'rl_games_amd: central value network outside the fused chain kernels ({e}); using autograd')
         self.frame = 0

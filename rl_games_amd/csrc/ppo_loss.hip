@@ -148,7 +148,8 @@ constexpr int kMaxBranches = 16;
 struct DiscreteLossArgs {
   const float* logits;       // [mb, n] row stride ld; n = sum of branch widths
   long long ld;
-  const float* values;       // [mb]
+  const float* values;       // [mb], element stride ld_values
+  long long ld_values;
   const long long* actions;  // [mb, nb] int64 (nb = 1: [mb])
   const unsigned char* action_masks;   // [mb, n] bool (1 = allowed) or nullptr
   const float* old_neglogp;
@@ -157,8 +158,9 @@ struct DiscreteLossArgs {
   const float* returns;
   const float* mask;         // or nullptr
   const float* mask_sum;
-  float* d_logits;           // [mb, n] contiguous
-  float* d_values;           // [mb]
+  float* d_logits;           // [mb, n], row stride ld_d_logits
+  float* d_values;           // [mb], element stride ld_d_values
+  long long ld_d_logits, ld_d_values;
   double* partials;          // [gridDim.x][kLossScalars]
   int mb, n, nb;
   int off[kMaxBranches + 1]; // branch b covers logits [off[b], off[b+1])
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
       a_loss = nlp * adv;
       g_nlp = adv;
     }
-    const float v = p.values[i], vo = p.old_values[i], R = p.returns[i];
+    const float v = p.values[i * p.ld_values], vo = p.old_values[i], R = p.returns[i];
     float c_loss, g_v;
     if (p.clip_value) {
       const float delta = v - vo;
@@ -255,10 +257,10 @@ __global__ __launch_bounds__(256) void ppo_loss_discrete_kernel(DiscreteLossArgs
           const float dH = -pj * (lp + H_b[b]);
           g = w * (g_nlp * dnlp - p.entropy_coef * dH);
         }
-        p.d_logits[i * p.n + j] = g;
+        p.d_logits[i * p.ld_d_logits + j] = g;
       }
     }
-    p.d_values[i] = (0.5f * p.critic_coef) * g_v * w;
+    p.d_values[i * p.ld_d_values] = (0.5f * p.critic_coef) * g_v * w;
     const float dk = old_nlp - nlp;
     acc[0] = static_cast<double>(a_loss) * m;
     acc[1] = static_cast<double>(c_loss) * m;
@@ -399,17 +401,19 @@ int rlg_value_loss(const float* values, const float* old_values, const float* re
 
 int rlg_ppo_loss_discrete_num_blocks(int minibatch) { return (minibatch + 255) / 256; }
 
-int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
-                          const long long* actions, const unsigned char* action_masks_or_null,
-                          const int* branch_sizes, int num_branches, const float* old_neglogp,
-                          const float* advantages, const float* old_values, const float* returns,
-                          const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
-                          float* d_values, double* partials, int minibatch, float e_clip, float critic_coef,
-                          float entropy_coef, int clip_value, int use_smooth_clamp, void* stream) {
+int rlg_ppo_loss_discrete_strided(const float* logits, long long ld_logits, const float* values, long long ld_values,
+                                  const long long* actions, const unsigned char* action_masks_or_null,
+                                  const int* branch_sizes, int num_branches, const float* old_neglogp,
+                                  const float* advantages, const float* old_values, const float* returns,
+                                  const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
+                                  long long ld_d_logits, float* d_values, long long ld_d_values, double* partials,
+                                  int minibatch, float e_clip, float critic_coef, float entropy_coef, int clip_value,
+                                  int use_smooth_clamp, void* stream) {
   using namespace rlg;
   if (minibatch <= 0 || num_branches <= 0 || num_branches > kMaxBranches)
     return static_cast<int>(hipErrorInvalidValue);
   if (mask_or_null && !mask_sum_or_null) return static_cast<int>(hipErrorInvalidValue);
+  if (ld_values <= 0 || ld_d_values <= 0) return static_cast<int>(hipErrorInvalidValue);
   DiscreteLossArgs p;
   p.off[0] = 0;
   for (int b = 0; b < num_branches; ++b) {
@@ -419,6 +423,7 @@ int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float*
   p.logits = logits;
   p.ld = ld_logits;
   p.values = values;
+  p.ld_values = ld_values;
   p.actions = actions;
   p.action_masks = action_masks_or_null;
   p.old_neglogp = old_neglogp;
@@ -429,10 +434,13 @@ int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float*
   p.mask_sum = mask_sum_or_null;
   p.d_logits = d_logits;
   p.d_values = d_values;
+  p.ld_d_logits = ld_d_logits;
+  p.ld_d_values = ld_d_values;
   p.partials = partials;
   p.mb = minibatch;
   p.nb = num_branches;
   p.n = p.off[num_branches];
+  if (ld_logits < p.n || ld_d_logits < p.n) return static_cast<int>(hipErrorInvalidValue);
   p.e_clip = e_clip;
   p.critic_coef = critic_coef;
   p.entropy_coef = entropy_coef;
@@ -441,6 +449,21 @@ int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float*
   hipLaunchKernelGGL(ppo_loss_discrete_kernel, dim3(rlg_ppo_loss_discrete_num_blocks(minibatch)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_ppo_loss_discrete(const float* logits, long long ld_logits, const float* values,
+                          const long long* actions, const unsigned char* action_masks_or_null,
+                          const int* branch_sizes, int num_branches, const float* old_neglogp,
+                          const float* advantages, const float* old_values, const float* returns,
+                          const float* mask_or_null, const float* mask_sum_or_null, float* d_logits,
+                          float* d_values, double* partials, int minibatch, float e_clip, float critic_coef,
+                          float entropy_coef, int clip_value, int use_smooth_clamp, void* stream) {
+  long long n = 0;
+  for (int b = 0; b < num_branches && b < rlg::kMaxBranches; ++b) n += branch_sizes[b];
+  return rlg_ppo_loss_discrete_strided(logits, ld_logits, values, 1, actions, action_masks_or_null, branch_sizes,
+                                       num_branches, old_neglogp, advantages, old_values, returns, mask_or_null,
+                                       mask_sum_or_null, d_logits, n, d_values, 1, partials, minibatch, e_clip,
+                                       critic_coef, entropy_coef, clip_value, use_smooth_clamp, stream);
 }
 
 int rlg_ppo_loss_finalize(const double* partials, int num_blocks, int actions_num, int minibatch,

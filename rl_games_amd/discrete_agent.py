@@ -8,14 +8,21 @@ Shares the rollout / GAE / dataset-preparation / optimiser path with `A2CAgent`;
     CategoricalMasked semantics (a2c_common.py:995-997,1224-1229; a2c_discrete.py:92-114);
   * the minibatch loss is the categorical one, a single fused HIP kernel
     (csrc/ppo_loss.hip `ppo_loss_discrete_kernel`) that emits d loss/d logits and d loss/d value;
-    the MLP backward runs through autograd (`torch.autograd.backward` on the two heads);
+  * the network around it runs on the fused chain kernels of the continuous hot path (chain_net.ChainNet: observation
+    normaliser + trunk + heads as one forward launch, one backward launch, MFMA weight gradients) - one chain over
+    [value | logits] behind a shared trunk, one chain per trunk with `separate: True` (ppo_cartpole.yaml:17) - where the
+    network has that form (plain Linear + ELU / ReLU / tanh trunks, widths that are multiples of 4, value_size 1);
+    anything else, or `fused_mlp: False`, keeps autograd around the loss kernel (`torch.autograd.backward` on the heads);
   * the lr schedule is stepped once per mini-epoch on the mean KL (a2c_common.py:1271-1278),
     whatever `schedule_type` says, and `train_epoch` returns the 10-tuple without bound losses.
 """
 import torch
 
+from torch import nn
+
 from . import ops
 from .agent import A2CAgent
+from .chain_net import ChainNet, arena_layout
 
 
 class DiscreteA2CAgent(A2CAgent):
@@ -45,6 +52,38 @@ class DiscreteA2CAgent(A2CAgent):
 
     def _supports_action_masks(self):
         return True
+
+    def _chain_heads(self):
+        """Head groups of the network, one per chain: [[value, logits...]] behind a shared trunk, [[logits...], [value]]
+        for separate actor / critic trunks."""
+        net = self.model.a2c_network
+        logits = list(net.logits) if net.is_multi_discrete else [net.logits]
+        return [logits, [net.value]] if net.is_separate_critic() else [[net.value] + logits]
+
+    def _arena_layout(self, config):
+        if not config.get('fused_mlp', True):
+            return None
+        net = self.model.a2c_network
+        rest = [p for p in self.model.parameters() if all(p is not q for q in net.parameters())]
+        return arena_layout(list(net.parameters()), self._chain_heads()) + rest
+
+    def _init_chains(self, config):
+        self._chains = None
+        net = self.model.a2c_network
+        if not config.get('fused_mlp', True):
+            return
+        try:
+            if self.value_size != 1 or not isinstance(net.value_act, nn.Identity):
+                raise NotImplementedError('one linear value column only')
+            if not getattr(net, 'plain_trunk', True):
+                raise NotImplementedError('plain Linear + activation trunks only')
+            rows = self.minibatch_size
+            groups = self._chain_heads()
+            trunks = [net.actor_mlp, net.critic_mlp] if net.is_separate_critic() else [net.actor_mlp]
+            self._chains = [ChainNet(t, g, self.optimizer, rows) for t, g in zip(trunks, groups)]
+        except NotImplementedError as e:
+            print(f'rl_games_amd: discrete network outside the fused chain kernels ({e}); using autograd')
+            self._chains = None
 
     def _alloc_loss_scratch(self, mb, dev):
         self._d_logits = torch.empty(mb, sum(self.branch_sizes), dtype=torch.float32, device=dev)
@@ -90,13 +129,32 @@ class DiscreteA2CAgent(A2CAgent):
         obs_batch = self._preproc_obs(input_dict['obs'])
         rnn_masks = input_dict.get('rnn_masks', None)
         opt.zero_grad()
-        logits, values = self.model.forward_heads({'is_train': True, 'obs': obs_batch})
-        mb, n = logits.shape
+        chains = self._chains if obs_batch.dtype == torch.float32 else None
+        if chains is not None:
+            # models.py:54-56 (norm_obs: training mode updates the statistics first), then each trunk + its heads as
+            # one launch that normalises on the way in
+            rms, eps = None, 1e-5
+            if self.normalize_input:
+                m = self.model.running_mean_std
+                if m.training:
+                    m.update(obs_batch)
+                rms, eps = (m.running_mean, m.running_var), m.epsilon
+            outs = [c.forward(obs_batch, rms, eps) for c in chains]
+            mb = obs_batch.shape[0]
+            if len(chains) == 1:                                   # [value | logits]
+                logits, values = outs[0][:, 1:], outs[0][:, 0]
+                d_logits, d_val = chains[0].d_heads[:mb, 1:], chains[0].d_heads[:mb, 0]
+            else:
+                logits, values = outs[0], outs[1][:, 0]
+                d_logits, d_val = chains[0].d_heads[:mb], chains[1].d_heads[:mb, 0]
+        else:
+            logits, values = self.model.forward_heads({'is_train': True, 'obs': obs_batch})
+            mb = logits.shape[0]
+            d_logits, d_val = self._d_logits[:mb], self._d_val[:mb]
         mask = mask_sum = None
         if rnn_masks is not None:
             mask = rnn_masks.reshape(-1).float().contiguous()
             mask_sum = mask.sum().reshape(1)
-        d_logits, d_val = self._d_logits[:mb], self._d_val[:mb]
         with torch.no_grad():
             lg = logits.detach()
             ops.ppo_loss_discrete(lg if lg.stride(1) == 1 else lg.contiguous(), values.detach().reshape(-1),
@@ -110,7 +168,11 @@ class DiscreteA2CAgent(A2CAgent):
                                   mask is not None, self.critic_coef if self.has_value_loss else 0.0,
                                   self.entropy_coef, 0.0, row,
                                   self._no_logstd, opt.kl_slot)
-        torch.autograd.backward([logits, values], [d_logits, d_val.view(mb, 1)])
+        if chains is not None:
+            for c in chains:
+                c.backward()
+        else:
+            torch.autograd.backward([logits, values], [d_logits, d_val.view(mb, 1)])
 
     def train_epoch(self):
         """a2c_common.py:1232-1289: (step_time, play_time, update_time, total_time, a_losses,

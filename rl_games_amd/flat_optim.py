@@ -75,12 +75,18 @@ class FlatArena:
     def span(self, first, last):
         """(params view, grads view) of the contiguous arena range covering parameters `first`
         .. `last` (which must be physically adjacent, in that order)."""
+        return self.span_of([first, last])
+
+    def span_of(self, params):
+        """(params view, grads view) of the contiguous arena range covering `params`, which must follow one another
+        physically in that order."""
         ids = {id(p): i for i, p in enumerate(self.params)}
-        o0, n0 = self.offsets[ids[id(first)]]
-        o1, n1 = self.offsets[ids[id(last)]]
-        if o1 != o0 + n0:
-            raise ValueError('parameters are not adjacent in the arena')
-        return self.flat_params[o0:o1 + n1], self.flat_grads[o0:o1 + n1]
+        spans = [self.offsets[ids[id(p)]] for p in params]
+        for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+            if o1 != o0 + n0:
+                raise ValueError('parameters are not adjacent in the arena')
+        start, end = spans[0][0], spans[-1][0] + spans[-1][1]
+        return self.flat_params[start:end], self.flat_grads[start:end]
 
 
 class FlatAdam(FlatArena):

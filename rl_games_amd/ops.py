@@ -447,15 +447,21 @@ def ppo_loss_discrete(logits, values, actions, old_neglogp, advantages, old_valu
         if tuple(action_masks.shape) != (mb, n):
             raise ValueError('action_masks must be [minibatch, sum(branch sizes)]')
         am = _need(action_masks, torch.uint8, 'action_masks')
+    # values / d_values / d_logits may be columns of wider rows (the fused chain's [value | logits] head matrix)
+    for name, t, shape in (('values', values, (mb,)), ('d_values', d_values, (mb,)), ('d_logits', d_logits, (mb, n))):
+        _lib.require_gpu(t, name)
+        if t.dtype != F32 or tuple(t.shape) != shape or (t.dim() == 2 and t.stride(1) != 1):
+            raise ValueError(f'{name}: fp32 {shape} with unit inner stride expected')
     arr = (ctypes.c_int * len(sizes))(*sizes)
-    _lib.check(lib.rlg_ppo_loss_discrete(
-        logits.data_ptr(), logits.stride(0), _need(values, F32, 'values'),
+    _lib.check(lib.rlg_ppo_loss_discrete_strided(
+        logits.data_ptr(), logits.stride(0), values.data_ptr(), max(values.stride(0), 1),
         _need(actions, torch.int64, 'actions'), am, arr, len(sizes), _need(old_neglogp, F32, 'old_neglogp'),
         _need(advantages, F32, 'advantages'), _need(old_values, F32, 'old_values'),
         _need(returns, F32, 'returns'), _opt(mask, F32, 'mask'), _opt(mask_sum, F32, 'mask_sum'),
-        _need(d_logits, F32, 'd_logits'), _need(d_values, F32, 'd_values'), _need(partials, F64, 'partials'),
+        d_logits.data_ptr(), d_logits.stride(0), d_values.data_ptr(), max(d_values.stride(0), 1),
+        _need(partials, F64, 'partials'),
         mb, float(np.float32(e_clip)), float(np.float32(critic_coef)), float(np.float32(entropy_coef)),
-        1 if clip_value else 0, _surrogate_kind(smooth), _stream(logits)), 'rlg_ppo_loss_discrete')
+        1 if clip_value else 0, _surrogate_kind(smooth), _stream(logits)), 'rlg_ppo_loss_discrete_strided')
 
 
 def ppo_loss_finalize(partials, num_blocks, actions_num, minibatch, masked, critic_coef,

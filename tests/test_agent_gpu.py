@@ -699,7 +699,7 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
 @pytest.mark.parametrize('state_dim,units,envs,mb', [(9, [32, 16], 64, 256), (24, [64, 32, 16], 64, 256),
                                                      (48, [256, 128, 64], 2048, 16384)])
 def test_central_value_chain_gradients_equal_autograd(state_dim, units, envs, mb):
-    """The central value network on the fused chain kernels (central_value._ValueChain: one forward launch, one backward
+    """The central value network on the fused chain kernels (chain_net.ChainNet: one forward launch, one backward
     launch, MFMA weight gradients where a layer's input width is a multiple of 4) against the autograd path it replaces
     (`fused_mlp: False`), same weights, same minibatch: values, loss, every gradient to 1e-5 of its scale, the state
     statistics bit for bit, and the parameters behind the optimiser step.  The 16,384-row case runs the split-bf16 chain

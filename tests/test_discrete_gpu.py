@@ -222,3 +222,81 @@ def test_multi_discrete_masked_train_epoch_runs():
     offs = [0, 3, 8]
     for b in range(3):                       # every sampled sub-action was allowed by its mask
         assert am.gather(1, (acts[:, b] + offs[b]).view(-1, 1)).all()
+
+
+def test_discrete_loss_kernel_reads_and_writes_columns_of_wider_rows():
+    """The strided entry point (values / d_values / d_logits as columns of a [value | logits] head matrix) gives the
+    bits of the contiguous launch."""
+    from rl_games_amd import ops
+    mb, sizes = 777, [3, 4]
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(5)
+    heads = (torch.randn(mb, 1 + n, generator=g) * 1.2).to(DEV)
+    acts = torch.stack([torch.randint(0, s, (mb,), generator=g) for s in sizes], 1).to(DEV)
+    f = lambda: torch.randn(mb, generator=g).to(DEV)
+    old_nlp, adv, old_v, ret = f().abs() + 1.0, f(), f(), f()
+    outs = []
+    for strided in (False, True):
+        if strided:
+            d_heads = torch.full((mb, 1 + n), 7.0, device=DEV)
+            lg, v, d_lg, d_v = heads[:, 1:], heads[:, 0], d_heads[:, 1:], d_heads[:, 0]
+        else:
+            lg, v = heads[:, 1:].contiguous(), heads[:, 0].contiguous()
+            d_lg, d_v = torch.empty(mb, n, device=DEV), torch.empty(mb, device=DEV)
+        partials = torch.empty(ops.ppo_loss_discrete_blocks(mb), ops.ppo_loss_partials_per_block(0),
+                               dtype=torch.float64, device=DEV)
+        ops.ppo_loss_discrete(lg, v, acts, old_nlp, adv, old_v, ret, d_lg, d_v, partials, 0.2, 1.0, 0.01, True, False,
+                              branch_sizes=sizes)
+        outs.append((d_lg.clone(), d_v.clone(), partials.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('layout', ['separate', 'shared', 'shared_multi_discrete', 'separate_tanh_wide'])
+def test_discrete_chain_gradients_equal_autograd(layout):
+    """The discrete agent's network on the fused chain kernels (chain_net.ChainNet: one forward and one backward launch
+    per trunk, MFMA weight gradients) against the autograd path it replaces (`fused_mlp: False`), same weights, same
+    minibatch: loss scalars, every gradient to 1e-5 of its scale, observation statistics bit for bit, and the parameters
+    behind the optimiser step."""
+    from rl_games_amd import configs
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    res = {}
+    for fused in (True, False):
+        params = configs.cartpole_discrete(num_actors=64, device=DEV, normalize_input=True, fused_mlp=fused,
+                                           minibatch_size=512, learning_rate=5e-4)
+        net = params['network']
+        net['separate'] = layout.startswith('separate')
+        if layout == 'shared_multi_discrete':
+            net['space'] = {'multi_discrete': None}
+            params['model']['name'] = 'multi_discrete_a2c'
+            params['config']['env_config'].update(discrete_actions=[3, 5, 2], obs_dim=12)
+        if layout == 'separate_tanh_wide':
+            net['mlp'].update(units=[128, 64, 32], activation='tanh')
+            params['config']['env_config'].update(obs_dim=20, discrete_actions=6)
+        torch.manual_seed(4)
+        agent = DiscreteA2CAgent('dchain', copy.deepcopy(params))
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        agent.set_eval()
+        with torch.no_grad():
+            batch = agent.play_steps()
+        agent.set_train()
+        agent.prepare_dataset(batch)
+        assert (agent._chains is not None) == fused
+        if fused:
+            assert len(agent._chains) == (2 if net['separate'] else 1)
+        out = agent.train_actor_critic(agent.dataset[0])
+        scalars = torch.stack([out[0], out[1], out[2], out[3]]).clone()
+        grads = {n: p.grad.clone() for n, p in agent.model.named_parameters()}
+        res[fused] = (scalars, grads, {n: p.detach().clone() for n, p in agent.model.named_parameters()},
+                      agent.model.running_mean_std.running_mean.clone(), agent.model.running_mean_std.count.clone())
+        if fused:
+            assert all(c.last_dw_path == 'mfma' for c in agent._chains)
+    a, b = res[True], res[False]
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-7), (a[0], b[0])
+    for n in a[1]:
+        scale = b[1][n].abs().max().item()
+        assert (a[1][n] - b[1][n]).abs().max().item() <= 1e-5 * scale + 1e-9, n
+        solid = b[1][n].abs() > 1e-3 * scale
+        assert torch.allclose(a[2][n][solid], b[2][n][solid], rtol=1e-4, atol=1e-6), n
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
