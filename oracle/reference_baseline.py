@@ -1,11 +1,11 @@
 """BASELINE INFRASTRUCTURE (never imported by rl_games_amd): the UNTOUCHED reference agent on the host's cores.
 
-bench.py's `cpu_baseline` leg (kind "reference") and tools/cpu_reference_baseline.py call this: it builds
+tools/cpu_reference_baseline.py calls this in the build container (the calibration of bench.py's "port" baseline): it builds
 rl_games.algos_torch.a2c_continuous.A2CAgent through the reference's own torch_runner.Runner (torch_runner.py:
 algo_factory, :217-226 torch_threads), `device: cpu`, on the same synthetic tensor env and the same parameters as the
 MI355X run, and times A2CAgent.train_epoch (a2c_common.py:1517-1584) with perf_counter - SURVEY.md 8(d).
-The reference comes from /root/reference where that exists, else from the archive oracle/stage_reference.py staged
-(tests/golden/ref_import.py decides); ReferenceUnavailable when neither is there."""
+The reference comes from /root/reference (tests/golden/ref_import.py); ReferenceUnavailable where that does not exist
+(the GPU box: the reference is Python and does not travel - bench.py times the oracle's port there)."""
 import copy
 import os
 import sys
@@ -24,7 +24,7 @@ def _ref_import():
 
 def available():
     ri = _ref_import()
-    return os.path.isdir(os.path.join(ri.REFERENCE, 'rl_games')) or os.path.isfile(ri.STAGED)
+    return os.path.isdir(os.path.join(ri.REFERENCE, 'rl_games'))
 
 
 def reference_agent(params, env):

@@ -51,8 +51,7 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'liboracle' not in src and 'ppo_oracle' not in src, f
-                # ... nor the staged reference (oracle/_ref/rl_games_ref.zip: the CPU baseline bench.py times and the
-                # caller of tests/test_runner_gpu.py) or the reference package itself
+                # ... nor the reference package itself or the test helper that makes it importable in the build container
                 assert 'rl_games_ref' not in src and 'ref_import' not in src and 'oracle/_ref' not in src, f
                 assert not re.search(r'^\s*(from|import)\s+rl_games(\.|\s|$)', src, flags=re.M), f
 

@@ -1,9 +1,10 @@
 """The REAL reference `Runner` drives this repository's agents ON THE DEVICE (SURVEY.md 8(b) seam 1;
 rl_games/torch_runner.py:117-120 register_builder, :233-315 run_train -> agent.train(), :342 run).
 
-The reference is imported through tests/golden/ref_import.py - on the GPU box from the archive
-oracle/stage_reference.py staged (byte-identical files, zipimport); nothing here reads /root/reference at run time
-unless it happens to exist.  The reference is the CALLER in these tests, never the thing under test: every kernel that
+The reference is imported through tests/golden/ref_import.py and is Python: it does not travel to the GPU box, so
+these tests run only on a machine that has BOTH an MI355X and the reference checkout (they skip on the driver's GPU
+box; rounds 4 - 5 ran them there from a staged copy of the reference, which round 6 removed - the record of those
+runs is profiles/r5_INDEX.md).  The reference is the CALLER in these tests, never the thing under test: every kernel that
 runs belongs to rl_games_amd (the A2CAgent asserts its engine / MFMA weight-gradient path)."""
 import copy
 import os
@@ -24,7 +25,7 @@ def _reference():
     import ref_import
     try:
         ref_import.enable()
-    except ref_import.ReferenceUnavailable as e:            # (a tree without build(): the archive was never staged)
+    except ref_import.ReferenceUnavailable as e:            # (the GPU box: no reference checkout)
         pytest.skip(str(e))
     from rl_games.torch_runner import Runner
     return Runner

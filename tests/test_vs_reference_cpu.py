@@ -398,37 +398,6 @@ def test_reference_runner_plugin_seam_constructs_our_agents():
             runner.algo_factory.create(runner.algo_name, base_name='run', params=runner.params)
 
 
-def test_staged_reference_archive_is_the_reference_byte_for_byte():
-    """oracle/stage_reference.py (run by __graft_entry__.build()): the archive bench.py's cpu_baseline leg imports on the
-    GPU box holds exactly the reference's own rl_games/**/*.py, and the reference agent it yields is the class from that
-    archive."""
-    import hashlib
-    import json
-    import os
-    import subprocess
-    import sys
-    import zipfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([sys.executable, os.path.join(root, 'oracle', 'stage_reference.py')], check=True, capture_output=True)
-    arc = os.path.join(root, 'oracle', '_ref', 'rl_games_ref.zip')
-    manifest = json.load(open(os.path.join(root, 'oracle', '_ref', 'MANIFEST.json')))
-    with zipfile.ZipFile(arc) as z:
-        names = sorted(z.namelist())
-        assert names == sorted(manifest['files']) and len(names) > 50
-        for n in names:
-            data = z.read(n)
-            assert hashlib.sha256(data).hexdigest() == manifest['files'][n]
-            assert data == open(os.path.join(ref_import.REFERENCE, n), 'rb').read(), n
-    # a process that cannot see the checkout imports the archive
-    code = ("import sys; sys.path.insert(0, %r); from oracle import reference_baseline as RB; assert RB.available(); "
-            "ri = RB._ref_import(); ri.enable(); import rl_games.algos_torch.a2c_continuous as m; "
-            "print(ri.source(), m.__file__)" % root)
-    res = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, RLG_REFERENCE='/nonexistent'),
-                         capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-2000:]
-    assert 'staged archive' in res.stdout and 'rl_games_ref.zip' in res.stdout
-
-
 # ----------------------------------------------------------------------------- value_size > 1 torch forms (round 5)
 
 @pytest.mark.parametrize('V,masked,smooth,bound', [(1, False, False, 'bound'), (2, False, False, 'bound'), (3, True, False, 'regularisation'),
