@@ -139,7 +139,7 @@ def cpu_baseline(workload, sample_envs):
                     rows[label] = run(threads)
         finally:
             torch.set_num_threads(prev)
-    d = rows['default_threads']
+    d = max(rows.values(), key=lambda r: r['value'])           # the faster row is the baseline (the conservative choice)
     return {
         'value': d['value'], 'unit': 'env-steps/s', 'cores': d['threads'], 'kind': 'port',
         'what': "oracle/ppo_epoch_oracle.OracleAgent - the oracle's CPU restatement of rl_games "
@@ -148,7 +148,8 @@ def cpu_baseline(workload, sample_envs):
                   f'model / minibatch / mini-epochs, 1 warm-up + <= 2 timed epochs per row, host cores {cores}',
         'seconds_per_epoch': d['seconds_per_epoch'], 'rows': rows, 'host_cores': cores,
         'torch_threads_default_rule': 'min(4, cores) (torch_runner.py:217-226)',
-        'rows_note': "'all_cores' uses min(host cores, 16) torch threads (more threads run this workload slower)",
+        'rows_note': "`value` is the faster of the two rows; 'default_threads' is what the reference's Runner would use, "
+                     "'all_cores' uses min(host cores, 16) torch threads (more threads run this workload slower)",
         'calibration': 'the untouched reference agent ran at 0.84 x this port\'s rate at the default thread count in the '
                        'build container (profiles/cpu_baseline_calibration.json) and at 0.90 x on a GPU-box host (round 5, '
                        'BENCH_r05.json port_cross_check); the reference, being Python, is not shipped to the GPU box',
