@@ -365,31 +365,47 @@ def main():
     mfma = None
     eng = getattr(agent, '_engine', None)
     if eng is not None and getattr(eng, 'last_dw_jobs', None):
-        jobs, plan = eng.last_dw_jobs
+        jobs, plan, mx = eng.last_dw_jobs
+        kw = {}
+        if mx is not None:
+            # the fp16 form scales each operand by its largest magnitude: the slots were zeroed behind the step's own launch,
+            # so they are filled again from the operands as the last step left them, and kept across the repetitions
+            slots, xs, dzs = mx
+            for (dz, x, _), xi, di in zip(jobs, xs, dzs):
+                slots[xi] = x.abs().max()
+                slots[di] = dz.abs().max()
+            kw = dict(maxima=mx, reset_maxima=False)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
-            plan.launch(jobs)
+            plan.launch(jobs, **kw)
         reps = 20
         ev0.record()
         for _ in range(reps):
-            plan.launch(jobs)
+            plan.launch(jobs, **kw)
         ev1.record()
         torch.cuda.synchronize()
+        if mx is not None:
+            mx[0][:16].zero_()
         us = ev0.elapsed_time(ev1) * 1e3 / reps
         rows = jobs[0][0].shape[0]
         flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
         split = os.environ.get('RLG_DW_BF16', '1') != '0'
+        f16 = split and mx is not None and os.environ.get('RLG_DW_F16', '1') != '0'
         useful = flops / us / 1e6                               # fp32 products per second, as TFLOP/s
         if split:
-            # six bf16 plane products per fp32 product (csrc/mlp_dw.hip): priced against the bf16 peak
-            mfma = {'kernel': 'rlg::mlp_dw_bf16x6_kernel + rlg::mlp_dw_finalize_kernel (all weight gradients, one '
-                              'launch pair; fp32 products as six exact bf16 plane products)',
-                    'bound': 'mfma', 'achieved': 6.0 * useful, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': 6.0 * useful / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
-                    'algorithmic_flops_per_launch': 6.0 * flops, 'avg_launch_us': us, 'launches': reps,
+            # three fp16 (or six bf16) plane products per fp32 product (csrc/mlp_dw.hip): priced against the peak of the
+            # instruction that issues them - v_mfma_f32_16x16x32_f16 and _bf16 have the same dense rate
+            k = 3.0 if f16 else 6.0
+            name = 'rlg::mlp_dw_f16x3_kernel' if f16 else 'rlg::mlp_dw_bf16x6_kernel'
+            form = ('three exact fp16 plane products, operands scaled by the power of two their largest magnitude asks for'
+                    if f16 else 'six exact bf16 plane products')
+            mfma = {'kernel': f'{name} + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch pair; fp32 products as {form})',
+                    'bound': 'mfma', 'achieved': k * useful, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': k * useful / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'algorithmic_flops_per_launch': k * flops, 'avg_launch_us': us, 'launches': reps,
                     'fp32_equivalent_tflops': useful, 'fp32_equivalent_over_fp32_mfma_peak': useful / FP32_MFMA_PEAK_TFLOPS,
-                    'note': 'issued flops = 6 x useful 2*rows*sum(No*Mi) (tile padding not counted) against the dense '
-                            'bf16 MFMA peak (v_mfma_f32_16x16x32_bf16, MI355X_MICROARCH.md); fp32_equivalent_* = the '
+                    'note': f'issued flops = {int(k)} x useful 2*rows*sum(No*Mi) (tile padding not counted) against the dense '
+                            '16-bit MFMA peak (v_mfma_f32_16x16x32_f16 / _bf16, MI355X_MICROARCH.md); fp32_equivalent_* = the '
                             'useful fp32 products against the fp32 MFMA peak (157.3) that RLG_DW_BF16=0 would be '
                             'priced on; timed after the timed region'}
         else:
@@ -435,48 +451,58 @@ def main():
                 'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
                           'timed region (= rocprofv3 --kernel-trace begin/end); exact fp32 products on '
                           'v_mfma_f32_16x16x4_f32, useful flops 2*rows*sum(in*out), tile padding not counted'}
+            kp, ptype = ops.chain_split_form()
+            pwords = {3: 'three', 6: 'six'}[kp]
+            insn = f'v_mfma_f32_16x16x32_{"f16" if ptype == "fp16" else "bf16"}'
             if key in ('roofline_fwd', 'roofline_fwd_infer') and eng.chain.split_products(rows, 0):
                 pad = sum(-(-o // 16) * 16 * -(-i // 32) * 32 for i, o in zip(ins, outs))
-                issued = 6 * 2.0 * rows * pad / us / 1e6
+                issued = kp * 2.0 * rows * pad / us / 1e6
                 chain_roof[key].update({
                     'kernel': 'rlg::mlp_chain_fwd_bx_kernel (' + ('training forward: statistics fold + normalise + every layer '
                               '+ heads, activations written' if key == 'roofline_fwd' else 'rollout inference forward') +
-                              '; split-bf16 products on pre-split weight planes)',
-                    # priced on the unit the kernel issues on: 6 x padded-tile flops against the dense bf16 MFMA peak
+                              f'; split-{ptype} products on pre-split weight planes)',
+                    # priced on the unit the kernel issues on: k x padded-tile flops against the dense 16-bit MFMA peak
                     'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'frac': issued / BF16_MFMA_PEAK_TFLOPS,
-                    'algorithmic_flops_per_launch': 6 * 2.0 * rows * pad,
+                    'algorithmic_flops_per_launch': kp * 2.0 * rows * pad, 'plane_products': kp,
                     'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': tf / FP32_MFMA_PEAK_TFLOPS,
                     'issued_tflops_bf16': issued, 'issued_frac_of_bf16_peak': issued / BF16_MFMA_PEAK_TFLOPS,
                     'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
                               'timed region (= rocprofv3 --kernel-trace begin/end; the plane-pack launch in front of it '
-                              'is not included); six exact bf16 plane products per fp32 product on '
-                              'v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx_fwd.hip); achieved / frac = the ISSUED flops - '
-                              '6 x the padded-tile flops - against the dense bf16 MFMA peak (the unit the kernel issues '
-                              'on); fp32_equivalent_* = useful fp32 flops 2*rows*sum(in*out) against the fp32 MFMA peak'})
+                              f'is not included); {pwords} exact {ptype} plane products per fp32 product on '
+                              f'{insn} (csrc/mlp_chain_bx_fwd.hip); achieved / frac = the ISSUED flops - '
+                              f'{kp} x the padded-tile flops - against the dense 16-bit MFMA peak (the unit the kernel issues '
+                              'on; fp16 and bf16 share it); fp32_equivalent_* = useful fp32 flops 2*rows*sum(in*out) against '
+                              'the fp32 MFMA peak'})
             if key == 'roofline_bwd' and eng.chain.split_products(rows, 1):
                 # the split-bf16 kernel: fp32-equivalent flops against the fp32 peak (comparable with the other rows)
                 # and what it ISSUES - six bf16 plane products per product over 16 x 32 padded tiles - on the bf16 peak
                 pad = sum(-(-i // 16) * 16 * -(-o // 32) * 32 for i, o in zip(ins[1:], outs[1:]))
-                issued = 6 * 2.0 * rows * pad / us / 1e6
+                issued = kp * 2.0 * rows * pad / us / 1e6
                 chain_roof[key].update({
-                    'kernel': 'rlg::mlp_chain_bwd_bx_kernel (PPO loss tile + dX chain on split-bf16 products + activation '
-                              'backward + bias partials; weight planes packed by the forward launch)',
+                    'kernel': f'rlg::mlp_chain_bwd_bx_kernel (PPO loss tile + dX chain on split-{ptype} products + activation '
+                              'backward + bias partials; weight planes written by the optimiser launch)',
                     'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'frac': issued / BF16_MFMA_PEAK_TFLOPS,
-                    'algorithmic_flops_per_launch': 6 * 2.0 * rows * pad,
+                    'algorithmic_flops_per_launch': kp * 2.0 * rows * pad, 'plane_products': kp,
                     'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': tf / FP32_MFMA_PEAK_TFLOPS,
                     'issued_tflops_bf16': issued, 'issued_frac_of_bf16_peak': issued / BF16_MFMA_PEAK_TFLOPS,
                     'timing': 'HIP start/stop events bound to every dispatch of this kernel in one eager epoch after the '
-                              'timed region (= rocprofv3 --kernel-trace begin/end); six exact bf16 plane products per fp32 '
-                              'product on v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bx.hip); achieved / frac = the ISSUED '
-                              'flops - 6 x the padded-tile flops - against the dense bf16 MFMA peak; fp32_equivalent_* = '
+                              f'timed region (= rocprofv3 --kernel-trace begin/end); {pwords} exact {ptype} plane products per fp32 '
+                              f'product on {insn} (csrc/mlp_chain_bx.hip); achieved / frac = the ISSUED '
+                              f'flops - {kp} x the padded-tile flops - against the dense 16-bit MFMA peak; fp32_equivalent_* = '
                               'useful fp32 flops 2*rows*sum(in*out) against the fp32 MFMA peak'})
 
     # what arithmetic the forward / backward chain launches of the timed region ran on
     chain_products = None
     if eng is not None and getattr(eng, 'chain', None) is not None:
         mbr = global_mb // world
-        form = {True: 'split-bf16 (6 exact bf16 plane products per fp32 product on v_mfma_f32_16x16x32_bf16, fp32 '
-                      'accumulation; dropped terms <= 3*2^-24 |x||w|)', False: 'exact fp32 (v_mfma_f32_16x16x4_f32)'}
+        from rl_games_amd import ops as _ops
+        kp, ptype = _ops.chain_split_form()
+        form = {True: (f'split-{ptype} ({kp} exact {ptype} plane products per fp32 product on '
+                       f'v_mfma_f32_16x16x32_{"f16" if ptype == "fp16" else "bf16"}, fp32 accumulation; dropped terms and plane '
+                       'rounding <= 3*2^-24 |x||w|' + ('; operands scaled by powers of two: rows of raw inputs and of '
+                       'gradient tiles by their own maxima, weights / hidden activations / normalised observations by fixed ones)'
+                       if ptype == 'fp16' else ')')),
+                False: 'exact fp32 (v_mfma_f32_16x16x4_f32)'}
         def launch_form(rows, direction):
             text = form[bool(eng.chain.split_products(rows, direction))]
             if eng.chain.lean_used(rows, direction):
@@ -489,9 +515,9 @@ def main():
     for key in ('roofline_fwd', 'roofline_fwd_infer', 'roofline_bwd'):
         r = chain_roof.get(key)
         if r is not None and 'issued_tflops_bf16' in r:
-            # the scheme's own ceiling: six bf16 products per useful fp32 product
-            r['split_ceiling_tflops'] = BF16_MFMA_PEAK_TFLOPS / 6.0
-            r['split_ceiling_frac'] = r['fp32_equivalent_tflops'] / (BF16_MFMA_PEAK_TFLOPS / 6.0)
+            # the scheme's own ceiling: k 16-bit plane products per useful fp32 product
+            r['split_ceiling_tflops'] = BF16_MFMA_PEAK_TFLOPS / r['plane_products']
+            r['split_ceiling_frac'] = r['fp32_equivalent_tflops'] / (BF16_MFMA_PEAK_TFLOPS / r['plane_products'])
 
     traffic, traffic_note = None, 'no rocprofv3 --pmc record for this workload'
     try:
@@ -523,9 +549,7 @@ def main():
                 'mlp': 'fused chain kernels' if (eng is not None and getattr(eng, 'chain', None) is not None)
                        else 'per-layer engine',
                 'chain_products': chain_products,
-                'weight_gradient_products': ('split-bf16 (six exact bf16 plane products per fp32 product, fp32 '
-                                             'accumulation; as accurate against fp64 as exact fp32 products)'
-                                             if os.environ.get('RLG_DW_BF16', '1') != '0' else 'exact fp32'),
+                'weight_gradient_products': (mfma['kernel'].split(' ')[0] if mfma else None),
             },
             'roofline': {
                 'kernel': f'rlg::gae_envmajor_kernel<{horizon},false> (GAE + returns + advantages + fp64 moments)',

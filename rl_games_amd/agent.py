@@ -1693,6 +1693,7 @@ class A2CAgent:
                                    f'Raise native_allreduce_timeout_s / RLG_IPC_TIMEOUT_S for legitimately long rank '
                                    f'skews, or set native_allreduce: False to use RCCL.')
         self._eager_epochs += 0 if use_graphs else 1
+        self._check_split_range()
         if device_schedule:
             # one host read per epoch: [lr the last minibatch was stepped with, lr for the next one]
             used, nxt = self.optimizer.last_and_next_lr()
@@ -1706,6 +1707,24 @@ class A2CAgent:
         total_time = update_time_end - play_time_start
         return (batch_dict['step_time'], play_time, update_time, total_time, a_losses, c_losses, b_losses,
                 entropies, kls, last_lr, lr_mul)
+
+    def _check_split_range(self):
+        """Split-fp16 chain launches (csrc/bx_form.hpp) scale hidden activations by a FIXED power of two: an activation of
+        4,094 or more becomes Inf in its plane and NaN in everything computed from it.  One host read per epoch of the
+        largest magnitude the launches have seen, so that the run ends with the reason instead of with NaN losses."""
+        chain = getattr(self._engine, 'chain', None) if self._engine is not None else None
+        if chain is None or ops.chain_split_form()[1] != 'fp16':
+            return
+        seen = chain.largest_inputs_ever()
+        if seen is None:
+            return
+        limit = 65504.0 / 16.0
+        for layer, m in enumerate(seen[1:], start=1):
+            if not m < limit:
+                raise RuntimeError(
+                    f'hidden activations of layer {layer - 1} reached {m:.4g}: beyond the range of the split-fp16 chain '
+                    f'kernels (|h| < {limit:.0f}); the launches behind it produced non-finite values.  Run with '
+                    f'RLG_CHAIN_BX=0 (exact fp32 products) for a network with activations of this size.')
 
     # ================================================================== multi-GPU stats
     def _stats_sync_modules(self):

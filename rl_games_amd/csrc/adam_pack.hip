@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
         for (int r = 0; r < 4; ++r) {
           const int o = o0 + r;
           if (o < O) {
-            unsigned pl[3][2];
-            split4_planes(pn[r], pl);
+            unsigned pl[kBxPlanes][2];
+            bx_split4(pn[r], kBxScaleW, pl);
             unsigned char* dst = ap.planes + ap.fwd_off[L] + (static_cast<long long>(o >> 4) * KC + c) * kBxChunk +
                                  ((o & 15) + 16 * q) * 16 + half * 8;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
+            for (int p = 0; p < kBxPlanes; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
           }
         }
       }
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs ap) {
         for (int e = 0; e < 4; ++e) {
           const int i = i0 + e;
           const f32x4 col = {pn[0][e], pn[1][e], pn[2][e], pn[3][e]};
-          unsigned pl[3][2];
-          split4_planes(col, pl);
+          unsigned pl[kBxPlanes][2];
+          bx_split4(col, kBxScaleW, pl);
           unsigned char* dst = ap.planes + ap.bwd_off[L] + (static_cast<long long>(i >> 4) * KC + c) * kBxChunk +
                                ((i & 15) + 16 * q) * 16 + half * 8;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
+          for (int p = 0; p < kBxPlanes; ++p) ap_store8(dst + p * kBxFrag, pl[p]);
         }
       }
     }

@@ -153,10 +153,42 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
   }
 
   // ---- prologue: d heads tile -> planes in LDS -----------------------------------------------------
+  // scales of the rows (lane & 15 of every row group) of the tile the current step reads (fp16 form: from each row's
+  // largest magnitude; 1 in the bf16 form)
+  float scale_in[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) scale_in[g] = 1.0f;
   {
     const int w = a.layer[num_layers - 1].out;
     const int KC0 = (w + 31) >> 5;
     const bool xv = vec4_ok(a.x, a.ldx);
+    float scale_mine = 1.0f;                    // of row (lane & 15) of row group `wave`: W == G, a wave splits ITS group's rows
+    float* row_scales = reinterpret_cast<float*>(ldsb + a.bx_scales_off);
+    if (RLG_BX_F16) {
+      static_assert(W == G, "the prologue deals row group g to wave g");
+      float mine = 0.0f;
+      const long long row = row0 + wave * 16 + (lane & 15);
+      if (row < n_rows) {
+        for (int c = 0; c < KC0; ++c) {
+          const int f = c * 32 + q4;
+          if (via_lds) {
+            const float* d = reinterpret_cast<const float*>(ldsb + a.bx_handoff_off) + (wave * 16 + (lane & 15)) * a.bx_handoff_ld;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (f + e < w) mine = __builtin_fmaxf(mine, bx_finite_abs(d[f + e]));
+              if (f + 16 + e < w) mine = __builtin_fmaxf(mine, bx_finite_abs(d[f + 16 + e]));
+            }
+          } else {
+            const f32x4 lo = load_row4(a.x, a.ldx, row, f, w, xv), hi = load_row4(a.x, a.ldx, row, f + 16, w, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine = __builtin_fmaxf(mine, __builtin_fmaxf(bx_finite_abs(lo[e]), bx_finite_abs(hi[e])));
+          }
+        }
+      }
+      scale_mine = bx_row_scale(mine);
+      if (lane < 16) row_scales[wave * 16 + lane] = scale_mine;
+      bx_publish_max(a.amax, kBxAmaxDz + num_layers - 1, mine, false);
+    }
     for (int u = wave; u < KC0 * G; u += W) {
       const int c = u / G;
       const int g = u - c * G;
@@ -177,12 +209,16 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
         }
       }
       const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      u32x4 plane[3];
-      dw_split8(x, plane);
+      u32x4 plane[kBxPlanes];
+      bx_split8(x, scale_mine, plane);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(tile_a + (u * 3 + p) * kBxFrag + lane * 16) = plane[p];
+      for (int p = 0; p < kBxPlanes; ++p) *reinterpret_cast<u32x4*>(tile_a + (u * kBxPlanes + p) * kBxFrag + lane * 16) = plane[p];
     }
     __syncthreads();
+    if (RLG_BX_F16) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) scale_in[g] = row_scales[g * 16 + (lane & 15)];
+    }
   }
   chain_stamp(a.dbg, wave, stamp);                                   // prologue + barrier
 
@@ -204,11 +240,22 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     const unsigned d_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(p_lddz) + q4) * 4);
     const unsigned d_group = static_cast<unsigned>(16 * static_cast<int>(p_lddz) * 4);
 
+    // fp16 form: the accumulators hold (weight scale x input-tile scale) x the sums; the tile this step writes is scaled
+    // one step below the one it reads (a layer's dZ may exceed the dZ above it)
+    float inv[G], scale_out[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      inv[g] = 1.0f / (kBxScaleW * scale_in[g]);
+      scale_out[g] = scale_in[g] * kBxScaleStepBwd;
+    }
     // dZ = acc * act'(h): fp32 to global, planes to the output tile; returns the lane's 4 feature values (rows past
     // the end are exact zeros: their d heads are, and out-of-range H reads 0)
-    auto epilogue = [&](int ob, int g, const f32x4& accv, const f32x4& hval) -> f32x4 {
+    float dz_max = 0.0f;                        // largest |dZ_{L-1}| this lane produced (fp16 form)
+    auto epilogue = [&](int ob, int g, const f32x4& acc_scaled, const f32x4& hval) -> f32x4 {
       const int f = ob * 16 + q4;
       f32x4 v;
+      f32x4 accv = acc_scaled;
+      if constexpr (RLG_BX_F16) accv = acc_scaled * inv[g];
       if constexpr (PACT == kChElu) {
         // h > 0 ? 1 : h + 1  ==  min(h, 0) + 1, the same bits with one VALU instruction less per element
 #pragma unroll
@@ -216,13 +263,17 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
       } else {
         v = chain_act_grad4(accv, hval, p_act);
       }
+      if constexpr (RLG_BX_F16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz_max = __builtin_fmaxf(dz_max, bx_finite_abs(v[e]));
+      }
       if (!(kAbl & 2)) buf_store4(dr, f < width ? d_lane + static_cast<unsigned>(g) * d_group + static_cast<unsigned>(ob) * 64u : kOob, v);
       if (keep_tile) {
-        unsigned plane[3][2];
-        split4_planes(v, plane);
-        char* dst = tout + (((ob >> 1) * G + g) * 3) * kBxFrag + lane * 16 + (ob & 1) * 8;
+        unsigned plane[kBxPlanes][2];
+        bx_split4(v, scale_out[g], plane);
+        char* dst = tout + (((ob >> 1) * G + g) * kBxPlanes) * kBxFrag + lane * 16 + (ob & 1) * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * kBxFrag) = make_uint2(plane[p][0], plane[p][1]);
+        for (int p = 0; p < kBxPlanes; ++p) *reinterpret_cast<uint2*>(dst + p * kBxFrag) = make_uint2(plane[p][0], plane[p][1]);
       }
       return v;
     };
@@ -286,16 +337,19 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     };
     whole(std::integral_constant<int, 2>{}, first_ob, units2);
     whole(std::integral_constant<int, 1>{}, first_ob + 2 * units2, left);
+    if (RLG_BX_F16) bx_publish_max(a.amax, kBxAmaxDz + L - 1, dz_max, false);
     if (nb_w == 0) request_after(false);        // a wave without a block here still owes itself the next layer's first H
     chain_stamp(a.dbg, wave, stamp);                                 // per layer: units done
     // an odd number of blocks leaves half a chunk of the output tile unwritten: zero it (the weights there are zero,
     // but 0 x stale bits may be NaN)
     if (keep_tile && (NOB & 1)) {
-      for (int u = wave; u < G * 3; u += W)
-        *reinterpret_cast<uint2*>(tout + (((NOB >> 1) * G) * 3 + u) * kBxFrag + lane * 16 + 8) = make_uint2(0u, 0u);
+      for (int u = wave; u < G * kBxPlanes; u += W)
+        *reinterpret_cast<uint2*>(tout + (((NOB >> 1) * G) * kBxPlanes + u) * kBxFrag + lane * 16 + 8) = make_uint2(0u, 0u);
     }
     __syncthreads();
     chain_stamp(a.dbg, wave, stamp);                                 // barrier
+#pragma unroll
+    for (int g = 0; g < G; ++g) scale_in[g] = scale_out[g];
     char* t = tin;
     tin = tout;
     tout = t;
@@ -370,6 +424,10 @@ int chain_bx_launch_bwd(const ChainArgs& args, int G, int lds_bytes, hipStream_t
 // C ABI (declared in include/rlg_hip.h)
 // ---------------------------------------------------------------------------------
 extern "C" {
+
+/* plane products per fp32 product of the chain's split-product kernels: 3 = two fp16 planes per operand (round 6), 6 = three
+ * bf16 planes (a build with -DRLG_BX_F16=0) */
+int rlg_mlp_chain_split_products(void) { return rlg::kBxProducts; }
 
 long long rlg_mlp_chain_planes_bytes(int num_layers, const int* in_features, const int* out_features, int direction) {
   if (num_layers < 1 || num_layers > rlg::kChainMaxLayers || direction < 0 || direction > 2) return -1;

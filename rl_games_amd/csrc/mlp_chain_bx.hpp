@@ -3,14 +3,11 @@
 #pragma once
 
 #include "mlp_chain_common.hpp"
-#include "split_bf16.hpp"
 
 namespace rlg {
 
 constexpr int kBxW = 4;                  // waves per workgroup: one per SIMD (the tiles fill the LDS: one workgroup per
                                          // CU; eight waves on the same tile measured 1.7x SLOWER, 128 + 128 registers)
-constexpr int kBxFrag = 1024;            // bytes of one plane fragment: 64 lanes x 8 bf16
-constexpr int kBxChunk = 3 * kBxFrag;    // the three planes of one (block, chunk) / (chunk, row group)
 
 static inline int bx_kc(int K) { return (K + 31) >> 5; }
 static inline int bx_nb(int I) { return (I + 15) >> 4; }
@@ -31,7 +28,7 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
   if (nunits <= 0) return;
   const unsigned lane16 = static_cast<unsigned>(lane_id()) * 16u;
   const int block_stride = KC * kBxChunk;            // bytes between the fragments of consecutive blocks
-  u32x4 a0[NF][3], a1[NF][3], b0[NG][3], b1[NG][3];
+  u32x4 a0[NF][kBxPlanes], a1[NF][kBxPlanes], b0[NG][kBxPlanes], b1[NG][kBxPlanes];
   auto unit_off = [&](int j) -> int {
     const int jj = j < nunits ? j : nunits - 1;
     if (kAbl & 64) return static_cast<int>(layer_off);      // timing only: every A load from the same fragments
@@ -42,23 +39,23 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
     const int jj = j < nunits ? j : nunits - 1;
     return g_of(jj);
   };
-  auto load_a = [&](u32x4 (&av)[NF][3], int soff) {
+  auto load_a = [&](u32x4 (&av)[NF][kBxPlanes], int soff) {
     if ((kAbl & 256) && soff != static_cast<int>(layer_off)) return;       // timing only: no weight loads after the first
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < kBxPlanes; ++p)
         av[f][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, lane16 + static_cast<unsigned>(p * kBxFrag),
                                                                                   (kAbl & 64) ? soff : soff + f * block_stride, 0));
     }
   };
-  auto load_b = [&](u32x4 (&bv)[NG][3], int c, int g0) {
+  auto load_b = [&](u32x4 (&bv)[NG][kBxPlanes], int c, int g0) {
     if (kAbl & 128) return;                                  // timing only: no LDS reads
     const char* p = tile_lane + (c * G + g0) * kBxChunk;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bv[g][pl] = *reinterpret_cast<const u32x4*>(p + (g * 3 + pl) * kBxFrag);
+      for (int pl = 0; pl < kBxPlanes; ++pl) bv[g][pl] = *reinterpret_cast<const u32x4*>(p + (g * kBxPlanes + pl) * kBxFrag);
     }
   };
 
@@ -66,7 +63,7 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < kBxPlanes; ++pl) {
         b0[g][pl] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
         b1[g][pl] = b0[g][pl];
         asm volatile("" : "+v"(b0[g][pl]), "+v"(b1[g][pl]));
@@ -91,19 +88,15 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
   // the full rate (16.3 cycles per MFMA: the accumulator is forwarded inside the matrix core), a rotation through
   // many accumulators does not (21.7 cycles with 16 of them, profiles/r3_mfma_peak_probe.txt).
   // (a unit's first chunk starts from the constant 0 as SrcC: no accumulator is zeroed by hand)
-  auto mfmas = [&](auto first_tag, const u32x4 (&av)[NF][3], const u32x4 (&bv)[NG][3]) {
+  auto mfmas = [&](auto first_tag, const u32x4 (&av)[NF][kBxPlanes], const u32x4 (&bv)[NG][kBxPlanes]) {
     constexpr bool kFirst = decltype(first_tag)::value;
-    constexpr int kPa[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int kPb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[f][kPa[t]]),
-                                                             __builtin_bit_cast(bf16x8, bv[g][kPb[t]]),
-                                                             (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g], 0, 0, 0);
+        for (int t = 0; t < kBxProducts; ++t)
+          acc[f][g] = bx_mfma(av[f][kBxPa[t]], bv[g][kBxPb[t]], (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g]);
         if constexpr (kFirst) asm volatile("" : "+a"(acc[f][g]));      // accumulators live in AGPRs
       }
     }
@@ -119,16 +112,17 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
     mfmas(first_tag, kCur1 ? a1 : a0, kCur1 ? b1 : b0);
     if constexpr (kPf) {
 #pragma unroll
-      for (int i = 0; i < 3 * NF; ++i) {
+      for (int i = 0; i < kBxPlanes * NF; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 3 * NG; ++i) {
+      for (int i = 0; i < kBxPlanes * NG; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      if constexpr (6 * NF * NG - 3 * NF - 3 * NG > 0) __builtin_amdgcn_sched_group_barrier(0x008, 6 * NF * NG - 3 * NF - 3 * NG, 0);
+      if constexpr (kBxProducts * NF * NG - kBxPlanes * (NF + NG) > 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, kBxProducts * NF * NG - kBxPlanes * (NF + NG), 0);
     }
     RLG_PIN();
   };

@@ -34,37 +34,33 @@ __device__ __forceinline__ void bx_span(rsrc_t pr, unsigned layer_off, int KC, c
     const int ob = ob_first + (f < nb_valid ? f : nb_valid - 1);
     boff[f] = __builtin_amdgcn_readfirstlane(static_cast<int>(layer_off) + ob * KC * kBxChunk);
   }
-  u32x4 a0[NF][3], a1[NF][3], b0[G][3], b1[G][3];
-  auto load_a = [&](u32x4 (&av)[NF][3], int c) {
+  u32x4 a0[NF][kBxPlanes], a1[NF][kBxPlanes], b0[G][kBxPlanes], b1[G][kBxPlanes];
+  auto load_a = [&](u32x4 (&av)[NF][kBxPlanes], int c) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < kBxPlanes; ++p)
         av[f][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, lane16 + static_cast<unsigned>(p * kBxFrag),
                                                                                   boff[f] + c * kBxChunk, 0));
     }
   };
-  auto load_b = [&](u32x4 (&bv)[G][3], int c) {
+  auto load_b = [&](u32x4 (&bv)[G][kBxPlanes], int c) {
     const char* p = tile_lane + c * G * kBxChunk;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bv[g][pl] = *reinterpret_cast<const u32x4*>(p + (g * 3 + pl) * kBxFrag);
+      for (int pl = 0; pl < kBxPlanes; ++pl) bv[g][pl] = *reinterpret_cast<const u32x4*>(p + (g * kBxPlanes + pl) * kBxFrag);
     }
   };
-  auto mfmas = [&](auto first_tag, const u32x4 (&av)[NF][3], const u32x4 (&bv)[G][3]) {
+  auto mfmas = [&](auto first_tag, const u32x4 (&av)[NF][kBxPlanes], const u32x4 (&bv)[G][kBxPlanes]) {
     constexpr bool kFirst = decltype(first_tag)::value;
-    constexpr int kPa[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int kPb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-          acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[f][kPa[t]]),
-                                                             __builtin_bit_cast(bf16x8, bv[g][kPb[t]]),
-                                                             (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g], 0, 0, 0);
+        for (int t = 0; t < kBxProducts; ++t)
+          acc[f][g] = bx_mfma(av[f][kBxPa[t]], bv[g][kBxPb[t]], (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g]);
         asm volatile("" : "+a"(acc[f][g]));      // accumulators live in AGPRs
       }
     }
@@ -79,16 +75,17 @@ __device__ __forceinline__ void bx_span(rsrc_t pr, unsigned layer_off, int KC, c
     mfmas(first_tag, kCur1 ? a1 : a0, kCur1 ? b1 : b0);
     if constexpr (kPf) {
 #pragma unroll
-      for (int i = 0; i < 3 * NF; ++i) {
+      for (int i = 0; i < kBxPlanes * NF; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 3 * G; ++i) {
+      for (int i = 0; i < kBxPlanes * G; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      if constexpr (6 * NF * G - 3 * NF - 3 * G > 0) __builtin_amdgcn_sched_group_barrier(0x008, 6 * NF * G - 3 * NF - 3 * G, 0);
+      if constexpr (kBxProducts * NF * G - kBxPlanes * (NF + G) > 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, kBxProducts * NF * G - kBxPlanes * (NF + G), 0);
     }
     RLG_PIN();
   };
@@ -137,6 +134,10 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
   int stamp = 0;
   chain_stamp(a.dbg, wave, stamp);
 
+  // scales of the rows (lane & 15 of every row group) of the tile the current layer reads (fp16 form; 1 in the bf16 form)
+  float scale_in[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) scale_in[g] = kBxScaleObsNorm;
   // ---- prologue: observation tile -> planes in LDS, normalised on the way ------------------------------------------
   {
     const int in0 = a.layer[0].in;
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         }
       }
     };
-    auto put_frags = [&](int u0) {
+    float in_max = 0.0f;
+    auto put_frags = [&](int u0, float scale) {
 #pragma unroll
       for (int k = 0; k < kProBatch; ++k) {
         const int u = u0 + k * W;
@@ -205,10 +207,14 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
             }
           }
           const float x[8] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
-          u32x4 plane[3];
-          dw_split8(x, plane);
+          if constexpr (RLG_BX_F16) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(t0 + (u * 3 + p) * kBxFrag + lane * 16) = plane[p];
+            for (int e = 0; e < 8; ++e) in_max = __builtin_fmaxf(in_max, bx_finite_abs(x[e]));
+          }
+          u32x4 plane[kBxPlanes];
+          bx_split8(x, scale, plane);
+#pragma unroll
+          for (int p = 0; p < kBxPlanes; ++p) *reinterpret_cast<u32x4*>(t0 + (u * kBxPlanes + p) * kBxFrag + lane * 16) = plane[p];
         }
       }
     };
@@ -217,12 +223,35 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       chain_norm_stats<W>(a, stats, in0, in0p);
       __syncthreads();
     }
-    put_frags(wave);
+    float scale_mine = kBxScaleObsNorm;         // of row (lane & 15) of row group `wave`: W == G, a wave splits ITS group's rows
+    if (RLG_BX_F16 && !norm) {
+      // raw observations have no bound: every row gets its scale from its largest magnitude (one more pass over the
+      // rows, which the loads behind it find in the cache)
+      static_assert(W == G, "the prologue deals row group g to wave g");
+      float mine = 0.0f;
+      const long long row = row0 + wave * 16 + (lane & 15);
+      if (row < n_rows) {
+        for (int c = 0; c < KC0; ++c) {
+          const f32x4 lo = load_row4(a.x, a.ldx, row, c * 32 + q4, in0, xv), hi = load_row4(a.x, a.ldx, row, c * 32 + 16 + q4, in0, xv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mine = __builtin_fmaxf(mine, __builtin_fmaxf(bx_finite_abs(lo[e]), bx_finite_abs(hi[e])));
+        }
+      }
+      scale_mine = bx_row_scale(mine);
+      if (lane < 16) stats[wave * 16 + lane] = scale_mine;          // (the normaliser scratch is free without a normaliser)
+    }
+    put_frags(wave, scale_mine);
     for (int u0 = wave + W * kProBatch; u0 < nfrag; u0 += W * kProBatch) {
       load_frags(u0);
-      put_frags(u0);
+      put_frags(u0, scale_mine);
     }
+    if (RLG_BX_F16) bx_publish_max(a.amax, kBxAmaxX + 0, in_max, true);
     __syncthreads();
+    if (RLG_BX_F16 && !norm) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) scale_in[g] = stats[g * 16 + (lane & 15)];
+      __syncthreads();                          // (the scratch shares its bytes with a later tile)
+    }
   }
   chain_stamp(a.dbg, wave, stamp);                                   // prologue + barrier
 
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
 
     // bias + activation of a fragment of layer `layer`: fp32 to global memory (training / heads), planes to `dst_tile`
     // at chunk (ob >> 1) - chunk_base.  Padded features come out as act(0 + 0) = 0.
-    auto make_epilogue = [&](int layer, char* dst_tile, int chunk_base) {
+    auto make_epilogue = [&](int layer, char* dst_tile, int chunk_base, const float (&in_scale)[G], float* out_max) {
       const int width = pin_s(a.layer[layer].out), act = pin_s(a.layer[layer].act);
       float* ph = pin_s(a.layer[layer].h);
       const long long ld = pin_s(a.layer[layer].ldh);
@@ -251,9 +280,20 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(ld) * 4);
       // (rows of 4-float groups at 16-byte aligned addresses: one store per fragment; else - the 22-wide head - four)
       const bool h_fast = pin_s(static_cast<int>(h_on && vec4_ok(ph, ld) && (width & 3) == 0)) != 0;
+      // the accumulators hold (weight scale x input-tile scale) x the sums: un-scaled by a power of two on the way to the bias
+      float inv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) inv[g] = 1.0f / (kBxScaleW * in_scale[g]);
       return [=](int ob, int g, const f32x4& accv, const f32x4& bias) {
         const int f = ob * 16 + q4;
-        const f32x4 v = chain_act4<HACT>(accv + bias, act);
+        f32x4 z;
+        if constexpr (RLG_BX_F16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = __builtin_fmaf(accv[e], inv[g], bias[e]);
+        } else {
+          z = accv + bias;
+        }
+        const f32x4 v = chain_act4<HACT>(z, act);
         if (h_on) {
           const unsigned off = h_lane + static_cast<unsigned>(g) * h_group + static_cast<unsigned>(ob) * 64u;
           if (h_fast) {
@@ -264,11 +304,15 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
           }
         }
         if (dst_tile != nullptr) {
-          unsigned plane[3][2];
-          split4_planes(v, plane);
-          char* dst = dst_tile + ((((ob >> 1) - chunk_base) * G + g) * 3) * kBxFrag + lane * 16 + (ob & 1) * 8;
+          if constexpr (RLG_BX_F16) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * kBxFrag) = make_uint2(plane[p][0], plane[p][1]);
+            for (int e = 0; e < 4; ++e) *out_max = __builtin_fmaxf(*out_max, bx_finite_abs(v[e]));
+          }
+          unsigned plane[kBxPlanes][2];
+          bx_split4(v, kBxScaleH, plane);
+          char* dst = dst_tile + ((((ob >> 1) - chunk_base) * G + g) * kBxPlanes) * kBxFrag + lane * 16 + (ob & 1) * 8;
+#pragma unroll
+          for (int p = 0; p < kBxPlanes; ++p) *reinterpret_cast<uint2*>(dst + p * kBxFrag) = make_uint2(plane[p][0], plane[p][1]);
         }
       };
     };
@@ -287,13 +331,14 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       return pin_s(static_cast<int>(aligned16(a.layer[layer].bias) && (a.layer[layer].out & 3) == 0)) != 0;
     };
     // blocks [b0, b1) of layer L for all row groups: this wave's share, two blocks per unit, then one
+    float out_max = 0.0f;                   // largest |H_L| this lane produced (fp16 form)
     auto run_blocks = [&](int b0, int b1, char* dst_tile, int chunk_base) {
       const int nb = b1 - b0;
       const int nb_w = wave_blocks(nb), first_ob = b0 + wave_first(nb);
       const int units2 = nb_w >> 1, left = nb_w & 1;
       const rsrc_t br = bias_rsrc(L);
       const bool bfast = bias_fast(L);
-      auto epilogue = make_epilogue(L, dst_tile, chunk_base);
+      auto epilogue = make_epilogue(L, dst_tile, chunk_base, scale_in, &out_max);
       auto whole = [&](auto nf_tag, int first, int nunits) {
         constexpr int NF = decltype(nf_tag)::value;
         bx_units<G, G, NF>(
@@ -328,17 +373,20 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     // 0 x stale bits may be NaN)
     auto zero_pad = [&](char* tile, int nob, int chunk_base) {
       if (tile != nullptr && (nob & 1)) {
-        for (int u = wave; u < G * 3; u += W)
-          *reinterpret_cast<uint2*>(tile + ((((nob >> 1) - chunk_base) * G) * 3 + u) * kBxFrag + lane * 16 + 8) = make_uint2(0u, 0u);
+        for (int u = wave; u < G * kBxPlanes; u += W)
+          *reinterpret_cast<uint2*>(tile + ((((nob >> 1) - chunk_base) * G) * kBxPlanes + u) * kBxFrag + lane * 16 + 8) = make_uint2(0u, 0u);
       }
     };
 
     if (L + 1 != pass_layer) {
       run_blocks(0, NOB, tout, 0);
+      if (RLG_BX_F16 && tout != nullptr) bx_publish_max(a.amax, kBxAmaxX + L + 1, out_max, true);
       zero_pad(tout, NOB, 0);
       chain_stamp(a.dbg, wave, stamp);                               // per layer: units done
       __syncthreads();
       chain_stamp(a.dbg, wave, stamp);                               // barrier
+#pragma unroll
+      for (int g = 0; g < G; ++g) scale_in[g] = kBxScaleH;
       continue;
     }
 
@@ -351,6 +399,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     const bool p_last = (P == num_layers - 1);
     char* ptile = p_last ? nullptr : ldsb + pin_s(a.bx_tile_off[P + 1]);
     f32x4 pacc[kFwMaxPersist][G];
+    float p_max = 0.0f;
     for (int c0 = 0; c0 < KCP; c0 += win) {
       const int c1 = (c0 + win < KCP) ? c0 + win : KCP;
       const int b0 = 2 * c0, b1 = (2 * c1 < NOB) ? 2 * c1 : NOB;
@@ -364,7 +413,8 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     if (pnb > 0) {
       const rsrc_t br = bias_rsrc(P);
       const bool bfast = bias_fast(P);
-      auto epilogue = make_epilogue(P, ptile, 0);
+      const float hidden_scale[G] = {kBxScaleH, kBxScaleH, kBxScaleH, kBxScaleH};
+      auto epilogue = make_epilogue(P, ptile, 0, hidden_scale, &p_max);
       f32x4 pb[kFwMaxPersist];
 #pragma unroll
       for (int f = 0; f < kFwMaxPersist; ++f) {
@@ -380,10 +430,16 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         }
       }
     }
+    if (RLG_BX_F16) {
+      bx_publish_max(a.amax, kBxAmaxX + L + 1, out_max, true);
+      if (ptile != nullptr) bx_publish_max(a.amax, kBxAmaxX + P + 1, p_max, true);
+    }
     zero_pad(ptile, NOBP, 0);
     chain_stamp(a.dbg, wave, stamp);                                 // consumer epilogue
     __syncthreads();
     chain_stamp(a.dbg, wave, stamp);                                 // barrier
+#pragma unroll
+    for (int g = 0; g < G; ++g) scale_in[g] = kBxScaleH;
     ++L;
   }
 }
@@ -398,7 +454,8 @@ int chain_bx_fwd_plan(ChainArgs& args) {
   long long kc[kChainMaxLayers];
   for (int L = 0; L < n; ++L) kc[L] = bx_kc(args.layer[L].in);
   const long long chunk = kFwG * kBxChunk;
-  const long long stats = ((2LL * ((args.layer[0].in + 3) & ~3) * 4) + 15) & ~15LL;     // prologue only: shares the top
+  long long stats = ((2LL * ((args.layer[0].in + 3) & ~3) * 4) + 15) & ~15LL;     // prologue only: shares the top
+  if (stats < 16 * kFwG * 4) stats = 16 * kFwG * 4;                                // (... or the row scales of raw observations)
   // the smallest LDS that holds every consecutive pair (small networks then run several workgroups per CU), else all of it
   long long need = kc[0] * chunk + stats;
   for (int L = 0; L < n; ++L) {

@@ -4,7 +4,7 @@
 
 #include "rlg_device.hpp"
 #include "ppo_loss_tile.hpp"
-#include "split_bf16.hpp"
+#include "bx_form.hpp"
 #include "rlg_hip.h"
 
 #include <hip/hip_ext.h>
@@ -90,6 +90,8 @@ struct ChainArgs {
   unsigned p_off[kChainMaxLayers];     // byte offset of layer L's fragments
   int bx_handoff_off;                  // split-bf16 backward: byte offset in LDS of the loss tile's d heads, or -1
   int bx_handoff_ld;                   //   (the loss writes exactly the array the chain reads: no fence + re-load)
+  int bx_scales_off;                   // split-fp16 backward: byte offset in LDS of the 64 row scales of the d heads tile
+  float* amax;                         // split-fp16 kernels: operand maxima slots (kBxAmax* below) or nullptr
   // split-bf16 forward: byte offset of tile L (the input of layer L) in LDS, of the normaliser scratch; the tile of
   // layer bx_pass_layer (-1: none) does not fit and is produced / consumed in windows of bx_pass_chunks chunks
   int bx_tile_off[kChainMaxLayers + 1];
@@ -300,11 +302,11 @@ __device__ __forceinline__ void chain_pack_planes_block(const PackArgs& a, int b
     if (i < J.I && k < J.K) v = J.transposed ? J.w[static_cast<long long>(k) * J.in + i] : J.w[static_cast<long long>(i) * J.in + k];
     x[e] = v;
   }
-  u32x4 plane[3];
-  dw_split8(x, plane);
-  unsigned char* dst = a.dst + J.dst_off + static_cast<long long>(local) * 3072 + lane * 16;
+  u32x4 plane[kBxPlanes];
+  bx_split8(x, kBxScaleW, plane);
+  unsigned char* dst = a.dst + J.dst_off + static_cast<long long>(local) * kBxChunk + lane * 16;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 1024) = plane[p];
+  for (int p = 0; p < kBxPlanes; ++p) *reinterpret_cast<u32x4*>(dst + p * kBxFrag) = plane[p];
 }
 int chain_bx_pack_blocks(const PackArgs& a);
 int chain_bx_pack_launch(const PackArgs& a, hipStream_t st);

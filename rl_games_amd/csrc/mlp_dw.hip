@@ -34,6 +34,7 @@
 
 #include "rlg_device.hpp"
 #include "split_bf16.hpp"
+#include "split_f16.hpp"
 #include "rlg_hip.h"
 
 namespace rlg {
@@ -55,7 +56,12 @@ constexpr int kDwSets = RLG_DW_SETS;   // register sets: kDwSets-1 batches of lo
 #endif
 constexpr int kDwSplitBatch = 8;       // k-steps per batch of the split-bf16 form (K = 32 of one bf16 MFMA)
 
-// RLG_DW_BF16=0 selects exact f32 products (the round-1 kernel: 1.3x slower, same accuracy class)
+// Product forms of the launch
+constexpr int kDwExact = 0;     // exact f32 products on v_mfma_f32_16x16x4_f32 (the round-1 kernel: 1.3x slower than kDwBf16)
+constexpr int kDwBf16 = 1;      // six exact bf16 plane products per fp32 product (split_bf16.hpp)
+constexpr int kDwF16 = 2;       // three exact fp16 plane products per fp32 product, operands scaled (split_f16.hpp)
+
+// RLG_DW_BF16=0 selects exact f32 products; RLG_DW_F16=1 the fp16 form (the layers then carry their operands' maxima)
 static bool dw_split_products() {
   static const bool on = [] {
     const char* e = std::getenv("RLG_DW_BF16");
@@ -63,6 +69,17 @@ static bool dw_split_products() {
   }();
   return on;
 }
+static bool dw_f16_products() {
+  static const bool on = [] {
+    const char* e = std::getenv("RLG_DW_F16");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  return on && dw_split_products();
+}
+
+// rlg_mlp_dw_operand_maxima: one-shot, consumed by the next rlg_mlp_dw_launch
+static const float* g_dw_amax = nullptr;
+static int g_dw_amax_x[kDwMaxLayers], g_dw_amax_dz[kDwMaxLayers], g_dw_amax_n = 0, g_dw_amax_reset = 1;
 
 struct DwLayer {
   const float* dz;     // [rows, lda]
@@ -73,6 +90,11 @@ struct DwLayer {
   int No, Mi;
   int tiles_o, tiles_i, ksplit;
   int block_begin;     // first blockIdx.x of this layer
+  // fp16 form: device words holding the largest magnitudes of dz and x (left by the launches that produced them), or
+  // nullptr - then amax_* below (host-side bounds) are used
+  const float* amax_dz_ptr;
+  const float* amax_x_ptr;
+  float amax_dz, amax_x;
   // tile t of a dimension covers columns [start[t], start[t] + 16 * b[t]), b in {1, 2, 4}
   short o_start[kDwMaxTiles], i_start[kDwMaxTiles];
   signed char o_b[kDwMaxTiles], i_b[kDwMaxTiles];
@@ -113,7 +135,7 @@ template <int B> __device__ __forceinline__ typename DwVec<B>::type dw_zero() { 
 // profiles/r2_dw_bf16x6.txt).
 // kSplit = false: exact f32 products (v_mfma_f32_16x16x4_f32).  kSplit = true: split-bf16 products, two
 // register sets of 32 rows.
-template <int BO, int BI, bool kSplit>
+template <int BO, int BI, int kMode>
 __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int i0, int z, float* lds) {
   using VA = typename DwVec<BO>::type;
   using VB = typename DwVec<BI>::type;
@@ -144,7 +166,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       // f32 form: accumulators pinned to AGPRs (keeps every MFMA in place and the 114 VGPRs for the three
       // load sets).  Split form: NO AGPRs - hipcc halves the register budget of a kernel that uses any
       // (128 + 128 at two workgroups per CU), and the two 64-register load sets + planes need ~244 VGPRs.
-      if constexpr (!kSplit) asm volatile("" : "+a"(acc[a][b]));
+      if constexpr (kMode == kDwExact) asm volatile("" : "+a"(acc[a][b]));
     }
   }
   // row pointers of this lane, advanced by one batch (16 rows) at a time
@@ -168,7 +190,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(dw_get<BO>(av, a), dw_get<BI>(bv, b), acc[a][b], 0, 0, 0);
     }
   };
-  if constexpr (!kSplit) {
+  if constexpr (kMode == kDwExact) {
   // Full batches: kDwSets register sets, kDwSets-1 batches of loads in flight while one issues its
   // MFMAs.  All tiles of a K-slice stream their band of rows at the same time, so every load of a
   // workgroup sees first-touch (HBM / Infinity Cache) latency even when the line counts as an L2 hit:
@@ -240,7 +262,43 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       ra += KB * step_a;
       rb += KB * step_b;
     };
-    auto compute8 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
+    float scale_a = 1.0f, scale_b = 1.0f;
+    if constexpr (kMode == kDwF16) {
+      scale_a = f16_scale_for(L.amax_dz_ptr ? *L.amax_dz_ptr : L.amax_dz);
+      scale_b = f16_scale_for(L.amax_x_ptr ? *L.amax_x_ptr : L.amax_x);
+    }
+    auto compute8_f16 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
+      RLG_DW_PIN();
+      u32x4 pb[BI][2];
+#pragma unroll
+      for (int b = 0; b < BI; ++b) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BI>(bv[u], b);
+        f16_split8(x, scale_b, pb[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < BO; ++a) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) x[u] = dw_get<BO>(av[u], a);
+        u32x4 pa[2];
+        f16_split8(x, scale_a, pa);
+        // small terms first; consecutive MFMAs go to different accumulators
+        constexpr int kPa[3] = {1, 0, 0};
+        constexpr int kPb[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+          for (int b = 0; b < BI; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, pa[kPa[t]]),
+                                                               __builtin_bit_cast(f16x8, pb[b][kPb[t]]),
+                                                               acc[a][b], 0, 0, 0);
+        }
+      }
+      RLG_DW_PIN();
+    };
+    auto compute8_bf16 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
       RLG_DW_PIN();
       // blocks are split two at a time where a lane's row vector holds two (dw_split8x2: packed residuals)
       u32x4 pb[BI][3];
@@ -298,6 +356,10 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       }
       RLG_DW_PIN();
     };
+    auto compute8 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
+      if constexpr (kMode == kDwF16) compute8_f16(av, bv);
+      else compute8_bf16(av, bv);
+    };
     int s = s_begin;
     const int nb = (s_full_end > s_begin) ? (s_full_end - s_begin) / KB : 0;
     {
@@ -344,6 +406,17 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
         }
       }
       compute8(av, bv);
+    }
+  }
+
+  if constexpr (kMode == kDwF16) {
+    // the accumulators hold S_dz S_x times the sums: un-scale (a power of two - exact) before they meet other slices
+    const float inv = 1.0f / (f16_scale_for(L.amax_dz_ptr ? *L.amax_dz_ptr : L.amax_dz) *
+                              f16_scale_for(L.amax_x_ptr ? *L.amax_x_ptr : L.amax_x));
+#pragma unroll
+    for (int a = 0; a < BO; ++a) {
+#pragma unroll
+      for (int b = 0; b < BI; ++b) acc[a][b] *= inv;
     }
   }
 
@@ -401,7 +474,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
   }
 }
 
-template <bool kSplit>
+template <int kMode>
 __device__ __forceinline__ void mlp_dw_body(const DwArgs& args) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 16 * 64 * 4];     // 64 KiB
   int l = 0;
@@ -432,7 +505,7 @@ __device__ __forceinline__ void mlp_dw_body(const DwArgs& args) {
   const int o0 = L.o_start[to], i0 = L.i_start[ti];
   const int bo = L.o_b[to], bi = L.i_b[ti];
 #define RLG_DW_CASE(BO_, BI_) \
-  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_, kSplit>(L, args.rows, o0, i0, z, lds); return; }
+  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_, kMode>(L, args.rows, o0, i0, z, lds); return; }
   RLG_DW_CASE(4, 4)
   RLG_DW_CASE(4, 2)
   RLG_DW_CASE(4, 1)
@@ -445,8 +518,9 @@ __device__ __forceinline__ void mlp_dw_body(const DwArgs& args) {
 #undef RLG_DW_CASE
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) { mlp_dw_body<false>(args); }
-__global__ __launch_bounds__(256, 2) void mlp_dw_bf16x6_kernel(DwArgs args) { mlp_dw_body<true>(args); }
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs args) { mlp_dw_body<kDwExact>(args); }
+__global__ __launch_bounds__(256, 2) void mlp_dw_bf16x6_kernel(DwArgs args) { mlp_dw_body<kDwBf16>(args); }
+__global__ __launch_bounds__(256, 2) void mlp_dw_f16x3_kernel(DwArgs args) { mlp_dw_body<kDwF16>(args); }
 
 // The PPO loss partials ride along too (what ppo_loss_finalize_kernel does in a launch of its own,
 // csrc/ppo_loss.hip): block 0 of the item folds the 7 scalar columns (losses, KL, sum of d values),
@@ -553,6 +627,7 @@ struct NormItem {
   double* partials;          // [gridDim.x] or nullptr
   long long* step_counter;   // or nullptr
   float grad_scale;
+  float* amax_reset;         // fp16 form: the operand-maxima slots [0, 16) are zeroed behind the launch that read them, or nullptr
 };
 
 // grad[e] = sum_z partial[z][e].  A block covers kFinElems consecutive float4 elements (a 256-byte
@@ -688,6 +763,7 @@ __device__ __forceinline__ double fin_vblock(int vb, const DwArgs& args, const C
 
 __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf,
                                                               NormItem nrm) {
+  if (nrm.amax_reset != nullptr && blockIdx.x == 0 && threadIdx.x < 16) nrm.amax_reset[threadIdx.x] = 0.0f;
   const double sq = fin_vblock(blockIdx.x, args, cs, lf, nrm.grad_scale);
   if (nrm.partials) {                                // (uniform: every thread of the block gets here)
     __shared__ double nscratch[256 / kWave];
@@ -781,6 +857,16 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   DwArgs args;
   args.num_layers = num_layers;
   args.rows = rows;
+  // fp16 form: the operands' largest magnitudes - device words left by the chain launches (rlg_mlp_dw_operand_maxima), or,
+  // for the tools, host-side bounds from the environment; neither: the bf16 form
+  const float* amax = (g_dw_amax_n == num_layers) ? g_dw_amax : nullptr;
+  g_dw_amax = nullptr;
+  g_dw_amax_n = 0;
+  const char* ea = std::getenv("RLG_DW_F16_AMAX_DZ");
+  const char* eb = std::getenv("RLG_DW_F16_AMAX_X");
+  const float host_amax_dz = ea ? static_cast<float>(std::atof(ea)) : 0.0f;
+  const float host_amax_x = eb ? static_cast<float>(std::atof(eb)) : 0.0f;
+  const bool f16 = dw_f16_products() && (amax != nullptr || (ea != nullptr && eb != nullptr));
   int blocks = 0, fin_blocks = 0;
   for (int l = 0; l < num_layers; ++l) {
     DwLayer& L = args.layer[l];
@@ -793,6 +879,10 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
     L.lda = L.No;
     L.ldb = L.Mi;
     L.ksplit = plans4[4 * l + 3];
+    L.amax_dz_ptr = amax ? amax + g_dw_amax_dz[l] : nullptr;
+    L.amax_x_ptr = amax ? amax + g_dw_amax_x[l] : nullptr;
+    L.amax_dz = host_amax_dz;
+    L.amax_x = host_amax_x;
     if (L.ksplit < 1 || (reinterpret_cast<uintptr_t>(L.partial) | reinterpret_cast<uintptr_t>(L.grad)) % 16 != 0 ||
         (static_cast<long long>(L.No) * L.Mi) % 4 != 0)
       return static_cast<int>(hipErrorInvalidValue);
@@ -825,12 +915,31 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   }
   const int total_vb = lf.num_blocks + cs_blocks + fin_blocks;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dw_split_products()) hipLaunchKernelGGL(mlp_dw_bf16x6_kernel, dim3(blocks), dim3(256), 0, st, args);
+  if (f16) hipLaunchKernelGGL(mlp_dw_f16x3_kernel, dim3(blocks), dim3(256), 0, st, args);
+  else if (dw_split_products()) hipLaunchKernelGGL(mlp_dw_bf16x6_kernel, dim3(blocks), dim3(256), 0, st, args);
   else hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
   if (finalize_blocks_out) *finalize_blocks_out = total_vb;
-  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
+  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale, const_cast<float*>((f16 && g_dw_amax_reset) ? amax : nullptr)};
   hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(total_vb), dim3(256), 0, st, args, cs, lf, nrm);
   RLG_RETURN_LAUNCH_STATUS();
+}
+
+int rlg_mlp_dw_operand_maxima(const float* slots, const int* x_slot, const int* dz_slot, int num_layers, int reset) {
+  using namespace rlg;
+  if (slots == nullptr || num_layers <= 0 || num_layers > kDwMaxLayers) {
+    g_dw_amax = nullptr;
+    g_dw_amax_n = 0;
+    return slots == nullptr ? 0 : static_cast<int>(hipErrorInvalidValue);
+  }
+  for (int l = 0; l < num_layers; ++l) {
+    if (x_slot[l] < 0 || x_slot[l] >= 8 || dz_slot[l] < 8 || dz_slot[l] >= 16) return static_cast<int>(hipErrorInvalidValue);
+    g_dw_amax_x[l] = x_slot[l];
+    g_dw_amax_dz[l] = dz_slot[l];
+  }
+  g_dw_amax = slots;
+  g_dw_amax_n = num_layers;
+  g_dw_amax_reset = reset;
+  return 0;
 }
 
 int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const* x, float* const* partial,

@@ -1,0 +1,60 @@
+// Two-way split of fp32 values into fp16 planes for the split-product kernels (round 6): with a power-of-two scale S
+// that puts the operand's largest magnitude below 2^15,  x S = h0 + h1 + e,  h0 = RN16(x S), h1 = RN16(x S - h0),
+// |e| <= max(2^-22 |x S|, 2^-25) in the worst case, ~2^-24 |x S| rms  (fp16: 11 significant bits per plane, gradual
+// underflow below 2^-14 - the matrix core keeps subnormal inputs, tools/exp/f16_mfma_probe.hip).  A product is the THREE
+// plane products h0 g0 + h0 g1 + h1 g0 on v_mfma_f32_16x16x32_f16 (each exact in fp32, the rate of the bf16 MFMA),
+// un-scaled by 1 / (S_x S_y) behind the accumulation.  The dropped h1 g1 and the representation errors are <= 3 * 2^-22
+// |x||y| per product in the worst case (the six-product bf16 form of split_bf16.hpp: 3 * 2^-24) and ~2^-24 rms - below the
+// roundings of the fp32 accumulation either way: against fp64 the sums of both forms are as accurate as with exact fp32
+// products (tools/exp/split_f16_numerics.py, tests/test_split_products_cpu.py, tools/exp/dw_bf16_check.py on the device) -
+// at half the MFMAs and two thirds of the planes of the bf16 form.
+// What the bf16 form does not need: the scale.  An operand element beyond 65504 / S becomes Inf (non-finite out, never a
+// finite wrong value); the launches take their scales from the measured maxima of the tensors they multiply.
+#pragma once
+
+#include "rlg_device.hpp"
+#include "split_bf16.hpp"
+
+namespace rlg {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 split_f16x2 __attribute__((ext_vector_type(2)));
+
+// RNE conversion of a pair: ONE v_cvt_pk_f16_f32 (a compiler builtin, not asm: the hazard recogniser must see the producer
+// of an MFMA operand, see split_bf16.hpp)
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((split_f32x2{lo, hi}), split_f16x2));
+}
+
+// One pair of ALREADY SCALED fp32 values -> its dword of each of the two planes: v_cvt_pk_f16_f32, two v_cvt_f32_f16, two
+// v_sub_f32, v_cvt_pk_f16_f32 = 6 VALU instructions (the bf16 form: 9).
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned& p0, unsigned& p1) {
+  const split_f16x2 h = __builtin_convertvector((split_f32x2{x0, x1}), split_f16x2);
+  p0 = __builtin_bit_cast(unsigned, h);
+  const float r0 = x0 - static_cast<float>(h[0]);
+  const float r1 = x1 - static_cast<float>(h[1]);
+  p1 = cvt_pk_f16(r0, r1);
+}
+
+// 8 floats (the lane's 8 k values of one 16-wide block), times `scale` -> 2 planes of 8 packed fp16; x[2q], x[2q + 1]
+// share a dword.
+__device__ __forceinline__ void f16_split8(const float (&x)[8], float scale, u32x4 (&plane)[2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned p0, p1;
+    split_pair_f16(x[2 * q] * scale, x[2 * q + 1] * scale, p0, p1);
+    plane[0][q] = p0;
+    plane[1][q] = p1;
+  }
+}
+
+// power-of-two scale that puts `amax` (the largest magnitude of an operand, >= 0, finite) into [2^13, 2^14): two bits below
+// the fp16 overflow threshold.  Zero / denormal maxima: the largest scale that keeps 1 / (S_x S_y) a normal fp32.
+__device__ __forceinline__ float f16_scale_for(float amax) {
+  const int e = (__float_as_int(amax) >> 23) & 0xff;            // biased exponent: amax in [2^(e-127), 2^(e-126))
+  int s = 127 + 13 - (e - 127);                                 // biased exponent of 2^(13 - (e - 127))
+  s = min(max(s, 127 - 40), 127 + 40);
+  return __int_as_float(s << 23);
+}
+
+}  // namespace rlg

@@ -312,13 +312,14 @@ class ManualMLP:
                     self.chain.forward(fwd['x'], fwd['heads'], act_out=fwd['act_out'], rms=fwd['rms'], eps=fwd['eps'],
                                        xn_out=fwd['xn_out'], rms_fold=fwd['rms_fold'])
                 self.chain.backward(d_heads, acts, dzs, parts, ppo_loss=ppo_loss)
-            jobs = [(d_heads, acts[-1], self.head_w_grad)]
+            # (dZ, X, grad, layer): the layer index names the operands' slots of the chain's maxima (fp16 form)
+            jobs = [(d_heads, acts[-1], self.head_w_grad, L)]
             colsums = []
             for l in range(L - 1, -1, -1):
                 lin = self.linears[l]
-                jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad))
+                jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad, l))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm)
+            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm, maxima=self.chain.operand_maxima(rows))
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
@@ -372,8 +373,9 @@ class ManualMLP:
                 d = d_prev
         return self._weight_grads(jobs, rows, colsums, loss_finalize)
 
-    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None):
-        """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi]).  Everything inside the MFMA kernel's
+    def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None, maxima=None):
+        """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi][, layer index]).  maxima: ops.MlpChain.operand_maxima() of the
+        step, or None (then, or when a job carries no layer index, the launch runs its bf16 form).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
         fast, slow = [], []
@@ -382,17 +384,17 @@ class ManualMLP:
             for job in jobs:
                 g = job[2]
                 ok = (g.shape[1] % 4 == 0 and g.shape[1] >= 4
-                      and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in job))
+                      and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in job[:3]))
                 (fast if ok else slow).append(job)
         else:
             slow = list(jobs)
         if fast:
             fast.sort(key=lambda job: -job[2].numel())          # heaviest layer's blocks first in the launch
-            key = (rows,) + tuple(tuple(g.shape) for _, _, g in fast)
+            key = (rows,) + tuple(tuple(j[2].shape) for j in fast)
             plan = self._dw_plans.get(key)
             if plan is None:
                 try:
-                    plan = ops.MlpDwPlan([tuple(g.shape) for _, _, g in fast], rows, fast[0][2].device)
+                    plan = ops.MlpDwPlan([tuple(j[2].shape) for j in fast], rows, fast[0][2].device)
                 except NotImplementedError:
                     plan = False
                 self._dw_plans[key] = plan
@@ -403,12 +405,16 @@ class ManualMLP:
                 #  launch takes over instead of an error in the middle of an epoch)
                 whole = (norm is not None and not slow and loss_finalize is not None
                          and norm[0].numel() >= plan.finalize_blocks(colsums, loss_finalize))
-                norm_blocks = plan.launch(fast, colsums, loss_finalize, norm if whole else None)
+                mx = None
+                if maxima is not None and all(len(j) == 4 for j in fast):
+                    mx = (maxima, [j[3] for j in fast], [8 + j[3] for j in fast])
+                triples = [j[:3] for j in fast]
+                norm_blocks = plan.launch(triples, colsums, loss_finalize, norm if whole else None, maxima=mx)
                 if not whole:
                     norm_blocks = None
                 colsums = ()
                 loss_finalize = None
-                self.last_dw_jobs = (fast, plan)        # bench.py times this launch after the run
+                self.last_dw_jobs = (triples, plan, mx)        # bench.py times this launch after the run
             else:
                 slow = slow + fast
                 fast = []
@@ -418,7 +424,7 @@ class ManualMLP:
             ops.colsum_finalize(part, nb, cols, out)
         self.last_dw_path = 'mfma' if fast else 'library'
         self.last_dw_library_jobs = 0
-        for dz, x, g in slow:
+        for dz, x, g in (j[:3] for j in slow):
             if (g.shape[1] <= ops.NARROW_MAX and g.shape[0] <= 256 and dz.stride(1) == 1 and x.stride(1) == 1
                     and g.is_contiguous()):
                 ops.narrow_dw(dz, x, g)            # a first layer over a few observations (config #5: obs 3)

@@ -558,17 +558,29 @@ def _bf16_bits_to_f64(u16):
     return (u16.to(torch.int32) << 16).view(torch.float32).double()
 
 
+def _split_form():
+    """(planes per operand, plane bits -> fp64, weight scale) of this build's split-product chain kernels."""
+    from rl_games_amd import ops
+    products, ptype = ops.chain_split_form()
+    if ptype == 'fp16':
+        return 2, (lambda u16: u16.view(torch.float16).double()), 64.0           # csrc/bx_form.hpp kBxScaleW
+    return 3, _bf16_bits_to_f64, 1.0
+
+
 @pytest.mark.parametrize('direction', [0, 1])
 @pytest.mark.parametrize('in_dim,units,out_dim,act', SHAPES)
-def test_weight_planes_are_an_exact_split_in_fragment_order(in_dim, units, out_dim, act, direction):
-    """rlg_mlp_chain_pack_planes: fragment (block, chunk, plane) = 64 lanes x 8 bf16; lane l, element e holds
+def test_weight_planes_are_a_split_in_fragment_order(in_dim, units, out_dim, act, direction):
+    """rlg_mlp_chain_pack_planes: fragment (block, chunk, plane) = 64 lanes x 8 half-width values; lane l, element e holds
     A[16 block + (l & 15)][32 chunk + (e < 4 ? 4 (l >> 4) + e : 16 + 4 (l >> 4) + e - 4)], A = W (forward) or W^T
-    (backward), zero outside the matrix; the three planes add up to the fp32 weight EXACTLY."""
+    (backward), zero outside the matrix.  fp16 form (the default build): two planes of 64 W, h0 = RN16(64 W) and
+    h1 = RN16(64 W - h0) bit for bit, their sum within 2^-22 of 64 W (2^-25 absolute below the fp16 normal range);
+    bf16 form: the three planes add up to the fp32 weight EXACTLY."""
     from rl_games_amd import ops
     layers, _ = _net(in_dim, units, out_dim, act, seed=5 + in_dim)
     chain = ops.MlpChain(layers, DEV)
     planes = chain.pack_planes(direction, layers[0][0])
     torch.cuda.synchronize()
+    np_, to64, wscale = _split_form()
     raw = planes.cpu().view(torch.int16)
     off = 0
     lane = torch.arange(64)
@@ -579,17 +591,25 @@ def test_weight_planes_are_an_exact_split_in_fragment_order(in_dim, units, out_d
         A = w.cpu() if direction == 0 else w.cpu().t()
         I, K = A.shape
         nb, kc = (I + 15) // 16, (K + 31) // 32
-        frag = raw[off // 2: off // 2 + nb * kc * 3 * 512].view(nb, kc, 3, 64, 8)
-        off += nb * kc * 3 * 1024
-        total = sum(_bf16_bits_to_f64(frag[:, :, p]) for p in range(3))          # [nb, kc, 64, 8]
+        frag = raw[off // 2: off // 2 + nb * kc * np_ * 512].view(nb, kc, np_, 64, 8)
+        off += nb * kc * np_ * 1024
         i = (torch.arange(nb)[:, None, None, None] * 16 + (lane & 15)[None, None, :, None]).expand(nb, kc, 64, 8)
         q4 = 4 * (lane >> 4)[None, None, :, None]
         k = torch.arange(kc)[None, :, None, None] * 32 + torch.where(e < 4, q4 + e, 16 + q4 + e - 4)
         k = k.expand(nb, kc, 64, 8)
         inside = (i < I) & (k < K)
-        want = torch.zeros(nb, kc, 64, 8, dtype=torch.float64)
-        want[inside] = A.double()[i[inside], k[inside]]
-        assert torch.equal(total, want)
+        want = torch.zeros(nb, kc, 64, 8, dtype=torch.float32)
+        want[inside] = A[i[inside], k[inside]] * wscale
+        if np_ == 3:
+            total = sum(to64(frag[:, :, p]) for p in range(3))          # [nb, kc, 64, 8]
+            assert torch.equal(total, want.double())
+        else:
+            h0 = want.half()
+            h1 = (want - h0.float()).half()
+            assert torch.equal(frag[:, :, 0].contiguous().view(torch.float16), h0)
+            assert torch.equal(frag[:, :, 1].contiguous().view(torch.float16), h1)
+            err = (h0.double() + h1.double() - want.double()).abs()
+            assert torch.all(err <= torch.maximum(want.double().abs() * 2.0 ** -22, torch.tensor(2.0 ** -25, dtype=torch.float64)))
     assert off == planes.numel()
     if direction == 1:
         # one launch for both directions leaves the same fragments (the backward ones behind the forward ones)
@@ -674,29 +694,40 @@ def test_split_bf16_forward_agrees_with_the_exact_product_kernel(in_dim, units, 
     assert torch.equal(heads2, out[None][0][-1])
 
 
-def test_split_bf16_forward_is_invariant_under_power_of_two_rescaling():
-    """The plane split works on the significand: observations times 2^40 with first-layer weights times 2^-40 (and the same
-    with 2^-60 / 2^60) give the same products plane by plane, so every output is the SAME BITS - no hidden dependence on
-    the magnitude of the operands (bf16 has fp32's exponent range).  Documented limit: a +-Inf operand becomes NaN in
-    the split (Inf - Inf in the residual), where an exact product would propagate the infinity."""
+def test_split_forward_scales_raw_observation_rows_by_their_own_maxima():
+    """Raw (un-normalised) observations have no bound: the fp16 form scales every ROW by the power of two its largest
+    magnitude asks for.  (1) Rows of very different magnitude in one tile do not disturb one another: a row gives the SAME
+    BITS whatever its neighbours hold.  (2) Observations times 2^-e with first-layer weights times 2^e are the same
+    network: the outputs agree to the split kernels' tolerance (not bit for bit - the WEIGHT scale is fixed at 2^6, and
+    the low plane of a small weight sits in fp16's gradual underflow or not depending on e; the bf16 form of rounds 3 - 5,
+    with fp32's exponent range, reproduced the bits for any e).  Documented limit of both forms: a +-Inf operand becomes
+    NaN in the split (Inf - Inf in the residual), where an exact product would propagate the infinity."""
     from rl_games_amd import ops
     rows = 16384
     base, g = _net(60, [256, 128], 9, 'elu', seed=77)
     x = (2 * torch.randn(rows, 60, generator=g)).to(DEV)
 
-    def run(scale_x, scale_w):
+    def run(scale_x, scale_w, xin=None):
         layers = [(w.clone(), b.clone(), a) for w, b, a in base]
         layers[0][0].mul_(scale_w)
         chain = ops.MlpChain(layers, DEV)
         assert chain.split_products(rows, 0)
         heads = torch.empty(rows, 9, device=DEV)
         acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
-        chain.forward(x * scale_x, heads, act_out=acts)
+        chain.forward((x if xin is None else xin) * scale_x, heads, act_out=acts)
         return acts + [heads]
     ref = run(1.0, 1.0)
-    for e in (40, -60):
-        got = run(2.0 ** e, 2.0 ** -e)
-        assert all(torch.equal(p, q) for p, q in zip(got, ref)), e
+    for e in (3, 7):
+        got = run(2.0 ** -e, 2.0 ** e)
+        for p, q in zip(got, ref):
+            assert (p - q).abs().max().item() <= 4e-6 * q.abs().max().item(), e
+    # every third row a million times smaller: its outputs are what it gives inside a tile of rows like itself
+    small = x.clone()
+    small[::3] *= 2.0 ** -20
+    mixed = run(1.0, 1.0, small)
+    alone = run(1.0, 1.0, x * 2.0 ** -20)
+    for m, a_ in zip(mixed, alone):
+        assert torch.equal(m[::3], a_[::3])
 
 
 # ----------------------------------------------------------------------------- non-finite inputs (round 4)

@@ -30,10 +30,13 @@ def main():
         dz = (torch.randn(args.rows, No, generator=g) * torch.exp(2.0 * torch.randn(args.rows, 1, generator=g)) * 1e-4).to(dev)
         x = torch.nn.functional.elu(torch.randn(args.rows, Mi, generator=g)).to(dev)
         jobs.append((dz, x, torch.empty(No, Mi, device=dev)))
+    # (RLG_DW_F16=1: the launch scales its operands by powers of two taken from these bounds)
+    os.environ.setdefault('RLG_DW_F16_AMAX_DZ', repr(max(j[0].abs().max().item() for j in jobs)))
+    os.environ.setdefault('RLG_DW_F16_AMAX_X', repr(max(j[1].abs().max().item() for j in jobs)))
     plan = ops.MlpDwPlan(shapes, args.rows, dev)
     plan.launch(jobs)
     torch.cuda.synchronize()
-    print(f'RLG_DW_BF16={mode} rows {args.rows}')
+    print(f'RLG_DW_BF16={mode} RLG_DW_F16={os.environ.get("RLG_DW_F16", "0")} rows {args.rows}')
     for dz, x, grad in jobs:
         t64 = dz.double().t() @ x.double()
         scale = dz.double().abs().t() @ x.double().abs()
