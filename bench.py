@@ -222,7 +222,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='humanoid')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-row', action='store_true', help='skip the exact-fp32-product comparison run (a child '
@@ -366,15 +366,8 @@ def main():
     eng = getattr(agent, '_engine', None)
     if eng is not None and getattr(eng, 'last_dw_jobs', None):
         jobs, plan, mx = eng.last_dw_jobs
-        kw = {}
-        if mx is not None:
-            # the fp16 form scales each operand by its largest magnitude: the slots were zeroed behind the step's own launch,
-            # so they are filled again from the operands as the last step left them, and kept across the repetitions
-            slots, xs, dzs = mx
-            for (dz, x, _), xi, di in zip(jobs, xs, dzs):
-                slots[xi] = x.abs().max()
-                slots[di] = dz.abs().max()
-            kw = dict(maxima=mx, reset_maxima=False)
+        # (the fp16 form takes its gradient scales from the maxima the step's backward left: still there - plain stores)
+        kw = dict(maxima=mx) if mx is not None else {}
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             plan.launch(jobs, **kw)
@@ -384,8 +377,6 @@ def main():
             plan.launch(jobs, **kw)
         ev1.record()
         torch.cuda.synchronize()
-        if mx is not None:
-            mx[0][:16].zero_()
         us = ev0.elapsed_time(ev1) * 1e3 / reps
         rows = jobs[0][0].shape[0]
         flops = sum(2.0 * rows * g.shape[0] * g.shape[1] for _, _, g in jobs)
@@ -397,8 +388,8 @@ def main():
             # instruction that issues them - v_mfma_f32_16x16x32_f16 and _bf16 have the same dense rate
             k = 3.0 if f16 else 6.0
             name = 'rlg::mlp_dw_f16x3_kernel' if f16 else 'rlg::mlp_dw_bf16x6_kernel'
-            form = ('three exact fp16 plane products, operands scaled by the power of two their largest magnitude asks for'
-                    if f16 else 'six exact bf16 plane products')
+            form = ('three exact fp16 plane products, gradients scaled by the power of two their largest magnitude over a '
+                    "wave's rows asks for, activations by the forward's fixed scales" if f16 else 'six exact bf16 plane products')
             mfma = {'kernel': f'{name} + rlg::mlp_dw_finalize_kernel (all weight gradients, one launch pair; fp32 products as {form})',
                     'bound': 'mfma', 'achieved': k * useful, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': k * useful / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
@@ -538,6 +529,7 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'ms_per_step_stats': {'min': min(per_epoch_ms), 'median': statistics.median(per_epoch_ms),
                                   'mean': sum(per_epoch_ms) / len(per_epoch_ms), 'max': max(per_epoch_ms),
+                                  'each': [round(v, 3) for v in per_epoch_ms],
                                   'note': 'per-epoch HIP event intervals on rank 0'},
             'config': {
                 'workload': w['desc'],

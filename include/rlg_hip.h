@@ -466,16 +466,17 @@ int rlg_mlp_chain_lds_bytes(int num_layers, const int* in_features, const int* o
 int rlg_mlp_chain_debug_stamps(long long* buffer);
 /* HIP events (rlg_event_create) bound to the NEXT chain dispatch (forward or backward), one-shot; not for
  * launches inside a graph capture.  bench.py's roofline_fwd / roofline_bwd. */
-/* Split-fp16 chain launches (round 6): the next rlg_mlp_chain_forward / _backward launch leaves the largest magnitudes of the
- * tensors it multiplies in `slots` (32 floats: [l] input of layer l, [8 + l] dZ of layer l, [16 + l] largest input of layer
- * l ever seen); one-shot.  rlg_mlp_dw_operand_maxima hands them to the NEXT rlg_mlp_dw_launch, whose sums run over the batch
- * rows and therefore scale each operand by ONE power of two (x_slot / dz_slot: the slot of each layer of that launch, in
- * its order); its finalise launch zeroes slots [0, 16) unless `reset` is 0 (tools that repeat one launch).  Without maxima
- * the weight-gradient launch runs the bf16 form. */
-int rlg_mlp_chain_operand_maxima(float* slots);
+/* Split-fp16 launches (round 6).  The weight-gradient launch sums over the batch rows, so it scales an operand by ONE power
+ * of two per K-slice of rows.  rlg_mlp_chain_gradient_maxima: the next rlg_mlp_chain_backward launch, if it runs the
+ * split-fp16 kernel, leaves per 64-row workgroup the largest magnitude of dZ of layer l (the last layer: of the d heads it
+ * read) in entries[l * stride + workgroup] (plain stores; stride >= ceil(rows / 64)); one-shot.
+ * rlg_mlp_dw_gradient_maxima hands them to the NEXT rlg_mlp_dw_launch: dz_slot[k] = the layer of job k's dz, x_scale[k] = the
+ * fixed power of two job k's x is split under (the forward's: 16 for hidden activations, 4096 for normalised
+ * observations); every wave takes the largest entry over its own rows.  Without them the launch runs the bf16 form. */
+int rlg_mlp_chain_gradient_maxima(float* entries, int stride);
+int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, const int* dz_slot, const float* x_scale, int num_layers);
 /* plane products per fp32 product of the split-product chain kernels of this build: 3 (fp16 planes) or 6 (bf16 planes) */
 int rlg_mlp_chain_split_products(void);
-int rlg_mlp_dw_operand_maxima(const float* slots, const int* x_slot, const int* dz_slot, int num_layers, int reset);
 int rlg_mlp_chain_time_next(void* ev_start, void* ev_stop);
 
 int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const float* const* biases,

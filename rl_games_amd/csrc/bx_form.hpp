@@ -76,12 +76,18 @@ __device__ __forceinline__ float bx_row_scale(float mine) {
   return 1.0f;
 #endif
 }
-// Operand maxima: 32 floats the fp16-form chain launches leave behind for the weight-gradient launch, whose sums run over the
-// batch rows - its operand scales must hold for ALL rows, so they come from the largest magnitude of each tensor:
-//   [l]       the input of layer l (normalised observations, H_{l-1}),        [8 + l]   dZ of layer l (the last: d heads)
-//   [16 + l]  the largest input of layer l EVER seen (never reset: the host's check against the fixed forward scales)
-// The weight-gradient finalise launch zeroes [0, 16) behind its reads.  Non-negative floats order like their bit patterns.
-constexpr int kBxAmaxX = 0, kBxAmaxDz = 8, kBxAmaxEver = 16, kBxAmaxSlots = 32;
+// Gradient maxima for the weight-gradient launch.  Its sums run over the batch rows, so an operand's scale must hold for
+// every row of a K-slice: the split-fp16 BACKWARD leaves, per 64-row workgroup and dZ tensor, the largest magnitude it
+// produced - entries[(kBxAmaxDz + l) * stride + workgroup] for dZ of layer l (the last layer: the d heads tile it read) -
+// with plain stores (every launch overwrites its own entries: nothing to reset), and a wave of the weight-gradient launch
+// takes the largest entry over ITS rows.  (Measured on the way: one device-scope atomicMax per wave and tensor instead of
+// the per-workgroup stores cost the chain launches 40 us; a maximum that maps NaN to Inf - three VALU instructions per
+// element instead of one - 11 us; no tracking at all, the backward's own bound of 8 x the dZ above per layer instead, is
+// free but costs the weight gradients of the deep layers 3 - 9 bits: the benchmarked epoch's losses then leave the oracle's
+// band.)  The other operand needs none: hidden activations and normalised observations are split under the forward's
+// fixed scales.
+constexpr int kBxAmaxDz = 0, kBxAmaxSlots = 8;
+constexpr int kBxRowsPerEntry = 64;
 
 // largest value of a wave (uniform result): row rotations inside the 16-lane rows, then the four rows through SGPRs
 __device__ __forceinline__ float bx_wave_max(float t) {
@@ -96,14 +102,10 @@ __device__ __forceinline__ float bx_wave_max(float t) {
   const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
   return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
 }
-// one atomic per wave: `mine` = this lane's largest finite |value| of the tensor behind slot `slot`
-__device__ __forceinline__ void bx_publish_max(float* amax, int slot, float mine, bool ever) {
-  if (amax == nullptr) return;
-  const float m = bx_wave_max(mine);
-  if (lane_id() == 0) {
-    atomicMax(reinterpret_cast<unsigned*>(amax) + slot, __float_as_uint(m));
-    if (ever) atomicMax(reinterpret_cast<unsigned*>(amax) + kBxAmaxEver + slot, __float_as_uint(m));
-  }
+// |x| for a reported maximum: a non-finite element reports +Inf (fmax would drop a NaN)
+__device__ __forceinline__ float bx_abs_or_inf(float x) {
+  const float a = __builtin_fabsf(x);
+  return a <= 3.4028234664e38f ? a : __builtin_inff();
 }
 
 // |x| for the row maximum: finite values only

@@ -1604,12 +1604,14 @@ int rlg_mlp_chain_time_next(void* ev_start, void* ev_stop) {
   return 0;
 }
 
-// The next rlg_mlp_chain_forward / _backward launch, if it runs the split-fp16 kernels, leaves the largest magnitudes of the
-// tensors it reads and writes in `slots` (32 floats, csrc/bx_form.hpp kBxAmax*) - what rlg_mlp_dw_operand_maxima hands to the
-// weight-gradient launch.  One-shot, like the timing events.
+// The next rlg_mlp_chain_backward launch, if it runs the split-fp16 kernel, leaves per 64-row workgroup the largest magnitude
+// of every dZ tensor it produces (and of the d heads it reads) in entries[(layer) * stride + workgroup] (csrc/bx_form.hpp) -
+// what rlg_mlp_dw_gradient_maxima hands to the weight-gradient launch.  One-shot, like the timing events.
 static float* g_chain_amax = nullptr;
-int rlg_mlp_chain_operand_maxima(float* slots) {
-  g_chain_amax = slots;
+static int g_chain_amax_stride = 0;
+int rlg_mlp_chain_gradient_maxima(float* entries, int stride) {
+  g_chain_amax = entries;
+  g_chain_amax_stride = stride;
   return 0;
 }
 
@@ -1629,12 +1631,11 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
                           long long rows, int groups, void* pack_backward_planes_or_null,
                           const void* weight_planes_or_null, void* stream) {
   using namespace rlg;
-  float* const amax = g_chain_amax;
-  g_chain_amax = nullptr;
   if (rows <= 0) return 0;
   ChainArgs args;
   if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
   args.amax = nullptr;
+  args.amax_stride = 0;
   // the backward launch's weight planes ride along as extra workgroups (with the tools' phase stamps, which index
   // their buffer by workgroup, as a launch of their own)
   if (pack_backward_planes_or_null != nullptr &&
@@ -1684,7 +1685,6 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
     const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, 0, bx.p_off);
     bx.planes = weight_planes_or_null;
     bx.planes_bytes = static_cast<unsigned>(total);
-    bx.amax = amax;
     const int bx_lds = chain_bx_fwd_plan(bx);
     if (bx_lds >= 0 && total < static_cast<long long>(kOob) && chain_bx_fwd_eligible(bx)) {
       hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
@@ -1716,12 +1716,14 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
                            const void* weight_planes_or_null, void* stream) {
   using namespace rlg;
   float* const amax = g_chain_amax;
+  const int amax_stride = g_chain_amax_stride;
   g_chain_amax = nullptr;
   if (rows <= 0) return 0;
   if (num_layers < 2) return static_cast<int>(hipErrorInvalidValue);
   ChainArgs args;
   if (chain_fill(args, num_layers, weights, in_features, out_features, acts)) return static_cast<int>(hipErrorInvalidValue);
   args.amax = nullptr;
+  args.amax_stride = 0;
   for (int L = 0; L + 1 < num_layers; ++L) {
     args.layer[L].h = const_cast<float*>(act_in[L]);
     args.layer[L].ldh = act_ld[L];
@@ -1794,7 +1796,10 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
     bx.dbg = g_chain_dbg;
     bx.planes = weight_planes_or_null;
     bx.planes_bytes = static_cast<unsigned>(total);
-    bx.amax = amax;
+    if (amax != nullptr && amax_stride >= (rows + 16 * G - 1) / (16 * G)) {
+      bx.amax = amax;
+      bx.amax_stride = amax_stride;
+    }
     int bx_lds = chain_bx_bwd_lds(bx, G);
     if (bx_lds >= 0 && total < static_cast<long long>(kOob) && chain_bx_bwd_eligible(bx)) {
       bx.bx_handoff_off = -1;
@@ -1816,7 +1821,7 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
         }
       }
       bx.bx_scales_off = (bx_lds + 15) & ~15;                  // (row scales of the d heads tile, fp16 form)
-      bx_lds = bx.bx_scales_off + 16 * G * 4;
+      bx_lds = bx.bx_scales_off + 16 * G * 4 + kChainMaxLayers * 4 * 4;      // (+ the waves' gradient maxima of every layer)
       hipEvent_t ev0 = g_chain_ev_start, ev1 = g_chain_ev_stop;
       g_chain_ev_start = g_chain_ev_stop = nullptr;
       if (bx_lds <= 160 * 1024) return chain_bx_launch_bwd(bx, G, bx_lds, st, lp, ev0, ev1);

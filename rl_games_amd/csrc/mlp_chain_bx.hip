@@ -26,6 +26,10 @@
 #include "mlp_chain_bx.hpp"
 #include "optim_common.hpp"
 
+#ifndef RLG_BX_TRACK
+#define RLG_BX_TRACK 1          // tools: 0 = no gradient maxima, 2 = tracked but not published (timing experiments)
+#endif
+
 namespace rlg {
 
 // direction 0: forward products of layer L (i = out, k = in); 1: backward (i = in, k = out; layer 0 needs no dX)
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     const bool xv = vec4_ok(a.x, a.ldx);
     float scale_mine = 1.0f;                    // of row (lane & 15) of row group `wave`: W == G, a wave splits ITS group's rows
     float* row_scales = reinterpret_cast<float*>(ldsb + a.bx_scales_off);
+    float* wg_max = row_scales + 16 * G + (num_layers - 1) * W;      // [layers][W]: the waves' maxima of every dZ tensor
     if (RLG_BX_F16) {
       static_assert(W == G, "the prologue deals row group g to wave g");
       float mine = 0.0f;
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
       }
       scale_mine = bx_row_scale(mine);
       if (lane < 16) row_scales[wave * 16 + lane] = scale_mine;
-      bx_publish_max(a.amax, kBxAmaxDz + num_layers - 1, mine, false);
+      const float wmax = bx_wave_max(mine);
+      if (lane == 0) wg_max[wave] = wmax;
     }
     for (int u = wave; u < KC0 * G; u += W) {
       const int c = u / G;
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
       for (int g = 0; g < G; ++g) scale_in[g] = row_scales[g * 16 + (lane & 15)];
     }
   }
+  float* const wg_max_all = reinterpret_cast<float*>(ldsb + a.bx_scales_off) + 16 * G;
   chain_stamp(a.dbg, wave, stamp);                                   // prologue + barrier
 
   char* tin = tile_a;
@@ -250,7 +257,9 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     }
     // dZ = acc * act'(h): fp32 to global, planes to the output tile; returns the lane's 4 feature values (rows past
     // the end are exact zeros: their d heads are, and out-of-range H reads 0)
-    float dz_max = 0.0f;                        // largest |dZ_{L-1}| this lane produced (fp16 form)
+    // largest |dZ_{L-1}| this lane produced (fp16 form; one v_max_f32 with |.| per element: a NaN is dropped by the maximum
+    // and poisons everything computed from its row whatever the scales)
+    float dz_max = 0.0f;
     auto epilogue = [&](int ob, int g, const f32x4& acc_scaled, const f32x4& hval) -> f32x4 {
       const int f = ob * 16 + q4;
       f32x4 v;
@@ -263,9 +272,9 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
       } else {
         v = chain_act_grad4(accv, hval, p_act);
       }
-      if constexpr (RLG_BX_F16) {
+      if constexpr (RLG_BX_F16 && RLG_BX_TRACK != 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dz_max = __builtin_fmaxf(dz_max, bx_finite_abs(v[e]));
+        for (int e = 0; e < 4; ++e) dz_max = __builtin_fmaxf(dz_max, __builtin_fabsf(v[e]));
       }
       if (!(kAbl & 2)) buf_store4(dr, f < width ? d_lane + static_cast<unsigned>(g) * d_group + static_cast<unsigned>(ob) * 64u : kOob, v);
       if (keep_tile) {
@@ -337,7 +346,12 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     };
     whole(std::integral_constant<int, 2>{}, first_ob, units2);
     whole(std::integral_constant<int, 1>{}, first_ob + 2 * units2, left);
-    if (RLG_BX_F16) bx_publish_max(a.amax, kBxAmaxDz + L - 1, dz_max, false);
+    float* const wg_max = wg_max_all + (L - 1) * W;
+    if (RLG_BX_F16 && RLG_BX_TRACK == 1 && a.amax != nullptr) {
+      const float wmax = bx_wave_max(dz_max);
+      if (lane == 0) wg_max[wave] = wmax;
+    }
+    if (RLG_BX_TRACK == 2) asm volatile("" :: "v"(dz_max));
     if (nb_w == 0) request_after(false);        // a wave without a block here still owes itself the next layer's first H
     chain_stamp(a.dbg, wave, stamp);                                 // per layer: units done
     // an odd number of blocks leaves half a chunk of the output tile unwritten: zero it (the weights there are zero,
@@ -353,6 +367,15 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     char* t = tin;
     tin = tout;
     tout = t;
+  }
+  // The workgroup's gradient maxima (csrc/bx_form.hpp), stored behind the last layer's barrier: every wave has left the
+  // largest |dZ_l| it produced in LDS, thread l combines layer l's.  (Stored BETWEEN the layers by a thread that kept
+  // them in registers, the launch lost 7 us: 8 more live registers across the unit engine cost 260 accumulator moves and
+  // turned 22 exact vmcnt waits into vmcnt(0).)
+  if (RLG_BX_F16 && a.amax != nullptr && static_cast<int>(threadIdx.x) < num_layers) {
+    const float* m = wg_max_all + threadIdx.x * W;
+    a.amax[static_cast<long long>(kBxAmaxDz + threadIdx.x) * a.amax_stride + blockIdx.x] =
+        __builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3]));
   }
 }
 

@@ -175,7 +175,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         }
       }
     };
-    float in_max = 0.0f;
     auto put_frags = [&](int u0, float scale) {
 #pragma unroll
       for (int k = 0; k < kProBatch; ++k) {
@@ -207,10 +206,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
             }
           }
           const float x[8] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
-          if constexpr (RLG_BX_F16) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) in_max = __builtin_fmaxf(in_max, bx_finite_abs(x[e]));
-          }
           u32x4 plane[kBxPlanes];
           bx_split8(x, scale, plane);
 #pragma unroll
@@ -245,7 +240,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       load_frags(u0);
       put_frags(u0, scale_mine);
     }
-    if (RLG_BX_F16) bx_publish_max(a.amax, kBxAmaxX + 0, in_max, true);
     __syncthreads();
     if (RLG_BX_F16 && !norm) {
 #pragma unroll
@@ -270,7 +264,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
 
     // bias + activation of a fragment of layer `layer`: fp32 to global memory (training / heads), planes to `dst_tile`
     // at chunk (ob >> 1) - chunk_base.  Padded features come out as act(0 + 0) = 0.
-    auto make_epilogue = [&](int layer, char* dst_tile, int chunk_base, const float (&in_scale)[G], float* out_max) {
+    auto make_epilogue = [&](int layer, char* dst_tile, int chunk_base, const float (&in_scale)[G]) {
       const int width = pin_s(a.layer[layer].out), act = pin_s(a.layer[layer].act);
       float* ph = pin_s(a.layer[layer].h);
       const long long ld = pin_s(a.layer[layer].ldh);
@@ -304,10 +298,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
           }
         }
         if (dst_tile != nullptr) {
-          if constexpr (RLG_BX_F16) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) *out_max = __builtin_fmaxf(*out_max, bx_finite_abs(v[e]));
-          }
           unsigned plane[kBxPlanes][2];
           bx_split4(v, kBxScaleH, plane);
           char* dst = dst_tile + ((((ob >> 1) - chunk_base) * G + g) * kBxPlanes) * kBxFrag + lane * 16 + (ob & 1) * 8;
@@ -331,14 +321,13 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       return pin_s(static_cast<int>(aligned16(a.layer[layer].bias) && (a.layer[layer].out & 3) == 0)) != 0;
     };
     // blocks [b0, b1) of layer L for all row groups: this wave's share, two blocks per unit, then one
-    float out_max = 0.0f;                   // largest |H_L| this lane produced (fp16 form)
     auto run_blocks = [&](int b0, int b1, char* dst_tile, int chunk_base) {
       const int nb = b1 - b0;
       const int nb_w = wave_blocks(nb), first_ob = b0 + wave_first(nb);
       const int units2 = nb_w >> 1, left = nb_w & 1;
       const rsrc_t br = bias_rsrc(L);
       const bool bfast = bias_fast(L);
-      auto epilogue = make_epilogue(L, dst_tile, chunk_base, scale_in, &out_max);
+      auto epilogue = make_epilogue(L, dst_tile, chunk_base, scale_in);
       auto whole = [&](auto nf_tag, int first, int nunits) {
         constexpr int NF = decltype(nf_tag)::value;
         bx_units<G, G, NF>(
@@ -380,7 +369,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
 
     if (L + 1 != pass_layer) {
       run_blocks(0, NOB, tout, 0);
-      if (RLG_BX_F16 && tout != nullptr) bx_publish_max(a.amax, kBxAmaxX + L + 1, out_max, true);
       zero_pad(tout, NOB, 0);
       chain_stamp(a.dbg, wave, stamp);                               // per layer: units done
       __syncthreads();
@@ -399,7 +387,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     const bool p_last = (P == num_layers - 1);
     char* ptile = p_last ? nullptr : ldsb + pin_s(a.bx_tile_off[P + 1]);
     f32x4 pacc[kFwMaxPersist][G];
-    float p_max = 0.0f;
     for (int c0 = 0; c0 < KCP; c0 += win) {
       const int c1 = (c0 + win < KCP) ? c0 + win : KCP;
       const int b0 = 2 * c0, b1 = (2 * c1 < NOB) ? 2 * c1 : NOB;
@@ -414,7 +401,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       const rsrc_t br = bias_rsrc(P);
       const bool bfast = bias_fast(P);
       const float hidden_scale[G] = {kBxScaleH, kBxScaleH, kBxScaleH, kBxScaleH};
-      auto epilogue = make_epilogue(P, ptile, 0, hidden_scale, &p_max);
+      auto epilogue = make_epilogue(P, ptile, 0, hidden_scale);
       f32x4 pb[kFwMaxPersist];
 #pragma unroll
       for (int f = 0; f < kFwMaxPersist; ++f) {
@@ -429,10 +416,6 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
           for (int g = 0; g < G; ++g) epilogue(pfirst + f, g, pacc[f][g], pb[f]);
         }
       }
-    }
-    if (RLG_BX_F16) {
-      bx_publish_max(a.amax, kBxAmaxX + L + 1, out_max, true);
-      if (ptile != nullptr) bx_publish_max(a.amax, kBxAmaxX + P + 1, p_max, true);
     }
     zero_pad(ptile, NOBP, 0);
     chain_stamp(a.dbg, wave, stamp);                                 // consumer epilogue

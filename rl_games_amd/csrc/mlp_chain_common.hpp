@@ -91,7 +91,8 @@ struct ChainArgs {
   int bx_handoff_off;                  // split-bf16 backward: byte offset in LDS of the loss tile's d heads, or -1
   int bx_handoff_ld;                   //   (the loss writes exactly the array the chain reads: no fence + re-load)
   int bx_scales_off;                   // split-fp16 backward: byte offset in LDS of the 64 row scales of the d heads tile
-  float* amax;                         // split-fp16 kernels: operand maxima slots (kBxAmax* below) or nullptr
+  float* amax;                         // split-fp16 backward: per-workgroup gradient maxima (csrc/bx_form.hpp kBxAmaxDz) or nullptr
+  int amax_stride;                     //   entries per tensor
   // split-bf16 forward: byte offset of tile L (the input of layer L) in LDS, of the normaliser scratch; the tile of
   // layer bx_pass_layer (-1: none) does not fit and is produced / consumed in windows of bx_pass_chunks chunks
   int bx_tile_off[kChainMaxLayers + 1];

@@ -33,6 +33,7 @@
 // the same class as the library kernels it replaces; only the summation order differs.
 
 #include "rlg_device.hpp"
+#include <cmath>
 #include "split_bf16.hpp"
 #include "split_f16.hpp"
 #include "rlg_hip.h"
@@ -69,6 +70,14 @@ static bool dw_split_products() {
   }();
   return on;
 }
+// host-side twin of f16_scale_for
+static float f16_scale_host(float amax) {
+  if (!(amax > 0.0f)) return 1.0f;
+  int e;
+  std::frexp(amax, &e);                       // amax in [2^(e-1), 2^e)
+  return std::ldexp(1.0f, 13 - (e - 1));
+}
+
 static bool dw_f16_products() {
   static const bool on = [] {
     const char* e = std::getenv("RLG_DW_F16");
@@ -77,9 +86,10 @@ static bool dw_f16_products() {
   return on && dw_split_products();
 }
 
-// rlg_mlp_dw_operand_maxima: one-shot, consumed by the next rlg_mlp_dw_launch
+// rlg_mlp_dw_gradient_maxima: one-shot, consumed by the next rlg_mlp_dw_launch
 static const float* g_dw_amax = nullptr;
-static int g_dw_amax_x[kDwMaxLayers], g_dw_amax_dz[kDwMaxLayers], g_dw_amax_n = 0, g_dw_amax_reset = 1;
+static int g_dw_amax_stride = 0, g_dw_amax_dz[kDwMaxLayers], g_dw_amax_n = 0;
+static float g_dw_scale_x[kDwMaxLayers];
 
 struct DwLayer {
   const float* dz;     // [rows, lda]
@@ -90,11 +100,11 @@ struct DwLayer {
   int No, Mi;
   int tiles_o, tiles_i, ksplit;
   int block_begin;     // first blockIdx.x of this layer
-  // fp16 form: device words holding the largest magnitudes of dz and x (left by the launches that produced them), or
-  // nullptr - then amax_* below (host-side bounds) are used
-  const float* amax_dz_ptr;
-  const float* amax_x_ptr;
-  float amax_dz, amax_x;
+  // fp16 form: dz is scaled by the power of two that the largest entry over a wave's rows asks for - amax_dz_entries[e] =
+  // the largest |dz| of rows [64 e, 64 e + 64) (left by the split-fp16 backward launch, csrc/bx_form.hpp), or nullptr:
+  // then the host-side bound amax_dz; x by the fixed scale the forward splits the same tensor with (scale_x)
+  const float* amax_dz_entries;
+  float amax_dz, scale_x;
   // tile t of a dimension covers columns [start[t], start[t] + 16 * b[t]), b in {1, 2, 4}
   short o_start[kDwMaxTiles], i_start[kDwMaxTiles];
   signed char o_b[kDwMaxTiles], i_b[kDwMaxTiles];
@@ -157,6 +167,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
   const int s_end = min(min(s_begin + steps_per_wave, (z + 1) * steps_per_block), steps_total);
   const int s_full_end = min(s_end, rows >> 2);      // steps whose 4 rows all exist
 
+  float scale_a = 1.0f, scale_b = 1.0f;          // fp16 form: this wave's operand scales
   f32x4 acc[BO][BI];
 #pragma unroll
   for (int a = 0; a < BO; ++a) {
@@ -262,10 +273,16 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       ra += KB * step_a;
       rb += KB * step_b;
     };
-    float scale_a = 1.0f, scale_b = 1.0f;
     if constexpr (kMode == kDwF16) {
-      scale_a = f16_scale_for(L.amax_dz_ptr ? *L.amax_dz_ptr : L.amax_dz);
-      scale_b = f16_scale_for(L.amax_x_ptr ? *L.amax_x_ptr : L.amax_x);
+      float amax = L.amax_dz;
+      if (L.amax_dz_entries != nullptr) {
+        // (wave-uniform addresses: scalar loads; a wave's rows span one to three 64-row entries)
+        amax = 0.0f;
+        const int e0 = (4 * s_begin) >> 6, e1 = (min(4 * s_end, rows) - 1) >> 6;
+        for (int e = e0; e <= e1; ++e) amax = __builtin_fmaxf(amax, L.amax_dz_entries[e]);
+      }
+      scale_a = f16_scale_for(amax);
+      scale_b = L.scale_x;
     }
     auto compute8_f16 = [&](const VA (&av)[KB], const VB (&bv)[KB]) {
       RLG_DW_PIN();
@@ -411,8 +428,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
 
   if constexpr (kMode == kDwF16) {
     // the accumulators hold S_dz S_x times the sums: un-scale (a power of two - exact) before they meet other slices
-    const float inv = 1.0f / (f16_scale_for(L.amax_dz_ptr ? *L.amax_dz_ptr : L.amax_dz) *
-                              f16_scale_for(L.amax_x_ptr ? *L.amax_x_ptr : L.amax_x));
+    const float inv = 1.0f / (scale_a * scale_b);
 #pragma unroll
     for (int a = 0; a < BO; ++a) {
 #pragma unroll
@@ -627,7 +643,6 @@ struct NormItem {
   double* partials;          // [gridDim.x] or nullptr
   long long* step_counter;   // or nullptr
   float grad_scale;
-  float* amax_reset;         // fp16 form: the operand-maxima slots [0, 16) are zeroed behind the launch that read them, or nullptr
 };
 
 // grad[e] = sum_z partial[z][e].  A block covers kFinElems consecutive float4 elements (a 256-byte
@@ -763,7 +778,6 @@ __device__ __forceinline__ double fin_vblock(int vb, const DwArgs& args, const C
 
 __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(DwArgs args, ColsumItems cs, LossFinalizeItem lf,
                                                               NormItem nrm) {
-  if (nrm.amax_reset != nullptr && blockIdx.x == 0 && threadIdx.x < 16) nrm.amax_reset[threadIdx.x] = 0.0f;
   const double sq = fin_vblock(blockIdx.x, args, cs, lf, nrm.grad_scale);
   if (nrm.partials) {                                // (uniform: every thread of the block gets here)
     __shared__ double nscratch[256 / kWave];
@@ -857,9 +871,12 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   DwArgs args;
   args.num_layers = num_layers;
   args.rows = rows;
-  // fp16 form: the operands' largest magnitudes - device words left by the chain launches (rlg_mlp_dw_operand_maxima), or,
-  // for the tools, host-side bounds from the environment; neither: the bf16 form
-  const float* amax = (g_dw_amax_n == num_layers) ? g_dw_amax : nullptr;
+  // fp16 form: the gradients' largest magnitudes per 64 rows - left by the split-fp16 backward (rlg_mlp_dw_gradient_maxima) -
+  // and the other operand's fixed scale; or, for the tools, host-side bounds from the environment; neither: the bf16 form
+  const float* amax = (g_dw_amax_n == num_layers && g_dw_amax_stride >= (rows + 63) / 64) ? g_dw_amax : nullptr;
+  const int amax_stride = g_dw_amax_stride;
+  float scale_x[kDwMaxLayers];
+  for (int l = 0; l < kDwMaxLayers; ++l) scale_x[l] = g_dw_scale_x[l];
   g_dw_amax = nullptr;
   g_dw_amax_n = 0;
   const char* ea = std::getenv("RLG_DW_F16_AMAX_DZ");
@@ -879,10 +896,9 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
     L.lda = L.No;
     L.ldb = L.Mi;
     L.ksplit = plans4[4 * l + 3];
-    L.amax_dz_ptr = amax ? amax + g_dw_amax_dz[l] : nullptr;
-    L.amax_x_ptr = amax ? amax + g_dw_amax_x[l] : nullptr;
+    L.amax_dz_entries = amax ? amax + static_cast<long long>(g_dw_amax_dz[l]) * amax_stride : nullptr;
     L.amax_dz = host_amax_dz;
-    L.amax_x = host_amax_x;
+    L.scale_x = amax ? scale_x[l] : f16_scale_host(host_amax_x);
     if (L.ksplit < 1 || (reinterpret_cast<uintptr_t>(L.partial) | reinterpret_cast<uintptr_t>(L.grad)) % 16 != 0 ||
         (static_cast<long long>(L.No) * L.Mi) % 4 != 0)
       return static_cast<int>(hipErrorInvalidValue);
@@ -919,26 +935,25 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   else if (dw_split_products()) hipLaunchKernelGGL(mlp_dw_bf16x6_kernel, dim3(blocks), dim3(256), 0, st, args);
   else hipLaunchKernelGGL(mlp_dw_kernel, dim3(blocks), dim3(256), 0, st, args);
   if (finalize_blocks_out) *finalize_blocks_out = total_vb;
-  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale, const_cast<float*>((f16 && g_dw_amax_reset) ? amax : nullptr)};
+  NormItem nrm = {norm_partials, norm_partials ? step_counter : nullptr, grad_scale};
   hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3(total_vb), dim3(256), 0, st, args, cs, lf, nrm);
   RLG_RETURN_LAUNCH_STATUS();
 }
 
-int rlg_mlp_dw_operand_maxima(const float* slots, const int* x_slot, const int* dz_slot, int num_layers, int reset) {
+int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, const int* dz_slot, const float* x_scale, int num_layers) {
   using namespace rlg;
-  if (slots == nullptr || num_layers <= 0 || num_layers > kDwMaxLayers) {
-    g_dw_amax = nullptr;
-    g_dw_amax_n = 0;
-    return slots == nullptr ? 0 : static_cast<int>(hipErrorInvalidValue);
-  }
+  g_dw_amax = nullptr;
+  g_dw_amax_n = 0;
+  if (entries == nullptr) return 0;
+  if (num_layers <= 0 || num_layers > kDwMaxLayers || stride <= 0) return static_cast<int>(hipErrorInvalidValue);
   for (int l = 0; l < num_layers; ++l) {
-    if (x_slot[l] < 0 || x_slot[l] >= 8 || dz_slot[l] < 8 || dz_slot[l] >= 16) return static_cast<int>(hipErrorInvalidValue);
-    g_dw_amax_x[l] = x_slot[l];
+    if (dz_slot[l] < 0 || dz_slot[l] >= 8 || !(x_scale[l] > 0.0f)) return static_cast<int>(hipErrorInvalidValue);
     g_dw_amax_dz[l] = dz_slot[l];
+    g_dw_scale_x[l] = x_scale[l];
   }
-  g_dw_amax = slots;
+  g_dw_amax = entries;
+  g_dw_amax_stride = stride;
   g_dw_amax_n = num_layers;
-  g_dw_amax_reset = reset;
   return 0;
 }
 

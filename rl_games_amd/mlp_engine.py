@@ -41,6 +41,7 @@ class ManualMLP:
         self._dw_plans = {}
         self.last_dw_path = None
         self.last_dw_jobs = None
+        self._x_normalised = False
         self.arena = arena
         self.linears = [m for m in net.actor_mlp if isinstance(m, nn.Linear)]
         acts = [m for m in net.actor_mlp if not isinstance(m, nn.Linear)]
@@ -259,6 +260,7 @@ class ManualMLP:
             else:
                 self.chain.forward(obs, heads, act_out=acts, rms=rms, eps=eps, xn_out=xn, rms_fold=rms_fold)
             self._x = xn if rms is not None else obs
+            self._x_normalised = rms is not None          # (went through the normaliser's clamp to [-5, 5])
             self._rows, self._last = rows, acts[-1]
             self._pending_backward = True
         else:
@@ -312,14 +314,17 @@ class ManualMLP:
                     self.chain.forward(fwd['x'], fwd['heads'], act_out=fwd['act_out'], rms=fwd['rms'], eps=fwd['eps'],
                                        xn_out=fwd['xn_out'], rms_fold=fwd['rms_fold'])
                 self.chain.backward(d_heads, acts, dzs, parts, ppo_loss=ppo_loss)
-            # (dZ, X, grad, layer): the layer index names the operands' slots of the chain's maxima (fp16 form)
+            # (dZ, X, grad, layer): the layer index names dZ's row of the backward's gradient maxima (fp16 form)
             jobs = [(d_heads, acts[-1], self.head_w_grad, L)]
             colsums = []
             for l in range(L - 1, -1, -1):
                 lin = self.linears[l]
                 jobs.append((dzs[l], acts[l - 1] if l > 0 else self._x, lin.weight.grad, l))
                 colsums.append((parts[l], nblk, lin.out_features, lin.bias.grad))
-            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm, maxima=self.chain.operand_maxima(rows))
+            # the fp16 form of the weight-gradient launch splits X under the forward's FIXED scales: hidden activations, and
+            # observations that went through the normaliser's clamp (raw observations have no bound: the bf16 form then)
+            maxima = self.chain.gradient_maxima(rows) if self._x_normalised else None
+            return self._weight_grads(jobs, rows, colsums, loss_finalize, norm, maxima=maxima)
         jobs = [(d_heads, self._last, self.head_w_grad)]           # (dZ, X, grad) per weight matrix
         colsums = []                                               # (partials, blocks, cols, bias.grad)
         if self.lstm is not None:
@@ -374,7 +379,7 @@ class ManualMLP:
         return self._weight_grads(jobs, rows, colsums, loss_finalize)
 
     def _weight_grads(self, jobs, rows, colsums=(), loss_finalize=None, norm=None, maxima=None):
-        """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi][, layer index]).  maxima: ops.MlpChain.operand_maxima() of the
+        """jobs: (dZ [rows, No], X [rows, Mi], grad [No, Mi][, layer index]).  maxima: ops.MlpChain.gradient_maxima() of the
         step, or None (then, or when a job carries no layer index, the launch runs its bf16 form).  Everything inside the MFMA kernel's
         envelope (Mi % 4 == 0, 16-byte aligned contiguous operands) goes into one launch; the rest
         (e.g. a first layer over 3 observations) uses the library GEMM."""
@@ -407,7 +412,8 @@ class ManualMLP:
                          and norm[0].numel() >= plan.finalize_blocks(colsums, loss_finalize))
                 mx = None
                 if maxima is not None and all(len(j) == 4 for j in fast):
-                    mx = (maxima, [j[3] for j in fast], [8 + j[3] for j in fast])
+                    mx = (maxima, [j[3] for j in fast],
+                          [ops.SPLIT_SCALE_OBS_NORM if j[3] == 0 else ops.SPLIT_SCALE_HIDDEN for j in fast])
                 triples = [j[:3] for j in fast]
                 norm_blocks = plan.launch(triples, colsums, loss_finalize, norm if whole else None, maxima=mx)
                 if not whole:

@@ -634,6 +634,11 @@ def narrow_dw(dz, x, grad):
 chain_timers = None     # bench.py: {'fwd': [...], 'bwd': [...]} of gae.HipEventPair, one per eager chain launch
 
 
+# fixed operand scales of the split-fp16 form (csrc/bx_form.hpp kBxScaleH / kBxScaleObsNorm)
+SPLIT_SCALE_HIDDEN = 16.0
+SPLIT_SCALE_OBS_NORM = 4096.0
+
+
 def chain_split_form():
     """(plane products per fp32 product, plane type) of this build's split-product chain kernels: (3, 'fp16') or (6, 'bf16')."""
     k = int(_lib.load().rlg_mlp_chain_split_products())
@@ -705,26 +710,24 @@ class MlpChain:
         self._planes_fresh = None  # (rows, weights version) of the training forward that packed the backward planes
         self._planes_for = None    # weights version for which BOTH directions' planes are valid (optimiser-written or packed)
         self._planes_packed_once = False
-        # split-fp16 launches: the largest magnitudes of the tensors they multiply (csrc/bx_form.hpp kBxAmax*), for the
-        # weight-gradient launch that follows them; rows of the last training forward / backward that left theirs
-        self._maxima = None
-        self._maxima_fwd = self._maxima_bwd = None
+        # split-fp16 backward: per 64-row workgroup the largest magnitude of every dZ tensor (csrc/bx_form.hpp), for the
+        # weight-gradient launch that follows it; rows of the last backward that left them
+        self._grad_maxima = None
+        self._maxima_bwd = None
 
-    def _maxima_buffer(self):
-        if self._maxima is None:
-            self._maxima = torch.zeros(32, dtype=F32, device=self.device)
-        return self._maxima
+    def _grad_maxima_buffer(self, rows):
+        need = max(1024, -(-int(rows) // 64))
+        if self._grad_maxima is None or self._grad_maxima.shape[1] < need:
+            self._grad_maxima = torch.zeros(8, need, dtype=F32, device=self.device)
+        return self._grad_maxima
 
-    def operand_maxima(self, rows):
-        """The maxima slots when BOTH the training forward and the backward of this step (`rows` rows) ran the split-fp16
-        kernels - then MlpDwPlan.launch(maxima=...) may run its fp16 form - else None."""
-        if self._maxima is not None and self._maxima_fwd == rows and self._maxima_bwd == rows:
-            return self._maxima
+    def gradient_maxima(self, rows):
+        """[8, entries] fp32: row l = per 64-row workgroup the largest |dZ of layer l| of the backward of this step - when
+        that backward (`rows` rows) ran the split-fp16 kernel, else None.  MlpDwPlan.launch(maxima=...) then runs its
+        fp16 form."""
+        if self._grad_maxima is not None and self._maxima_bwd == rows:
+            return self._grad_maxima
         return None
-
-    def largest_inputs_ever(self):
-        """Host copy of the largest magnitude every layer's input has had in any split-fp16 forward launch (one sync)."""
-        return None if self._maxima is None else self._maxima[16:16 + self.n].tolist()
 
     def invalidate_planes(self):
         """The weights changed behind this object's back: backward() re-packs its planes (and the lean kernels'
@@ -899,8 +902,6 @@ class MlpChain:
         # of the exact-product forward launch.  backward() uses those planes once; any other caller packs for itself.
         if split_products is not False and groups in (0, 1) and self.lean_used(rows, 0):
             self._planes_fresh = None
-            if act_out is not None:
-                self._maxima_fwd = None
             self.ensure_frags(x)
             _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
             err = _lib.load().rlg_mlp_chain_forward_lean(
@@ -922,12 +923,6 @@ class MlpChain:
             fwd_planes = self._planes_ptr(0)
         elif bwd_split and not self.planes_current():
             planes = self._planes_ptr(1)
-        if fwd_planes is not None:
-            _lib.load().rlg_mlp_chain_operand_maxima(self._maxima_buffer().data_ptr())
-            if train:
-                self._maxima_fwd = rows
-        elif train:
-            self._maxima_fwd = None
         _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
@@ -1037,8 +1032,10 @@ class MlpChain:
             if not self.planes_current() and (self._planes_fresh is None or self._planes_fresh != (rows, self._version())):
                 self.pack_planes(1, d_heads)                    # (else: packed with the forward launch of this step)
             planes = self._planes_ptr(1)
-            _lib.load().rlg_mlp_chain_operand_maxima(self._maxima_buffer().data_ptr())
-        self._maxima_bwd = rows if planes is not None else None
+            if chain_split_form()[1] == 'fp16':
+                buf = self._grad_maxima_buffer(rows)
+                _lib.load().rlg_mlp_chain_gradient_maxima(buf.data_ptr(), buf.shape[1])
+        self._maxima_bwd = rows if (planes is not None and self._grad_maxima is not None) else None
         self._planes_fresh = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
@@ -1092,11 +1089,11 @@ class MlpDwPlan:
             n += 1 + (2 * loss_finalize.actions_num + 7) // 8
         return n
 
-    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None, maxima=None, reset_maxima=True):
-        """jobs: (dz, x, grad) per planned layer.  maxima = (slots fp32 [32] of MlpChain.operand_maxima, x slot per job,
-        dz slot per job): the launch runs on three fp16 plane products per fp32 product, each operand scaled by the power
-        of two its largest magnitude asks for (csrc/split_f16.hpp), and zeroes the slots behind it (reset_maxima);
-        without them: six bf16 plane products.  colsums: optional (partials fp64 [blocks*cols],
+    def launch(self, jobs, colsums=(), loss_finalize=None, norm=None, maxima=None):
+        """jobs: (dz, x, grad) per planned layer.  maxima = (MlpChain.gradient_maxima() [8, entries], layer of each job's
+        dz, fixed scale of each job's x - SPLIT_SCALE_HIDDEN / SPLIT_SCALE_OBS_NORM): the launch runs on three fp16 plane
+        products per fp32 product (csrc/split_f16.hpp), dz scaled by the power of two the largest entry over a wave's
+        rows asks for, x by the scale the forward splits the same tensor with; without them: six bf16 plane products.  colsums: optional (partials fp64 [blocks*cols],
         blocks, cols, out fp32 [cols]) items - bias gradients finished in the same finalise launch.
         loss_finalize: ops.loss_finalize_desc(...) - the PPO loss partials are folded there as well.
         norm = (partials fp64 [>= finalise blocks], grad_scale, step_counter int64 [1]): the finalise
@@ -1130,13 +1127,12 @@ class MlpDwPlan:
             self._x[k] = _need(x, F32, 'x')
             self._grad[k] = _need(grad, F32, 'grad')
         if maxima is not None:
-            slots, xs, dzs = maxima
-            if len(xs) != self.n or len(dzs) != self.n:
-                raise ValueError('maxima: one x slot and one dz slot per job')
-            I = ctypes.c_int * self.n
-            _lib.check(_lib.load().rlg_mlp_dw_operand_maxima(_need(slots, F32, 'maxima'), I(*[int(v) for v in xs]),
-                                                             I(*[int(v) for v in dzs]), self.n, 1 if reset_maxima else 0),
-                       'rlg_mlp_dw_operand_maxima')
+            entries, dzs, xscales = maxima
+            if len(dzs) != self.n or len(xscales) != self.n or entries.dim() != 2 or entries.shape[0] != 8:
+                raise ValueError('maxima: [8, entries] fp32, one dz layer and one x scale per job')
+            _lib.check(_lib.load().rlg_mlp_dw_gradient_maxima(
+                _need(entries, F32, 'gradient maxima'), int(entries.shape[1]), (ctypes.c_int * self.n)(*[int(v) for v in dzs]),
+                (ctypes.c_float * self.n)(*[float(v) for v in xscales]), self.n), 'rlg_mlp_dw_gradient_maxima')
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,
                                                  cs_cols, cs_out,
