@@ -19,6 +19,10 @@
 namespace rlg {
 
 constexpr int kFwG = 4;
+#ifndef RLG_BX_FWD_NF
+#define RLG_BX_FWD_NF 2
+#endif
+constexpr int kFwUnitBlocks = RLG_BX_FWD_NF;   // blocks of the widest unit (4: a B fragment read from LDS feeds four MFMA chains)
 constexpr int kFwMaxPersist = 4;        // blocks of the windowed tile's consumer per wave (accumulators across passes)
 
 // Chunks [c0, c1) of the reduction of NF blocks (block f: ob_first + min(f, nb_valid - 1); the surplus ones repeat the
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
   auto wave_blocks = [&](int nob) -> int { return nob / W + (wave < nob % W ? 1 : 0); };
   auto wave_first = [&](int nob) -> int { return wave * (nob / W) + (wave < nob % W ? wave : nob % W); };
   const int pass_layer = pin_s(a.bx_pass_layer), win = pin_s(a.bx_pass_chunks);
-  f32x4 bval[2], bnext[2];
+  f32x4 bval[kFwUnitBlocks], bnext[kFwUnitBlocks];
 
   for (int L = 0; L < num_layers; ++L) {
     const bool last = (L == num_layers - 1);
@@ -320,11 +324,15 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     auto bias_fast = [&](int layer) -> bool {
       return pin_s(static_cast<int>(aligned16(a.layer[layer].bias) && (a.layer[layer].out & 3) == 0)) != 0;
     };
-    // blocks [b0, b1) of layer L for all row groups: this wave's share, two blocks per unit, then one
+    // blocks [b0, b1) of layer L for all row groups: this wave's share, four blocks per unit, then two, then one
     auto run_blocks = [&](int b0, int b1, char* dst_tile, int chunk_base) {
       const int nb = b1 - b0;
       const int nb_w = wave_blocks(nb), first_ob = b0 + wave_first(nb);
-      const int units2 = nb_w >> 1, left = nb_w & 1;
+      // widest units first: kFwUnitBlocks blocks each, then (unless the widest is 3: pairs would be a third instantiation of
+      // the engine and its registers) pairs, then single blocks
+      const int unitsw = (kFwUnitBlocks > 2) ? nb_w / kFwUnitBlocks : 0;
+      const int rest = nb_w - kFwUnitBlocks * unitsw;
+      const int units2 = (kFwUnitBlocks == 3) ? 0 : rest >> 1, left = rest - 2 * units2;
       const rsrc_t br = bias_rsrc(L);
       const bool bfast = bias_fast(L);
       auto epilogue = make_epilogue(L, dst_tile, chunk_base, scale_in);
@@ -355,8 +363,9 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
             },
             false);
       };
-      whole(std::integral_constant<int, 2>{}, first_ob, units2);
-      whole(std::integral_constant<int, 1>{}, first_ob + 2 * units2, left);
+      if constexpr (kFwUnitBlocks > 2) whole(std::integral_constant<int, kFwUnitBlocks>{}, first_ob, unitsw);
+      if constexpr (kFwUnitBlocks != 3) whole(std::integral_constant<int, 2>{}, first_ob + kFwUnitBlocks * unitsw, units2);
+      whole(std::integral_constant<int, 1>{}, first_ob + kFwUnitBlocks * unitsw + 2 * units2, left);
     };
     // an odd number of blocks leaves half a chunk of a tile unwritten: zero it (the weights there are zero, but
     // 0 x stale bits may be NaN)

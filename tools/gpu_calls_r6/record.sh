@@ -1,7 +1,7 @@
 # round 6 record run: bench lines (default + ant + lstm), rocprofv3 kernel summary of the bench command, the rank-shape emulation
 # + its kernel summary, PMC traffic of the in-epoch GAE launch
 cd $GRAFT_REPO_ROOT
-R=gpurun_out/r6_record; mkdir -p $R
+R=gpurun_out/r6_record_f16; mkdir -p $R
 python bench.py > $R/bench.json 2> $R/bench.err; tail -c 300 $R/bench.json; echo
 python bench.py --workload ant --no-cpu-baseline > $R/bench_ant.json 2> /dev/null; python bench.py --workload lstm --no-cpu-baseline > $R/bench_lstm.json 2>/dev/null
 python tools/rank_shapes.py 2>&1 | grep -v amdgpu.ids > $R/rank_shapes.txt; cat $R/rank_shapes.txt
