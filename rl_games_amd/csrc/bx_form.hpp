@@ -58,7 +58,7 @@ __device__ __forceinline__ void bx_split8(const float (&x)[8], float scale, u32x
 __device__ __forceinline__ void bx_split4(const f32x4& v, float scale, unsigned (&plane)[kBxPlanes][2]) {
 #if RLG_BX_F16
 #pragma unroll
-  for (int q = 0; q < 2; ++q) split_pair_f16(v[2 * q] * scale, v[2 * q + 1] * scale, plane[0][q], plane[1][q]);
+  for (int q = 0; q < 2; ++q) split_pair_f16(v[2 * q], v[2 * q + 1], scale, plane[0][q], plane[1][q]);
 #else
   split4_planes(v, plane);
 #endif

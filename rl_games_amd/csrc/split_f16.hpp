@@ -26,13 +26,37 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((split_f32x2{lo, hi}), split_f16x2));
 }
 
-// One pair of ALREADY SCALED fp32 values -> its dword of each of the two planes: v_cvt_pk_f16_f32, two v_cvt_f32_f16, two
-// v_sub_f32, v_cvt_pk_f16_f32 = 6 VALU instructions (the bf16 form: 9).
-__device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned& p0, unsigned& p1) {
-  const split_f16x2 h = __builtin_convertvector((split_f32x2{x0, x1}), split_f16x2);
+#ifndef RLG_F16_FMA_MIX
+#define RLG_F16_FMA_MIX 1          // 0: residual by v_cvt_f32_f16 + subtraction (the same bits, two more conversion-rate instructions per pair)
+#endif
+
+// x * scale - (float) half `hi` of the packed fp16 pair h, ONE rounding: v_fma_mix_f32 reads the fp16 operand in place, so
+// the plane is not converted back (conversions issue at a quarter of the plain VALU rate: the back-conversions were a
+// third of the split's cycles).  x * scale is exact (a power of two) and so is the difference: the same bits as
+// (x * scale) - (float) h.  An asm statement is fine HERE: its result feeds a VALU conversion, not an MFMA (the hazard
+// recogniser does not see inside asm - what an MFMA reads must come from a builtin, see split_bf16.hpp).
+template <bool kHi>
+__device__ __forceinline__ float f16_residual(float x, float scale, unsigned h) {
+  float r;
+  if constexpr (kHi)
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(scale), "v"(h));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(scale), "v"(h));
+  return r;
+}
+
+// One pair of fp32 values, times `scale` -> its dword of each of the two planes: v_pk_mul_f32, v_cvt_pk_f16_f32, two
+// v_fma_mix_f32, v_cvt_pk_f16_f32 = 5 VALU instructions, two of them at the conversion rate (the bf16 form: 9, three).
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, float scale, unsigned& p0, unsigned& p1) {
+  const split_f16x2 h = __builtin_convertvector((split_f32x2{x0 * scale, x1 * scale}), split_f16x2);
   p0 = __builtin_bit_cast(unsigned, h);
-  const float r0 = x0 - static_cast<float>(h[0]);
-  const float r1 = x1 - static_cast<float>(h[1]);
+#if RLG_F16_FMA_MIX
+  const float r0 = f16_residual<false>(x0, scale, p0);
+  const float r1 = f16_residual<true>(x1, scale, p0);
+#else
+  const float r0 = x0 * scale - static_cast<float>(h[0]);
+  const float r1 = x1 * scale - static_cast<float>(h[1]);
+#endif
   p1 = cvt_pk_f16(r0, r1);
 }
 
@@ -42,7 +66,7 @@ __device__ __forceinline__ void f16_split8(const float (&x)[8], float scale, u32
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     unsigned p0, p1;
-    split_pair_f16(x[2 * q] * scale, x[2 * q + 1] * scale, p0, p1);
+    split_pair_f16(x[2 * q], x[2 * q + 1], scale, p0, p1);
     plane[0][q] = p0;
     plane[1][q] = p1;
   }

@@ -1,4 +1,4 @@
-"""Shader-clock phase stamps (s_memtime = core clock cycles) of the split-bf16 forward (csrc/mlp_chain_bx_fwd.hip), humanoid
+"""Shader-clock phase stamps (s_memtime = core clock cycles) of the split-product forward (csrc/mlp_chain_bx_fwd.hip), humanoid
 network; ideal = MFMA cycles at 16 per v_mfma_f32_16x16x32_bf16 for the wave with the most blocks."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -27,7 +27,8 @@ heads = torch.empty(rows, out_dim, device=dev)
 acts = [torch.empty(rows, u, device=dev) for u in units] if train else None
 xn = torch.empty(rows, in_dim, device=dev) if train else None
 nb = (rows + 63) // 64
-names = ['start', 'prologue + barrier', 'L0+L1 passes', 'L1 epilogue', 'L1 barrier', 'L2 units', 'L2 barrier', 'head units', 'head barrier']
+# (round 6, fp16 planes: the humanoid network's tiles fit without a windowed layer - one 'units' + 'barrier' stamp pair per layer)
+names = ['start', 'prologue + barrier'] + [x for L in range(len(dims) - 1) for x in (f'L{L} units', f'L{L} barrier')]
 for rep in range(3):
     chain.forward(x, heads, act_out=acts, rms=(mean, var), xn_out=xn)
 dbg = torch.zeros(nb * 4 * 32, dtype=torch.int64, device=dev)
