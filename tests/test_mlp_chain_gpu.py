@@ -945,3 +945,123 @@ def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch)
         if act == 'elu':
             a = torch.nn.functional.elu(a)
     assert float((out['lean'][0].double() - a).abs().max() / a.abs().max()) < 1e-6
+
+
+# ----------------------------------------------------------------------------- split-fp16 form (round 6)
+
+def _fp16_form():
+    from rl_games_amd import ops
+    return ops.chain_split_form()[1] == 'fp16'
+
+
+@pytest.mark.parametrize('rows', [32768, 16384 + 640, 4096])
+def test_dw_fp16_form_with_per_wave_gradient_scales_matches_fp64(rows):
+    """The weight-gradient launch on three fp16 plane products (MlpDwPlan.launch(maxima=...)): dZ whose magnitude varies
+    over 2^-20 .. 1 from one 64-row block to the next (every wave scales by the largest entry over ITS rows), blocks of
+    all-zero rows (entry 0), activations under the forward's fixed scales - against fp64, judged like the bf16 form, and
+    beside it."""
+    from rl_games_amd import ops
+    if not _fp16_form():
+        pytest.skip('bf16 build')
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(200, 400), (400, 108), (100, 200), (22, 100)]
+    nblk = -(-rows // 64)
+    jobs, entries = [], torch.zeros(8, max(1024, nblk), device=DEV)
+    for k, (No, Mi) in enumerate(shapes):
+        block_scale = torch.exp2(-20.0 * torch.rand(nblk, generator=g))
+        block_scale[::7] = 0.0                                               # whole blocks of zero gradient (masked rows)
+        dz = torch.randn(rows, No, generator=g) * block_scale.repeat_interleave(64)[:rows, None] * 3e-4
+        x = torch.nn.functional.elu(torch.randn(rows, Mi, generator=g))
+        if k == 1:
+            x = x.clamp(-5.0, 5.0)                                           # "normalised observations"
+        dz, x = dz.to(DEV), x.to(DEV)
+        pad = torch.zeros(nblk * 64, No, device=DEV)
+        pad[:rows] = dz.abs()
+        entries[k, :nblk] = pad.view(nblk, 64 * No).max(dim=1).values
+        jobs.append((dz, x, torch.full((No, Mi), float('nan'), device=DEV)))
+    plan = ops.MlpDwPlan(shapes, rows, DEV)
+    xscale = [ops.SPLIT_SCALE_HIDDEN, ops.SPLIT_SCALE_OBS_NORM, ops.SPLIT_SCALE_HIDDEN, ops.SPLIT_SCALE_HIDDEN]
+    plan.launch(jobs, maxima=(entries, [0, 1, 2, 3], xscale))
+    f16 = [j[2].clone() for j in jobs]
+    plan.launch(jobs)                                                        # the bf16 form on the same operands
+    for (dz, x, bf), got in zip(jobs, f16):
+        assert torch.isfinite(got).all()
+        t64 = dz.double().t() @ x.double()
+        scale = dz.double().abs().t() @ x.double().abs()
+        e16 = ((got.double() - t64).abs() / scale.clamp_min(1e-300))
+        eb = ((bf.double() - t64).abs() / scale.clamp_min(1e-300))
+        lib = (((dz.t() @ x).double() - t64).abs() / scale.clamp_min(1e-300))
+        assert e16.max() <= max(2.0 * eb.max().item(), lib.max().item()), (e16.max(), eb.max(), lib.max())
+        assert e16.pow(2).mean().sqrt() <= 1.5 * eb.pow(2).mean().sqrt() + 1e-10
+
+
+def test_split_fp16_backward_scales_gradient_rows_by_their_own_maxima():
+    """The fp16 backward splits the d heads tile ROW BY ROW: a row of gradients a million times smaller than its tile
+    neighbours gives the same dZ bits as in a tile of rows like itself, and the gradient maxima it leaves for the
+    weight-gradient launch are the per-64-row maxima of what it wrote."""
+    from rl_games_amd import ops
+    if not _fp16_form():
+        pytest.skip('bf16 build')
+    rows = 16384
+    layers, g = _net(60, [256, 128], 9, 'elu', seed=31)
+    chain = ops.MlpChain(layers, DEV)
+    assert chain.split_products(rows, 1)
+    x = torch.randn(rows, 60, generator=g).to(DEV)
+    heads = torch.empty(rows, 9, device=DEV)
+    acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+    chain.forward(x, heads, act_out=acts)
+    d = (1e-4 * torch.randn(rows, 9, generator=g)).to(DEV)
+
+    def run(d_heads):
+        dzs = [torch.full((rows, 256), float('nan'), device=DEV), torch.full((rows, 128), float('nan'), device=DEV)]
+        nb = chain.num_blocks(rows, 1)
+        parts = [torch.empty(nb * 256, dtype=torch.float64, device=DEV), torch.empty(nb * 128, dtype=torch.float64, device=DEV)]
+        chain.backward(d_heads, acts, dzs, parts)
+        return dzs
+    small = d.clone()
+    small[::3] *= 2.0 ** -20
+    mixed = run(small)
+    maxima = chain.gradient_maxima(rows)
+    assert maxima is not None
+    nblk = rows // 64
+    for l, dz in enumerate(mixed):
+        assert torch.equal(maxima[l, :nblk], dz.abs().view(nblk, -1).max(dim=1).values), l
+    assert torch.equal(maxima[2, :nblk], small.abs().view(nblk, -1).max(dim=1).values)
+    alone = run(d * 2.0 ** -20)
+    for m, a_ in zip(mixed, alone):
+        assert torch.equal(m[::3], a_[::3])
+
+
+def test_split_fp16_range_limits_end_in_non_finite_values_never_in_wrong_ones():
+    """The fixed scales of the fp16 form hold |weight| < 1023 and |hidden activation| < 4094: beyond them the planes are
+    Inf and what is computed from them is Inf / NaN - in the rows concerned (an activation) or everywhere (a weight) -
+    while everything inside the range is what the exact-product kernels give."""
+    from rl_games_amd import ops
+    if not _fp16_form():
+        pytest.skip('bf16 build')
+    rows = 16384
+    layers, g = _net(60, [256, 128], 9, 'elu', seed=32)
+    x = torch.randn(rows, 60, generator=g).to(DEV)
+
+    def run(layers, x, split):
+        chain = ops.MlpChain(layers, DEV)
+        heads = torch.empty(rows, 9, device=DEV)
+        acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
+        chain.forward(x, heads, act_out=acts, split_products=None if split else False)
+        return acts, heads
+    # a row whose first-layer activations reach 1e4 (raw observations have no bound; the activations they produce do)
+    big = x.clone()
+    big[5] *= 3e4
+    acts, heads = run(layers, big, True)
+    ex_acts, ex_heads = run(layers, big, False)
+    assert ex_acts[0][5].abs().max() > 4094 and torch.isfinite(ex_heads).all()
+    assert not torch.isfinite(heads[5]).all()
+    keep = torch.ones(rows, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert torch.isfinite(heads[keep]).all()
+    assert (heads[keep] - ex_heads[keep]).abs().max() <= 4e-6 * ex_heads[keep].abs().max()
+    # a weight of 2,000
+    heavy = [(w.clone(), b.clone(), a) for w, b, a in layers]
+    heavy[1][0][3, 7] = 2000.0
+    acts, heads = run(heavy, x, True)
+    assert not torch.isfinite(acts[1][:, 3]).any()
