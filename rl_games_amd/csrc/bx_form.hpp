@@ -88,6 +88,8 @@ __device__ __forceinline__ float bx_row_scale(float mine) {
 // fixed scales.
 constexpr int kBxAmaxDz = 0, kBxAmaxSlots = 8;
 constexpr int kBxRowsPerEntry = 64;
+// LDS bytes of the backward behind its tiles: 64 row scales of the d heads tile + 8 layers x 4 waves of gradient maxima (+ alignment)
+constexpr int kBxBwdScratch = RLG_BX_F16 ? 16 + 64 * 4 + 8 * 4 * 4 : 0;
 
 // largest value of a wave (uniform result): row rotations inside the 16-lane rows, then the four rows through SGPRs
 __device__ __forceinline__ float bx_wave_max(float t) {

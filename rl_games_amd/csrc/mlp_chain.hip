@@ -1814,7 +1814,7 @@ int rlg_mlp_chain_backward(int num_layers, const float* const* weights, const in
         const int hld = (w + 1) | 1;
         const int hbytes = 16 * G * hld * 4;
         if (w == 1 + d.actions_num && d.d_values == d_out && d.d_mu == d_out + 1 && d.ld_d_values == ld_dout &&
-            d.ld_d_mu == ld_dout && d.actions_num <= 32 && bx_lds + hbytes <= 160 * 1024) {
+            d.ld_d_mu == ld_dout && d.actions_num <= 32 && bx_lds + hbytes + kBxBwdScratch <= 160 * 1024) {
           bx.bx_handoff_off = (bx_lds + 15) & ~15;
           bx.bx_handoff_ld = hld;
           bx_lds = bx.bx_handoff_off + hbytes;

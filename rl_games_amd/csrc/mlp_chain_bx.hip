@@ -393,7 +393,8 @@ int chain_bx_bwd_lds(ChainArgs& args, int G) {
   const long long a_bytes = a_chunks * G * kBxChunk, b_bytes = b_chunks * G * kBxChunk;
   const long long bytes = a_bytes + b_bytes;
   args.lds_b_floats = static_cast<int>(a_bytes / 4);
-  return bytes <= 160 * 1024 ? static_cast<int>(bytes) : -1;
+  // (room for the fp16 form's row scales and the waves' gradient maxima behind the tiles: kBxBwdScratch)
+  return bytes + kBxBwdScratch <= 160 * 1024 ? static_cast<int>(bytes) : -1;
 }
 
 bool chain_bx_bwd_eligible(const ChainArgs& args) {

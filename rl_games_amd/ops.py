@@ -1032,10 +1032,15 @@ class MlpChain:
             if not self.planes_current() and (self._planes_fresh is None or self._planes_fresh != (rows, self._version())):
                 self.pack_planes(1, d_heads)                    # (else: packed with the forward launch of this step)
             planes = self._planes_ptr(1)
-            if chain_split_form()[1] == 'fp16':
-                buf = self._grad_maxima_buffer(rows)
-                _lib.load().rlg_mlp_chain_gradient_maxima(buf.data_ptr(), buf.shape[1])
-        self._maxima_bwd = rows if (planes is not None and self._grad_maxima is not None) else None
+        # the split-fp16 launch leaves the gradient maxima the weight-gradient launch scales by - claimed only where the
+        # library is sure to take that launch (chain_bx_bwd_eligible: 16-byte aligned H / dZ rows of 4-float groups)
+        left_maxima = False
+        if planes is not None and chain_split_form()[1] == 'fp16' and all(
+                t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.shape[1] % 4 == 0 for t in list(acts) + list(dz_out)):
+            buf = self._grad_maxima_buffer(rows)
+            _lib.load().rlg_mlp_chain_gradient_maxima(buf.data_ptr(), buf.shape[1])
+            left_maxima = True
+        self._maxima_bwd = rows if left_maxima else None
         self._planes_fresh = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
