@@ -72,10 +72,12 @@ static bool dw_split_products() {
 }
 // host-side twin of f16_scale_for
 static float f16_scale_host(float amax) {
-  if (!(amax > 0.0f)) return 1.0f;
+  if (!(amax > 0.0f)) return std::ldexp(1.0f, 100);
   int e;
   std::frexp(amax, &e);                       // amax in [2^(e-1), 2^e)
-  return std::ldexp(1.0f, 13 - (e - 1));
+  int s = 13 - (e - 1);
+  s = s < -100 ? -100 : (s > 100 ? 100 : s);
+  return std::ldexp(1.0f, s);
 }
 
 static bool dw_f16_products() {

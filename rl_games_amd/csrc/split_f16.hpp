@@ -73,11 +73,12 @@ __device__ __forceinline__ void f16_split8(const float (&x)[8], float scale, u32
 }
 
 // power-of-two scale that puts `amax` (the largest magnitude of an operand, >= 0, finite) into [2^13, 2^14): two bits below
-// the fp16 overflow threshold.  Zero / denormal maxima: the largest scale that keeps 1 / (S_x S_y) a normal fp32.
+// the fp16 overflow threshold.  The exponent is held within +- 100 (operands of 2^-87 .. 2^113 are scaled exactly into that
+// range; zero / denormal maxima take the largest scale, and 1 / (S_x S_y) stays a normal fp32 for every pair of scales).
 __device__ __forceinline__ float f16_scale_for(float amax) {
   const int e = (__float_as_int(amax) >> 23) & 0xff;            // biased exponent: amax in [2^(e-127), 2^(e-126))
   int s = 127 + 13 - (e - 127);                                 // biased exponent of 2^(13 - (e - 127))
-  s = min(max(s, 127 - 40), 127 + 40);
+  s = min(max(s, 127 - 100), 127 + 100);
   return __int_as_float(s << 23);
 }
 
