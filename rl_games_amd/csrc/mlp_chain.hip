@@ -1256,13 +1256,22 @@ static bool chain_bx_enabled() {
   return on;
 }
 
+// minibatches of at least this many rows run the 64-row split-product kernels (RLG_CHAIN_BX_MIN_ROWS: tools, A/B)
+static long long chain_bx_min_rows() {
+  static const long long n = [] {
+    const char* e = std::getenv("RLG_CHAIN_BX_MIN_ROWS");
+    return (e && std::atoll(e) > 0) ? std::atoll(e) : 16384LL;
+  }();
+  return n;
+}
+
 static bool chain_bx_fwd_wanted(long long rows, int groups) {
   static const bool on = [] {
     const char* e = std::getenv("RLG_CHAIN_BX_FWD");     // tools: A/B against the exact-product forward kernels
     return !(e && std::atoi(e) == 0);
   }();
   // (2: what pick_groups resolves the automatic choice to at these sizes - the callers pass the resolved value)
-  return on && chain_bx_enabled() && rows >= 16384 && (groups == 0 || groups == 2 || groups == 4);
+  return on && chain_bx_enabled() && rows >= chain_bx_min_rows() && (groups == 0 || groups == 2 || groups == 4);
 }
 
 // Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
@@ -1275,13 +1284,13 @@ static int pick_groups(long long rows, int requested, int direction = 0) {
     static const int forced_fwd = [] { const char* e = std::getenv("RLG_CHAIN_FWD_GROUPS"); return e ? std::atoi(e) : 0; }();
     static const int forced_bwd = [] { const char* e = std::getenv("RLG_CHAIN_BWD_GROUPS"); return e ? std::atoi(e) : 0; }();
     const int f = direction == 1 ? forced_bwd : forced_fwd;       // tools: A/B measurements inside bench.py
-    if (rows >= 16384 && (f == 1 || f == 2 || f == 4)) return f;
+    if (rows >= chain_bx_min_rows() && (f == 1 || f == 2 || f == 4)) return f;
   }
   // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU.
   // forward: two 32-row workgroups per CU (two waves per SIMD) - in the epoch that beats one 64-row workgroup for
   // both forward kernels (bench.py roofline_fwd via tools/bench_ab.sh: 122.8 / 132.6 us pipelined, 125 / 130.4 us
   // unit-structured), although a back-to-back microbenchmark says the opposite for the pipelined one
-  if (rows >= 16384) return direction == 1 ? 4 : 2;
+  if (rows >= chain_bx_min_rows()) return direction == 1 ? 4 : 2;
   return 1;
 }
 
