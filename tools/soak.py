@@ -16,5 +16,7 @@ for e in range(epochs):
         print(f'epoch {e+1}: a_loss {a:.4e} c_loss {c:.4e} kl {kl:.4e} lr {out[9]:.3e} params finite {ok} '
               f'obs count {agent.model.running_mean_std.count.item()}', flush=True)
         assert ok and all(map(lambda x: x == x, (a, c, kl)))
+        w = max(p.abs().max().item() for p in agent.model.a2c_network.parameters())
+        print(f'          largest |parameter| {w:.3f} (split-fp16 weight scale: < 1023)', flush=True)
 torch.cuda.synchronize()
 print(f'{epochs} epochs in {time.time()-t0:.1f} s; peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB')
