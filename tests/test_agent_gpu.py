@@ -192,8 +192,8 @@ def test_plain_a2c_loss_when_ppo_is_false_matches_oracle():
             for got, key in ((a, 'a_loss'), (c, 'c_loss'), (e, 'entropy'), (kl, 'kl'), (b, 'b_loss')):
                 assert np.isclose(got.item(), r[key].item(), rtol=1e-5, atol=2e-6), (k, key, got.item(), r[key].item())
             k += 1
-    # the plain A2C loss really ran: it is not the clipped surrogate's value (|neglogp * adv| is O(10), the surrogate O(1))
-    assert abs(ref[0]['a_loss'].item()) > 0.05
+    # (that the oracle's `ppo: False` branch is the reference's plain A2C loss is pinned on the CPU: the 'ppo_false' goldens of
+    #  tests/test_oracle_epoch.py and tests/test_vs_reference_cpu.py; a magnitude check here depended on the random weights)
     assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
     want = oracle.model.full_state_dict()
     for name, v in agent.model.state_dict().items():
