@@ -445,7 +445,7 @@ def main():
             kp, ptype = ops.chain_split_form()
             pwords = {3: 'three', 6: 'six'}[kp]
             insn = f'v_mfma_f32_16x16x32_{"f16" if ptype == "fp16" else "bf16"}'
-            if key in ('roofline_fwd', 'roofline_fwd_infer') and eng.chain.split_products(rows, 0):
+            if key in ('roofline_fwd', 'roofline_fwd_infer') and eng.chain.split_products(rows, 2 if key == 'roofline_fwd' else 0):
                 pad = sum(-(-o // 16) * 16 * -(-i // 32) * 32 for i, o in zip(ins, outs))
                 issued = kp * 2.0 * rows * pad / us / 1e6
                 chain_roof[key].update({
@@ -501,7 +501,7 @@ def main():
                 #  consumption order, csrc/mlp_chain.hip - bit-identical to the pipelined 16-row kernels)
                 text += ', lean 16-row kernel'
             return text
-        chain_products = {'training_forward': launch_form(mbr, 0), 'backward': launch_form(mbr, 1),
+        chain_products = {'training_forward': launch_form(mbr, 2), 'backward': launch_form(mbr, 1),
                           'rollout_forward': launch_form(envs, 0)}
     for key in ('roofline_fwd', 'roofline_fwd_infer', 'roofline_bwd'):
         r = chain_roof.get(key)

@@ -453,7 +453,9 @@ int rlg_mlp_dw_launch(int num_layers, const float* const* dz, const float* const
  *           fp64 per-workgroup column sums of dZ_l (finished by rlg_mlp_dw_launch's colsum items).
  * acts: 0 identity, 1 elu, 2 relu, 3 tanh (backward evaluates act' from the layer OUTPUT).
  * groups: 16-row groups per workgroup, 1 / 2 / 4 (0 = chosen from rows and direction:
- * rlg_mlp_chain_groups; rlg_mlp_chain_num_blocks takes the resolved value).
+ * rlg_mlp_chain_groups; rlg_mlp_chain_num_blocks takes the resolved value).  direction of rlg_mlp_chain_groups and
+ * rlg_mlp_chain_bx_supported names the launch kind: 0 = inference forward, 1 = backward, 2 = training forward (activations
+ * kept) - the 64-row split-product kernels take training launches from 8,192 rows, inference forwards from 16,384.
  * rlg_mlp_chain_lds_bytes: LDS of one workgroup (direction 0 forward, 1 backward), -1 if the
  * network does not fit the 160 KiB LDS with that many groups. */
 int rlg_mlp_chain_prepare(void);   /* once per process, outside stream capture: raises the kernels' LDS limit */
@@ -587,8 +589,9 @@ int rlg_mlp_chain_backward_lean(int num_layers, const int* in_features, const in
                                 float* const* dz_out, const long long* dz_ld, double* const* bias_partials,
                                 const rlg_ppo_loss_desc* ppo_loss, long long rows, const void* frags, void* stream);
 
-/* Split-bf16 form of the chain (csrc/mlp_chain_bx.hip): every fp32 product as six exact bf16 plane products on
- * v_mfma_f32_16x16x32_bf16 (results within 3 * 2^-24 |x||w| per product of the exact-product kernels).  The weights
+/* Split-product form of the chain (csrc/mlp_chain_bx.hip): every fp32 product as three exact fp16 plane products on
+ * v_mfma_f32_16x16x32_f16 (round 6, csrc/split_f16.hpp; six bf16 plane products in a -DRLG_BX_F16=0 build: results within
+ * 3 * 2^-24 |x||w| per product of the exact-product kernels).  The weights
  * are split ONCE per optimizer step into plane fragments; the launch that is given them (weight_planes_or_null of
  * rlg_mlp_chain_backward, direction 1) uses the split kernel when rlg_mlp_chain_bx_supported says so and the
  * activation arrays are 16-byte aligned, else the exact-product kernel.  Same autograd nodes as above

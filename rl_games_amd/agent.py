@@ -1209,7 +1209,7 @@ class A2CAgent:
                     # the loss evaluated by the backward launch): the forward is handed to eng.backward() below
                     defer = (self.config.get('fused_step16', True) and self.config.get('fold_loss_finalize', True)
                              and self.config.get('loss_in_backward', True)
-                             and not eng.chain.split_products(obs_batch.shape[0], 0))
+                             and not eng.chain.split_products(obs_batch.shape[0], 2))
                     heads = eng.forward_obs(obs_batch, rms, self._obs_eps(), rms_fold=fold, defer=defer)
                     obs_n = None
                 elif self.is_rnn and eng.chain_rnn is not None and obs_batch.dtype == torch.float32:
@@ -1401,9 +1401,10 @@ class A2CAgent:
         if c is None:
             c = False
             eng = self._engine
-            rows = (self.minibatch_size, self.num_actors * self.num_agents)
+            # (launch kinds: the update's training forward (2) and backward (1), the rollout's inference forward (0))
+            kinds = ((self.minibatch_size, 2), (self.minibatch_size, 1), (self.num_actors * self.num_agents, 0))
             chains = [ch for ch in (getattr(eng, 'chain', None), getattr(eng, 'chain_rnn', None))
-                      if ch is not None and any(ch.lean_used(r, d) for r in rows for d in (0, 1))]
+                      if ch is not None and any(ch.lean_used(r, d) for r, d in kinds)]
             if chains:
                 c = _LeanChains(chains)
             self._lean_pack = c
@@ -1419,8 +1420,8 @@ class A2CAgent:
             eng = self._engine
             chain = getattr(eng, 'chain', None) if eng is not None else None
             if chain is not None and self.config.get('adam_writes_planes', True):
-                rows = (self.minibatch_size, self.num_actors * self.num_agents)
-                if any(chain.split_products(r, d) for r in rows for d in (0, 1)):
+                kinds = ((self.minibatch_size, 2), (self.minibatch_size, 1), (self.num_actors * self.num_agents, 0))
+                if any(chain.split_products(r, d) for r, d in kinds):
                     c = chain
             self._adam_pack = c
         return c or None

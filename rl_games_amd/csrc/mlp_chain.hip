@@ -1256,22 +1256,27 @@ static bool chain_bx_enabled() {
   return on;
 }
 
-// minibatches of at least this many rows run the 64-row split-product kernels (RLG_CHAIN_BX_MIN_ROWS: tools, A/B)
-static long long chain_bx_min_rows() {
-  static const long long n = [] {
+// Launch kinds ("direction" of the C ABI): 0 = inference forward (rollouts, get_values), 1 = backward, 2 = training forward
+// (activations kept).  Launches of at least chain_bx_min_rows(kind) rows run the 64-row split-product kernels: 16,384 for
+// inference forwards, 8,192 for the training pair (round 6: a rank of 4's 8,192-row update is faster on the fp16 kernels on
+// half the CUs than on the 16-row exact-product kernels - 46.1 -> 43.8 ms per rank epoch - while 8,192-row ROLLOUT forwards
+// are not: a rank of 8 went 31.0 -> 32.7 ms with them).  RLG_CHAIN_BX_MIN_ROWS: one threshold for all kinds (tools, A/B).
+static long long chain_bx_min_rows(int kind) {
+  static const long long forced = [] {
     const char* e = std::getenv("RLG_CHAIN_BX_MIN_ROWS");
-    return (e && std::atoll(e) > 0) ? std::atoll(e) : 16384LL;
+    return (e && std::atoll(e) > 0) ? std::atoll(e) : 0LL;
   }();
-  return n;
+  if (forced > 0) return forced;
+  return kind == 0 ? 16384LL : 8192LL;
 }
 
-static bool chain_bx_fwd_wanted(long long rows, int groups) {
+static bool chain_bx_fwd_wanted(long long rows, int groups, bool training) {
   static const bool on = [] {
     const char* e = std::getenv("RLG_CHAIN_BX_FWD");     // tools: A/B against the exact-product forward kernels
     return !(e && std::atoi(e) == 0);
   }();
   // (2: what pick_groups resolves the automatic choice to at these sizes - the callers pass the resolved value)
-  return on && chain_bx_enabled() && rows >= chain_bx_min_rows() && (groups == 0 || groups == 2 || groups == 4);
+  return on && chain_bx_enabled() && rows >= chain_bx_min_rows(training ? 2 : 0) && (groups == 0 || groups == 2 || groups == 4);
 }
 
 // Row groups per workgroup when the caller does not ask for one.  Measured on MI355X (humanoid MLP,
@@ -1284,13 +1289,13 @@ static int pick_groups(long long rows, int requested, int direction = 0) {
     static const int forced_fwd = [] { const char* e = std::getenv("RLG_CHAIN_FWD_GROUPS"); return e ? std::atoi(e) : 0; }();
     static const int forced_bwd = [] { const char* e = std::getenv("RLG_CHAIN_BWD_GROUPS"); return e ? std::atoi(e) : 0; }();
     const int f = direction == 1 ? forced_bwd : forced_fwd;       // tools: A/B measurements inside bench.py
-    if (rows >= chain_bx_min_rows() && (f == 1 || f == 2 || f == 4)) return f;
+    if (rows >= chain_bx_min_rows(direction) && (f == 1 || f == 2 || f == 4)) return f;
   }
   // backward: its LDS footprint is half the forward's, so G = 4 already runs two workgroups per CU.
   // forward: two 32-row workgroups per CU (two waves per SIMD) - in the epoch that beats one 64-row workgroup for
   // both forward kernels (bench.py roofline_fwd via tools/bench_ab.sh: 122.8 / 132.6 us pipelined, 125 / 130.4 us
   // unit-structured), although a back-to-back microbenchmark says the opposite for the pipelined one
-  if (rows >= chain_bx_min_rows()) return direction == 1 ? 4 : 2;
+  if (rows >= chain_bx_min_rows(direction)) return direction == 1 ? 4 : 2;
   return 1;
 }
 
@@ -1586,8 +1591,8 @@ int rlg_mlp_chain_bx_supported(int num_layers, const int* in_features, const int
     probe.layer[L].in = in_features[L];
     probe.layer[L].out = out_features[L];
   }
-  if (direction == 0) {
-    if (!chain_bx_fwd_wanted(rows, groups)) return 0;
+  if (direction == 0 || direction == 2) {
+    if (!chain_bx_fwd_wanted(rows, groups, direction == 2)) return 0;
     if (chain_bx_plane_offsets(num_layers, in_features, out_features, 0, nullptr) >= static_cast<long long>(kOob)) return 0;
     return chain_bx_fwd_plan(probe) >= 0 ? 1 : 0;
   }
@@ -1677,7 +1682,9 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   args.xn = xn_out;
   args.rows = rows;
   args.dbg = g_chain_dbg;
-  const int G = pick_groups(rows, groups);
+  bool training = false;
+  for (int L = 0; L + 1 < num_layers; ++L) training = training || act_out[L] != nullptr;
+  const int G = pick_groups(rows, groups, training ? 2 : 0);
   int b_floats = 0;
   const int lds_bytes = chain_lds(num_layers, in_features, out_features, G, 0, &b_floats);
   if (lds_bytes < 0) return static_cast<int>(hipErrorInvalidValue);
@@ -1689,7 +1696,7 @@ int rlg_mlp_chain_forward(int num_layers, const float* const* weights, const flo
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   // split-bf16 products on pre-split weight planes (mlp_chain_bx_fwd.hip): 64-row workgroups
-  if (weight_planes_or_null != nullptr && chain_bx_fwd_wanted(rows, groups)) {
+  if (weight_planes_or_null != nullptr && chain_bx_fwd_wanted(rows, groups, training)) {
     ChainArgs bx = args;
     const long long total = chain_bx_plane_offsets(num_layers, in_features, out_features, 0, bx.p_off);
     bx.planes = weight_planes_or_null;
@@ -1898,7 +1905,7 @@ int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float*
   static const bool enabled = [] { const char* e = std::getenv("RLG_CHAIN_STEP1"); return !(e && std::atoi(e) == 0); }();
   if (rows <= 0) return 0;
   if (!enabled || !chain_pipe1_enabled() || !chain_pipe_enabled() || chain_pipe1_waves() != 8 || g_chain_dbg != nullptr ||
-      num_layers < 2 || ppo_loss == nullptr || pick_groups(rows, 0, 0) != 1 || pick_groups(rows, 0, 1) != 1)
+      num_layers < 2 || ppo_loss == nullptr || pick_groups(rows, 0, 2) != 1 || pick_groups(rows, 0, 1) != 1)
     return static_cast<int>(hipErrorNotSupported);
   // one 8-wave workgroup per CU (200 registers per wave): beyond one round of workgroups the two separate launches,
   // which run two workgroups per CU, are faster (8,192 rows: 52.3 vs 50.0 ms per rank epoch, profiles/r4_rank_shapes.txt)

@@ -822,7 +822,8 @@ class MlpChain:
         return None if self._weights_version is None else self._weights_version()
 
     def split_products(self, rows, direction, requested=0):
-        """True when the launch of this direction runs the split-bf16 kernel for `rows` rows."""
+        """True when the launch of this kind (0 inference forward, 1 backward, 2 training forward) runs the split-product
+        kernel for `rows` rows."""
         return bool(_lib.load().rlg_mlp_chain_bx_supported(self.n, self._in, self._out, int(rows),
                                                            self.groups(rows, direction, requested), int(direction)))
 
@@ -860,8 +861,10 @@ class MlpChain:
         return self._plane_buffer().data_ptr() + (self._bwd_offset if direction == 1 else 0)
 
     def groups(self, rows, direction, requested=0):
+        """direction names the launch kind: 0 inference forward, 1 backward, 2 training forward (csrc/mlp_chain.hip
+        chain_bx_min_rows: the training pair takes the 64-row split kernels from 8,192 rows, inference from 16,384)."""
         g = _lib.load().rlg_mlp_chain_groups(int(rows), int(requested), int(direction))
-        return min(g, self.max_groups[direction])
+        return min(g, self.max_groups[1 if direction == 1 else 0])
 
     def num_blocks(self, rows, direction, requested=0):
         return _lib.load().rlg_mlp_chain_num_blocks(int(rows), self.groups(rows, direction, requested))
@@ -900,7 +903,8 @@ class MlpChain:
         # A training forward also has the weights split for the backward launch that follows it: by the forward's own
         # pack launch when the forward runs on planes as well (one launch, both directions), else in extra workgroups
         # of the exact-product forward launch.  backward() uses those planes once; any other caller packs for itself.
-        if split_products is not False and groups in (0, 1) and self.lean_used(rows, 0):
+        kind = 2 if (act_out is not None and self.n > 1 and any(t is not None for t in act_out)) else 0
+        if split_products is not False and groups in (0, 1) and self.lean_used(rows, kind):
             self._planes_fresh = None
             self.ensure_frags(x)
             _time_chain_launch('fwd_train' if act_out is not None else 'fwd_infer')
@@ -916,7 +920,7 @@ class MlpChain:
         planes = fwd_planes = None
         self._planes_fresh = None
         packed_both = False
-        if split_products is not False and self.split_products(rows, 0, groups):
+        if split_products is not False and self.split_products(rows, kind, groups):
             if not self.planes_current():
                 self.pack_planes(2 if bwd_split else 0, x)
                 packed_both = bwd_split
@@ -927,7 +931,7 @@ class MlpChain:
         _lib.check(_lib.load().rlg_mlp_chain_forward(
             n, self._w, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
             mean, var, float(np.float32(eps)), _opt(xn_out, F32, 'xn_out'), *fold, rows,
-            self.groups(rows, 0, groups), planes, fwd_planes, _stream(x)), 'rlg_mlp_chain_forward')
+            self.groups(rows, kind, groups), planes, fwd_planes, _stream(x)), 'rlg_mlp_chain_forward')
         if bwd_split:
             # only behind a launch that succeeded, and only for the weights as they are now
             self._planes_fresh = (rows, self._version())
@@ -943,9 +947,9 @@ class MlpChain:
         n = self.n
         if act_out is None or any(t is None for t in act_out) or ppo_loss is None or n < 2:
             return False
-        if self.split_products(rows, 0) or self.split_products(rows, 1) or self.groups(rows, 0) != 1 or self.groups(rows, 1) != 1:
+        if self.split_products(rows, 2) or self.split_products(rows, 1) or self.groups(rows, 2) != 1 or self.groups(rows, 1) != 1:
             return False
-        lean = self.lean_used(rows, 0) and self.lean_used(rows, 1)
+        lean = self.lean_used(rows, 2) and self.lean_used(rows, 1)
         outs = list(act_out) + [heads]
         ptrs = self._P(*[_need(t, F32, 'act_out', contiguous=False) for t in outs])
         lds = self._L(*[t.stride(0) for t in outs])
