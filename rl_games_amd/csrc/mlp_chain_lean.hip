@@ -8,7 +8,126 @@
 #include "mlp_chain_shared.hpp"
 #include "optim_common.hpp"
 
+// Round 6 (second half): the lean kernels on the split-fp16 form of csrc/bx_form.hpp - same streams, same tiles, same loop:
+// a GROUP (32 k values) was two 1-KiB fp32 chunks of 16 k values and 8 x v_mfma_f32_16x16x4_f32; it is now the two fp16
+// planes of the same 32 values (plane 0 where the even chunk was, plane 1 where the odd one was - byte for byte the same
+// buffers and LDS tiles) and 3 x v_mfma_f32_16x16x32_f16.  Lane l holds, per plane, 8 values: features 4q .. 4q + 3 of the
+// group's first 16-feature block (elements 0 - 3) and of its second (4 - 7), q = l >> 4 - what the fp32 chunks held as
+// their 4 floats each, so the pack launch splits exactly the values it used to copy, and an epilogue writes 8 bytes per
+// plane where it wrote 16 bytes of fp32.  Scales as in the 64-row kernels: weights 2^6, hidden activations 2^4, normalised
+// observations 2^12, raw observations and gradient rows by their own maxima (a 16-row tile: a lane's row is lane & 15).
+// RLG_LEAN_F16=0 (or a -DRLG_BX_F16=0 build): exact fp32 products, bit-identical to the pipelined kernels of mlp_chain.hip.
+#ifndef RLG_LEAN_F16
+#define RLG_LEAN_F16 RLG_BX_F16
+#endif
+
 namespace rlg {
+
+#if RLG_LEAN_F16
+// block `ob` (16 features) of a tile in the group layout: this lane's 4 features -> 8 bytes of each plane
+__device__ __forceinline__ void lean_put_planes(float* tile, int ob, int lane, const f32x4& v, float scale) {
+  unsigned pl[kBxPlanes][2];
+  bx_split4(v, scale, pl);
+  float* base = tile + ((ob & ~1) * 64 + lane) * 4 + (ob & 1) * 2;
+  *reinterpret_cast<uint2*>(base) = make_uint2(pl[0][0], pl[0][1]);
+  *reinterpret_cast<uint2*>(base + 256) = make_uint2(pl[1][0], pl[1][1]);
+}
+__device__ __forceinline__ void lean_zero_block(float* tile, int ob, int lane) {
+  float* base = tile + ((ob & ~1) * 64 + lane) * 4 + (ob & 1) * 2;
+  *reinterpret_cast<uint2*>(base) = make_uint2(0u, 0u);
+  *reinterpret_cast<uint2*>(base + 256) = make_uint2(0u, 0u);
+}
+// one group of the reduction: three plane products (small terms into acc1)
+__device__ __forceinline__ void lean_group_mfma(const f32x4 (&aq)[2], const f32x4 (&bq)[2], f32x4& acc0, f32x4& acc1) {
+  const u32x4 a0 = __builtin_bit_cast(u32x4, aq[0]), a1 = __builtin_bit_cast(u32x4, aq[1]);
+  const u32x4 b0 = __builtin_bit_cast(u32x4, bq[0]), b1 = __builtin_bit_cast(u32x4, bq[1]);
+  acc1 = bx_mfma(a1, b0, acc1);
+  acc1 = bx_mfma(a0, b1, acc1);
+  acc0 = bx_mfma(a0, b0, acc0);
+}
+
+// Forward prologue of the fp16 form (cf. chain_fwd_prologue<1, W>): the observation tile of 16 rows -> planes in tile_a,
+// normalised on the way; returns the scale of this lane's row (lane & 15).
+template <int W>
+__device__ __forceinline__ float lean_fwd_prologue_f16(const ChainArgs& a, float* tile_a, float* tile_b, long long row0, int lane,
+                                                       int wave, int& stamp) {
+  const int in0 = a.layer[0].in;
+  const int in0p = (in0 + 3) & ~3;
+  const bool norm = a.rms_mean != nullptr;
+  const int KC0 = (in0 + 15) >> 4;
+  const int ng = (KC0 + 1) >> 1;                     // groups of two 16-feature blocks
+  const bool xv = vec4_ok(a.x, a.ldx);
+  const bool xnv = a.xn != nullptr && vec4_ok(a.xn, in0);
+  const int q4 = 4 * (lane >> 4);
+  const long long row = row0 + (lane & 15);
+  constexpr int kProBatch = 4;
+  f32x4 xlo[kProBatch], xhi[kProBatch];
+  auto load_groups = [&](int u0) {
+#pragma unroll
+    for (int k = 0; k < kProBatch; ++k) {
+      const int u = u0 + k * W;
+      xlo[k] = xhi[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (u < ng && row < a.rows) {
+        xlo[k] = load_row4(a.x, a.ldx, row, u * 32 + q4, in0, xv);
+        xhi[k] = load_row4(a.x, a.ldx, row, u * 32 + 16 + q4, in0, xv);
+      }
+    }
+  };
+  auto put_groups = [&](int u0, float scale) {
+#pragma unroll
+    for (int k = 0; k < kProBatch; ++k) {
+      const int u = u0 + k * W;
+      if (u < ng) {
+        f32x4 v[2] = {xlo[k], xhi[k]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int f = u * 32 + 16 * h + q4;
+          if (row < a.rows) {
+            if (norm) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (f + e < in0) v[h][e] = clamp_nan((v[h][e] - tile_b[f + e]) / tile_b[in0p + f + e], -5.0f, 5.0f);
+              }
+            }
+            if (a.xn && f < in0) store_row4(a.xn, in0, row, f, in0, v[h], xnv);
+          }
+        }
+        const float x[8] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
+        u32x4 plane[kBxPlanes];
+        bx_split8(x, scale, plane);
+        *reinterpret_cast<u32x4*>(tile_a + ((2 * u) * 64 + lane) * 4) = plane[0];
+        *reinterpret_cast<u32x4*>(tile_a + ((2 * u + 1) * 64 + lane) * 4) = plane[1];
+      }
+    }
+  };
+  load_groups(wave);
+  float scale = kBxScaleObsNorm;
+  if (norm) {
+    chain_norm_stats<W>(a, tile_b, in0, in0p);
+    __syncthreads();
+  } else {
+    // raw observations have no bound: the row's scale from its largest magnitude (every wave reads the whole row - the
+    // loads of the groups it splits find it in the cache)
+    float mine = 0.0f;
+    if (row < a.rows) {
+      for (int c = 0; c < KC0; ++c) {
+        const f32x4 t = load_row4(a.x, a.ldx, row, c * 16 + q4, in0, xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine = __builtin_fmaxf(mine, bx_finite_abs(t[e]));
+      }
+    }
+    scale = bx_row_scale(mine);
+  }
+  put_groups(wave, scale);
+  for (int u0 = wave + W * kProBatch; u0 < ng; u0 += W * kProBatch) {
+    load_groups(u0);
+    put_groups(u0, scale);
+  }
+  chain_stamp(a.dbg, wave, stamp);
+  __syncthreads();
+  return scale;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Lean 16-row forward (round 4, experimental - the C entry rlg_mlp_chain_forward_lean; tools/exp/lean_probe.py).
@@ -65,16 +184,29 @@ __device__ __forceinline__ void chain_fwd_lean_body(const ChainArgs& a, const Le
   request(0);
   request(1);
   request(2);
+#if RLG_LEAN_F16
+  auto zero_chunk = [&](float* tile, int c) { lean_zero_block(tile, c, lane); };        // (block c of the group layout)
+#else
   auto zero_chunk = [&](float* tile, int c) { *reinterpret_cast<f32x4*>(tile + (c * 64 + lane) * 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+#endif
   int stamp = 0;
   chain_stamp(a.dbg, wave, stamp);
+  float scale_in = 1.0f;          // fp16 form: scale of this lane's row in the tile the current layer reads
   {
     const int in0 = pin_s(a.layer[0].in);
     const int KC0 = (in0 + 15) >> 4;
+#if RLG_LEAN_F16
+    if (wave == W - 1) {
+      // (behind the last group the prologue writes: its second block when KC0 is odd is written - as zeros - by the prologue)
+      for (int c = (KC0 + 1) & ~1; c < la.kc2[0]; ++c) zero_chunk(tile_a, c);
+    }
+    scale_in = lean_fwd_prologue_f16<W>(a, tile_a, tile_b, row0, lane, wave, stamp);     // (ends with a barrier)
+#else
     if (wave == W - 1) {
       for (int c = KC0; c < la.kc2[0]; ++c) zero_chunk(tile_a, c);
     }
     chain_fwd_prologue<1, W>(a, tile_a, tile_b, row0, lane, wave, stamp);     // (ends with a barrier)
+#endif
   }
   chain_stamp(a.dbg, wave, stamp);
 
@@ -122,11 +254,22 @@ __device__ __forceinline__ void chain_fwd_lean_body(const ChainArgs& a, const Le
     };
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
     int gu = 0, unit = 0;
+#if RLG_LEAN_F16
+    const float inv = 1.0f / (kBxScaleW * scale_in);
+#endif
     auto epilogue = [&]() {
       const int ob = unit_block(unit);
       const int f = ob * 16 + q4;
+#if RLG_LEAN_F16
+      f32x4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = __builtin_fmaf(acc0[e] + acc1[e], inv, bv[e]);
+      const f32x4 v = chain_act4<HACT>(z, l_act);
+      if (!last) lean_put_planes(tout, ob, lane, v, kBxScaleH);
+#else
       const f32x4 v = chain_act4<HACT>((acc0 + acc1) + bv, l_act);
       if (!last) *reinterpret_cast<f32x4*>(tout + (ob * 64 + lane) * 4) = v;
+#endif
       const long long row = row0 + (lane & 15);
       if (h_on && row < n_rows) store_row4(l_h, l_ldh, row, f, l_out, v, h_vec);
     };
@@ -140,6 +283,9 @@ __device__ __forceinline__ void chain_fwd_lean_body(const ChainArgs& a, const Le
       for (int s = 0; s < 4; ++s) {
         request((s + 3) & 3);
         read_b((s + 1) & 1);
+#if RLG_LEAN_F16
+        lean_group_mfma(aq[s], bq[s & 1], acc0, acc1);
+#else
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][0], bq[s & 1][ch][0], acc0, 0, 0, 0);
@@ -147,6 +293,7 @@ __device__ __forceinline__ void chain_fwd_lean_body(const ChainArgs& a, const Le
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][2], bq[s & 1][ch][2], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][3], bq[s & 1][ch][3], acc1, 0, 0, 0);
         }
+#endif
         ++gu;
         if (gu == gpu) {
           gu = 0;
@@ -160,6 +307,7 @@ __device__ __forceinline__ void chain_fwd_lean_body(const ChainArgs& a, const Le
     chain_stamp(a.dbg, wave, stamp);
     __syncthreads();
     chain_stamp(a.dbg, wave, stamp);
+    scale_in = kBxScaleH;
     float* t = tin;
     tin = tout;
     tout = t;
@@ -199,7 +347,11 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
   request(0);
   request(1);
   request(2);
+#if RLG_LEAN_F16
+  auto zero_chunk = [&](float* tile, int c) { lean_zero_block(tile, c, lane); };        // (block c of the group layout)
+#else
   auto zero_chunk = [&](float* tile, int c) { *reinterpret_cast<f32x4*>(tile + (c * 64 + lane) * 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+#endif
   // ---- the PPO loss of this row tile (training steps), as in mlp_chain_bwd_pipe_kernel
   if (a.with_loss) {
     if constexpr (kPreloaded) ppo_loss_quad_run<16, 64 * W>(loss, lds, blockIdx.x, preloaded);   // (inputs requested long ago)
@@ -208,16 +360,44 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
     __syncthreads();
   }
   // ---- prologue: d heads tile -> LDS (fragment layout), zero chunks up to the first step's chunk count
+  float scale_in = 1.0f;          // fp16 form: scale of this lane's row in the tile the current step reads
   {
     const int w = a.layer[num_layers - 1].out;
     const int KC0 = (w + 15) >> 4;
     const bool xv = vec4_ok(a.x, a.ldx);
+#if RLG_LEAN_F16
+    // the row's scale from its largest magnitude (every wave reads the whole row of d heads: a few loads), then the groups
+    // of two 16-feature blocks, dealt to the waves, as planes
+    const long long row = row0 + r16;
+    float mine = 0.0f;
+    if (row < n_rows) {
+      for (int c = 0; c < KC0; ++c) {
+        const f32x4 t = load_row4(a.x, a.ldx, row, c * 16 + q4, w, xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine = __builtin_fmaxf(mine, bx_finite_abs(t[e]));
+      }
+    }
+    scale_in = bx_row_scale(mine);
+    for (int u = wave; u < (la.kc2[0] >> 1); u += W) {
+      f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = lo;
+      if (row < n_rows) {
+        if (2 * u < KC0) lo = load_row4(a.x, a.ldx, row, u * 32 + q4, w, xv);
+        if (2 * u + 1 < KC0) hi = load_row4(a.x, a.ldx, row, u * 32 + 16 + q4, w, xv);
+      }
+      const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      u32x4 plane[kBxPlanes];
+      bx_split8(x, scale_in, plane);
+      *reinterpret_cast<u32x4*>(tile_a + ((2 * u) * 64 + lane) * 4) = plane[0];
+      *reinterpret_cast<u32x4*>(tile_a + ((2 * u + 1) * 64 + lane) * 4) = plane[1];
+    }
+#else
     for (int u = wave; u < la.kc2[0]; u += W) {
       const long long row = row0 + r16;
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
       if (u < KC0 && row < n_rows) v = load_row4(a.x, a.ldx, row, u * 16 + q4, w, xv);
       *reinterpret_cast<f32x4*>(tile_a + (u * 64 + lane) * 4) = v;
     }
+#endif
     __syncthreads();
   }
   float* tin = tile_a;
@@ -261,12 +441,24 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
       const int f = unit_block(u) * 16 + q4;
       hv = buf_load4(hr, (u < nun && f < width) ? h_lane + static_cast<unsigned>(unit_block(u)) * 64u : kOob);
     };
+#if RLG_LEAN_F16
+    // the accumulators hold (weight scale x row scale) x the sums; the tile this step writes is split one step below the one
+    // it reads (csrc/bx_form.hpp)
+    const float inv = 1.0f / (kBxScaleW * scale_in);
+    const float scale_out = scale_in * kBxScaleStepBwd;
+#endif
     auto epilogue = [&]() {
       const int ob = unit_block(unit);
       const int f = ob * 16 + q4;
+#if RLG_LEAN_F16
+      f32x4 v = chain_act_grad4((acc0 + acc1) * inv, hv, p_act);
+      if (!row_ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (keep_tile) lean_put_planes(tout, ob, lane, v, scale_out);
+#else
       f32x4 v = chain_act_grad4(acc0 + acc1, hv, p_act);
       if (!row_ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (keep_tile) *reinterpret_cast<f32x4*>(tout + (ob * 64 + lane) * 4) = v;
+#endif
       buf_store4(dzr, f < width ? dz_lane + static_cast<unsigned>(ob) * 64u : kOob, v);
       if (bpart != nullptr) {
         f32x4 sm;
@@ -290,6 +482,9 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
       for (int s = 0; s < 4; ++s) {
         request((s + 3) & 3);
         read_b((s + 1) & 1);
+#if RLG_LEAN_F16
+        lean_group_mfma(aq[s], bq[s & 1], acc0, acc1);
+#else
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][0], bq[s & 1][ch][0], acc0, 0, 0, 0);
@@ -297,6 +492,7 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][2], bq[s & 1][ch][2], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s][ch][3], bq[s & 1][ch][3], acc1, 0, 0, 0);
         }
+#endif
         ++gu;
         if (gu == gpu) {
           gu = 0;
@@ -308,6 +504,9 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
       }
     }
     __syncthreads();
+#if RLG_LEAN_F16
+    scale_in = scale_out;
+#endif
     float* tt = tin;
     tin = tout;
     tout = tt;
@@ -357,7 +556,11 @@ __global__ __launch_bounds__(256) void chain_pack_frags2_kernel(LeanPackArgs p0,
 }
 __device__ __forceinline__ void chain_pack_frags_block(const LeanPackArgs& p) {
   const unsigned t = blockIdx.x * 256u + threadIdx.x;
+#if RLG_LEAN_F16
+  const unsigned frag = 2u * (t >> 6);           // one thread per (group = fragment pair, lane)
+#else
   const unsigned frag = t >> 6;
+#endif
   const int lane = static_cast<int>(t & 63u);
   if (frag >= p.total_frags) return;
   int w = 0, st = 0;
@@ -369,33 +572,48 @@ __device__ __forceinline__ void chain_pack_frags_block(const LeanPackArgs& p) {
   const int q = static_cast<int>(frag - p.seg_begin[w][st]);
   const int KC2 = p.la.kc2[st];
   const int j = q / KC2, c = q - j * KC2;
-  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (j < p.la.nunits[w][st]) {
-    const int full = p.la.full[st];
-    const int ob = j < full ? w * full + j : kLeanW * full + w;
-    const int i = ob * 16 + (lane & 15);
-    const int k0 = c * 16 + 4 * (lane >> 4);
-    if (p.dir == 0) {
-      const int L = st;
-      if (i < p.out[L]) {
+  // the 4 weights of this lane in chunk cc (16 k values) of unit j: A[16 ob + (lane & 15)][16 cc + 4 (lane >> 4) .. + 3]
+  auto chunk_values = [&](int cc) -> f32x4 {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (j < p.la.nunits[w][st]) {
+      const int full = p.la.full[st];
+      const int ob = j < full ? w * full + j : kLeanW * full + w;
+      const int i = ob * 16 + (lane & 15);
+      const int k0 = cc * 16 + 4 * (lane >> 4);
+      if (p.dir == 0) {
+        const int L = st;
+        if (i < p.out[L]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = k0 + e;
-          if (k < p.in[L]) v[e] = p.w[L][static_cast<long long>(i) * p.in[L] + k];
+          for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            if (k < p.in[L]) v[e] = p.w[L][static_cast<long long>(i) * p.in[L] + k];
+          }
         }
-      }
-    } else {
-      const int L = p.num_layers - 1 - st;
-      if (i < p.in[L]) {
+      } else {
+        const int L = p.num_layers - 1 - st;
+        if (i < p.in[L]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = k0 + e;
-          if (k < p.out[L]) v[e] = p.w[L][static_cast<long long>(k) * p.in[L] + i];
+          for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            if (k < p.out[L]) v[e] = p.w[L][static_cast<long long>(k) * p.in[L] + i];
+          }
         }
       }
     }
-  }
-  *reinterpret_cast<f32x4*>(p.dst + (static_cast<long long>(frag) * 64 + lane) * 4) = v;
+    return v;
+  };
+#if RLG_LEAN_F16
+  // a group = the two chunks (c, c + 1), c even: their 8 values per lane as two fp16 planes - plane 0 where chunk c was,
+  // plane 1 where chunk c + 1 was (the slack fragments behind the last stream stay zero: q runs past every unit there)
+  const f32x4 lo = chunk_values(c), hi = chunk_values(c + 1);       // (c is even: segments and units hold whole groups)
+  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  u32x4 plane[kBxPlanes];
+  bx_split8(x, kBxScaleW, plane);
+  *reinterpret_cast<u32x4*>(p.dst + (static_cast<long long>(frag) * 64 + lane) * 4) = plane[0];
+  *reinterpret_cast<u32x4*>(p.dst + (static_cast<long long>(frag + 1) * 64 + lane) * 4) = plane[1];
+#else
+  *reinterpret_cast<f32x4*>(p.dst + (static_cast<long long>(frag) * 64 + lane) * 4) = chunk_values(c);
+#endif
 }
 
 // host: the stream layout of one direction.  Returns the buffer size in bytes (incl. the slack the 3-groups-ahead requests
@@ -481,7 +699,7 @@ int rlg_mlp_chain_pack_frags(int num_layers, const float* const* weights, const 
     pk.bias[L] = biases_or_null ? biases_or_null[L] : nullptr;
   }
   pk.dst = static_cast<float*>(frags);
-  const unsigned threads = pk.total_frags * 64u;
+  const unsigned threads = pk.total_frags * 64u / (RLG_LEAN_F16 ? 2u : 1u);
   hipLaunchKernelGGL(chain_pack_frags_kernel, dim3((threads + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), pk);
   RLG_RETURN_LAUNCH_STATUS();
 }
@@ -661,7 +879,7 @@ int rlg_mlp_chain_pack_frags_both(int num_layers, const float* const* weights, c
   }
   p0.dst = static_cast<float*>(frags_fwd);
   p1.dst = static_cast<float*>(frags_bwd_or_null);
-  const unsigned threads = (p0.total_frags > p1.total_frags ? p0.total_frags : p1.total_frags) * 64u;
+  const unsigned threads = (p0.total_frags > p1.total_frags ? p0.total_frags : p1.total_frags) * 64u / (RLG_LEAN_F16 ? 2u : 1u);
   hipLaunchKernelGGL(chain_pack_frags2_kernel, dim3((threads + 255u) / 256u, 2), dim3(256), 0, static_cast<hipStream_t>(stream), p0, p1);
   RLG_RETURN_LAUNCH_STATUS();
 }

@@ -72,19 +72,31 @@ def _check_epoch(res, ref, nmb, mini_epochs, bounds=True):
     assert torch.allclose(got_kl, want_kl, rtol=1e-4, atol=ATOL['kl']), (got_kl, want_kl)
 
 
-def _check_final_params(agent, oracle, steps, lr_max):
+def _check_final_params(agent, oracle, steps, lr_max, truth=None):
     """Parameters after `steps` Adam steps.  Adam's first updates are +-lr * g/|g|-like, so an element
     whose gradient is at rounding-noise level (|g| ~ 1e-9: dead units, bound-loss-only paths) can move
     by lr in the opposite direction when its fp32 gradient differs in the last bits between the GPU's
     and the CPU's summation order.  Hence: (i) the bulk agrees to rtol 1e-4 / atol 2e-6, at most 0.2 % of
-    a tensor's elements may deviate, and (ii) no element deviates by more than the total step budget."""
+    a tensor's elements may deviate, and (ii) no element deviates by more than the total step budget.
+    truth: a callable returning the fp64 trajectory's final parameters (the oracle evaluated in double precision on the same
+    inputs, _truth_for).  An element outside (i) is then judged like the loss scalars are: it passes when the agent is no
+    farther from the fp64 value than 1.5 x the fp32 oracle is - log sigma's gradient is a sum that nearly cancels at the
+    start of training, the loss tile forms it in fp64 and the oracle in fp32 (config #2: |agent - fp64| 3e-10,
+    |oracle - fp64| 1.1e-5 in one element, tools/exp/ant_sigma_probe.py)."""
     final, want = agent.model.state_dict(), oracle.model.full_state_dict()
+    tru = None
     for name, v in want.items():
         got = final[name].cpu().to(v.dtype)
         if not v.is_floating_point():
             assert torch.equal(got, v), name
             continue
         bad = ~torch.isclose(got, v, rtol=1e-4, atol=2e-6)
+        if bad.float().mean().item() > 2e-3 and truth is not None:
+            if tru is None:
+                tru = truth()
+            t = tru[name].double()
+            closer = (got.double() - t).abs() <= 1.5 * (v.double() - t).abs() + 1e-9
+            bad = bad & ~closer
         assert bad.float().mean().item() <= 2e-3, (name, bad.float().mean().item())
         assert (got - v).abs().max().item() <= 2.1 * steps * lr_max, (name, (got - v).abs().max().item())
 
@@ -177,7 +189,11 @@ def test_config2_ant_epoch_matches_oracle(graphs):
     assert tb['rewards'].shape[:2] == (H, N)
     _check_epoch(res, ref, nmb=2, mini_epochs=4)
     assert agent.optimizer.last_and_next_lr()[1] == oracle.lr
-    _check_final_params(agent, oracle, steps=8, lr_max=max(oracle.lr, 3e-4))
+    def fp64_final():
+        truth = _truth_for(params, caps[0], N, 60, 8)
+        truth.update(_batch64(batch))
+        return truth.model.full_state_dict()
+    _check_final_params(agent, oracle, steps=8, lr_max=max(oracle.lr, 3e-4), truth=fp64_final)
 
 
 def test_dataset_preparation_and_obs_statistics_at_65536x32():

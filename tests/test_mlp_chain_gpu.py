@@ -889,11 +889,14 @@ def test_adam_step_pack_equals_adam_then_pack(in_dim, units, out_dim):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('rows', [4096, 1000, 37])
-def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch):
-    """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain_lean.hip: weights as fp32 fragments in each wave's
-    consumption order, the default of MlpChain below 16,384 rows) against the pipelined kernels they replace
-    (RLG_CHAIN_LEAN=0; their own one-launch step included): the same products in the same order - heads, activations, normalised observations, d heads, loss
-    partials, dZ and bias partial sums equal bit for bit, ragged last tile included - and within 1e-6 of fp64."""
+def test_lean_kernels_against_the_pipelined_ones(rows, monkeypatch):
+    """The lean 16-row forward / backward / one-launch step (csrc/mlp_chain_lean.hip: the weights as fragments in each wave's
+    consumption order, the default of MlpChain below the 64-row kernels' thresholds) against the pipelined exact-product kernels
+    they replace (RLG_CHAIN_LEAN=0; their own one-launch step included) - heads, activations, normalised observations, d heads,
+    loss partials, dZ and bias partial sums, ragged last tile included.  Round 6: the lean kernels run three fp16 plane
+    products per fp32 product - within the split kernels' tolerance of the exact-product kernels (4e-6 of a tensor's scale),
+    the lean forward + backward pair and the lean one-launch step bit-identical to each other; a -DRLG_BX_F16=0 build runs
+    exact fp32 products in the pipelined kernels' order: everything bit for bit.  Both: within 1e-6 of fp64."""
     from rl_games_amd import ops
     layers, g = _net(108, [400, 200, 100], 22, 'elu', seed=3)
     x = (3 * torch.randn(rows, 108, generator=g) + 1).to(DEV)
@@ -929,11 +932,17 @@ def test_lean_kernels_are_bit_identical_to_the_pipelined_ones(rows, monkeypatch)
             chain.backward(dh, acts, dzs, parts, ppo_loss=desc)
         torch.cuda.synchronize()
         out[mode] = [heads, xn, dh, partials, om, osg] + acts + dzs + parts
+    exact_lean = ops.chain_split_form()[1] != 'fp16'
     for k, (a, b, c, d) in enumerate(zip(out['pipe'], out['lean'], out['lean_step'], out['pipe_step'])):
         assert torch.isfinite(a.double()).all(), k
-        assert torch.equal(a, b), k
-        assert torch.equal(a, c), k
         assert torch.equal(a, d), k
+        assert torch.equal(b, c), k
+        if exact_lean or k == 1:                                   # (k = 1: the normalised observations - no product in them)
+            assert torch.equal(a, b), k
+        else:
+            assert torch.isfinite(b.double()).all(), k
+            scale = a.double().abs().max().item()
+            assert (a.double() - b.double()).abs().max().item() <= 4e-6 * scale + 1e-30, (k, scale)
     # inference form = training form
     chain = ops.MlpChain(layers, DEV)
     heads_i = torch.empty(rows, 22, device=DEV)
