@@ -549,7 +549,7 @@ int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float*
                        const rlg_ppo_loss_desc* ppo_loss, long long rows, void* stream);
 
 /* The 16-row launches of a data-parallel rank's minibatches (< 16,384 rows; rollouts of that size) in their LEAN form
- * (round 4; csrc/mlp_chain_lean.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as fp32 FRAGMENTS in
+ * (round 4; csrc/mlp_chain_lean.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as FRAGMENTS (round 6: two fp16 planes of 64 w per group of 32 k values where rounds 4 - 5 had two fp32 chunks - the same bytes; csrc/split_f16.hpp) in
  * the order each of the 8 waves of a workgroup consumes them - one linear stream per wave across blocks and layers, zero
  * padding instead of out-of-range selects; the backward's fragments are the transposed matrices (one 16-byte load per lane and chunk where the row-major matrix
  * needs four strided dword loads).  Same maths as rlg_mlp_chain_forward / rlg_mlp_chain_backward in their 16-row form

@@ -907,7 +907,7 @@ class A2CAgent:
         mb_valid = None
         fast = self._fast_rollout_ok()
         if fast:
-            # the step graphs contain no pack launch: the weights' derived forms (bf16 planes, fp32 fragments) must belong
+            # the step graphs contain no pack launch: the weights' derived forms (plane fragments of both kernel families) must belong
             # to the weights as they are - they do behind an optimiser step, not behind set_weights / a broadcast
             self._planes_before_replay()
         if self.mask_autoreset_rows:
@@ -1383,7 +1383,7 @@ class A2CAgent:
         # behind the in-graph all-reduce the step takes the collective's error word: a step whose gradients
         # are invalid (a peer never arrived) changes nothing
         skip = self._ipc_comm.error_word if (self.multi_gpu and self._ipc_comm) else None
-        # the lean 16-row kernels read the weights as fp32 fragments: one pack launch behind the step writes them - inside
+        # the lean 16-row kernels read the weights as fragments in each wave's consumption order: one pack launch behind the step writes them - inside
         # the captured graphs too: no launch of this agent ever packs on demand.  (Round 4 had the Adam launch write them
         # itself on one GPU, adam_frags_kernel; that kernel family left two ranks that SHARE a GPU one exp_avg_sq update
         # apart and is gone - profiles/r5_two_rank_sync.txt.)

@@ -697,7 +697,7 @@ class MlpChain:
                 raise NotImplementedError('MLP does not fit the LDS of the fused chain kernels')
             self.max_groups[direction] = best
         # lean 16-row kernels (csrc/mlp_chain_lean.hip, mlp_chain_fwd_lean_kernel / mlp_chain_bwd_lean_kernel): the weights as
-        # fp32 fragments in each wave's consumption order; RLG_CHAIN_LEAN=0 keeps the pipelined kernels
+        # plane fragments in each wave's consumption order; RLG_CHAIN_LEAN=0 keeps the pipelined kernels
         self._lean = os.environ.get('RLG_CHAIN_LEAN', '1') != '0'
         self._frag_bytes = [int(lib.rlg_mlp_chain_frags_bytes(n, self._in, self._out, 0)),
                             int(lib.rlg_mlp_chain_frags_bytes(n, self._in, self._out, 1)) if n > 1 else -1]
@@ -754,7 +754,7 @@ class MlpChain:
     def restore_cache_state(self, state):
         self._planes_fresh, self._planes_for, self._frags_for, self._planes_packed_once = state
 
-    # ---- fp32 fragments of the lean 16-row kernels
+    # ---- fragments of the lean 16-row kernels (fp16 planes; the buffer is typed fp32 for its size only)
     def lean_used(self, rows, direction, requested=0):
         """True when the launch of this direction runs the lean 16-row kernel for `rows` rows (16-row workgroups, exact
         products; the backward additionally needs 16-byte aligned H / dZ rows, checked at its launch)."""
