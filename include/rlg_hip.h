@@ -553,8 +553,8 @@ int rlg_mlp_chain_step(int num_layers, const float* const* weights, const float*
  * the order each of the 8 waves of a workgroup consumes them - one linear stream per wave across blocks and layers, zero
  * padding instead of out-of-range selects; the backward's fragments are the transposed matrices (one 16-byte load per lane and chunk where the row-major matrix
  * needs four strided dword loads).  Same maths as rlg_mlp_chain_forward / rlg_mlp_chain_backward in their 16-row form
- * (network_builder.py:447-512 and autograd's backward of it), the same products in the same order: results bit-identical
- * to the pipelined kernels'.
+ * (network_builder.py:447-512 and autograd's backward of it); round 6: three fp16 plane products per fp32 product - results
+ * within the split kernels' tolerance of the pipelined exact-product kernels (bit-identical to them in a -DRLG_LEAN_F16=0 build).
  *   rlg_mlp_chain_frags_bytes: size of one direction's fragment buffer (0 forward, 1 backward), < 0: shape
  *     outside the format.
  *   rlg_mlp_chain_pack_frags / _both: weights -> fragments, one launch (the bias pointers are not read); to be repeated behind every change of
