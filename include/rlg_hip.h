@@ -471,12 +471,15 @@ int rlg_mlp_chain_debug_stamps(long long* buffer);
 /* Split-fp16 launches (round 6).  The weight-gradient launch sums over the batch rows, so it scales an operand by ONE power
  * of two per K-slice of rows.  rlg_mlp_chain_gradient_maxima: the next rlg_mlp_chain_backward launch, if it runs the
  * split-fp16 kernel, leaves per 64-row workgroup the largest magnitude of dZ of layer l (the last layer: of the d heads it
- * read) in entries[l * stride + workgroup] (plain stores; stride >= ceil(rows / 64)); one-shot.
+ * read) in entries[l * stride + workgroup] (plain stores; stride >= ceil(rows / 64)); one-shot.  The lean 16-row launches
+ * (rlg_mlp_chain_backward_lean / _step_lean) take the same setter and leave one entry per 16-row workgroup (stride >=
+ * ceil(rows / 16)); rows_per_entry of rlg_mlp_dw_gradient_maxima says which (64 or 16).
  * rlg_mlp_dw_gradient_maxima hands them to the NEXT rlg_mlp_dw_launch: dz_slot[k] = the layer of job k's dz, x_scale[k] = the
  * fixed power of two job k's x is split under (the forward's: 16 for hidden activations, 4096 for normalised
  * observations); every wave takes the largest entry over its own rows.  Without them the launch runs the bf16 form. */
 int rlg_mlp_chain_gradient_maxima(float* entries, int stride);
-int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, const int* dz_slot, const float* x_scale, int num_layers);
+int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, int rows_per_entry, const int* dz_slot, const float* x_scale,
+                               int num_layers);
 /* plane products per fp32 product of the split-product chain kernels of this build: 3 (fp16 planes) or 6 (bf16 planes) */
 int rlg_mlp_chain_split_products(void);
 int rlg_mlp_chain_time_next(void* ev_start, void* ev_stop);

@@ -85,7 +85,7 @@ _PROTOTYPES = {
     'rlg_mlp_chain_time_next': [_P, _P],
     'rlg_mlp_chain_gradient_maxima': [_P, _c_int],
     'rlg_mlp_chain_split_products': [],
-    'rlg_mlp_dw_gradient_maxima': [_P, _c_int, _P, _P, _c_int],
+    'rlg_mlp_dw_gradient_maxima': [_P, _c_int, _c_int, _P, _P, _c_int],
     'rlg_mlp_chain_forward': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,
                               _P, _P, _P, _P, _P, _c_ll, _c_int, _P, _P, _P],
     'rlg_mlp_chain_step': [_c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_ll, _P, _P, _c_float, _P,

@@ -2046,4 +2046,9 @@ void chain_take_events(hipEvent_t* ev_start, hipEvent_t* ev_stop) {
   *ev_stop = g_chain_ev_stop;
   g_chain_ev_start = g_chain_ev_stop = nullptr;
 }
+void chain_take_gradient_maxima(float** entries, int* stride) {
+  *entries = ::g_chain_amax;
+  *stride = ::g_chain_amax_stride;
+  ::g_chain_amax = nullptr;
+}
 }  // namespace rlg

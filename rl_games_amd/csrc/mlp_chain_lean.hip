@@ -378,6 +378,12 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
       }
     }
     scale_in = bx_row_scale(mine);
+    if (a.amax != nullptr) {
+      // gradient maxima for the weight-gradient launch (csrc/bx_form.hpp), one entry per 16-row workgroup here: every wave
+      // leaves the largest magnitude it produced per tensor in LDS, thread l combines tensor l's behind the last barrier
+      const float m = bx_wave_max(mine);
+      if (lane == 0) (lds + (a.bx_scales_off >> 2))[(num_layers - 1) * W + wave] = m;
+    }
     for (int u = wave; u < (la.kc2[0] >> 1); u += W) {
       f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = lo;
       if (row < n_rows) {
@@ -446,6 +452,7 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
     // it reads (csrc/bx_form.hpp)
     const float inv = 1.0f / (kBxScaleW * scale_in);
     const float scale_out = scale_in * kBxScaleStepBwd;
+    float dz_max = 0.0f;
 #endif
     auto epilogue = [&]() {
       const int ob = unit_block(unit);
@@ -453,6 +460,8 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
 #if RLG_LEAN_F16
       f32x4 v = chain_act_grad4((acc0 + acc1) * inv, hv, p_act);
       if (!row_ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dz_max = __builtin_fmaxf(dz_max, __builtin_fabsf(v[e]));
       if (keep_tile) lean_put_planes(tout, ob, lane, v, scale_out);
 #else
       f32x4 v = chain_act_grad4(acc0 + acc1, hv, p_act);
@@ -503,6 +512,12 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
         }
       }
     }
+#if RLG_LEAN_F16
+    if (a.amax != nullptr) {
+      const float m = bx_wave_max(dz_max);
+      if (lane == 0) (lds + (a.bx_scales_off >> 2))[(L - 1) * W + wave] = m;
+    }
+#endif
     __syncthreads();
 #if RLG_LEAN_F16
     scale_in = scale_out;
@@ -511,6 +526,15 @@ __device__ __forceinline__ void chain_bwd_lean_body(const ChainArgs& a, const Le
     tin = tout;
     tout = tt;
   }
+#if RLG_LEAN_F16
+  if (a.amax != nullptr && static_cast<int>(threadIdx.x) < num_layers) {
+    const float* m = lds + (a.bx_scales_off >> 2) + threadIdx.x * W;
+    float t = m[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) t = __builtin_fmaxf(t, m[w]);
+    a.amax[static_cast<long long>(kBxAmaxDz + threadIdx.x) * a.amax_stride + blockIdx.x] = t;
+  }
+#endif
 }
 
 __global__ __launch_bounds__(64 * kLeanW) void mlp_chain_bwd_lean_kernel(ChainArgs a, LeanArgs la, LossArgs loss) {
@@ -845,6 +869,22 @@ int rlg_mlp_chain_backward_lean(int num_layers, const int* in_features, const in
     const int need = static_cast<int>(ppo_loss_lds_bytes(16, d.actions_num, 512));
     if (need > lds_bytes) lds_bytes = need;
   }
+  // gradient maxima for the weight-gradient launch (rlg_mlp_chain_gradient_maxima; one entry per 16-row workgroup here): the
+  // waves' maxima sit behind everything else in LDS
+  args.amax = nullptr;
+  args.amax_stride = 0;
+  {
+    float* entries = nullptr;
+    int stride = 0;
+    chain_take_gradient_maxima(&entries, &stride);
+    if (RLG_LEAN_F16 && entries != nullptr) {
+      if (stride < (rows + 15) / 16) return static_cast<int>(hipErrorInvalidValue);
+      args.amax = entries;
+      args.amax_stride = stride;
+      args.bx_scales_off = (lds_bytes + 15) & ~15;
+      lds_bytes = args.bx_scales_off + kChainMaxLayers * kLeanW * 4;
+    }
+  }
   if (lds_bytes > 64 * 1024) return static_cast<int>(hipErrorNotSupported);
   LeanArgs la = pk.la;
   la.wf = static_cast<const float*>(frags);
@@ -1002,6 +1042,22 @@ int rlg_mlp_chain_step_lean(int num_layers, const float* const* biases, const in
   if (chain_lean_tile_floats(bplan) * 4 > lds_bytes) lds_bytes = chain_lean_tile_floats(bplan) * 4;
   const int need = static_cast<int>(ppo_loss_lds_bytes(16, d.actions_num, 512));
   if (need > lds_bytes) lds_bytes = need;
+  // gradient maxima for the weight-gradient launch (rlg_mlp_chain_gradient_maxima; one entry per 16-row workgroup here): the
+  // waves' maxima sit behind everything else in LDS
+  ba.amax = nullptr;
+  ba.amax_stride = 0;
+  {
+    float* entries = nullptr;
+    int stride = 0;
+    chain_take_gradient_maxima(&entries, &stride);
+    if (RLG_LEAN_F16 && entries != nullptr) {
+      if (stride < (rows + 15) / 16) return static_cast<int>(hipErrorInvalidValue);
+      ba.amax = entries;
+      ba.amax_stride = stride;
+      ba.bx_scales_off = (lds_bytes + 15) & ~15;
+      lds_bytes = ba.bx_scales_off + kChainMaxLayers * kLeanW * 4;
+    }
+  }
   if (lds_bytes > 64 * 1024) return static_cast<int>(hipErrorNotSupported);
   LeanArgs fla = fpk.la, bla = bpk.la;
   fla.wf = static_cast<const float*>(frags_fwd);

@@ -81,6 +81,8 @@ int chain_fill(ChainArgs& args, int num_layers, const float* const* weights, con
 long long* chain_debug_stamps();
 // rlg_mlp_chain_time_next: the HIP events the NEXT chain launch carries on its dispatch (taken = cleared)
 void chain_take_events(hipEvent_t* ev_start, hipEvent_t* ev_stop);
+// rlg_mlp_chain_gradient_maxima: where the NEXT backward launch leaves its gradient maxima (taken = cleared)
+void chain_take_gradient_maxima(float** entries, int* stride);
 static inline bool vec4_ok_host(const void* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0; }
 
 }  // namespace rlg

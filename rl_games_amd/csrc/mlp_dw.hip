@@ -90,7 +90,7 @@ static bool dw_f16_products() {
 
 // rlg_mlp_dw_gradient_maxima: one-shot, consumed by the next rlg_mlp_dw_launch
 static const float* g_dw_amax = nullptr;
-static int g_dw_amax_stride = 0, g_dw_amax_dz[kDwMaxLayers], g_dw_amax_n = 0;
+static int g_dw_amax_stride = 0, g_dw_amax_dz[kDwMaxLayers], g_dw_amax_n = 0, g_dw_amax_rows = 64;
 static float g_dw_scale_x[kDwMaxLayers];
 
 struct DwLayer {
@@ -116,6 +116,7 @@ struct DwArgs {
   DwLayer layer[kDwMaxLayers];
   int num_layers;
   int rows;
+  int amax_shift;      // fp16 form: log2 of the rows one gradient-maxima entry covers (6: the 64-row kernels, 4: the lean ones)
 };
 
 // Bias gradients ride along in the finalise launch: out[c] = sum_b partials[b][c] over the
@@ -148,7 +149,7 @@ template <int B> __device__ __forceinline__ typename DwVec<B>::type dw_zero() { 
 // kSplit = false: exact f32 products (v_mfma_f32_16x16x4_f32).  kSplit = true: split-bf16 products, two
 // register sets of 32 rows.
 template <int BO, int BI, int kMode>
-__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int i0, int z, float* lds) {
+__device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int i0, int z, float* lds, int amax_shift) {
   using VA = typename DwVec<BO>::type;
   using VB = typename DwVec<BI>::type;
   const int lane = lane_id();
@@ -280,7 +281,7 @@ __device__ __forceinline__ void dw_tile(const DwLayer& L, int rows, int o0, int 
       if (L.amax_dz_entries != nullptr) {
         // (wave-uniform addresses: scalar loads; a wave's rows span one to three 64-row entries)
         amax = 0.0f;
-        const int e0 = (4 * s_begin) >> 6, e1 = (min(4 * s_end, rows) - 1) >> 6;
+        const int e0 = (4 * s_begin) >> amax_shift, e1 = (min(4 * s_end, rows) - 1) >> amax_shift;
         for (int e = e0; e <= e1; ++e) amax = __builtin_fmaxf(amax, L.amax_dz_entries[e]);
       }
       scale_a = f16_scale_for(amax);
@@ -523,7 +524,7 @@ __device__ __forceinline__ void mlp_dw_body(const DwArgs& args) {
   const int o0 = L.o_start[to], i0 = L.i_start[ti];
   const int bo = L.o_b[to], bi = L.i_b[ti];
 #define RLG_DW_CASE(BO_, BI_) \
-  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_, kMode>(L, args.rows, o0, i0, z, lds); return; }
+  if (bo == BO_ && bi == BI_) { dw_tile<BO_, BI_, kMode>(L, args.rows, o0, i0, z, lds, args.amax_shift); return; }
   RLG_DW_CASE(4, 4)
   RLG_DW_CASE(4, 2)
   RLG_DW_CASE(4, 1)
@@ -875,7 +876,8 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   args.rows = rows;
   // fp16 form: the gradients' largest magnitudes per 64 rows - left by the split-fp16 backward (rlg_mlp_dw_gradient_maxima) -
   // and the other operand's fixed scale; or, for the tools, host-side bounds from the environment; neither: the bf16 form
-  const float* amax = (g_dw_amax_n == num_layers && g_dw_amax_stride >= (rows + 63) / 64) ? g_dw_amax : nullptr;
+  const float* amax = (g_dw_amax_n == num_layers && g_dw_amax_stride >= (rows + g_dw_amax_rows - 1) / g_dw_amax_rows) ? g_dw_amax : nullptr;
+  args.amax_shift = g_dw_amax_rows == 16 ? 4 : 6;
   const int amax_stride = g_dw_amax_stride;
   float scale_x[kDwMaxLayers];
   for (int l = 0; l < kDwMaxLayers; ++l) scale_x[l] = g_dw_scale_x[l];
@@ -942,12 +944,15 @@ static int dw_launch_impl(int num_layers, const float* const* dz, const float* c
   RLG_RETURN_LAUNCH_STATUS();
 }
 
-int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, const int* dz_slot, const float* x_scale, int num_layers) {
+int rlg_mlp_dw_gradient_maxima(const float* entries, int stride, int rows_per_entry, const int* dz_slot, const float* x_scale,
+                               int num_layers) {
   using namespace rlg;
   g_dw_amax = nullptr;
   g_dw_amax_n = 0;
   if (entries == nullptr) return 0;
-  if (num_layers <= 0 || num_layers > kDwMaxLayers || stride <= 0) return static_cast<int>(hipErrorInvalidValue);
+  if (num_layers <= 0 || num_layers > kDwMaxLayers || stride <= 0 || (rows_per_entry != 16 && rows_per_entry != 64))
+    return static_cast<int>(hipErrorInvalidValue);
+  g_dw_amax_rows = rows_per_entry;
   for (int l = 0; l < num_layers; ++l) {
     if (dz_slot[l] < 0 || dz_slot[l] >= 8 || !(x_scale[l] > 0.0f)) return static_cast<int>(hipErrorInvalidValue);
     g_dw_amax_dz[l] = dz_slot[l];

@@ -413,7 +413,8 @@ class ManualMLP:
                 mx = None
                 if maxima is not None and all(len(j) == 4 for j in fast):
                     mx = (maxima, [j[3] for j in fast],
-                          [ops.SPLIT_SCALE_OBS_NORM if j[3] == 0 else ops.SPLIT_SCALE_HIDDEN for j in fast])
+                          [ops.SPLIT_SCALE_OBS_NORM if j[3] == 0 else ops.SPLIT_SCALE_HIDDEN for j in fast],
+                          self.chain.maxima_rows_per_entry)
                 triples = [j[:3] for j in fast]
                 norm_blocks = plan.launch(triples, colsums, loss_finalize, norm if whole else None, maxima=mx)
                 if not whole:

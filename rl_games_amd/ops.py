@@ -714,12 +714,21 @@ class MlpChain:
         # weight-gradient launch that follows it; rows of the last backward that left them
         self._grad_maxima = None
         self._maxima_bwd = None
+        self.maxima_rows_per_entry = 64       # 64: left by the 64-row split kernels, 16: by the lean 16-row kernels
 
-    def _grad_maxima_buffer(self, rows):
-        need = max(1024, -(-int(rows) // 64))
+    def _grad_maxima_buffer(self, rows, per=64):
+        need = max(1024, -(-int(rows) // per))
         if self._grad_maxima is None or self._grad_maxima.shape[1] < need:
             self._grad_maxima = torch.zeros(8, need, dtype=F32, device=self.device)
         return self._grad_maxima
+
+    def _request_lean_maxima(self, rows):
+        """The lean 16-row backward / one-launch step (fp16 form) leaves one gradient-maxima entry per 16-row workgroup."""
+        if chain_split_form()[1] != 'fp16':
+            return False
+        buf = self._grad_maxima_buffer(rows, 16)
+        _lib.load().rlg_mlp_chain_gradient_maxima(buf.data_ptr(), buf.shape[1])
+        return True
 
     def gradient_maxima(self, rows):
         """[8, entries] fp32: row l = per 64-row workgroup the largest |dZ of layer l| of the backward of this step - when
@@ -977,6 +986,8 @@ class MlpChain:
             # the lean form of the same launch (fp32 weight fragments); outside its envelope: the lean forward and the lean
             # backward as two launches (the caller's fallback), which beat the pipelined one-launch step
             self.ensure_frags(x)
+            self._maxima_bwd = None
+            lean_maxima = self._request_lean_maxima(rows)
             _time_chain_launch('step16')
             err = _lib.load().rlg_mlp_chain_step_lean(
                 n, self._b, self._in, self._out, self._act, ptrs, lds, x.data_ptr(), x.stride(0),
@@ -988,6 +999,8 @@ class MlpChain:
                 return False
             _lib.check(err, 'rlg_mlp_chain_step_lean')
             self._planes_fresh = None
+            if lean_maxima:
+                self._maxima_bwd, self.maxima_rows_per_entry = rows, 16
             return True
         _time_chain_launch('step16')
         err = _lib.load().rlg_mlp_chain_step(
@@ -1023,12 +1036,15 @@ class MlpChain:
             self._planes_fresh = None
             self._maxima_bwd = None
             self.ensure_frags(d_heads)
+            lean_maxima = self._request_lean_maxima(rows)
             _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
             err = _lib.load().rlg_mlp_chain_backward_lean(
                 n, self._in, self._out, self._act, h, hl, d_heads.data_ptr(), d_heads.stride(0), dz, dl, bp,
                 None if ppo_loss is None else ctypes.addressof(ppo_loss), rows, self._frags_ptr(1), _stream(d_heads))
             if err != 801:
                 _lib.check(err, 'rlg_mlp_chain_backward_lean')
+                if lean_maxima:
+                    self._maxima_bwd, self.maxima_rows_per_entry = rows, 16
                 return
             _untime_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         planes = None
@@ -1045,6 +1061,8 @@ class MlpChain:
             _lib.load().rlg_mlp_chain_gradient_maxima(buf.data_ptr(), buf.shape[1])
             left_maxima = True
         self._maxima_bwd = rows if left_maxima else None
+        if left_maxima:
+            self.maxima_rows_per_entry = 64
         self._planes_fresh = None
         _time_chain_launch('bwd_loss' if ppo_loss is not None else 'bwd')
         _lib.check(_lib.load().rlg_mlp_chain_backward(
@@ -1136,11 +1154,12 @@ class MlpDwPlan:
             self._x[k] = _need(x, F32, 'x')
             self._grad[k] = _need(grad, F32, 'grad')
         if maxima is not None:
-            entries, dzs, xscales = maxima
+            entries, dzs, xscales = maxima[:3]
+            per = int(maxima[3]) if len(maxima) > 3 else 64           # rows one entry covers: 64, or 16 (the lean kernels)
             if len(dzs) != self.n or len(xscales) != self.n or entries.dim() != 2 or entries.shape[0] != 8:
                 raise ValueError('maxima: [8, entries] fp32, one dz layer and one x scale per job')
             _lib.check(_lib.load().rlg_mlp_dw_gradient_maxima(
-                _need(entries, F32, 'gradient maxima'), int(entries.shape[1]), (ctypes.c_int * self.n)(*[int(v) for v in dzs]),
+                _need(entries, F32, 'gradient maxima'), int(entries.shape[1]), per, (ctypes.c_int * self.n)(*[int(v) for v in dzs]),
                 (ctypes.c_float * self.n)(*[float(v) for v in xscales]), self.n), 'rlg_mlp_dw_gradient_maxima')
         _lib.check(_lib.load().rlg_mlp_dw_launch(self.n, self._dz, self._x, self._ws, self._grad, self._no,
                                                  self._mi, self._plans, self.rows, nc, cs_part, cs_blocks,

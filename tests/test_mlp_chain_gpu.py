@@ -963,10 +963,11 @@ def _fp16_form():
     return ops.chain_split_form()[1] == 'fp16'
 
 
-@pytest.mark.parametrize('rows', [32768, 16384 + 640, 4096])
-def test_dw_fp16_form_with_per_wave_gradient_scales_matches_fp64(rows):
+@pytest.mark.parametrize('rows,per', [(32768, 64), (16384 + 640, 64), (4096, 64), (4096, 16), (1000, 16)])
+def test_dw_fp16_form_with_per_wave_gradient_scales_matches_fp64(rows, per):
     """The weight-gradient launch on three fp16 plane products (MlpDwPlan.launch(maxima=...)): dZ whose magnitude varies
-    over 2^-20 .. 1 from one 64-row block to the next (every wave scales by the largest entry over ITS rows), blocks of
+    over 2^-20 .. 1 from one block of `per` rows to the next (64: what the 64-row kernels leave, 16: the lean ones; every wave
+    scales by the largest entry over ITS rows), blocks of
     all-zero rows (entry 0), activations under the forward's fixed scales - against fp64, judged like the bf16 form, and
     beside it."""
     from rl_games_amd import ops
@@ -974,23 +975,23 @@ def test_dw_fp16_form_with_per_wave_gradient_scales_matches_fp64(rows):
         pytest.skip('bf16 build')
     g = torch.Generator().manual_seed(rows)
     shapes = [(200, 400), (400, 108), (100, 200), (22, 100)]
-    nblk = -(-rows // 64)
+    nblk = -(-rows // per)
     jobs, entries = [], torch.zeros(8, max(1024, nblk), device=DEV)
     for k, (No, Mi) in enumerate(shapes):
         block_scale = torch.exp2(-20.0 * torch.rand(nblk, generator=g))
         block_scale[::7] = 0.0                                               # whole blocks of zero gradient (masked rows)
-        dz = torch.randn(rows, No, generator=g) * block_scale.repeat_interleave(64)[:rows, None] * 3e-4
+        dz = torch.randn(rows, No, generator=g) * block_scale.repeat_interleave(per)[:rows, None] * 3e-4
         x = torch.nn.functional.elu(torch.randn(rows, Mi, generator=g))
         if k == 1:
             x = x.clamp(-5.0, 5.0)                                           # "normalised observations"
         dz, x = dz.to(DEV), x.to(DEV)
-        pad = torch.zeros(nblk * 64, No, device=DEV)
+        pad = torch.zeros(nblk * per, No, device=DEV)
         pad[:rows] = dz.abs()
-        entries[k, :nblk] = pad.view(nblk, 64 * No).max(dim=1).values
+        entries[k, :nblk] = pad.view(nblk, per * No).max(dim=1).values
         jobs.append((dz, x, torch.full((No, Mi), float('nan'), device=DEV)))
     plan = ops.MlpDwPlan(shapes, rows, DEV)
     xscale = [ops.SPLIT_SCALE_HIDDEN, ops.SPLIT_SCALE_OBS_NORM, ops.SPLIT_SCALE_HIDDEN, ops.SPLIT_SCALE_HIDDEN]
-    plan.launch(jobs, maxima=(entries, [0, 1, 2, 3], xscale))
+    plan.launch(jobs, maxima=(entries, [0, 1, 2, 3], xscale, per))
     f16 = [j[2].clone() for j in jobs]
     plan.launch(jobs)                                                        # the bf16 form on the same operands
     for (dz, x, bf), got in zip(jobs, f16):
@@ -1004,17 +1005,17 @@ def test_dw_fp16_form_with_per_wave_gradient_scales_matches_fp64(rows):
         assert e16.pow(2).mean().sqrt() <= 1.5 * eb.pow(2).mean().sqrt() + 1e-10
 
 
-def test_split_fp16_backward_scales_gradient_rows_by_their_own_maxima():
+@pytest.mark.parametrize('rows', [16384, 4096])
+def test_split_fp16_backward_scales_gradient_rows_by_their_own_maxima(rows):
     """The fp16 backward splits the d heads tile ROW BY ROW: a row of gradients a million times smaller than its tile
     neighbours gives the same dZ bits as in a tile of rows like itself, and the gradient maxima it leaves for the
-    weight-gradient launch are the per-64-row maxima of what it wrote."""
+    weight-gradient launch are the per-workgroup maxima (64 rows; 16 for the lean kernels of a 4,096-row launch) of what it wrote."""
     from rl_games_amd import ops
     if not _fp16_form():
         pytest.skip('bf16 build')
-    rows = 16384
     layers, g = _net(60, [256, 128], 9, 'elu', seed=31)
     chain = ops.MlpChain(layers, DEV)
-    assert chain.split_products(rows, 1)
+    assert chain.split_products(rows, 1) == (rows >= 8192) and chain.lean_used(rows, 1) == (rows < 8192)
     x = torch.randn(rows, 60, generator=g).to(DEV)
     heads = torch.empty(rows, 9, device=DEV)
     acts = [torch.empty(rows, 256, device=DEV), torch.empty(rows, 128, device=DEV)]
@@ -1032,7 +1033,9 @@ def test_split_fp16_backward_scales_gradient_rows_by_their_own_maxima():
     mixed = run(small)
     maxima = chain.gradient_maxima(rows)
     assert maxima is not None
-    nblk = rows // 64
+    per = chain.maxima_rows_per_entry
+    assert per == (64 if rows >= 8192 else 16)
+    nblk = rows // per
     for l, dz in enumerate(mixed):
         assert torch.equal(maxima[l, :nblk], dz.abs().view(nblk, -1).max(dim=1).values), l
     assert torch.equal(maxima[2, :nblk], small.abs().view(nblk, -1).max(dim=1).values)
