@@ -86,8 +86,7 @@ __device__ __forceinline__ float bx_row_scale(float mine) {
 // free but costs the weight gradients of the deep layers 3 - 9 bits: the benchmarked epoch's losses then leave the oracle's
 // band.)  The other operand needs none: hidden activations and normalised observations are split under the forward's
 // fixed scales.
-constexpr int kBxAmaxDz = 0, kBxAmaxSlots = 8;
-constexpr int kBxRowsPerEntry = 64;
+constexpr int kBxAmaxDz = 0;
 // LDS bytes of the backward behind its tiles: 64 row scales of the d heads tile + 8 layers x 4 waves of gradient maxima (+ alignment)
 constexpr int kBxBwdScratch = RLG_BX_F16 ? 16 + 64 * 4 + 8 * 4 * 4 : 0;
 
@@ -104,12 +103,6 @@ __device__ __forceinline__ float bx_wave_max(float t) {
   const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
   return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
 }
-// |x| for a reported maximum: a non-finite element reports +Inf (fmax would drop a NaN)
-__device__ __forceinline__ float bx_abs_or_inf(float x) {
-  const float a = __builtin_fabsf(x);
-  return a <= 3.4028234664e38f ? a : __builtin_inff();
-}
-
 // |x| for the row maximum: finite values only
 __device__ __forceinline__ float bx_finite_abs(float x) {
   const float a = __builtin_fabsf(x);
