@@ -961,6 +961,8 @@ class A2CAgent:
                     mb_s[n // self.seq_length, :, :, :] = s
             if fast:
                 res_dict = self._fast_policy_step(n)
+            elif self.use_action_masks:                          # a2c_common.py:1088-1090
+                res_dict = self.get_masked_action_values(self.obs, self.vec_env.get_action_masks())
             else:
                 res_dict = self.get_action_values(self.obs)
             self.rnn_states = [s.contiguous() for s in res_dict['rnn_states']]

@@ -75,7 +75,7 @@ class DiscreteA2CAgent(A2CAgent):
         try:
             if self.value_size != 1 or not isinstance(net.value_act, nn.Identity):
                 raise NotImplementedError('one linear value column only')
-            if not getattr(net, 'plain_trunk', True):
+            if not getattr(net, 'plain_trunk', True) or net.is_rnn():
                 raise NotImplementedError('plain Linear + activation trunks only')
             rows = self.minibatch_size
             groups = self._chain_heads()
@@ -148,7 +148,12 @@ class DiscreteA2CAgent(A2CAgent):
                 logits, values = outs[0], outs[1][:, 0]
                 d_logits, d_val = chains[0].d_heads[:mb], chains[1].d_heads[:mb, 0]
         else:
-            logits, values = self.model.forward_heads({'is_train': True, 'obs': obs_batch})
+            batch = {'is_train': True, 'obs': obs_batch}
+            if self.is_rnn:                                        # a2c_discrete.py:138-144
+                batch.update(rnn_states=input_dict['rnn_states'], seq_length=self.seq_length)
+                if self.zero_rnn_on_done:
+                    batch['dones'] = input_dict['dones']
+            logits, values = self.model.forward_heads(batch)
             mb = logits.shape[0]
             d_logits, d_val = self._d_logits[:mb], self._d_val[:mb]
         mask = mask_sum = None

@@ -4,7 +4,7 @@ reference agents (same `.pth` format): host mirror of `PpoPlayerContinuous` / `P
 (rl_games/common/player.py:17-102, :242-330): `restore(fn)`, `get_action(obs, is_deterministic)`,
 `reset()`, `run()`.  The policy is the same module the agents train (`policy.PolicyBuilder`), on
 the GPU; observation normalisation runs through the `RunningMeanStd` HIP kernels in eval mode.
-Not mirrored: the evaluation-worker checkpoint watcher, rendering, self-play hooks, action masks.
+Not mirrored: the evaluation-worker checkpoint watcher, rendering, self-play hooks.
 """
 import numpy as np
 import torch
@@ -99,13 +99,15 @@ class _BasePlayer:
             obs = obs.float()
         return obs
 
-    def _forward(self, obs):
+    def _forward(self, obs, action_masks=None):
         obs = self._to_device(obs)
         if not self.has_batch_dimension and obs.dim() == len(self.obs_shape):
             obs = obs.unsqueeze(0)
+        inputs = {'is_train': False, 'prev_actions': None, 'obs': obs.contiguous(), 'rnn_states': self.states}
+        if action_masks is not None:
+            inputs['action_masks'] = action_masks
         with torch.no_grad():
-            res = self.model({'is_train': False, 'prev_actions': None, 'obs': obs.contiguous(),
-                              'rnn_states': self.states})
+            res = self.model(inputs)
         self.states = res['rnn_states']
         return res
 
@@ -121,8 +123,13 @@ class _BasePlayer:
         cur_n = torch.zeros(self.batch_size, device=self.device)
         sum_r = sum_n = 0.0
         games = 0
+        mask_fn = getattr(self.env, 'has_action_mask', None)       # the reference's player-side name (player.py:284-294)
+        has_masks = bool(mask_fn()) if mask_fn is not None else False
         for _ in range(self.max_steps):
-            action = self.get_action(obs, self.is_deterministic)
+            if has_masks:
+                action = self.get_masked_action(obs, self.env.get_action_mask(), self.is_deterministic)
+            else:
+                action = self.get_action(obs, self.is_deterministic)
             if not self.is_tensor_obses:
                 action = action.cpu().numpy()
             obs, rewards, dones, _ = self.env.step(action)
@@ -166,14 +173,38 @@ class PpoPlayerContinuous(_BasePlayer):
 
 
 class PpoPlayerDiscrete(_BasePlayer):
+    """`Discrete` and `Tuple`-of-`Discrete` action spaces (players.py:85-181).  Deterministic play takes the arg-max
+    of every head (multi-discrete: stacked on the last axis), otherwise the model's own sample."""
+
     def __init__(self, params):
         super().__init__(params)
-        if type(self.action_space).__name__ != 'Discrete':
-            raise NotImplementedError('multi-discrete action spaces are not implemented on the MI355X path')
-        self.actions_num = self.action_space.n
+        kind = type(self.action_space).__name__
+        if kind == 'Discrete':
+            self.actions_num = self.action_space.n
+            self.is_multi_discrete = False
+        elif kind == 'Tuple':
+            self.actions_num = [a.n for a in self.action_space]
+            self.is_multi_discrete = True
+        else:
+            raise NotImplementedError(f'{kind} action spaces are not played by PpoPlayerDiscrete')
+        self.mask = [False]
         self._build_model(self.actions_num)
 
-    def get_action(self, obs, is_deterministic=True):
-        res = self._forward(obs)
-        action = torch.argmax(res['logits'], dim=-1) if is_deterministic else res['actions']
+    def _pick(self, res, is_deterministic):
+        if not is_deterministic:
+            action = res['actions']
+        elif self.is_multi_discrete:
+            action = torch.stack([torch.argmax(l, dim=-1) for l in res['logits']], dim=-1)
+        else:
+            action = torch.argmax(res['logits'], dim=-1)
         return action if self.has_batch_dimension else torch.squeeze(action.detach())
+
+    def get_action(self, obs, is_deterministic=True):
+        return self._pick(self._forward(obs), is_deterministic)
+
+    def get_masked_action(self, obs, action_masks, is_deterministic=True):
+        """action_masks: bool [rows, sum of the head sizes] (numpy or tensor), True = allowed (players.py:117-148)."""
+        masks = torch.as_tensor(action_masks).to(self.device).bool()
+        if not self.has_batch_dimension and masks.dim() == 1:
+            masks = masks.unsqueeze(0)
+        return self._pick(self._forward(obs, action_masks=masks), is_deterministic)

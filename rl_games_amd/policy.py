@@ -173,15 +173,46 @@ class ActorCriticNetwork(nn.Module):
                 float(self.space_config.get('min_sigma', 0.0)) > 0:
             raise NotImplementedError('only the plain exp sigma parametrisation is implemented')
         mlp = net_params['mlp']
-        self._trunk_kw = dict(activation=mlp['activation'], norm_func_name=net_params.get('normalization'),
-                              norm_only_first_layer=mlp.get('norm_only_first_layer', False), d2rl=mlp.get('d2rl', False))
-        self.units = list(mlp['units'])
         self.value_size = value_size
         self.num_seqs = num_seqs
         self.actions_num = actions_num
         assert len(input_shape) == 1, 'flat observations only'
         in_size = input_shape[0]
+        out_size = self._build_body(net_params, in_size)
+        self.value = nn.Linear(out_size, value_size)
+        self.value_act = _activation(net_params.get('value_activation', 'None'))
+        self.mu = nn.Linear(out_size, actions_num)
+        self.mu_act = _activation(self.space_config['mu_activation'])
+        self.sigma_act = _activation(self.space_config['sigma_activation'])
+        if self.fixed_sigma:
+            self.sigma = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
+        else:
+            self.sigma = nn.Linear(out_size, actions_num)
 
+        mlp_init = _initializer(mlp['initializer'])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                mlp_init(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        _initializer(self.space_config['mu_init'])(self.mu.weight)
+        if self.fixed_sigma:
+            _initializer(self.space_config['sigma_init'])(self.sigma)
+        elif (self.space_config.get('sigma_init') or {}).get('name') == 'const_initializer':
+            # init_state_dependent_sigma_head (network_builder.py:14-25): a constant initialiser means a uniform initial
+            # log sigma - the BIAS - over zeroed weights
+            si = self.space_config['sigma_init']
+            nn.init.zeros_(self.sigma.weight)
+            nn.init.constant_(self.sigma.bias, si.get('val', si.get('value', 0.0)))
+        else:
+            _initializer(self.space_config['sigma_init'])(self.sigma.weight)
+
+    def _build_body(self, net_params, in_size):
+        """MLP trunk(s) + optional RNN of a policy network (network_builder.py:250-296); returns the width the heads read."""
+        mlp = net_params['mlp']
+        self._trunk_kw = dict(activation=mlp['activation'], norm_func_name=net_params.get('normalization'),
+                              norm_only_first_layer=mlp.get('norm_only_first_layer', False), d2rl=mlp.get('d2rl', False))
+        self.units = list(mlp['units'])
         self.has_rnn = 'rnn' in net_params
         # sizes as network_builder.py:250-272
         mlp_in = in_size
@@ -211,33 +242,7 @@ class ActorCriticNetwork(nn.Module):
         # what the fused engines take (mlp_engine.ManualMLP): Linear + activation pairs, the RNN plainly behind them
         self.plain_trunk = (not self._trunk_kw['d2rl'] and self._trunk_kw['norm_func_name'] is None and
                             not (self.rnn_before_mlp or self.rnn_concat_input or self.rnn_concat_output or self.rnn_ln))
-        self.value = nn.Linear(out_size, value_size)
-        self.value_act = _activation(net_params.get('value_activation', 'None'))
-        self.mu = nn.Linear(out_size, actions_num)
-        self.mu_act = _activation(self.space_config['mu_activation'])
-        self.sigma_act = _activation(self.space_config['sigma_activation'])
-        if self.fixed_sigma:
-            self.sigma = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
-        else:
-            self.sigma = nn.Linear(out_size, actions_num)
-
-        mlp_init = _initializer(mlp['initializer'])
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                mlp_init(m.weight)
-                if m.bias is not None:
-                    nn.init.zeros_(m.bias)
-        _initializer(self.space_config['mu_init'])(self.mu.weight)
-        if self.fixed_sigma:
-            _initializer(self.space_config['sigma_init'])(self.sigma)
-        elif (self.space_config.get('sigma_init') or {}).get('name') == 'const_initializer':
-            # init_state_dependent_sigma_head (network_builder.py:14-25): a constant initialiser means a uniform initial
-            # log sigma - the BIAS - over zeroed weights
-            si = self.space_config['sigma_init']
-            nn.init.zeros_(self.sigma.weight)
-            nn.init.constant_(self.sigma.bias, si.get('val', si.get('value', 0.0)))
-        else:
-            _initializer(self.space_config['sigma_init'])(self.sigma.weight)
+        return out_size
 
     def _init_central_value(self, net_params, input_shape, value_size, num_seqs):
         """`central_value: True` networks (network_builder.py:497,556): MLP trunk + value head only."""
@@ -262,19 +267,9 @@ class ActorCriticNetwork(nn.Module):
     def _init_discrete(self, net_params, actions_num, input_shape, value_size, num_seqs):
         """Categorical head (network_builder.py:298-299): `logits` Linear in place of mu/sigma."""
         mlp = net_params['mlp']
-        if 'rnn' in net_params:
-            raise NotImplementedError('recurrent discrete policies are not implemented on this path')
-        self.units = list(mlp['units'])
         self.value_size, self.num_seqs, self.actions_num = value_size, num_seqs, actions_num
-        self.has_rnn = False
         assert len(input_shape) == 1, 'flat observations only'
-        kw = dict(activation=mlp['activation'], norm_func_name=net_params.get('normalization'),
-                  norm_only_first_layer=mlp.get('norm_only_first_layer', False), d2rl=mlp.get('d2rl', False))
-        self.plain_trunk = not kw['d2rl'] and kw['norm_func_name'] is None
-        last = self.units[-1] if self.units else input_shape[0]
-        self.actor_mlp = build_trunk(input_shape[0], self.units, **kw)
-        if self.separate:
-            self.critic_mlp = build_trunk(input_shape[0], self.units, **kw)
+        last = self._build_body(net_params, input_shape[0])      # (an RNN as for the continuous policy, round 6)
         self.value = nn.Linear(last, value_size)
         self.value_act = _activation(net_params.get('value_activation', 'None'))
         if self.is_multi_discrete:                              # network_builder.py:303-304
@@ -472,7 +467,7 @@ class DiscreteA2CModel(ContinuousA2CLogStdModel):
         [B, V]) for the fused categorical loss kernel."""
         obs = self.norm_obs(input_dict['obs'])
         net = self.a2c_network
-        out, _ = net.trunk(obs)
+        out, _ = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'), input_dict.get('seq_length', 1))
         logits = net.head_logits(out)
         if net.is_multi_discrete:
             logits = torch.cat(logits, dim=1)

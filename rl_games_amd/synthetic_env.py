@@ -88,6 +88,10 @@ class SyntheticTensorEnv:
             at += n
         return masks.cpu().numpy() if self.device.type == 'cpu' else masks
 
+    # the names the reference's players ask for (rl_games/common/player.py:284-329); agents use the plural ones
+    has_action_mask = has_action_masks
+    get_action_mask = get_action_masks
+
     def get_number_of_agents(self):
         return self.agents
 

@@ -133,12 +133,17 @@ def _make_agent(cap, **over):
     return agent
 
 
-@pytest.mark.parametrize('variant', ['masked_adaptive', 'plain', 'multi_discrete_masked'])
+@pytest.mark.parametrize('variant', ['masked_adaptive', 'plain', 'multi_discrete_masked',
+                                     'rnn:lstm', 'rnn:lstm_multi_masked', 'rnn:gru_before_mlp'])
 def test_discrete_update_matches_reference_epoch(golden, variant):
-    cap = golden('discrete.pt')[variant]
+    """The reference agent's rollout batch through this agent's dataset preparation and every minibatch step of the
+    epoch; `rnn:` variants (tests/golden/discrete_rnn.pt): recurrent categorical policies - sequence minibatches with
+    their initial states, done-zeroing inside the sequence, masked filler rows (a2c_discrete.py:138-144)."""
+    cap = golden('discrete_rnn.pt')[variant[4:]] if variant.startswith('rnn:') else golden('discrete.pt')[variant]
     agent = _make_agent(cap)
+    assert agent.is_rnn == variant.startswith('rnn:')
     agent.model.load_state_dict(cap['state_after_rollout'])
-    batch = {k: v.to(DEV) for k, v in cap['batch'].items()}
+    batch = {k: ([s.to(DEV) for s in v] if isinstance(v, (list, tuple)) else v.to(DEV)) for k, v in cap['batch'].items()}
     agent.set_train()
     agent.epoch_num = 1
     agent.prepare_dataset(batch)
@@ -222,6 +227,94 @@ def test_multi_discrete_masked_train_epoch_runs():
     offs = [0, 3, 8]
     for b in range(3):                       # every sampled sub-action was allowed by its mask
         assert am.gather(1, (acts[:, b] + offs[b]).view(-1, 1)).all()
+
+
+@pytest.mark.parametrize('masks', [False, True])
+def test_recurrent_discrete_train_epochs_run(masks, tmp_path):
+    """A recurrent categorical policy end to end (play_steps_rnn with masked sampling, a2c_common.py:1071-1202; sequence
+    minibatches): states advance and are zeroed on dones, sampled sub-actions respect the masks, losses finite, the
+    LSTM's weights move; the checkpoint plays in the discrete player with its own recurrent state."""
+    from rl_games_amd import configs
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    from rl_games_amd.player import PpoPlayerDiscrete
+    params = configs.cartpole_discrete(num_actors=32, seq_length=8, use_action_masks=masks, normalize_input=True)
+    params['network'].update(separate=False, rnn={'name': 'lstm', 'units': 16, 'layers': 1})
+    if masks:
+        params['network']['space'] = {'multi_discrete': None}
+        params['model']['name'] = 'multi_discrete_a2c'
+        params['config']['env_config'].update(discrete_actions=[3, 5, 2], action_masks=True)
+    agent = DiscreteA2CAgent('rd', copy.deepcopy(params))
+    assert agent.is_rnn and agent._chains is None
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    before = {k: v.clone() for k, v in agent.model.state_dict().items()}
+    for _ in range(2):
+        agent.epoch_num += 1
+        res = agent.train_epoch()
+    assert len(res) == 10 and all(torch.isfinite(x).all() for x in res[4] + res[5] + res[6] + res[7])
+    assert all(torch.isfinite(s).all() and s.abs().max() > 0 for s in agent.rnn_states)
+    vd = agent.dataset.values_dict
+    assert len(vd['rnn_states']) == 2 and vd['rnn_states'][0].shape[1] == 32 * 32 // 8
+    if masks:
+        acts, am = vd['actions'], vd['action_masks']
+        for b, off in enumerate([0, 3, 8]):
+            assert am.gather(1, (acts[:, b] + off).view(-1, 1)).all()
+    moved = [k for k, v in agent.model.state_dict().items() if not torch.equal(v, before[k])]
+    assert any('rnn' in k for k in moved) and any('logits' in k for k in moved)
+    path = agent.save(str(tmp_path / 'rd_ckpt'))
+    pp = copy.deepcopy(params)
+    pp['config']['player'] = {'games_num': 10, 'print_stats': False}
+    player = PpoPlayerDiscrete(pp)
+    player.restore(path)
+    assert player.is_rnn
+    mean_r, mean_n = player.run()
+    assert mean_n > 0 and all(torch.isfinite(s).all() for s in player.states)
+
+
+def test_multi_discrete_player_restores_and_plays_with_masks(tmp_path):
+    """players.py:85-181: a multi-discrete checkpoint in the discrete player - deterministic actions are the arg-max of
+    every head, masked play (deterministic and sampled) only ever picks allowed sub-actions, run() asks the env for
+    masks."""
+    from rl_games_amd import configs
+    from rl_games_amd.discrete_agent import DiscreteA2CAgent
+    from rl_games_amd.player import PpoPlayerDiscrete
+    params = configs.cartpole_discrete(num_actors=32, use_action_masks=True)
+    params['network']['space'] = {'multi_discrete': None}
+    params['model']['name'] = 'multi_discrete_a2c'
+    params['config']['env_config'].update(discrete_actions=[3, 5, 2], action_masks=True, autoreset_mode='same_step')
+    agent = DiscreteA2CAgent('mdp', copy.deepcopy(params))
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.epoch_num += 1
+    agent.train_epoch()
+    path = agent.save(str(tmp_path / 'md_ckpt'))
+    pp = copy.deepcopy(params)
+    pp['config']['player'] = {'games_num': 20, 'print_stats': False}
+    player = PpoPlayerDiscrete(pp)
+    assert player.is_multi_discrete and player.actions_num == [3, 5, 2]
+    player.restore(path)
+    player.has_batch_dimension = True
+    obs = agent.obs['obs']
+    agent.set_eval()
+    with torch.no_grad():
+        logits = agent.model({'is_train': False, 'prev_actions': None, 'obs': obs, 'rnn_states': None})['logits']
+    want = torch.stack([torch.argmax(l, dim=-1) for l in logits], dim=-1)
+    got = player.get_action(obs, is_deterministic=True)
+    assert got.shape == (32, 3) and torch.equal(got, want)
+    masks = agent.vec_env.get_action_masks()
+    offs = [0, 3, 8]
+    for det in (True, False):
+        a = player.get_masked_action(obs, masks, is_deterministic=det)
+        assert a.shape == (32, 3)
+        for b in range(3):
+            assert masks.gather(1, (a[:, b] + offs[b]).view(-1, 1)).all()
+    # a numpy mask for one observation without a batch axis
+    player.has_batch_dimension = False
+    one = player.get_masked_action(obs[0], masks[0].cpu().numpy(), is_deterministic=True)
+    assert one.shape == (3,) and all(masks[0, one[b] + offs[b]] for b in range(3))
+    mean_r, mean_n = player.run()
+    import numpy as np
+    assert np.isfinite(mean_r) and mean_n > 0
 
 
 def test_discrete_loss_kernel_reads_and_writes_columns_of_wider_rows():

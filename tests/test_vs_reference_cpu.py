@@ -554,6 +554,9 @@ _SPACE = {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None', 'm
                                         'concat_output': True}}),
     ('lstm_before_mlp', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'before_mlp': True, 'concat_output': True}}),
     ('discrete_d2rl_layer_norm', {'mlp': {'d2rl': True}, 'normalization': 'layer_norm', 'space': {'discrete': {}}}),
+    ('discrete_lstm', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1}, 'space': {'discrete': {}}}),
+    ('discrete_gru_before_mlp_concat', {'rnn': {'name': 'gru', 'units': 12, 'layers': 1, 'before_mlp': True,
+                                                'concat_output': True}, 'space': {'discrete': {}}}),
 ])
 def test_network_zoo_layouts_equal_the_reference_builder(name, over):
     """The network layouts that left the NotImplementedError list in round 6 - layer normalisation (network_builder.py:105-132),
@@ -578,7 +581,7 @@ def test_network_zoo_layouts_equal_the_reference_builder(name, over):
     ours = ActorCriticNetwork(copy.deepcopy(net_params), **kw)
     ref_sd = ref_net.state_dict()
     assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {k: tuple(v.shape) for k, v in ours.state_dict().items()}
-    assert not getattr(ours, 'plain_trunk', True) or name == 'gru_two_layers'
+    assert not getattr(ours, 'plain_trunk', True) or name in ('gru_two_layers', 'discrete_lstm')
     with torch.no_grad():                                       # LayerNorm weights away from their (1, 0) initialisation
         for k, v in ref_sd.items():
             if 'norm' in k:
