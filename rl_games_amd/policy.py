@@ -148,8 +148,6 @@ class ActorCriticNetwork(nn.Module):
         if 'cnn' in net_params:
             raise NotImplementedError('CNN encoders are outside the MI355X PPO hot path (SURVEY 2, row 15)')
         self.separate = bool(net_params.get('separate', False))
-        if self.separate and 'rnn' in net_params:
-            raise NotImplementedError('separate actor/critic trunks with an RNN are not implemented')
         self.central_value = bool(net_params.get('central_value', False))
         if self.central_value:
             self._init_central_value(net_params, input_shape, value_size, num_seqs)
@@ -233,15 +231,23 @@ class ActorCriticNetwork(nn.Module):
             else:
                 rnn_in = in_size
                 mlp_in = self.rnn_units + (in_size if self.rnn_concat_output else 0)
-            self.rnn = RnnWithDones(self.rnn_name, rnn_in, self.rnn_units, self.rnn_layers)
-            if self.rnn_ln:
-                self.layer_norm = nn.LayerNorm(self.rnn_units)
+            if self.separate:                                  # one RNN per trunk (network_builder.py:272-277)
+                self.a_rnn = RnnWithDones(self.rnn_name, rnn_in, self.rnn_units, self.rnn_layers)
+                self.c_rnn = RnnWithDones(self.rnn_name, rnn_in, self.rnn_units, self.rnn_layers)
+                if self.rnn_ln:
+                    self.a_layer_norm = nn.LayerNorm(self.rnn_units)
+                    self.c_layer_norm = nn.LayerNorm(self.rnn_units)
+            else:
+                self.rnn = RnnWithDones(self.rnn_name, rnn_in, self.rnn_units, self.rnn_layers)
+                if self.rnn_ln:
+                    self.layer_norm = nn.LayerNorm(self.rnn_units)
         self.actor_mlp = build_trunk(mlp_in, self.units, **self._trunk_kw)
         if self.separate:                                      # network_builder.py:292-293
             self.critic_mlp = build_trunk(mlp_in, self.units, **self._trunk_kw)
         # what the fused engines take (mlp_engine.ManualMLP): Linear + activation pairs, the RNN plainly behind them
         self.plain_trunk = (not self._trunk_kw['d2rl'] and self._trunk_kw['norm_func_name'] is None and
-                            not (self.rnn_before_mlp or self.rnn_concat_input or self.rnn_concat_output or self.rnn_ln))
+                            not (self.rnn_before_mlp or self.rnn_concat_input or self.rnn_concat_output or self.rnn_ln)
+                            and not (self.separate and self.has_rnn))
         return out_size
 
     def _init_central_value(self, net_params, input_shape, value_size, num_seqs):
@@ -311,20 +317,14 @@ class ActorCriticNetwork(nn.Module):
         if not self.has_rnn:
             return None
         z = lambda: torch.zeros((self.rnn_layers, self.num_seqs, self.rnn_units))
-        return (z(), z()) if self.rnn_name == 'lstm' else (z(),)
+        per = 2 if self.rnn_name == 'lstm' else 1               # separate trunks: the actor's states, then the critic's
+        return tuple(z() for _ in range(per * (2 if self.separate else 1)))
 
-    def critic_features(self, obs, actor_out):
-        """Input of the value head: the separate critic trunk of `obs`, or the shared features
-        (network_builder.py:424-429 vs :447-500)."""
-        return self.critic_mlp(obs) if self.separate else actor_out
-
-    def trunk(self, obs, states=None, dones=None, seq_length=1):
-        """network_builder.py:447-500 (the shared-trunk branch)."""
-        if not self.has_rnn:
-            return self.actor_mlp(obs), states
+    def _body(self, mlp, rnn, norm, obs, states, dones, seq_length):
+        """One trunk with its RNN (network_builder.py:447-500; :372-421 runs two of them side by side)."""
         out = obs
         if not self.rnn_before_mlp:
-            out = self.actor_mlp(out)
+            out = mlp(out)
             if self.rnn_concat_input:
                 out = torch.cat([out, obs], dim=1)
         batch = out.shape[0]
@@ -334,23 +334,40 @@ class ActorCriticNetwork(nn.Module):
             dones = dones.reshape(num_seqs, seq_length, -1).transpose(0, 1)
         if states is None:
             states = tuple()
-        out, states = self.rnn(out, states, dones)
+        out, states = rnn(out, states, dones)
         out = out.transpose(0, 1).contiguous().reshape(batch, -1)
-        if self.rnn_ln:
-            out = self.layer_norm(out)
+        if norm is not None:
+            out = norm(out)
         if self.rnn_concat_output:
             out = torch.cat([out, obs], dim=1)
         if self.rnn_before_mlp:
-            out = self.actor_mlp(out)
+            out = mlp(out)
         if not isinstance(states, tuple):
             states = (states,)
         return out, states
 
+    def bodies(self, obs, states=None, dones=None, seq_length=1):
+        """(actor features, critic features, next rnn states): one shared trunk, or `separate` ones - each with its own
+        RNN, the states of the actor's in front of the critic's (network_builder.py:372-421, :447-500)."""
+        if not self.has_rnn:
+            out = self.actor_mlp(obs)
+            return out, (self.critic_mlp(obs) if self.separate else out), states
+        if not self.separate:
+            out, states = self._body(self.actor_mlp, self.rnn, self.layer_norm if self.rnn_ln else None, obs, states,
+                                     dones, seq_length)
+            return out, out, states
+        half = len(states) // 2
+        a_out, a_states = self._body(self.actor_mlp, self.a_rnn, self.a_layer_norm if self.rnn_ln else None, obs,
+                                     tuple(states[:half]), dones, seq_length)
+        c_out, c_states = self._body(self.critic_mlp, self.c_rnn, self.c_layer_norm if self.rnn_ln else None, obs,
+                                     tuple(states[half:]), dones, seq_length)
+        return a_out, c_out, a_states + c_states
+
     def forward(self, obs_dict):
         """(mu, logstd_broadcast, value, states) - network_builder.py:447-512."""
-        out, states = self.trunk(obs_dict['obs'], obs_dict.get('rnn_states'), obs_dict.get('dones'),
-                                 obs_dict.get('seq_length', 1))
-        value = self.value_act(self.value(self.critic_features(obs_dict['obs'], out)))
+        out, c_out, states = self.bodies(obs_dict['obs'], obs_dict.get('rnn_states'), obs_dict.get('dones'),
+                                         obs_dict.get('seq_length', 1))
+        value = self.value_act(self.value(c_out))
         if self.central_value:                                  # (value, states) :497-498
             return value, states
         if self.is_discrete:                                   # (logits, value, states) :431-436,:500-504
@@ -412,9 +429,9 @@ class ContinuousA2CLogStdModel(nn.Module):
         rnn states)."""
         obs = self.norm_obs(input_dict['obs'])
         net = self.a2c_network
-        out, states = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
-                                input_dict.get('seq_length', 1))
-        value = net.value_act(net.value(net.critic_features(obs, out)))
+        out, c_out, states = net.bodies(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
+                                        input_dict.get('seq_length', 1))
+        value = net.value_act(net.value(c_out))
         mu = net.mu_act(net.mu(out))
         return mu, net.logstd_of(out), value, states
 
@@ -467,11 +484,12 @@ class DiscreteA2CModel(ContinuousA2CLogStdModel):
         [B, V]) for the fused categorical loss kernel."""
         obs = self.norm_obs(input_dict['obs'])
         net = self.a2c_network
-        out, _ = net.trunk(obs, input_dict.get('rnn_states'), input_dict.get('dones'), input_dict.get('seq_length', 1))
+        out, c_out, _ = net.bodies(obs, input_dict.get('rnn_states'), input_dict.get('dones'),
+                                   input_dict.get('seq_length', 1))
         logits = net.head_logits(out)
         if net.is_multi_discrete:
             logits = torch.cat(logits, dim=1)
-        return logits, net.value_act(net.value(net.critic_features(obs, out)))
+        return logits, net.value_act(net.value(c_out))
 
     @torch.compiler.disable       # (see ContinuousA2CLogStdModel: launches behind ctypes are opaque to Dynamo)
     def forward(self, input_dict):

@@ -105,12 +105,15 @@ def make_epoch(variants=None, filename='epoch.pt'):
         N, H, O_, A = 64, 8, 12, 3
         over = dict(over)
         rnn = over.pop('_rnn', None)
+        separate = over.pop('_separate', False)
         space = over.pop('_space', None)
         net_over = over.pop('_network', None)
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', games_to_track=100, **over)
         if rnn is not None:
             params['network']['rnn'] = rnn
+        if separate:
+            params['network']['separate'] = True
         if space is not None:
             params['network']['space']['continuous'].update(space)
         if net_over is not None:
@@ -195,6 +198,16 @@ def make_epoch_extra():
     }, 'epoch_extra.pt')
 
 
+def make_epoch_separate_rnn():
+    """Round 6: separate actor / critic trunks, each with its own RNN (network_builder.py:272-277, :372-421) - four LSTM
+    state tensors per environment, two with a GRU."""
+    make_epoch({
+        'separate_lstm': dict(seq_length=4, _separate=True, _rnn={'name': 'lstm', 'units': 16, 'layers': 1}),
+        'separate_gru_layer_norm': dict(seq_length=4, _separate=True,
+                                        _rnn={'name': 'gru', 'units': 12, 'layers': 1, 'layer_norm': True}),
+    }, 'epoch_separate_rnn.pt')
+
+
 def make_discrete(variants=None, filename='discrete.pt'):
     """One train_epoch of the REAL reference DiscreteA2CAgent (a2c_discrete.py) on CPU: CartPole-like
     shapes (BASELINE.json config #1 in miniature), separate actor/critic MLPs, next_step autoreset
@@ -223,6 +236,7 @@ def make_discrete(variants=None, filename='discrete.pt'):
         heads = over.pop('_heads', None)
         masks = over.pop('_masks', False)
         rnn = over.pop('_rnn', None)
+        separate = over.pop('_separate', False)
         params = configs.cartpole_discrete(num_actors=N, horizon_length=H, minibatch_size=32, mini_epochs=2,
                                            device='cpu', train_dir='/tmp/rlg_golden_runs', **over)
         env_kw = dict(obs_dim=O_, discrete_actions=heads or n_act, autoreset_mode=mode, p_done=p_done, seed=99,
@@ -234,7 +248,7 @@ def make_discrete(variants=None, filename='discrete.pt'):
             params['config']['use_action_masks'] = True
         if rnn:
             params['network']['rnn'] = dict(rnn)
-            params['network']['separate'] = False
+            params['network']['separate'] = separate
         params['config']['env_config'] = dict(env_kw)
         params['seed'] = 5
         env = SyntheticTensorEnv(N, device='cpu', **env_kw)
@@ -312,6 +326,9 @@ def make_discrete_rnn():
                                   normalize_input=True, lr_schedule='adaptive', learning_rate=3e-4, kl_threshold=0.002),
         'gru_before_mlp': dict(_autoreset='same_step', _rnn=dict(name='gru', units=12, layers=1, before_mlp=True),
                                seq_length=4, p_done=0.1),
+        # separate actor / critic trunks, each with its own LSTM + layer norm: four state tensors (network_builder.py:272-277)
+        'lstm_separate': dict(_rnn=dict(name='lstm', units=8, layers=1, layer_norm=True), _separate=True, seq_length=4,
+                              p_done=0.15, normalize_input=True, normalize_value=True),
     }, 'discrete_rnn.pt')
 
 
@@ -495,7 +512,7 @@ def make_lstm_full():
     print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'checkpoint': make_checkpoint,
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'checkpoint': make_checkpoint,
             'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':

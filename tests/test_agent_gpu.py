@@ -204,8 +204,11 @@ def test_plain_a2c_loss_when_ppo_is_false_matches_oracle():
 
 @pytest.mark.parametrize('rnn', [{'name': 'gru', 'units': 16, 'layers': 2},
                                  {'name': 'lstm', 'units': 16, 'layers': 1, 'layer_norm': True, 'concat_input': True, 'concat_output': True},
-                                 {'name': 'lstm', 'units': 16, 'layers': 1, 'before_mlp': True}],
-                         ids=['gru_two_layers', 'lstm_layer_norm_concat', 'lstm_before_mlp'])
+                                 {'name': 'lstm', 'units': 16, 'layers': 1, 'before_mlp': True},
+                                 {'name': 'lstm', 'units': 16, 'layers': 1, 'separate': True},
+                                 {'name': 'gru', 'units': 16, 'layers': 1, 'separate': True, 'concat_output': True}],
+                         ids=['gru_two_layers', 'lstm_layer_norm_concat', 'lstm_before_mlp', 'separate_lstm',
+                              'separate_gru_concat'])
 def test_recurrent_layouts_outside_the_engine_train_on_the_device(rnn):
     """GRU / multi-layer RNNs and the RNN layout options of network_builder.py:250-276 (construction and outputs pinned to the
     reference builder on the CPU: tests/test_vs_reference_cpu.py::test_network_zoo_layouts_...): two epochs through
@@ -215,7 +218,9 @@ def test_recurrent_layouts_outside_the_engine_train_on_the_device(rnn):
     from rl_games_amd import configs
     from rl_games_amd.agent import A2CAgent
     params = configs.tiny(num_actors=64, horizon=8, obs_dim=10, act_dim=3, seq_length=4)
-    params['network']['rnn'] = dict(rnn)
+    rnn = dict(rnn)
+    params['network']['separate'] = rnn.pop('separate', False)   # (each trunk with its own RNN: network_builder.py:272-277)
+    params['network']['rnn'] = rnn
     torch.manual_seed(11)
     agent = A2CAgent('zoo', copy.deepcopy(params))
     assert agent.is_rnn and agent._engine is None
@@ -339,14 +344,18 @@ def test_fused_rollout_step_matches_model_forward():
     assert torch.allclose(agent._fast_values(agent.obs).view(-1, 1), agent.get_values(agent.obs), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('manual_lstm', [True, False])
-def test_lstm_update_matches_reference_epoch(golden, manual_lstm):
+@pytest.mark.parametrize('variant,manual_lstm', [('lstm', True), ('lstm', False), ('separate_lstm', False),
+                                                 ('separate_gru_layer_norm', False)])
+def test_lstm_update_matches_reference_epoch(golden, variant, manual_lstm):
     """BASELINE.json config #5 path (play_steps_rnn / seq_length chunks / done resets) against the
     real reference's LSTM agent on identical rollout tensors and initial rnn states - through the
-    sequence-persistent LSTM kernels (manual engine) and through torch autograd (RnnWithDones)."""
-    cap = golden('epoch.pt')['lstm']
+    sequence-persistent LSTM kernels (manual engine) and through torch autograd (RnnWithDones).  `separate_*`
+    (tests/golden/epoch_separate_rnn.pt, round 6): separate actor / critic trunks, each with its own RNN - the actor's
+    states in front of the critic's (network_builder.py:372-421)."""
+    cap = golden('epoch.pt' if variant == 'lstm' else 'epoch_separate_rnn.pt')[variant]
     agent = _make_agent(cap, manual_lstm=manual_lstm)
     assert agent.is_rnn and (agent._engine is not None) == manual_lstm
+    assert len(agent.model.get_default_rnn_state()) == len(cap['batch']['rnn_states'])
     if manual_lstm:
         assert agent._engine.lstm is not None
     agent.model.load_state_dict(cap['state_after_rollout'])

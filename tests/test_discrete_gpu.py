@@ -134,7 +134,7 @@ def _make_agent(cap, **over):
 
 
 @pytest.mark.parametrize('variant', ['masked_adaptive', 'plain', 'multi_discrete_masked',
-                                     'rnn:lstm', 'rnn:lstm_multi_masked', 'rnn:gru_before_mlp'])
+                                     'rnn:lstm', 'rnn:lstm_multi_masked', 'rnn:gru_before_mlp', 'rnn:lstm_separate'])
 def test_discrete_update_matches_reference_epoch(golden, variant):
     """The reference agent's rollout batch through this agent's dataset preparation and every minibatch step of the
     epoch; `rnn:` variants (tests/golden/discrete_rnn.pt): recurrent categorical policies - sequence minibatches with

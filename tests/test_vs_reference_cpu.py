@@ -554,6 +554,10 @@ _SPACE = {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None', 'm
                                         'concat_output': True}}),
     ('lstm_before_mlp', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'before_mlp': True, 'concat_output': True}}),
     ('discrete_d2rl_layer_norm', {'mlp': {'d2rl': True}, 'normalization': 'layer_norm', 'space': {'discrete': {}}}),
+    ('separate_lstm_layer_norm', {'separate': True, 'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'layer_norm': True}}),
+    ('separate_gru_before_mlp', {'separate': True, 'rnn': {'name': 'gru', 'units': 12, 'layers': 2, 'before_mlp': True}}),
+    ('discrete_separate_lstm_concat', {'separate': True, 'space': {'discrete': {}},
+                                       'rnn': {'name': 'lstm', 'units': 12, 'layers': 1, 'concat_input': True}}),
     ('discrete_lstm', {'rnn': {'name': 'lstm', 'units': 12, 'layers': 1}, 'space': {'discrete': {}}}),
     ('discrete_gru_before_mlp_concat', {'rnn': {'name': 'gru', 'units': 12, 'layers': 1, 'before_mlp': True,
                                                 'concat_output': True}, 'space': {'discrete': {}}}),
@@ -593,7 +597,8 @@ def test_network_zoo_layouts_equal_the_reference_builder(name, over):
     d = {'obs': obs, 'rnn_states': None}
     if 'rnn' in net_params:
         layers, units = net_params['rnn']['layers'], net_params['rnn']['units']
-        n_states = 2 if net_params['rnn']['name'] == 'lstm' else 1
+        n_states = (2 if net_params['rnn']['name'] == 'lstm' else 1) * (2 if net_params['separate'] else 1)
+        assert len(ours.get_default_rnn_state()) == len(ref_net.get_default_rnn_state()) == n_states
         states = tuple(torch.randn(layers, S, units, generator=gen(6 + i)) for i in range(n_states))
         dones = (torch.rand(S * T, generator=gen(8)) < 0.3).float()
         d = {'obs': obs, 'rnn_states': states, 'seq_length': T, 'dones': dones}
@@ -603,6 +608,7 @@ def test_network_zoo_layouts_equal_the_reference_builder(name, over):
     for w, g_ in zip(want[:n_out], got[:n_out]):
         assert torch.allclose(w, g_, rtol=0, atol=0) or torch.allclose(w, g_, rtol=1e-6, atol=1e-7), name
     if 'rnn' in net_params:
+        assert len(want[n_out]) == len(got[n_out]) == n_states
         for w, g_ in zip(want[n_out], got[n_out]):
             assert torch.allclose(w, g_, rtol=1e-6, atol=1e-7)
     else:
