@@ -959,6 +959,8 @@ class A2CAgent:
             if n % self.seq_length == 0:
                 for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
                     mb_s[n // self.seq_length, :, :, :] = s
+            if self.has_central_value:
+                self.central_value_net.pre_step_rnn(n)           # a2c_common.py:1085-1086
             if fast:
                 res_dict = self._fast_policy_step(n)
             elif self.use_action_masks:                          # a2c_common.py:1088-1090
@@ -975,9 +977,13 @@ class A2CAgent:
                 if self.zero_rnn_on_done:
                     for s in self.rnn_states:
                         ops.rnn_zero_done_states(s, prev)
+                    if self.has_central_value:                   # (the critic absorbed the same filler row: :1112-1115)
+                        self.central_value_net.zero_states_where(prev)
             if not fast:
                 for k in self.update_list:
                     fields[k] = res_dict[k]
+                if self.has_central_value:
+                    fields['states'] = self.obs['states']
                 buf.store_step(n, fields)
             t0 = time.perf_counter()
             self.obs, rewards, dones, infos = self.env_step(res_dict['actions'], res_dict.get('env_actions'))
@@ -988,6 +994,8 @@ class A2CAgent:
             if self.zero_rnn_on_done:
                 for s in self.rnn_states:
                     ops.rnn_zero_done_states(s, self.dones)
+            if self.has_central_value:                           # a2c_common.py:1151-1152
+                self.central_value_net.zero_states_where(self.dones)
             self._rollout_step_tail(n, res_dict, rewards, infos, mb_valid)
         batch_dict = buf.get_transformed_list(swap_and_flatten01, self.tensor_list)
         batch_dict = self._finish_rollout(batch_dict, mb_valid, step_time)

@@ -13,8 +13,10 @@ the MFMA launch of csrc/mlp_dw.hip (chain_net.ChainNet) - where the network has 
 tanh trunk, widths that are multiples of 4, one value column); anything else keeps autograd around the loss kernel
 (`fused_mlp: False` in the central-value config forces that path).
 
-Scope: MLP central value networks, `num_agents == 1`; recurrent critics and multi-agent state
-broadcasting raise NotImplementedError.
+Scope: `num_agents == 1` (multi-agent state broadcasting raises NotImplementedError).  Recurrent critics (round 6,
+central_value.py:96-107,163-205): the network's RNN advances with the rollout (`pre_step_rnn` keeps the state every sequence
+starts from, `post_step_rnn` / `zero_states_where` zero it where an episode ended) and trains on sequence minibatches as a
+torch module between the loss and optimiser kernels.
 """
 import torch
 from torch import nn
@@ -33,7 +35,7 @@ def _value_chain(net, arena, max_rows):
     the optimiser.  Raises NotImplementedError for networks outside the kernels' envelope (the caller keeps autograd)."""
     if not isinstance(net.value_act, nn.Identity) or net.value.out_features != 1:
         raise NotImplementedError('one linear value column only')
-    if not getattr(net, 'plain_trunk', True):
+    if not getattr(net, 'plain_trunk', True) or net.is_rnn():
         raise NotImplementedError('plain Linear + activation trunks only')
     return ChainNet(net.actor_mlp, [net.value], arena, max_rows)
 
@@ -57,9 +59,7 @@ class CentralValueTrain(nn.Module):
             'num_agents': num_agents, 'num_seqs': num_actors, 'normalize_input': self.normalize_input,
             'normalize_value': self.normalize_value,
         }).to(ppo_device)
-        if self.model.is_rnn():
-            raise NotImplementedError('recurrent central value networks are not implemented on this path')
-        self.is_rnn = False
+        self.is_rnn = self.model.is_rnn()
         self.rnn_states = None
         self.lr = float(config['learning_rate'])
         self.linear_lr = config.get('lr_schedule') == 'linear'
@@ -95,7 +95,13 @@ class CentralValueTrain(nn.Module):
         self.world_size = 1
         if self.multi_gpu:
             self.local_rank, self.global_rank, self.world_size = rdist.env_ranks()
-        self.dataset = PPODataset(self.batch_size, self.minibatch_size, True, False, ppo_device, self.seq_length)
+        if self.is_rnn:                                            # central_value.py:96-107
+            self.rnn_states = [s.to(ppo_device) for s in self.model.get_default_rnn_state()]
+            num_seqs = self.horizon_length // self.seq_length
+            assert (self.horizon_length * self.num_actors // self.num_minibatches) % self.seq_length == 0
+            self.mb_rnn_states = [torch.zeros((num_seqs, s.size()[0], self.num_actors, s.size()[2]), dtype=torch.float32,
+                                              device=ppo_device) for s in self.rnn_states]
+        self.dataset = PPODataset(self.batch_size, self.minibatch_size, True, self.is_rnn, ppo_device, self.seq_length)
         mb = self.minibatch_size
         self._d_val = torch.empty(mb, dtype=torch.float32, device=ppo_device)
         self._partials = torch.empty((mb + 255) // 256, 7, dtype=torch.float64, device=ppo_device)
@@ -121,6 +127,12 @@ class CentralValueTrain(nn.Module):
         pass
 
     def update_dataset(self, batch_dict):
+        if self.is_rnn:                                            # central_value.py:163-170
+            states = []
+            for mb_s in self.mb_rnn_states:
+                t_size = mb_s.size()[0] * mb_s.size()[2]
+                states.append(mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, mb_s.size()[3]))
+            batch_dict['rnn_states'] = states
         self.dataset.update_values_dict(batch_dict)
 
     def _preproc_obs(self, obs_batch):
@@ -129,10 +141,24 @@ class CentralValueTrain(nn.Module):
         return obs_batch
 
     def pre_step_rnn(self, n):
-        return
+        """central_value.py:189-194: the state each sequence of the rollout starts from."""
+        if self.is_rnn and n % self.seq_length == 0:
+            for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                mb_s[n // self.seq_length, :, :, :] = s
 
     def post_step_rnn(self, all_done_indices, zero_rnn_on_done=True):
-        return
+        """central_value.py:196-203 (indices of finished rows)."""
+        if not self.is_rnn or not self.zero_rnn_on_done:
+            return
+        idx = all_done_indices[::self.num_agents] // self.num_agents
+        for s in self.rnn_states:
+            s[:, idx, :] = 0
+
+    def zero_states_where(self, done_mask):
+        """post_step_rnn for a device-side mask [num_actors] instead of an index list: nothing waits for the host."""
+        if self.is_rnn and self.zero_rnn_on_done:
+            for s in self.rnn_states:
+                ops.rnn_zero_done_states(s, done_mask)
 
     def forward(self, input_dict):
         return self.model(input_dict)
@@ -143,6 +169,8 @@ class CentralValueTrain(nn.Module):
         with torch.no_grad():
             res = self.forward({'obs': obs_batch, 'actions': input_dict.get('actions', None),
                                 'rnn_states': self.rnn_states, 'is_train': False})
+        if self.is_rnn:                                            # central_value.py:222
+            self.rnn_states = [s.contiguous() for s in res['rnn_states']]
         return res['values']
 
     def train_critic(self, input_dict):
@@ -192,7 +220,10 @@ class CentralValueTrain(nn.Module):
                 rms, eps = (m.running_mean, m.running_var), m.epsilon
             values = eng.forward(obs_batch, rms, eps)                       # [mb, 1]
         else:
-            values = self.model.forward_values(obs_batch)                   # [mb, 1], autograd graph
+            rnn = None
+            if self.is_rnn:                                                 # central_value.py:300-307
+                rnn = {'rnn_states': batch['rnn_states'], 'seq_length': self.seq_length, 'dones': batch['dones']}
+            values = self.model.forward_values(obs_batch, rnn)              # [mb, V], autograd graph
         mb = values.shape[0]
         mask = mask_sum = None
         if rnn_masks is not None:

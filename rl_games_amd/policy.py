@@ -253,16 +253,14 @@ class ActorCriticNetwork(nn.Module):
     def _init_central_value(self, net_params, input_shape, value_size, num_seqs):
         """`central_value: True` networks (network_builder.py:497,556): MLP trunk + value head only."""
         mlp = net_params['mlp']
-        if mlp.get('d2rl', False) or net_params.get('normalization') or 'rnn' in net_params or 'cnn' in net_params:
-            raise NotImplementedError('central value network: plain MLP only on this path')
+        if 'cnn' in net_params:
+            raise NotImplementedError('central value network: MLP (+ RNN) only on this path')
         self.is_discrete = False
         self.separate = False
-        self.units = list(mlp['units'])
         self.value_size, self.num_seqs, self.actions_num = value_size, num_seqs, 0
-        self.has_rnn = False
         assert len(input_shape) == 1, 'flat states only'
-        self.actor_mlp = self._mlp_like(input_shape[0], mlp['activation'])
-        self.value = nn.Linear(self.units[-1], value_size)
+        last = self._build_body(net_params, input_shape[0])      # (round 6: layer norm / D2RL trunks and an RNN as well)
+        self.value = nn.Linear(last, value_size)
         self.value_act = _activation(net_params.get('value_activation', 'None'))
         mlp_init = _initializer(mlp['initializer'])
         for m in self.modules():
@@ -527,15 +525,19 @@ class CentralValueModel(ContinuousA2CLogStdModel):
     @torch.compiler.disable       # (see ContinuousA2CLogStdModel: launches behind ctypes are opaque to Dynamo)
     def forward(self, input_dict):
         is_train = input_dict.get('is_train', True)
-        obs = self.norm_obs(input_dict['obs'])
-        value, states = self.a2c_network({'obs': obs})
+        inputs = dict(input_dict)
+        inputs['obs'] = self.norm_obs(input_dict['obs'])
+        value, states = self.a2c_network(inputs)                 # (rnn_states / dones / seq_length ride along)
         if not is_train:
             value = self.denorm_value(value)
         return {'values': value, 'rnn_states': states}
 
-    def forward_values(self, obs):
-        """Training fast path: normalise (and update) the states, return raw values [B, V]."""
-        value, _ = self.a2c_network({'obs': self.norm_obs(obs)})
+    def forward_values(self, obs, rnn=None):
+        """Training fast path: normalise (and update) the states, return raw values [B, V].  rnn: None or the
+        {'rnn_states', 'seq_length', 'dones'} of a sequence minibatch."""
+        inputs = dict(rnn or {})
+        inputs['obs'] = self.norm_obs(obs)
+        value, _ = self.a2c_network(inputs)
         return value
 
 

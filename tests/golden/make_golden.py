@@ -368,7 +368,7 @@ def make_checkpoint():
           os.path.getsize(os.path.join(HERE, 'ref_checkpoint.pth')) // 1024, 'KiB')
 
 
-def make_central_value():
+def make_central_value(variants=None, filename='central_value.pt'):
     """One train_epoch of the REAL reference A2CAgent with a central (asymmetric) value function
     (central_value.py CentralValueTrain): privileged states, own optimiser/minibatches."""
     import copy
@@ -378,8 +378,11 @@ def make_central_value():
     from rl_games_amd import configs
     from rl_games_amd.synthetic_env import SyntheticTensorEnv
     out = {}
-    for name, over in {'experimental_cv': dict(), 'no_actor_value_loss': dict(use_experimental_cv=False)}.items():
+    variants = variants or {'experimental_cv': dict(), 'no_actor_value_loss': dict(use_experimental_cv=False)}
+    for name, over in variants.items():
         N, H, O_, A, S_ = 64, 8, 12, 3, 20
+        over = dict(over)
+        rnn, cv_rnn = over.pop('_rnn', None), over.pop('_cv_rnn', None)
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', **over)
         params['config']['central_value_config'] = {
@@ -388,6 +391,10 @@ def make_central_value():
             'network': {'name': 'actor_critic', 'central_value': True,
                         'mlp': {'units': [24, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}},
         }
+        if rnn is not None:
+            params['network']['rnn'] = dict(rnn)
+        if cv_rnn is not None:
+            params['config']['central_value_config']['network']['rnn'] = dict(cv_rnn)
         params['config']['env_config']['state_dim'] = S_
         params['seed'] = 9
         env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=4321, state_dim=S_)
@@ -402,15 +409,21 @@ def make_central_value():
         agent.init_tensors()
         agent.obs = agent.env_reset()
         cap = {'lrs': []}
-        orig_play = agent.play_steps
+        play_name = 'play_steps_rnn' if agent.is_rnn else 'play_steps'
+        orig_play = getattr(agent, play_name)
 
         def play():
             b = orig_play()
             cap['batch'] = _clone({k: v for k, v in b.items() if isinstance(v, torch.Tensor)})
+            if 'rnn_states' in b:
+                cap['batch']['rnn_states'] = _clone(b['rnn_states'])
+            if agent.central_value_net.is_rnn:                   # what update_dataset reads (central_value.py:163-170)
+                cap['cv_mb_rnn_states'] = _clone(agent.central_value_net.mb_rnn_states)
+                cap['cv_rnn_states'] = _clone(agent.central_value_net.rnn_states)
             cap['state_after_rollout'] = _clone(agent.model.state_dict())
             cap['cv_state_after_rollout'] = _clone(agent.central_value_net.state_dict())
             return b
-        agent.play_steps = play
+        setattr(agent, play_name, play)
         orig_update_lr = agent.update_lr
 
         def update_lr(lr):
@@ -442,8 +455,21 @@ def make_central_value():
         out[name] = cap
         print('central_value', name, 'cv losses', cap['cv_losses'].tolist()[:3], 'c_losses', cap['c_losses'].tolist()[:2],
               'keys', sorted(cap['batch'])[:12])
-    torch.save(out, os.path.join(HERE, 'central_value.pt'))
-    print('central_value.pt written', os.path.getsize(os.path.join(HERE, 'central_value.pt')) // 1024, 'KiB')
+    torch.save(out, os.path.join(HERE, filename))
+    print(filename, 'written', os.path.getsize(os.path.join(HERE, filename)) // 1024, 'KiB')
+
+
+def make_central_value_rnn():
+    """Round 6: a recurrent actor with a central value function (the rollout of play_steps_rnn stores the privileged
+    states, a2c_common.py:1119-1120) - the critic a plain MLP, and the critic with an RNN of its own
+    (central_value.py:96-107,163-205: its states advance with the rollout and train on sequence minibatches)."""
+    lstm = {'name': 'lstm', 'units': 16, 'layers': 1}
+    make_central_value({
+        'rnn_actor_mlp_critic': dict(seq_length=4, _rnn=lstm),
+        'rnn_actor_rnn_critic': dict(seq_length=4, _rnn=lstm, _cv_rnn={'name': 'lstm', 'units': 12, 'layers': 1}),
+        'rnn_actor_gru_critic_layer_norm': dict(seq_length=4, _rnn=lstm, use_experimental_cv=False,
+                                                _cv_rnn={'name': 'gru', 'units': 12, 'layers': 1, 'layer_norm': True}),
+    }, 'central_value_rnn.pt')
 
 
 def make_lstm_full():
@@ -512,7 +538,7 @@ def make_lstm_full():
     print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'checkpoint': make_checkpoint,
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'central_value_rnn': make_central_value_rnn, 'checkpoint': make_checkpoint,
             'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':

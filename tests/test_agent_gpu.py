@@ -654,13 +654,17 @@ def test_ipc_allreduce_is_fail_safe_when_a_peer_never_arrives(two_phase):
     assert 'IPC_FAILSAFE_CHECK ok' in res.stdout
 
 
-@pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss'])
+@pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss', 'rnn_actor_mlp_critic',
+                                     'rnn_actor_rnn_critic', 'rnn_actor_gru_critic_layer_norm'])
 def test_central_value_update_matches_reference_epoch(golden, variant):
     """Central (asymmetric) value function: the update phase against golden vectors
     of the REAL reference agent with `central_value_config` - critic minibatches first
-    (CentralValueTrain.train_net), then the actor's, on identical rollout tensors."""
+    (CentralValueTrain.train_net), then the actor's, on identical rollout tensors.  `rnn_*`
+    (tests/golden/central_value_rnn.pt, round 6): a recurrent actor, and critics with an RNN of their own - sequence
+    minibatches that start from the states the rollout kept (central_value.py:163-170)."""
     from rl_games_amd.agent import A2CAgent
-    cap = golden('central_value.pt')[variant]
+    recurrent = variant.startswith('rnn_')
+    cap = golden('central_value_rnn.pt' if recurrent else 'central_value.pt')[variant]
     params = copy.deepcopy(cap['params'])
     params['config']['device'] = DEV
     env = SyntheticTensorEnv(cap['env']['num_envs'], cap['env']['obs_dim'], cap['env']['act_dim'], device=DEV,
@@ -668,22 +672,29 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
     params['config']['vec_env'] = env
     params['config']['env_info'] = env.get_env_info()
     agent = A2CAgent('cv', params)
-    assert agent.has_central_value and agent.has_value_loss == (variant == 'experimental_cv')
+    assert agent.has_central_value
+    assert agent.has_value_loss == cap['params']['config'].get('use_experimental_cv', True)
     agent.init_tensors()
     agent.model.load_state_dict(cap['state_after_rollout'])
     agent.central_value_net.load_state_dict(cap['cv_state_after_rollout'])
-    assert list(agent.central_value_net.state_dict().keys()) == list(cap['cv_state_after_rollout'].keys())
-    batch = {k: v.to(DEV) for k, v in cap['batch'].items()}
+    assert set(agent.central_value_net.state_dict().keys()) == set(cap['cv_state_after_rollout'].keys())
+    batch = {k: ([s.to(DEV) for s in v] if isinstance(v, (list, tuple)) else v.to(DEV)) for k, v in cap['batch'].items()}
+    cv = agent.central_value_net
+    assert agent.is_rnn == recurrent and cv.is_rnn == ('cv_mb_rnn_states' in cap)
+    if cv.is_rnn:                               # the states the critic's RNN had at the start of every rollout sequence
+        for dst, src in zip(cv.mb_rnn_states, cap['cv_mb_rnn_states']):
+            assert dst.shape == src.shape
+            dst.copy_(src)
     agent.set_train()
     agent.epoch_num = 1
     agent.prepare_dataset(batch)
     ds, vd = cap['dataset'], agent.dataset.values_dict
     for k in ('old_values', 'returns', 'advantages'):
         assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
-    cv = agent.central_value_net
-    assert cv._engine is not None               # (round 5: the critic's MLP on the fused chain kernels, not autograd)
+    # (round 5: the critic's MLP on the fused chain kernels, not autograd; a recurrent critic is a torch module)
+    assert (cv._engine is not None) == (not cv.is_rnn)
     cv.train_net()
-    assert cv._engine.last_dw_path is not None
+    assert cv.is_rnn or cv._engine.last_dw_path is not None
     n_cv = cv.mini_epoch * cv.num_minibatches
     assert torch.allclose(cv._rows[:n_cv, 5].cpu(), cap['cv_losses'], rtol=1e-5, atol=1e-6)
     agent.set_train()
@@ -704,6 +715,44 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
         for k, v in want.items():
             tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
             assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+
+
+def test_recurrent_actor_and_critic_train_epochs_run():
+    """Rollout side of a recurrent central value network: its states advance with play_steps_rnn, are kept at every
+    sequence start (pre_step_rnn), are zero where an episode just ended, and the privileged states reach the buffer;
+    three epochs with finite losses and a critic whose RNN weights move."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=64, horizon=8, obs_dim=10, act_dim=3, seq_length=4)
+    params['network']['rnn'] = {'name': 'lstm', 'units': 16, 'layers': 1}
+    params['config']['central_value_config'] = {
+        'minibatch_size': 128, 'mini_epochs': 2, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
+        'truncate_grads': True, 'grad_norm': 1.0,
+        'network': {'name': 'actor_critic', 'central_value': True, 'rnn': {'name': 'gru', 'units': 12, 'layers': 1},
+                    'mlp': {'units': [24, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}}
+    params['config']['env_config'].update(state_dim=9, p_done=0.2)
+    torch.manual_seed(3)
+    agent = A2CAgent('rcv', copy.deepcopy(params))
+    cv = agent.central_value_net
+    assert agent.is_rnn and cv.is_rnn and cv._engine is None and len(cv.rnn_states) == 1
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    before = {k: v.detach().clone() for k, v in cv.state_dict().items()}
+    for _ in range(3):
+        agent.update_epoch()
+        out = agent.train_epoch()
+        assert all(torch.isfinite(x).all() for x in out[4] + out[5] + out[7])
+    # the state kept for the rollout's second sequence (step 4): zero where step 3 ended an episode (the buffer's dones of
+    # step n are the flags the env returned at step n - 1), the critic's running state elsewhere
+    done = agent.experience_buffer.tensor_dict['dones'][4].bool()
+    assert done.any() and not done.all()
+    kept = cv.mb_rnn_states[0][1]
+    assert kept[:, done].abs().max() == 0 and (kept[:, ~done].abs().amax(dim=(0, 2)) > 0).all()
+    assert agent.experience_buffer.tensor_dict['states'].abs().max() > 0
+    vd = cv.dataset.values_dict
+    assert vd['rnn_states'][0].shape == (1, 64 * 8 // 4, 12)
+    after = cv.state_dict()
+    assert any('rnn' in k and not torch.equal(after[k], v) for k, v in before.items())
 
 
 @pytest.mark.parametrize('state_dim,units,envs,mb', [(9, [32, 16], 64, 256), (24, [64, 32, 16], 64, 256),
