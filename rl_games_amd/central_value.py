@@ -13,7 +13,8 @@ the MFMA launch of csrc/mlp_dw.hip (chain_net.ChainNet) - where the network has 
 tanh trunk, widths that are multiples of 4, one value column); anything else keeps autograd around the loss kernel
 (`fused_mlp: False` in the central-value config forces that path).
 
-Scope: `num_agents == 1` (multi-agent state broadcasting raises NotImplementedError).  Recurrent critics (round 6,
+Multi-agent envs (round 6, central_value.py:153-158,223-234): one state row per env, its value repeated for the env's agents
+in the rollout, the critic trained on agent 0's values and returns.  Recurrent critics (round 6,
 central_value.py:96-107,163-205): the network's RNN advances with the rollout (`pre_step_rnn` keeps the state every sequence
 starts from, `post_step_rnn` / `zero_states_where` zero it where an episode ended) and trains on sequence minibatches as a
 torch module between the loss and optimiser kernels.
@@ -45,8 +46,6 @@ class CentralValueTrain(nn.Module):
                  num_actions, seq_length, normalize_value, network, config, writter, max_epochs, multi_gpu,
                  zero_rnn_on_done):
         super().__init__()
-        if num_agents != 1:
-            raise NotImplementedError('central value with num_agents > 1 is not implemented on this path')
         self.ppo_device = ppo_device
         self.num_agents, self.horizon_length, self.num_actors = num_agents, horizon_length, num_actors
         self.seq_length, self.normalize_value, self.num_actions = seq_length, normalize_value, num_actions
@@ -127,6 +126,10 @@ class CentralValueTrain(nn.Module):
         pass
 
     def update_dataset(self, batch_dict):
+        if self.num_agents > 1:                                    # central_value.py:153-158
+            res = self.update_multiagent_tensors(batch_dict['old_values'], batch_dict['returns'], batch_dict['actions'],
+                                                 batch_dict['dones'])
+            batch_dict['old_values'], batch_dict['returns'], batch_dict['actions'], batch_dict['dones'] = res
         if self.is_rnn:                                            # central_value.py:163-170
             states = []
             for mb_s in self.mb_rnn_states:
@@ -155,10 +158,25 @@ class CentralValueTrain(nn.Module):
             s[:, idx, :] = 0
 
     def zero_states_where(self, done_mask):
-        """post_step_rnn for a device-side mask [num_actors] instead of an index list: nothing waits for the host."""
+        """post_step_rnn for a device-side mask [num_actors * num_agents] instead of an index list (nothing waits for the
+        host).  Multi-agent: post_step_rnn looks at every num_agents-th finished row, whichever agents those are; this
+        form asks for agent 0 of an env - the same thing wherever the agents of an env finish together."""
         if self.is_rnn and self.zero_rnn_on_done:
+            if self.num_agents > 1:
+                done_mask = done_mask[::self.num_agents].contiguous()
             for s in self.rnn_states:
                 ops.rnn_zero_done_states(s, done_mask)
+
+    def update_multiagent_tensors(self, value_preds, returns, actions, dones):
+        """central_value.py:225-234: the critic trains on one row per env and step - agent 0's values and returns in
+        env-major order (the order of the flattened states); `dones` are cut, not re-ordered, exactly as there."""
+        batch_size = self.batch_size
+        ma_batch_size = self.num_actors * self.num_agents * self.horizon_length
+        shape = (self.num_actors, self.num_agents, self.horizon_length, self.value_size)
+        value_preds = value_preds.reshape(shape).transpose(0, 1).contiguous().view(ma_batch_size, self.value_size)[:batch_size]
+        returns = returns.reshape(shape).transpose(0, 1).contiguous().view(ma_batch_size, self.value_size)[:batch_size]
+        dones = dones.contiguous().view(ma_batch_size, self.value_size)[:batch_size]
+        return value_preds, returns, actions, dones
 
     def forward(self, input_dict):
         return self.model(input_dict)
@@ -171,7 +189,11 @@ class CentralValueTrain(nn.Module):
                                 'rnn_states': self.rnn_states, 'is_train': False})
         if self.is_rnn:                                            # central_value.py:222
             self.rnn_states = [s.contiguous() for s in res['rnn_states']]
-        return res['values']
+        value = res['values']
+        if self.num_agents > 1:                                    # every agent of an env gets the env's value (:223-225)
+            value = value.repeat(1, self.num_agents)
+            value = value.view(value.size()[0] * self.num_agents, -1)
+        return value
 
     def train_critic(self, input_dict):
         self.train()

@@ -162,8 +162,13 @@ class ExperienceBuffer:
                     pairs.append(self._pair(v, phys[k], f'{name}.{k}'))
             else:
                 pairs.append(self._pair(val, phys, name))
-        rows = pairs[0][1].shape[0]
-        ops.rollout_store_step(pairs, rows, self.horizon_length, index)
+        # one launch per row count: the privileged states of a multi-agent env have one row per env, everything else one
+        # per agent (experience.py:346,380-383)
+        by_rows = {}
+        for pair in pairs:
+            by_rows.setdefault(pair[1].shape[0], []).append(pair)
+        for rows, group in by_rows.items():
+            ops.rollout_store_step(group, rows, self.horizon_length, index)
 
     @staticmethod
     def _pair(val, phys, name):

@@ -382,7 +382,9 @@ def make_central_value(variants=None, filename='central_value.pt'):
     for name, over in variants.items():
         N, H, O_, A, S_ = 64, 8, 12, 3, 20
         over = dict(over)
-        rnn, cv_rnn = over.pop('_rnn', None), over.pop('_cv_rnn', None)
+        rnn, cv_rnn, agents = over.pop('_rnn', None), over.pop('_cv_rnn', None), over.pop('_agents', 1)
+        if agents > 1:
+            N = 32
         params = configs.tiny(num_actors=N, horizon=H, obs_dim=O_, act_dim=A, device='cpu',
                               train_dir='/tmp/rlg_golden_runs', **over)
         params['config']['central_value_config'] = {
@@ -396,8 +398,10 @@ def make_central_value(variants=None, filename='central_value.pt'):
         if cv_rnn is not None:
             params['config']['central_value_config']['network']['rnn'] = dict(cv_rnn)
         params['config']['env_config']['state_dim'] = S_
+        if agents > 1:
+            params['config']['env_config']['agents'] = agents
         params['seed'] = 9
-        env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=4321, state_dim=S_)
+        env = SyntheticTensorEnv(N, O_, A, device='cpu', seed=4321, state_dim=S_, agents=agents)
         stored = copy.deepcopy(params)
         runner = Runner()
         runner.load({'params': copy.deepcopy(params)})
@@ -451,7 +455,9 @@ def make_central_value(variants=None, filename='central_value.pt'):
         cap['final_state'] = _clone(agent.model.state_dict())
         cap['cv_final_state'] = _clone(agent.central_value_net.state_dict())
         cap['params'] = stored
-        cap['env'] = {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 4321, 'state_dim': S_}
+        cap['env'] = {'num_envs': N, 'obs_dim': O_, 'act_dim': A, 'seed': 4321, 'state_dim': S_, 'agents': agents}
+        cvd = agent.central_value_net.dataset.values_dict
+        cap['cv_dataset'] = _clone({k: cvd[k] for k in ('old_values', 'returns', 'dones')})
         out[name] = cap
         print('central_value', name, 'cv losses', cap['cv_losses'].tolist()[:3], 'c_losses', cap['c_losses'].tolist()[:2],
               'keys', sorted(cap['batch'])[:12])
@@ -470,6 +476,16 @@ def make_central_value_rnn():
         'rnn_actor_gru_critic_layer_norm': dict(seq_length=4, _rnn=lstm, use_experimental_cv=False,
                                                 _cv_rnn={'name': 'gru', 'units': 12, 'layers': 1, 'layer_norm': True}),
     }, 'central_value_rnn.pt')
+
+
+def make_central_value_multi_agent():
+    """Round 6: multi-agent envs under a central value function (central_value.py:153-158,223-234) - 3 agents per env
+    with an MLP critic, and 2 agents with a recurrent actor and a recurrent critic."""
+    lstm = {'name': 'lstm', 'units': 16, 'layers': 1}
+    make_central_value({
+        'three_agents': dict(_agents=3),
+        'two_agents_recurrent': dict(_agents=2, seq_length=4, _rnn=lstm, _cv_rnn={'name': 'lstm', 'units': 12, 'layers': 1}),
+    }, 'central_value_multi_agent.pt')
 
 
 def make_lstm_full():
@@ -538,7 +554,7 @@ def make_lstm_full():
     print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'central_value_rnn': make_central_value_rnn, 'checkpoint': make_checkpoint,
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'central_value_rnn': make_central_value_rnn, 'central_value_multi_agent': make_central_value_multi_agent, 'checkpoint': make_checkpoint,
             'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':

@@ -655,23 +655,29 @@ def test_ipc_allreduce_is_fail_safe_when_a_peer_never_arrives(two_phase):
 
 
 @pytest.mark.parametrize('variant', ['experimental_cv', 'no_actor_value_loss', 'rnn_actor_mlp_critic',
-                                     'rnn_actor_rnn_critic', 'rnn_actor_gru_critic_layer_norm'])
+                                     'rnn_actor_rnn_critic', 'rnn_actor_gru_critic_layer_norm',
+                                     'three_agents', 'two_agents_recurrent'])
 def test_central_value_update_matches_reference_epoch(golden, variant):
     """Central (asymmetric) value function: the update phase against golden vectors
     of the REAL reference agent with `central_value_config` - critic minibatches first
     (CentralValueTrain.train_net), then the actor's, on identical rollout tensors.  `rnn_*`
     (tests/golden/central_value_rnn.pt, round 6): a recurrent actor, and critics with an RNN of their own - sequence
-    minibatches that start from the states the rollout kept (central_value.py:163-170)."""
+    minibatches that start from the states the rollout kept (central_value.py:163-170).  `*_agents*`
+    (central_value_multi_agent.pt): several agents per env - one state row per env, the critic's dataset is agent 0's
+    values and returns in env-major order (update_multiagent_tensors, :225-234)."""
     from rl_games_amd.agent import A2CAgent
-    recurrent = variant.startswith('rnn_')
-    cap = golden('central_value_rnn.pt' if recurrent else 'central_value.pt')[variant]
+    recurrent = variant.startswith('rnn_') or variant.endswith('_recurrent')
+    fixture = ('central_value_multi_agent.pt' if 'agents' in variant else
+               'central_value_rnn.pt' if recurrent else 'central_value.pt')
+    cap = golden(fixture)[variant]
     params = copy.deepcopy(cap['params'])
     params['config']['device'] = DEV
     env = SyntheticTensorEnv(cap['env']['num_envs'], cap['env']['obs_dim'], cap['env']['act_dim'], device=DEV,
-                             seed=cap['env']['seed'], state_dim=cap['env']['state_dim'])
+                             seed=cap['env']['seed'], state_dim=cap['env']['state_dim'], agents=cap['env'].get('agents', 1))
     params['config']['vec_env'] = env
     params['config']['env_info'] = env.get_env_info()
     agent = A2CAgent('cv', params)
+    assert agent.num_agents == cap['env'].get('agents', 1)
     assert agent.has_central_value
     assert agent.has_value_loss == cap['params']['config'].get('use_experimental_cv', True)
     agent.init_tensors()
@@ -691,6 +697,11 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
     ds, vd = cap['dataset'], agent.dataset.values_dict
     for k in ('old_values', 'returns', 'advantages'):
         assert torch.allclose(vd[k].cpu().reshape(ds[k].shape), ds[k], rtol=1e-5, atol=1e-6), k
+    if 'cv_dataset' in cap:                     # what the critic trains on
+        cvd = cv.dataset.values_dict
+        for k, want in cap['cv_dataset'].items():
+            got = cvd[k].cpu().reshape(want.shape)
+            assert torch.allclose(got.to(want.dtype), want, rtol=1e-5, atol=1e-6), k
     # (round 5: the critic's MLP on the fused chain kernels, not autograd; a recurrent critic is a torch module)
     assert (cv._engine is not None) == (not cv.is_rnn)
     cv.train_net()
@@ -715,6 +726,42 @@ def test_central_value_update_matches_reference_epoch(golden, variant):
         for k, v in want.items():
             tol = dict(rtol=1e-4, atol=2e-6) if v.is_floating_point() else dict(rtol=0, atol=0)
             assert torch.allclose(final[k].cpu().to(v.dtype), v, **tol), k
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+def test_multi_agent_central_value_train_epochs_run(recurrent):
+    """Rollout side of a multi-agent central value function (central_value.py:223-225): one privileged state row per
+    env, every agent of the env gets the env's value; epochs run with finite losses and the critic's dataset holds one
+    row per env and step."""
+    from rl_games_amd import configs
+    from rl_games_amd.agent import A2CAgent
+    params = configs.tiny(num_actors=32, horizon=8, obs_dim=10, act_dim=3, seq_length=4)
+    cv_net = {'name': 'actor_critic', 'central_value': True,
+              'mlp': {'units': [24, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}
+    if recurrent:
+        params['network']['rnn'] = {'name': 'lstm', 'units': 16, 'layers': 1}
+        cv_net['rnn'] = {'name': 'lstm', 'units': 12, 'layers': 1}
+    params['config']['central_value_config'] = {
+        'minibatch_size': 64, 'mini_epochs': 2, 'learning_rate': 5e-4, 'clip_value': True, 'normalize_input': True,
+        'truncate_grads': True, 'grad_norm': 1.0, 'network': cv_net}
+    params['config']['env_config'].update(state_dim=9, agents=3)
+    torch.manual_seed(3)
+    agent = A2CAgent('macv', copy.deepcopy(params))
+    cv = agent.central_value_net
+    assert agent.num_agents == 3 and cv.num_agents == 3 and cv.batch_size == 32 * 8 and agent.batch_size == 32 * 3 * 8
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    for _ in range(2):
+        agent.update_epoch()
+        out = agent.train_epoch()
+        assert all(torch.isfinite(x).all() for x in out[4] + out[5] + out[7])
+    values = agent.experience_buffer.tensor_dict['values'].reshape(8, 32, 3)
+    assert torch.equal(values[:, :, 0], values[:, :, 1]) and torch.equal(values[:, :, 0], values[:, :, 2])
+    assert agent.experience_buffer.tensor_dict['states'].shape[:2] == (8, 32)
+    vd = cv.dataset.values_dict
+    assert vd['old_values'].shape[0] == vd['returns'].shape[0] == vd['obs'].shape[0] == 32 * 8
+    if recurrent:
+        assert cv.rnn_states[0].shape == (1, 32, 12) and vd['rnn_states'][0].shape == (1, 32 * 8 // 4, 12)
 
 
 def test_recurrent_actor_and_critic_train_epochs_run():
