@@ -346,8 +346,10 @@ class A2CAgent:
         # (value_size > 1: the fused loss kernels carry one value column - that agent takes autograd through
         #  rl_games_amd/torch_fallback.py instead, SURVEY 8a'-13)
         # (... and so does a state-dependent sigma head, fixed_sigma False: the kernels carry log sigma as a parameter vector)
+        # (... and a sigma that is not exp of an unbounded log sigma: logstd_bounds, min_sigma, softplus / linear forms)
         self._general_forms = (not self.is_discrete) and (self.value_size != 1
-                                                          or not getattr(self.model.a2c_network, 'fixed_sigma', True))
+                                                          or not getattr(self.model.a2c_network, 'fixed_sigma', True)
+                                                          or not getattr(self.model.a2c_network, 'plain_sigma', True))
         self._use_engine = ((not self.is_discrete) and config.get('manual_mlp', True) and not self._general_forms
                             and getattr(self.model.a2c_network, 'plain_trunk', True)
                             and not self.model.a2c_network.is_separate_critic()
@@ -1147,13 +1149,15 @@ class A2CAgent:
         opt.zero_grad()
         mu, logstd, values, _ = self.model.forward_heads(batch)
         mb = mu.shape[0]
+        net = self.model.a2c_network
         kind = 0 if self.bounds_loss_coef is None else ops.BOUND_KINDS.get(self.bound_loss_type, 0)
         loss, scalars, sigma = tf.ppo_loss(
             mu, logstd, values.reshape(mb, -1), input_dict['actions'], input_dict['old_logp_actions'], input_dict['advantages'],
             input_dict['old_values'].reshape(mb, -1), input_dict['returns'].reshape(mb, -1), e_clip=self.e_clip,
             critic_coef=self.critic_coef if self.has_value_loss else 0.0, entropy_coef=self.entropy_coef,
             bounds_coef=self.bounds_loss_coef if self.bounds_loss_coef is not None else 0.0, bound_kind=kind,
-            clip_value=self.clip_value, smooth=self.surrogate, mask=mask)
+            clip_value=self.clip_value, smooth=self.surrogate, mask=mask,
+            sigma_fn=None if net.plain_sigma else net.sigma_and_logstd)
         loss.backward()
         with torch.no_grad():
             sig = sigma.detach().expand_as(mu)

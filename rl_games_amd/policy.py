@@ -166,10 +166,17 @@ class ActorCriticNetwork(nn.Module):
         # as torch ops with autograd around this library's rollout, GAE, dataset and optimiser kernels
         # (agent._forward_loss_backward_general, torch_fallback.py; pinned to the reference on the CPU).
         self.fixed_sigma = bool(self.space_config['fixed_sigma'])
-        if self.space_config.get('sigma_parametrization', 'exp') != 'exp' or \
-                self.space_config.get('logstd_bounds') is not None or \
-                float(self.space_config.get('min_sigma', 0.0)) > 0:
-            raise NotImplementedError('only the plain exp sigma parametrisation is implemented')
+        # how the sigma head's raw output becomes sigma (network_builder.py:311-322, models.py:272-301): the fused kernels
+        # know `exp` of an unbounded log sigma; a floor, bounds or the softplus / linear forms run as torch ops like a
+        # state-dependent head does (`plain_sigma` False)
+        self.min_sigma = float(self.space_config.get('min_sigma', 0.0))
+        self.logstd_bounds = self.space_config.get('logstd_bounds', None)
+        self.sigma_parametrization = self.space_config.get('sigma_parametrization', 'exp')
+        if self.sigma_parametrization == 'scalar':
+            self.sigma_parametrization = 'linear'
+        if self.sigma_parametrization not in ('exp', 'softplus', 'linear'):
+            raise NotImplementedError(f"sigma_parametrization '{self.sigma_parametrization}'")
+        self.plain_sigma = (self.sigma_parametrization == 'exp' and self.logstd_bounds is None and self.min_sigma <= 0)
         mlp = net_params['mlp']
         self.value_size = value_size
         self.num_seqs = num_seqs
@@ -373,6 +380,22 @@ class ActorCriticNetwork(nn.Module):
         mu = self.mu_act(self.mu(out))
         return mu, mu * 0 + self.logstd_of(out), value, states
 
+    def sigma_and_logstd(self, raw):
+        """(sigma, log sigma) of the sigma head's raw output - `apply_sigma_parametrization` (models.py:272-301)."""
+        if self.sigma_parametrization == 'softplus':
+            sigma = torch.nn.functional.softplus(raw) + self.min_sigma
+        elif self.sigma_parametrization == 'linear':            # sigma ~ raw above a smooth floor
+            floor = max(self.min_sigma, 1e-3)
+            sigma = floor + torch.nn.functional.softplus(raw - floor)
+        else:
+            if self.logstd_bounds is not None:
+                raw = torch.clamp(raw, self.logstd_bounds[0], self.logstd_bounds[1])
+            sigma = torch.exp(raw)
+            if self.min_sigma <= 0:
+                return sigma, raw
+            sigma = sigma + self.min_sigma
+        return sigma, torch.log(sigma)
+
     def logstd_of(self, out):
         """log sigma: the parameter vector [A], or the sigma head of the trunk's features [B, A] (network_builder.py:508-511)."""
         return self.sigma_act(self.sigma) if self.fixed_sigma else self.sigma_act(self.sigma(out))
@@ -444,7 +467,7 @@ class ContinuousA2CLogStdModel(nn.Module):
         input_dict = dict(input_dict)
         input_dict['obs'] = self.norm_obs(input_dict['obs'])
         mu, logstd, value, states = self.a2c_network(input_dict)
-        sigma = torch.exp(logstd)
+        sigma, logstd = self.a2c_network.sigma_and_logstd(logstd)
         if is_train:
             entropy = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(sigma)).sum(dim=-1)
             prev_neglogp = self.neglogp(prev_actions, mu, sigma, logstd)

@@ -22,14 +22,19 @@ def _clip_surrogate(ratio, lo, hi, smooth):
 
 
 def ppo_loss(mu, logstd, values, actions, old_neglogp, advantages, old_values, returns, *, e_clip, critic_coef,
-             entropy_coef, bounds_coef, bound_kind, clip_value, smooth, mask=None):
+             entropy_coef, bounds_coef, bound_kind, clip_value, smooth, mask=None, sigma_fn=None):
     """The model epilogue + calc_losses of the continuous agent (models.py:329-364, a2c_continuous.py:97-134,
     common_losses.py:16-82) for a fixed-sigma policy: mu [mb, A], logstd [A] (the parameter), values / old_values /
     returns [mb, V].  bound_kind: 0 none, 1 'bound', 2 'regularisation' (ops.BOUND_KINDS); smooth: ops.SURROGATE_* (False /
     True / 2 = ppo: False).
+    sigma_fn: None (sigma = exp(logstd)) or the network's raw -> (sigma, log sigma) map (`apply_sigma_parametrization`,
+    models.py:272-301: bounds, a floor, the softplus / linear forms).
     Returns (loss, dict of the detached scalars a_loss / c_loss / entropy / b_loss, sigma [A])."""
     mb, A = mu.shape
-    sigma = torch.exp(logstd)
+    if sigma_fn is None:
+        sigma = torch.exp(logstd)
+    else:
+        sigma, logstd = sigma_fn(logstd)
     z = (actions - mu) / sigma
     neglogp = 0.5 * (z * z).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * A + logstd.sum(dim=-1)
     entropy = (0.5 + 0.5 * math.log(2.0 * math.pi) + torch.log(sigma)).sum(dim=-1).expand(mb)

@@ -198,6 +198,19 @@ def make_epoch_extra():
     }, 'epoch_extra.pt')
 
 
+def make_epoch_sigma_forms():
+    """Round 6: the sigma head's parametrisations (network_builder.py:311-322, models.py:272-301) - softplus with a floor on
+    a state-dependent head, exp with log-sigma bounds (active: the initial 0.3 sits above the upper bound) and a floor on
+    the parameter vector, and the linear ('scalar') form."""
+    const = lambda v: {'name': 'const_initializer', 'val': v}
+    make_epoch({
+        'softplus_state_sigma': dict(_space={'fixed_sigma': False, 'sigma_parametrization': 'softplus', 'min_sigma': 0.05,
+                                             'sigma_init': const(0.5)}),
+        'bounded_exp_floor': dict(_space={'logstd_bounds': [-1.0, 0.1], 'min_sigma': 0.1, 'sigma_init': const(0.3)}),
+        'linear_sigma': dict(_space={'sigma_parametrization': 'scalar', 'sigma_init': const(0.8)}, entropy_coef=0.01),
+    }, 'epoch_sigma_forms.pt')
+
+
 def make_epoch_separate_rnn():
     """Round 6: separate actor / critic trunks, each with its own RNN (network_builder.py:272-277, :372-421) - four LSTM
     state tensors per environment, two with a GRU."""
@@ -554,7 +567,7 @@ def make_lstm_full():
     print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'central_value_rnn': make_central_value_rnn, 'central_value_multi_agent': make_central_value_multi_agent, 'checkpoint': make_checkpoint,
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'epoch_sigma_forms': make_epoch_sigma_forms, 'central_value_rnn': make_central_value_rnn, 'central_value_multi_agent': make_central_value_multi_agent, 'checkpoint': make_checkpoint,
             'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':

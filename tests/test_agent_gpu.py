@@ -34,7 +34,10 @@ def _to_dev(batch):
     return {k: v.to(DEV) for k, v in batch.items()}
 
 
-@pytest.mark.parametrize('variant', ['default', 'smooth_reg_ema', 'state_sigma', 'ppo_false', 'd2rl_layer_norm'])
+_SIGMA_FORMS = ('softplus_state_sigma', 'bounded_exp_floor', 'linear_sigma')
+
+
+@pytest.mark.parametrize('variant', ('default', 'smooth_reg_ema', 'state_sigma', 'ppo_false', 'd2rl_layer_norm') + _SIGMA_FORMS)
 def test_update_matches_reference_epoch(golden, variant):
     """An epoch's update against the recording of the REAL reference agent's train_epoch on the same rollout
     (tests/golden/make_golden.py).  Round 6 (epoch_extra.pt): 'state_sigma' - a state-dependent sigma head
@@ -43,9 +46,12 @@ def test_update_matches_reference_epoch(golden, variant):
     fused loss tile - and 'd2rl_layer_norm' - a D2RL trunk with layer normalisation: torch modules + autograd between this
     library's loss, statistics and optimiser kernels."""
     extra = variant in ('state_sigma', 'ppo_false', 'd2rl_layer_norm')
-    cap = golden('epoch_extra.pt' if extra else 'epoch.pt')[variant]
+    # (epoch_sigma_forms.pt, round 6: the sigma parametrisations of models.py:272-301 - softplus + floor on a state-dependent
+    #  head, exp with active log-sigma bounds + floor, the linear form - as torch ops between the kernels)
+    fixture = 'epoch_sigma_forms.pt' if variant in _SIGMA_FORMS else 'epoch_extra.pt' if extra else 'epoch.pt'
+    cap = golden(fixture)[variant]
     agent = _make_agent(cap)
-    assert (agent._engine is None) == (variant in ('state_sigma', 'd2rl_layer_norm'))
+    assert (agent._engine is None) == (variant in ('state_sigma', 'd2rl_layer_norm') + _SIGMA_FORMS)
     agent.model.load_state_dict(cap['state_after_rollout'])
     batch = _to_dev(cap['batch'])
     agent.set_train()

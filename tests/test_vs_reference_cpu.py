@@ -540,6 +540,45 @@ def test_state_dependent_sigma_network_equals_the_reference_builder():
     assert torch.equal(logstd, got[1]) and torch.equal(mu, got[0])
 
 
+@pytest.mark.parametrize('space', [{'sigma_parametrization': 'softplus', 'min_sigma': 0.05},
+                                   {'sigma_parametrization': 'softplus'},
+                                   {'sigma_parametrization': 'scalar'}, {'sigma_parametrization': 'linear', 'min_sigma': 0.2},
+                                   {'logstd_bounds': [-1.0, 0.5]}, {'min_sigma': 0.1}, {'logstd_bounds': [-2.0, 0.0], 'min_sigma': 0.3},
+                                   {}])
+@pytest.mark.parametrize('fixed', [True, False])
+def test_sigma_parametrisations_equal_the_reference_model(space, fixed):
+    """network_builder.py:311-322 + models.py:272-301 (`apply_sigma_parametrization`): the reference's model and this
+    one on the same weights - sigmas, neglogp and entropy of a training call bit for bit; only the unbounded exp form is
+    `plain_sigma` (what the fused kernels compute)."""
+    from rl_games.algos_torch import network_builder, models
+    from rl_games_amd.policy import ActorCriticNetwork, ContinuousA2CLogStdModel
+    sp = copy.deepcopy(_SPACE)
+    sp['continuous'].update(space, fixed_sigma=fixed, sigma_init={'name': 'const_initializer', 'val': 0.4})
+    net_params = {'name': 'actor_critic', 'separate': False, 'space': sp,
+                  'mlp': {'units': [32, 16], 'activation': 'elu', 'initializer': {'name': 'default'}}}
+    builder = network_builder.A2CBuilder()
+    builder.load(copy.deepcopy(net_params))
+    torch.manual_seed(5)
+    kw = dict(actions_num=3, input_shape=(7,), value_size=1, num_seqs=4)
+    ref = models.ModelA2CContinuousLogStd(builder).build(dict(kw, normalize_value=False, normalize_input=False))
+    ours_net = ActorCriticNetwork(copy.deepcopy(net_params), **kw)
+    assert ours_net.plain_sigma == (space == {})
+    ours = ContinuousA2CLogStdModel(ours_net, (7,), False, False, 1)
+    sd = ref.state_dict()
+    with torch.no_grad():                                       # raw values on both sides of every bound / floor
+        for k, v in sd.items():
+            if 'sigma' in k:
+                sd[k] = v + 1.5 * torch.randn(v.shape, generator=gen(3))
+    ref.load_state_dict(sd)
+    ours.load_state_dict(sd)
+    obs = torch.randn(16, 7, generator=gen(4))
+    acts = torch.randn(16, 3, generator=gen(5))
+    want = ref({'is_train': True, 'obs': obs.clone(), 'prev_actions': acts})
+    got = ours({'is_train': True, 'obs': obs.clone(), 'prev_actions': acts})
+    for k in ('sigmas', 'mus', 'prev_neglogp', 'entropy', 'values'):
+        assert torch.equal(want[k].expand_as(got[k]), got[k]), k
+
+
 _SPACE = {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None', 'mu_init': {'name': 'default'},
                          'sigma_init': {'name': 'const_initializer', 'val': 0}, 'fixed_sigma': True}}
 
