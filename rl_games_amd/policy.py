@@ -92,6 +92,16 @@ class RnnWithDones(nn.Module):
         return torch.cat(outs, dim=0), st
 
 
+def _norm_layer(name, width):
+    """network_builder.py:126-129, d2rl.py:17-22: LayerNorm, BatchNorm1d (train / eval as the module's mode says: batch
+    statistics in the update, running ones in the rollout), or nothing - any other name builds no layer there either."""
+    if name == 'layer_norm':
+        return nn.LayerNorm(width)
+    if name == 'batch_norm':
+        return nn.BatchNorm1d(width)
+    return None
+
+
 class D2RLNet(nn.Module):
     """Dense-to-dense trunk (rl_games/algos_torch/d2rl.py:3-33): every layer behind the first sees the previous layer's
     output concatenated with the network input.  Parameter names as in the reference (`linears.N`, `norm_layers.N`)."""
@@ -106,7 +116,7 @@ class D2RLNet(nn.Module):
         for u in units:
             self.linears.append(nn.Linear(last, u))
             last = u + input_size
-            self.norm_layers.append(nn.LayerNorm(u) if norm_func_name == 'layer_norm' else nn.Identity())
+            self.norm_layers.append(_norm_layer(norm_func_name, u) or nn.Identity())
 
     def forward(self, x0):
         x = self.norm_layers[0](self.activations[0](self.linears[0](x0)))            # (:25-27: act, then norm)
@@ -118,8 +128,6 @@ class D2RLNet(nn.Module):
 def build_trunk(input_size, units, activation, norm_func_name=None, norm_only_first_layer=False, d2rl=False):
     """network_builder.py:105-145 (_build_sequential_mlp / _build_mlp), statement for statement - including that `in_size` is
     only advanced while a normalisation layer is still to come when `norm_only_first_layer` is set."""
-    if norm_func_name not in (None, 'layer_norm'):
-        raise NotImplementedError(f"normalization '{norm_func_name}' (only layer_norm is implemented on this path)")
     if d2rl:
         return D2RLNet(input_size, units, activation, norm_func_name)
     in_size, layers, need_norm = input_size, [], True
@@ -130,8 +138,9 @@ def build_trunk(input_size, units, activation, norm_func_name=None, norm_only_fi
             continue
         if norm_only_first_layer and norm_func_name is not None:
             need_norm = False
-        if norm_func_name == 'layer_norm':
-            layers.append(nn.LayerNorm(unit))
+        norm = _norm_layer(norm_func_name, unit)
+        if norm is not None:
+            layers.append(norm)
         in_size = unit
     return nn.Sequential(*layers)
 

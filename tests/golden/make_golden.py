@@ -211,6 +211,15 @@ def make_epoch_sigma_forms():
     }, 'epoch_sigma_forms.pt')
 
 
+def make_epoch_batch_norm():
+    """Round 6: BatchNorm1d behind every trunk layer (network_builder.py:128-129) - batch statistics in the update, the
+    running ones in the rollout - and inside a D2RL trunk (d2rl.py:19-20)."""
+    make_epoch({
+        'batch_norm': dict(_network={'normalization': 'batch_norm'}),
+        'd2rl_batch_norm': dict(_network={'mlp': {'d2rl': True}, 'normalization': 'batch_norm'}),
+    }, 'epoch_batch_norm.pt')
+
+
 def make_epoch_separate_rnn():
     """Round 6: separate actor / critic trunks, each with its own RNN (network_builder.py:272-277, :372-421) - four LSTM
     state tensors per environment, two with a GRU."""
@@ -567,7 +576,7 @@ def make_lstm_full():
     print('lstm_full.pt.gz written', os.path.getsize(path) // 1024, 'KiB (raw', len(buf.getvalue()) // 1024, 'KiB)')
 
 
-SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'epoch_sigma_forms': make_epoch_sigma_forms, 'central_value_rnn': make_central_value_rnn, 'central_value_multi_agent': make_central_value_multi_agent, 'checkpoint': make_checkpoint,
+SECTIONS = {'gae': make_gae, 'epoch': make_epoch, 'discrete': make_discrete, 'discrete_rnn': make_discrete_rnn, 'epoch_separate_rnn': make_epoch_separate_rnn, 'epoch_sigma_forms': make_epoch_sigma_forms, 'epoch_batch_norm': make_epoch_batch_norm, 'central_value_rnn': make_central_value_rnn, 'central_value_multi_agent': make_central_value_multi_agent, 'checkpoint': make_checkpoint,
             'central_value': make_central_value, 'lstm_full': make_lstm_full, 'epoch_extra': make_epoch_extra}
 
 if __name__ == '__main__':

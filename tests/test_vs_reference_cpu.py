@@ -586,6 +586,8 @@ _SPACE = {'continuous': {'mu_activation': 'None', 'sigma_activation': 'None', 'm
 @pytest.mark.parametrize('name,over', [
     ('layer_norm', {'normalization': 'layer_norm'}),
     ('layer_norm_first_only', {'normalization': 'layer_norm', 'mlp': {'units': [24, 24], 'norm_only_first_layer': True}}),
+    ('batch_norm', {'normalization': 'batch_norm'}),
+    ('d2rl_batch_norm_first_only', {'mlp': {'d2rl': True, 'norm_only_first_layer': True}, 'normalization': 'batch_norm'}),
     ('d2rl', {'mlp': {'d2rl': True}}),
     ('d2rl_layer_norm', {'mlp': {'d2rl': True}, 'normalization': 'layer_norm'}),
     ('gru_two_layers', {'rnn': {'name': 'gru', 'units': 12, 'layers': 2}}),
@@ -627,7 +629,7 @@ def test_network_zoo_layouts_equal_the_reference_builder(name, over):
     assert not getattr(ours, 'plain_trunk', True) or name in ('gru_two_layers', 'discrete_lstm')
     with torch.no_grad():                                       # LayerNorm weights away from their (1, 0) initialisation
         for k, v in ref_sd.items():
-            if 'norm' in k:
+            if 'norm' in k and v.is_floating_point():
                 ref_sd[k] = v + 0.2 * torch.randn(v.shape, generator=gen(3))
     ref_net.load_state_dict(ref_sd)
     ours.load_state_dict(ref_sd)
@@ -652,4 +654,11 @@ def test_network_zoo_layouts_equal_the_reference_builder(name, over):
             assert torch.allclose(w, g_, rtol=1e-6, atol=1e-7)
     else:
         for w, g_ in zip(want[:n_out], got[:n_out]):
+            assert torch.equal(w, g_), name
+    if 'batch_norm' in name:                                    # that call was in training mode: batch statistics, running
+        ref_net.eval()                                          # statistics updated; now the rollout's mode
+        ours.eval()
+        for (k, w), g_ in zip(ref_net.state_dict().items(), ours.state_dict().values()):
+            assert torch.equal(w, g_), k
+        for w, g_ in zip(ref_net(dict(d))[:n_out], ours(dict(d))[:n_out]):
             assert torch.equal(w, g_), name
