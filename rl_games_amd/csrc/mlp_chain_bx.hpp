@@ -6,6 +6,13 @@
 
 namespace rlg {
 
+// register class the accumulators are pinned to: AGPRs ("+a") in the 512-register kernels; a build that must fit two waves
+// per SIMD defines it as "+v" - without an AGPR constraint anywhere the compiler gives the kernel ONE file of 256
+// registers and issues the MFMAs on VGPR accumulators (with one it splits the file 128 + 128)
+#ifndef RLG_ACC_CLASS
+#define RLG_ACC_CLASS "+a"
+#endif
+#define RLG_ACC_REG(x) RLG_ACC_CLASS(x)
 constexpr int kBxW = 4;                  // waves per workgroup: one per SIMD (the tiles fill the LDS: one workgroup per
                                          // CU; eight waves on the same tile measured 1.7x SLOWER, 128 + 128 registers)
 
@@ -97,7 +104,7 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
 #pragma unroll
         for (int t = 0; t < kBxProducts; ++t)
           acc[f][g] = bx_mfma(av[f][kBxPa[t]], bv[g][kBxPb[t]], (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g]);
-        if constexpr (kFirst) asm volatile("" : "+a"(acc[f][g]));      // accumulators live in AGPRs
+        if constexpr (kFirst) asm volatile("" : RLG_ACC_REG(acc[f][g]));      // accumulators live in AGPRs
       }
     }
   };
@@ -137,12 +144,12 @@ __device__ __forceinline__ void bx_units(rsrc_t pr, unsigned layer_off, int KC, 
     load_b(b0, 0, g0);
     RLG_PIN();
     // wait states between the last MFMA and the first VALU read of an accumulator (tools/audit_mfma.py)
-    asm volatile("s_nop 7" : "+a"(acc[0][0]));
+    asm volatile("s_nop 7" : RLG_ACC_REG(acc[0][0]));
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (f + g > 0) asm volatile("" : "+a"(acc[f][g]));
+        if (f + g > 0) asm volatile("" : RLG_ACC_REG(acc[f][g]));
       }
     }
     epi(j, acc);

@@ -14,16 +14,32 @@
 // - with layer p's accumulators (all of a wave's blocks, at most 4) kept in registers across the passes; layer p's
 // epilogue follows the last pass.  The host picks the window (chain_bx_fwd_plan).
 
+// waves per workgroup: 8 = two per SIMD with 256 registers each - a wave's epilogue (VALU: bias, activation, the split
+// into planes, stores) issues under the other wave's MFMAs - every wave with half the column blocks of a layer; 4 = one per
+// SIMD with all 512 registers (rounds 3 - 6 until profiles/r6_fwd_two_waves.txt).  Two waves per SIMD need accumulators
+// in VGPRs: with an AGPR constraint anywhere in the kernel hipcc splits the 256 registers 128 + 128 and spills 163 of them,
+// without one it allocates one file of 256 and issues the MFMAs on VGPR accumulators.
+#ifndef RLG_BX_FWD_W
+#define RLG_BX_FWD_W 8
+#endif
+#if RLG_BX_FWD_W == 8 && !defined(RLG_ACC_CLASS)
+#define RLG_ACC_CLASS "+v"
+#endif
+// blocks of the widest unit (a B fragment read from LDS feeds that many MFMA chains).  One at two waves per SIMD: pairs
+// need 90 registers more than the 256 there are (scratch: + 5 % instead of - 11 %)
+#ifndef RLG_BX_FWD_NF
+#define RLG_BX_FWD_NF (RLG_BX_FWD_W == 8 ? 1 : 2)
+#endif
+
 #include "mlp_chain_bx.hpp"
 
 namespace rlg {
 
 constexpr int kFwG = 4;
-#ifndef RLG_BX_FWD_NF
-#define RLG_BX_FWD_NF 2
-#endif
-constexpr int kFwUnitBlocks = RLG_BX_FWD_NF;   // blocks of the widest unit (4: a B fragment read from LDS feeds four MFMA chains)
-constexpr int kFwMaxPersist = 4;        // blocks of the windowed tile's consumer per wave (accumulators across passes)
+constexpr int kFwUnitBlocks = RLG_BX_FWD_NF;
+constexpr int kFwW = RLG_BX_FWD_W;
+static_assert(kFwW % kFwG == 0, "the prologue deals row group (wave % G) to a wave");
+constexpr int kFwMaxPersist = 16 / kFwW;   // blocks of the windowed tile's consumer per wave (accumulators across passes)
 
 // Chunks [c0, c1) of the reduction of NF blocks (block f: ob_first + min(f, nb_valid - 1); the surplus ones repeat the
 // last valid block and are dropped by the caller) for all G row groups, accumulated into acc (first: from zero).
@@ -65,7 +81,7 @@ __device__ __forceinline__ void bx_span(rsrc_t pr, unsigned layer_off, int KC, c
 #pragma unroll
         for (int t = 0; t < kBxProducts; ++t)
           acc[f][g] = bx_mfma(av[f][kBxPa[t]], bv[g][kBxPb[t]], (kFirst && t == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[f][g]);
-        asm volatile("" : "+a"(acc[f][g]));      // accumulators live in AGPRs
+        asm volatile("" : RLG_ACC_REG(acc[f][g]));      // accumulators live in AGPRs
       }
     }
   };
@@ -120,11 +136,11 @@ __device__ __forceinline__ void bx_span(rsrc_t pr, unsigned layer_off, int KC, c
 }
 
 template <int HACT>
-__global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a) {
-  constexpr int G = kFwG, W = kBxW;
+__global__ __launch_bounds__(64 * kFwW) void mlp_chain_fwd_bx_kernel(ChainArgs a) {
+  constexpr int G = kFwG, W = kFwW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (static_cast<int>(blockIdx.x) >= a.fwd_blocks) {      // the workgroups behind the row tiles: the backward's planes
-    chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
+    if (threadIdx.x < 256) chain_pack_planes_block(a.pack, static_cast<int>(blockIdx.x) - a.fwd_blocks, threadIdx.x);
     return;
   }
   char* const ldsb = reinterpret_cast<char*>(lds);
@@ -222,13 +238,13 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       chain_norm_stats<W>(a, stats, in0, in0p);
       __syncthreads();
     }
-    float scale_mine = kBxScaleObsNorm;         // of row (lane & 15) of row group `wave`: W == G, a wave splits ITS group's rows
+    float scale_mine = kBxScaleObsNorm;         // of row (lane & 15) of row group wave % G: a wave splits ITS group's rows
     if (RLG_BX_F16 && !norm) {
       // raw observations have no bound: every row gets its scale from its largest magnitude (one more pass over the
       // rows, which the loads behind it find in the cache)
-      static_assert(W == G, "the prologue deals row group g to wave g");
       float mine = 0.0f;
-      const long long row = row0 + wave * 16 + (lane & 15);
+      const int group = wave % G;
+      const long long row = row0 + group * 16 + (lane & 15);
       if (row < n_rows) {
         for (int c = 0; c < KC0; ++c) {
           const f32x4 lo = load_row4(a.x, a.ldx, row, c * 32 + q4, in0, xv), hi = load_row4(a.x, a.ldx, row, c * 32 + 16 + q4, in0, xv);
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         }
       }
       scale_mine = bx_row_scale(mine);
-      if (lane < 16) stats[wave * 16 + lane] = scale_mine;          // (the normaliser scratch is free without a normaliser)
+      if (lane < 16 && wave < G) stats[group * 16 + lane] = scale_mine;   // (the normaliser scratch is free without a normaliser)
     }
     put_frags(wave, scale_mine);
     for (int u0 = wave + W * kProBatch; u0 < nfrag; u0 += W * kProBatch) {
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       // the engine and its registers) pairs, then single blocks
       const int unitsw = (kFwUnitBlocks > 2) ? nb_w / kFwUnitBlocks : 0;
       const int rest = nb_w - kFwUnitBlocks * unitsw;
-      const int units2 = (kFwUnitBlocks == 3) ? 0 : rest >> 1, left = rest - 2 * units2;
+      const int units2 = (kFwUnitBlocks == 3 || kFwUnitBlocks == 1) ? 0 : rest >> 1, left = rest - 2 * units2;
       const rsrc_t br = bias_rsrc(L);
       const bool bfast = bias_fast(L);
       auto epilogue = make_epilogue(L, dst_tile, chunk_base, scale_in);
@@ -364,7 +380,8 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
             false);
       };
       if constexpr (kFwUnitBlocks > 2) whole(std::integral_constant<int, kFwUnitBlocks>{}, first_ob, unitsw);
-      if constexpr (kFwUnitBlocks != 3) whole(std::integral_constant<int, 2>{}, first_ob + kFwUnitBlocks * unitsw, units2);
+      if constexpr (kFwUnitBlocks != 3 && kFwUnitBlocks != 1)
+        whole(std::integral_constant<int, 2>{}, first_ob + kFwUnitBlocks * unitsw, units2);
       whole(std::integral_constant<int, 1>{}, first_ob + kFwUnitBlocks * unitsw + 2 * units2, left);
     };
     // an odd number of blocks leaves half a chunk of a tile unwritten: zero it (the weights there are zero, but
@@ -409,7 +426,9 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
     if (pnb > 0) {
       const rsrc_t br = bias_rsrc(P);
       const bool bfast = bias_fast(P);
-      const float hidden_scale[G] = {kBxScaleH, kBxScaleH, kBxScaleH, kBxScaleH};
+      float hidden_scale[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) hidden_scale[g] = kBxScaleH;
       auto epilogue = make_epilogue(P, ptile, 0, hidden_scale);
       f32x4 pb[kFwMaxPersist];
 #pragma unroll
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_fwd_bx_kernel(ChainArgs a
         const int fo = (pfirst + f) * 16 + q4;
         pb[f] = load_bias(br, f < pnb ? fo : p_out, bfast);
       }
-      asm volatile("s_nop 7" : "+a"(pacc[0][0]));
+      asm volatile("s_nop 7" : RLG_ACC_REG(pacc[0][0]));
 #pragma unroll
       for (int f = 0; f < kFwMaxPersist; ++f) {
         if (f < pnb) {
@@ -481,7 +500,7 @@ int chain_bx_fwd_plan(ChainArgs& args) {
     if (p < 0 || kc[L] > kc[p]) p = L;
   }
   if (p < 1) return -1;
-  if (bx_nb(args.layer[p].out) > kFwMaxPersist * kBxW) return -1;     // the consumer's accumulators stay in registers
+  if (bx_nb(args.layer[p].out) > kFwMaxPersist * kFwW) return -1;     // the consumer's accumulators stay in registers
   for (long long passes = 2; passes <= kc[p]; ++passes) {
     const long long window = (kc[p] + passes - 1) / passes;
     if (place(p, window)) {
@@ -510,10 +529,10 @@ static int chain_bx_launch_fwd_as(const ChainArgs& args_in, int lds_bytes, hipSt
   args.fwd_blocks = grid;
   if (args.pack.total_pairs > 0) grid += chain_bx_pack_blocks(args.pack);
   if (ev0 != nullptr)
-    hipExtLaunchKernelGGL((mlp_chain_fwd_bx_kernel<HACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, ev0,
+    hipExtLaunchKernelGGL((mlp_chain_fwd_bx_kernel<HACT>), dim3(grid), dim3(64 * kFwW), static_cast<size_t>(lds_bytes), st, ev0,
                           ev1, 0, args);
   else
-    hipLaunchKernelGGL((mlp_chain_fwd_bx_kernel<HACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, args);
+    hipLaunchKernelGGL((mlp_chain_fwd_bx_kernel<HACT>), dim3(grid), dim3(64 * kFwW), static_cast<size_t>(lds_bytes), st, args);
   RLG_RETURN_LAUNCH_STATUS();
 }
 int chain_bx_fwd_prepare() {
