@@ -87,8 +87,9 @@ __device__ __forceinline__ float bx_row_scale(float mine) {
 // band.)  The other operand needs none: hidden activations and normalised observations are split under the forward's
 // fixed scales.
 constexpr int kBxAmaxDz = 0;
-// LDS bytes of the backward behind its tiles: 64 row scales of the d heads tile + 8 layers x 4 waves of gradient maxima (+ alignment)
-constexpr int kBxBwdScratch = RLG_BX_F16 ? 16 + 64 * 4 + 8 * 4 * 4 : 0;
+// LDS bytes of the backward behind its tiles: 64 row scales of the d heads tile + 8 layers x (up to) 8 waves of gradient maxima
+// (+ alignment)
+constexpr int kBxBwdScratch = RLG_BX_F16 ? 16 + 64 * 4 + 8 * 8 * 4 : 0;
 
 // largest value of a wave (uniform result): row rotations inside the 16-lane rows, then the four rows through SGPRs
 __device__ __forceinline__ float bx_wave_max(float t) {

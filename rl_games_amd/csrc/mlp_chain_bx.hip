@@ -23,6 +23,15 @@
 // mlp_chain_bwd_kernel<4, 4>; replaces the autograd dX / activation-backward / bias-sum nodes behind
 // rl_games/algos_torch/network_builder.py:447-512.
 
+// waves per workgroup of the backward (see mlp_chain_bx_fwd.hip: 8 = two per SIMD, 256 registers each, accumulators in
+// VGPRs, one block per unit)
+#ifndef RLG_BX_BWD_W
+#define RLG_BX_BWD_W 8
+#endif
+#if RLG_BX_BWD_W == 8 && !defined(RLG_ACC_CLASS)
+#define RLG_ACC_CLASS "+v"
+#endif
+
 #include "mlp_chain_bx.hpp"
 #include "optim_common.hpp"
 
@@ -97,9 +106,13 @@ bool chain_bx_fill_pack(PackArgs& args, int num_layers, const float* const* weig
 }
 
 // PACT: the activation of every hidden layer when the launch knows it (the usual network), else kChAny: per layer
+constexpr int kBwW = RLG_BX_BWD_W;
+constexpr int kBwNF = (kBwW == 8) ? 1 : 2;      // blocks of the widest unit
+
 template <int G, int PACT>
-__global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a, LossArgs loss) {
-  constexpr int W = kBxW;
+__global__ __launch_bounds__(64 * kBwW) void mlp_chain_bwd_bx_kernel(ChainArgs a, LossArgs loss) {
+  constexpr int W = kBwW, NFM = kBwNF;
+  static_assert(W % G == 0, "the prologue deals row group (wave % G) to a wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ldsb = reinterpret_cast<char*>(lds);
   const int lane = lane_id();
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
 
   // H fragments of the units: two register sets, "next" is requested one unit ahead (see bx_units) - also across the
   // calls and the layers: H does not depend on the barrier between two layers
-  f32x4 hval[2][G], hnext[2][G];
+  f32x4 hval[NFM][G], hnext[NFM][G];
   auto wave_blocks = [&](int nob) -> int { return nob / W + (wave < nob % W ? 1 : 0); };
   auto wave_first = [&](int nob) -> int { return wave * (nob / W) + (wave < nob % W ? wave : nob % W); };
   // blocks ob .. ob + nf - 1 (nf <= 2) of H_{L-1}, the layer whose dZ step L produces; every global access is a
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     const unsigned h_lane = static_cast<unsigned>(((lane & 15) * static_cast<int>(ld) + q4) * 4);
     const unsigned h_group = static_cast<unsigned>(16 * static_cast<int>(ld) * 4);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NFM; ++f) {
       const bool ok = !(kAbl & 4) && f < nf && (ob + f) * 16 + q4 < width;
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
   // (the first request goes out in front of the prologue, which covers part of its round trip)
   {
     const int nob = (pin_s(a.layer[num_layers - 1].in) + 15) >> 4;
-    request_h(num_layers - 1, wave_first(nob), wave_blocks(nob) >= 2 ? 2 : wave_blocks(nob));
+    request_h(num_layers - 1, wave_first(nob), wave_blocks(nob) >= NFM ? NFM : wave_blocks(nob));
   }
 
   // ---- prologue: d heads tile -> planes in LDS -----------------------------------------------------
@@ -166,18 +179,18 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     const int w = a.layer[num_layers - 1].out;
     const int KC0 = (w + 31) >> 5;
     const bool xv = vec4_ok(a.x, a.ldx);
-    float scale_mine = 1.0f;                    // of row (lane & 15) of row group `wave`: W == G, a wave splits ITS group's rows
+    float scale_mine = 1.0f;                    // of row (lane & 15) of row group wave % G: a wave splits ITS group's rows
+    const int group = wave % G;
     float* row_scales = reinterpret_cast<float*>(ldsb + a.bx_scales_off);
     float* wg_max = row_scales + 16 * G + (num_layers - 1) * W;      // [layers][W]: the waves' maxima of every dZ tensor
     if (RLG_BX_F16) {
-      static_assert(W == G, "the prologue deals row group g to wave g");
       float mine = 0.0f;
-      const long long row = row0 + wave * 16 + (lane & 15);
+      const long long row = row0 + group * 16 + (lane & 15);
       if (row < n_rows) {
         for (int c = 0; c < KC0; ++c) {
           const int f = c * 32 + q4;
           if (via_lds) {
-            const float* d = reinterpret_cast<const float*>(ldsb + a.bx_handoff_off) + (wave * 16 + (lane & 15)) * a.bx_handoff_ld;
+            const float* d = reinterpret_cast<const float*>(ldsb + a.bx_handoff_off) + (group * 16 + (lane & 15)) * a.bx_handoff_ld;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (f + e < w) mine = __builtin_fmaxf(mine, bx_finite_abs(d[f + e]));
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
         }
       }
       scale_mine = bx_row_scale(mine);
-      if (lane < 16) row_scales[wave * 16 + lane] = scale_mine;
+      if (lane < 16 && wave < G) row_scales[group * 16 + lane] = scale_mine;
       const float wmax = bx_wave_max(mine);
       if (lane == 0) wg_max[wave] = wmax;
     }
@@ -304,14 +317,14 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
     // MFMAs per chunk here, a unit of one row group would expose every load's latency behind 6 of them).
     // Two blocks per unit, then one.
     const int nb_w = wave_blocks(NOB), first_ob = wave_first(NOB);
-    const int units2 = nb_w >> 1, left = nb_w & 1;
+    const int units2 = (NFM == 2) ? nb_w >> 1 : 0, left = nb_w - 2 * units2;
     // what follows a call's last unit: the single-block unit of this layer, else the next layer's first unit
     auto request_after = [&](bool after_pairs) {
       if (after_pairs && left) {
         request_h(L, first_ob + 2 * units2, 1);
       } else if (L >= 2) {
         const int nob_n = (pin_s(a.layer[L - 1].in) + 15) >> 4;
-        request_h(L - 1, wave_first(nob_n), wave_blocks(nob_n) >= 2 ? 2 : wave_blocks(nob_n));
+        request_h(L - 1, wave_first(nob_n), wave_blocks(nob_n) >= NFM ? NFM : wave_blocks(nob_n));
       }
     };
     auto whole = [&](auto nf_tag, int first, int nunits) {
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
           },
           true, (NF == 2 && L == 1) ? a.dbg : nullptr, wave, &stamp);
     };
-    whole(std::integral_constant<int, 2>{}, first_ob, units2);
+    if constexpr (NFM == 2) whole(std::integral_constant<int, 2>{}, first_ob, units2);
     whole(std::integral_constant<int, 1>{}, first_ob + 2 * units2, left);
     float* const wg_max = wg_max_all + (L - 1) * W;
     if (RLG_BX_F16 && RLG_BX_TRACK == 1 && a.amax != nullptr) {
@@ -374,8 +387,10 @@ __global__ __launch_bounds__(64 * kBxW) void mlp_chain_bwd_bx_kernel(ChainArgs a
   // turned 22 exact vmcnt waits into vmcnt(0).)
   if (RLG_BX_F16 && a.amax != nullptr && static_cast<int>(threadIdx.x) < num_layers) {
     const float* m = wg_max_all + threadIdx.x * W;
-    a.amax[static_cast<long long>(kBxAmaxDz + threadIdx.x) * a.amax_stride + blockIdx.x] =
-        __builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), __builtin_fmaxf(m[2], m[3]));
+    float top = m[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) top = __builtin_fmaxf(top, m[w]);
+    a.amax[static_cast<long long>(kBxAmaxDz + threadIdx.x) * a.amax_stride + blockIdx.x] = top;
   }
 }
 
@@ -413,10 +428,10 @@ static int chain_bx_launch_bwd_as(const ChainArgs& args, int lds_bytes, hipStrea
   const int grid = static_cast<int>((args.rows + 16 * G - 1) / (16 * G));
   LossArgs none = {};
   if (ev0 != nullptr)
-    hipExtLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, ev0,
+    hipExtLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBwW), static_cast<size_t>(lds_bytes), st, ev0,
                           ev1, 0, args, loss ? *loss : none);
   else
-    hipLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBxW), static_cast<size_t>(lds_bytes), st, args,
+    hipLaunchKernelGGL((mlp_chain_bwd_bx_kernel<G, PACT>), dim3(grid), dim3(64 * kBwW), static_cast<size_t>(lds_bytes), st, args,
                        loss ? *loss : none);
   RLG_RETURN_LAUNCH_STATUS();
 }

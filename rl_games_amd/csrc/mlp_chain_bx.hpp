@@ -13,8 +13,9 @@ namespace rlg {
 #define RLG_ACC_CLASS "+a"
 #endif
 #define RLG_ACC_REG(x) RLG_ACC_CLASS(x)
-constexpr int kBxW = 4;                  // waves per workgroup: one per SIMD (the tiles fill the LDS: one workgroup per
-                                         // CU; eight waves on the same tile measured 1.7x SLOWER, 128 + 128 registers)
+// (waves per workgroup: RLG_BX_FWD_W / RLG_BX_BWD_W in the two kernels' files.  The tiles fill the LDS - one workgroup per
+//  CU; rounds 3 - 5 ran one wave per SIMD because eight waves on the same tile had measured 1.7x SLOWER - with AGPR-pinned
+//  accumulators, i.e. 128 + 128 registers and scratch; see RLG_ACC_CLASS above.)
 
 static inline int bx_kc(int K) { return (K + 31) >> 5; }
 static inline int bx_nb(int I) { return (I + 15) >> 4; }
