@@ -7,7 +7,8 @@
 // (rl_games/algos_torch/models.py:54-56) in front of it, like mlp_chain_fwd_kernel; same interface and outputs
 // (activations fp32 in global memory for the backward / weight-gradient launches, heads fp32).
 //
-// 64-row workgroups (G = 4), one wave per SIMD, activations as bf16 planes in LDS: 12 KiB per 32-feature chunk.  A
+// 64-row workgroups (G = 4), 8 waves (RLG_BX_FWD_W below), activations as planes in LDS: 12 KiB per 32-feature chunk (bf16
+// form; 8 KiB in the fp16 form).  A
 // 400-wide layer (156 KiB) does not fit next to its neighbours, so ONE tile of the chain may be WINDOWED: its
 // producer layer p-1 and its consumer layer p run interleaved in passes over windows of the tile's chunks -
 //   [units of layer p-1 for the blocks of the window]  barrier  [layer p accumulates the window's chunks]  barrier
