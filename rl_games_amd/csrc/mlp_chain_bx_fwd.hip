@@ -235,10 +235,13 @@ __global__ __launch_bounds__(64 * kFwW) void mlp_chain_fwd_bx_kernel(ChainArgs a
       }
     };
     load_frags(wave);
+    chain_stamp(a.dbg, wave, stamp);                                 // (tools: observation loads requested)
     if (norm) {
       chain_norm_stats<W>(a, stats, in0, in0p);
+      chain_stamp(a.dbg, wave, stamp);                               // (tools: statistics written)
       __syncthreads();
     }
+    chain_stamp(a.dbg, wave, stamp);                                 // (tools: statistics visible)
     float scale_mine = kBxScaleObsNorm;         // of row (lane & 15) of row group wave % G: a wave splits ITS group's rows
     if (RLG_BX_F16 && !norm) {
       // raw observations have no bound: every row gets its scale from its largest magnitude (one more pass over the

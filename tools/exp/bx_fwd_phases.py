@@ -28,7 +28,7 @@ acts = [torch.empty(rows, u, device=dev) for u in units] if train else None
 xn = torch.empty(rows, in_dim, device=dev) if train else None
 nb = (rows + 63) // 64
 # (round 6, fp16 planes: the humanoid network's tiles fit without a windowed layer - one 'units' + 'barrier' stamp pair per layer)
-names = ['start', 'prologue + barrier'] + [x for L in range(len(dims) - 1) for x in (f'L{L} units', f'L{L} barrier')]
+names = ['start', 'obs requested', 'stats written', 'stats barrier', 'prologue + barrier'] + [x for L in range(len(dims) - 1) for x in (f'L{L} units', f'L{L} barrier')]
 for rep in range(3):
     chain.forward(x, heads, act_out=acts, rms=(mean, var), xn_out=xn)
 dbg = torch.zeros(nb * 4 * 32, dtype=torch.int64, device=dev)
