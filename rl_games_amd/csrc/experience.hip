@@ -342,6 +342,69 @@ __global__ __launch_bounds__(256) void rollout_policy_head_kernel(PolicyHeadArgs
   }
 }
 
+// The same two phases with the block's heads and noise tiles staged in LDS: both are read from global memory ONCE, with
+// consecutive threads on consecutive addresses (phase A's one-thread-per-env walk over a 4*ld-byte row stride, and phase
+// B's second pass over both arrays, then run from LDS; row strides ld and A words - odd for the usual 1 + A heads - spread
+// the rows over the banks).  Same expressions in the same order: bit-identical outputs.  lds: kB * (ld + A) floats.
+template <int kB>
+__global__ __launch_bounds__(kB) void rollout_policy_head_lds_kernel(PolicyHeadArgs p) {
+  extern __shared__ float head_lds[];
+  const int env0 = blockIdx.x * kB;
+  const int rows = min(kB, p.N - env0);
+  float* const sh = head_lds;                  // [rows][ld]
+  float* const sn = head_lds + kB * p.ld;      // [rows][A]
+  const float* gh = p.heads + static_cast<long long>(env0) * p.ld;
+  const float* gn = p.noise + static_cast<long long>(env0) * p.A;
+  for (int i = threadIdx.x; i < rows * p.ld; i += kB) sh[i] = gh[i];
+  for (int i = threadIdx.x; i < rows * p.A; i += kB) sn[i] = gn[i];
+  __syncthreads();
+  const int env = env0 + threadIdx.x;
+  if (env < p.N) {
+    const float* h = sh + threadIdx.x * p.ld;
+    const float* nz = sn + threadIdx.x * p.A;
+    const long long slot = static_cast<long long>(env) * p.H + p.step;
+    float s_z2 = 0.0f, s_ls = 0.0f;
+    for (int a = 0; a < p.A; ++a) {
+      const float mu = h[1 + a];
+      const float ls = p.logstd[a];
+      const float sg = expf(ls);
+      const float act = mu + sg * nz[a];
+      const float z = (act - mu) / sg;
+      s_z2 += z * z;
+      s_ls += ls;
+    }
+    const float nlp = (0.5f * s_z2 + static_cast<float>(0.9189385332046727 * p.A)) + s_ls;
+    p.buf_neglogp[slot] = nlp;
+    float v = h[0];
+    if (p.v_mean) {
+      const float m = static_cast<float>(p.v_mean[0]);
+      const float d = sqrt_rn(static_cast<float>(p.v_var[0]) + p.eps);
+      v = d * clamp_nan(v, -5.0f, 5.0f) + m;
+    }
+    p.values_out[env] = v;
+    p.buf_values[slot] = v;
+  }
+  const int total = rows * p.A;
+  for (int idx = threadIdx.x; idx < total; idx += kB) {
+    const int el = idx / p.A;
+    const int a = idx - el * p.A;
+    const long long e = env0 + el;
+    const float mu = sh[el * p.ld + 1 + a];
+    const float sg = expf(p.logstd[a]);
+    const float act = mu + sg * sn[idx];
+    const long long o = (e * p.H + p.step) * p.A + a;
+    p.actions_out[e * p.A + a] = act;
+    if (p.env_actions_out) {
+      const float lo = p.act_low[a], hi = p.act_high[a];
+      const float d = (hi - lo) / 2.0f, m = (hi + lo) / 2.0f;
+      p.env_actions_out[e * p.A + a] = clamp_nan(act, -1.0f, 1.0f) * d + m;
+    }
+    p.buf_actions[o] = act;
+    p.buf_mus[o] = mu;
+    p.buf_sigmas[o] = sg;
+  }
+}
+
 // RNN rollout helpers (a2c_common.py:1081-1083 snapshot, :1150-1153 zero-on-done).
 // states: [L, N, U] contiguous.  snapshot dst: [num_seqs, L, N, U] slice `seq`.
 __global__ __launch_bounds__(256) void rnn_zero_done_kernel(float* __restrict__ states,
@@ -489,8 +552,19 @@ int rlg_rollout_policy_head(const float* heads, int ld_heads, const float* logst
   // memory round trips per workgroup, so it wants every CU (16 -> 8 us there); the layout of the work inside a
   // workgroup (phase A one thread per env, phase B consecutive threads on consecutive addresses) is unchanged
   constexpr int kHeadBlock = 64;
-  hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + kHeadBlock - 1) / kHeadBlock), dim3(kHeadBlock), 0,
-                     static_cast<hipStream_t>(stream), p);
+  // the LDS-staged form where a block's tiles fit 32 KiB (any realistic head width); RLG_ROLLOUT_HEAD_LDS=0: the direct form
+  static const bool staged = [] {
+    const char* e = getenv("RLG_ROLLOUT_HEAD_LDS");
+    return !(e && e[0] == '0');
+  }();
+  const size_t lds = static_cast<size_t>(kHeadBlock) * (static_cast<size_t>(ld_heads) + actions_num) * sizeof(float);
+  if (staged && ld_heads >= 1 + actions_num && lds <= 32 * 1024) {
+    hipLaunchKernelGGL(rlg::rollout_policy_head_lds_kernel<kHeadBlock>, dim3((num_envs + kHeadBlock - 1) / kHeadBlock),
+                       dim3(kHeadBlock), lds, static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(rlg::rollout_policy_head_kernel, dim3((num_envs + kHeadBlock - 1) / kHeadBlock), dim3(kHeadBlock), 0,
+                       static_cast<hipStream_t>(stream), p);
+  }
   RLG_RETURN_LAUNCH_STATUS();
 }
 

@@ -696,3 +696,55 @@ def test_narrow_dw_matches_fp64_and_is_deterministic(rows, No, Mi):
     ref = dz.double().t() @ x.double()
     scale = dz.abs().double().t() @ x.abs().double()
     assert ((g1.cpu().double() - ref).abs() <= 1e-5 * scale + 1e-30).all()
+
+
+_HEAD_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from rl_games_amd import ops
+out = {}
+for N, A, ld, H, vstats, envact in ((1000, 21, 43, 4, True, True), (64, 3, 4, 2, False, False), (4097, 8, 9, 3, True, False)):
+    g = torch.Generator().manual_seed(N + A)
+    dev = 'cuda:0'
+    heads = torch.randn(N, ld, generator=g).to(dev)
+    logstd = (0.3 * torch.randn(A, generator=g)).to(dev)
+    noise = torch.randn(N, A, generator=g).to(dev)
+    vs = (torch.tensor([0.3], dtype=torch.float64, device=dev), torch.tensor([2.5], dtype=torch.float64, device=dev)) if vstats else None
+    storage = {k: torch.zeros(N, H, A, device=dev) for k in ('actions', 'mus', 'sigmas')}
+    storage.update({k: torch.zeros(N, H, device=dev) for k in ('neglogpacs', 'values')})
+    actions, values = torch.empty(N, A, device=dev), torch.empty(N, device=dev)
+    env = None
+    if envact:
+        env = (torch.empty(N, A, device=dev), -torch.rand(A, generator=g).to(dev) - 0.5, torch.rand(A, generator=g).to(dev) + 0.5)
+    for t in range(H):
+        ops.rollout_policy_head(heads, logstd, noise, vs, 1e-5, actions, values, storage, H, t, env_actions=env)
+    torch.cuda.synchronize()
+    out[N] = {k: v.cpu() for k, v in storage.items()}
+    out[N].update(actions=actions.cpu(), values=values.cpu())
+    if envact:
+        out[N]['env'] = env[0].cpu()
+torch.save(out, sys.argv[2])
+'''
+
+
+def test_rollout_policy_head_staged_in_lds_gives_the_bits_of_the_direct_form(tmp_path):
+    """rlg_rollout_policy_head stages a block's heads / noise tiles in LDS (one coalesced read of each); RLG_ROLLOUT_HEAD_LDS=0
+    keeps the direct form (one thread walking an env's row, a second pass over both arrays).  Same expressions in the same
+    order: every output bit for bit - ragged row counts, wide and narrow heads, with and without value statistics /
+    rescaled env actions."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'head.py'
+    script.write_text(_HEAD_SCRIPT)
+    outs = {}
+    for mode in ('0', '1'):
+        path = str(tmp_path / f'out{mode}.pt')
+        env = dict(os.environ, RLG_ROLLOUT_HEAD_LDS=mode)
+        subprocess.run([sys.executable, str(script), root, path], check=True, env=env, timeout=600)
+        outs[mode] = torch.load(path)
+    for N, fields in outs['0'].items():
+        for k, v in fields.items():
+            assert torch.equal(v, outs['1'][N][k]), (N, k)
+        assert fields['neglogpacs'].abs().sum() > 0 and torch.isfinite(fields['actions']).all()
