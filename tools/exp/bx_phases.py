@@ -30,9 +30,13 @@ for L in range(3, 0, -1):
     full, rem = NOB // 4, (NOB % 4) * 4
     names += [f'dZ{L - 1} units', f'dZ{L - 1} barrier']
     ideal += [-(-NOB // 4) * KC * 4 * 6 * 16, 0]
-# fine stamps inside the two-block units of the last step (dZ0)
-names = names[:-2] + ['dZ0 call start'] + ['dZ0 first chunk'] + [x for j in range(3) for x in (f'dZ0 u{j} chunks', f'dZ0 u{j} epilogue', f'dZ0 u{j} next first chunk')] + ['dZ0 rest', 'dZ0 barrier']
-ideal = ideal[:-2] + [0, 2 * 4 * 6 * 16] + [x for j in range(3) for x in (6 * 2 * 4 * 6 * 16, 0, 2 * 4 * 6 * 16)] + [0, 0]
+# (the fine stamps inside the two-block units of the last step exist only in a 4-wave build, RLG_BX_BWD_W=4: the 8-wave
+#  kernel runs one block per unit and stamps the layers only; `ideal`: MFMA issue cycles of the wave with the most blocks at
+#  3 products x 16 cycles per chunk and row group)
+ideal = [0, 0, 0]
+for L in range(3, 0, -1):
+    KC, NOB = (dims[L + 1] + 31) // 32, (dims[L] + 15) // 16
+    ideal += [-(-NOB // 8) * KC * 4 * 3 * 16, 0]
 for rep in range(3):
     chain.backward(d_heads, acts, dzs, parts, groups=4)
 dbg = torch.zeros(nb * 4 * 32, dtype=torch.int64, device=dev)
@@ -43,13 +47,13 @@ _lib.load().rlg_mlp_chain_debug_stamps(None)
 d = dbg.view(nb, 4, 32).cpu().double()
 n = int((d[0, 0] != 0).sum())
 for label, sel in (('first round', d[:256, :, :n]), ('last round', d[-256:, :, :n])):
-    print(f'{label}: phase, mean ticks of 10 ns (min..max over waves and workgroups), ideal MFMA cycles / ticks at 2.4 GHz')
+    print(f'{label}: phase, mean s_memtime cycles (min..max over waves 0 - 3 and workgroups), ideal MFMA issue cycles of a wave')
     tot = 0
     for k in range(1, n):
         seg = sel[:, :, k] - sel[:, :, k - 1]
         tot += seg.mean().item()
         idl = ideal[k] if k < len(ideal) else 0
-        print(f'   {names[k] if k < len(names) else k:24s} {seg.mean().item():9.0f}  ({seg.min().item():8.0f} .. {seg.max().item():8.0f})   ideal {idl:7d} cyc = {idl / 24:6.0f} ticks   t = {tot:9.0f}')
+        print(f'   {names[k] if k < len(names) else k:24s} {seg.mean().item():9.0f}  ({seg.min().item():8.0f} .. {seg.max().item():8.0f})   ideal {idl:7d}   t = {tot:9.0f}')
 span = (d[:, :, n - 1].max() - d[:, :, 0].min()).item()
 print(f'   whole launch: {span:.0f} ticks from the first start stamp to the last end stamp')
 starts = d[:, 0, 0] - d[:, 0, 0].min()
